@@ -1,0 +1,149 @@
+"""Shared helpers: load the golden fixtures and describe the golden flows.
+
+The flow configurations below restate the constructor arguments used by
+``tools/gen_golden.py`` (the fixtures store weights, inputs and outputs only).
+"""
+import json
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def load_json(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def sub(npz, prefix):
+    """All arrays under ``prefix`` (prefix stripped)."""
+    return {k[len(prefix):]: npz[k] for k in npz.files if k.startswith(prefix)}
+
+
+SPLINE_VARIANTS = [
+    (False, False, False, False), (False, True, False, False), (False, False, True, False),
+    (False, False, False, True), (False, False, True, True), (False, True, True, False),
+    (False, True, False, True), (False, True, True, True), (True, False, False, False),
+    (True, True, False, False),
+]
+
+
+def spline_cfg(meta):
+    """Oracle kwargs from a spline meta entry of transformers.npz."""
+    cfg = dict(circular=meta['circular'], identity_boundary_slopes=meta['identity_boundary_slopes'],
+               learn_lower_bound=meta['learn_lower_bound'], learn_upper_bound=meta['learn_upper_bound'])
+    if meta['y0'] is not None:
+        cfg['y0'] = np.array(meta['y0'])
+        cfg['yf'] = np.array(meta['yf'])
+    return np.array(meta['x0']), np.array(meta['xf']), meta['n_bins'], cfg
+
+
+# ---------------------------------------------------------------------------
+# golden flows: name -> list of per-layer configs (see tools/gen_golden.py:gen_flows)
+# ---------------------------------------------------------------------------
+
+def _spl(D, lo, hi, K, **kw):
+    d = dict(type='spline', x0=np.full(D, lo), xf=np.full(D, hi), n_bins=K)
+    d.update(kw)
+    return d
+
+
+def flow_configs():
+    from oracle.made import generate_degrees as gd
+    cfgs = {}
+    cfgs['cfg1'] = [
+        dict(degrees_in=gd(66, 'ascending'), transformer=dict(type='affine'), hidden_layers=2, weight_norm=True),
+        dict(degrees_in=gd(66, 'descending'), transformer=dict(type='affine'), hidden_layers=2, weight_norm=True),
+    ]
+    cfgs['rq4'] = [
+        dict(degrees_in=gd(66, 'ascending' if i % 2 == 0 else 'descending'),
+             transformer=_spl(66, -5.0, 5.0, 8), hidden_layers=[96, 96], weight_norm=True)
+        for i in range(4)
+    ]
+    cfgs['cond'] = [
+        dict(degrees_in=gd(10, conditioning_indices=[0, 7], repeats=2),
+             transformer=dict(type='affine'), hidden_layers=2, weight_norm=True),
+        dict(degrees_in=gd(10, 'descending', conditioning_indices=[0, 7], repeats=2),
+             transformer=_spl(8, -4.0, 4.0, 5, identity_boundary_slopes=True),
+             hidden_layers=2, weight_norm=False),
+    ]
+    emb = dict(type='periodic', limits=(0.0, 1.0), periodic_indices=list(range(8)), nonperiodic_indices=[])
+    cfgs['circ'] = [
+        dict(degrees_in=gd(8, 'ascending' if i % 2 == 0 else 'descending'),
+             transformer=_spl(8, 0.0, 1.0, 8, circular=True), embedding=emb,
+             hidden_layers=2, weight_norm=True)
+        for i in range(2)
+    ]
+    cfgs['moeb'] = [
+        dict(degrees_in=gd(12, 'ascending' if i % 2 == 0 else 'descending', repeats=2),
+             transformer=dict(type='moebius', dimension=2, unit_sphere=True),
+             hidden_layers=2, weight_norm=True)
+        for i in range(2)
+    ]
+    cfgs['mixflow'] = [
+        dict(degrees_in=gd(6),
+             transformer=dict(type='mixed',
+                              transformers=[_spl(3, -3.0, 3.0, 4), dict(type='affine')],
+                              indices=[[0, 2, 4], [1, 3, 5]], par_lengths=[13 * 3, 2 * 3]),
+             hidden_layers=2, weight_norm=True),
+    ]
+    cfgs['ident'] = [
+        dict(degrees_in=gd(5), transformer=_spl(5, -2.0, 2.0, 4), hidden_layers=2, weight_norm=True),
+    ]
+    return cfgs
+
+
+def oracle_layers(flows_npz, name, dtype=np.float64):
+    """Build the oracle's layer dicts (weights from the fixture, masks regenerated)."""
+    from oracle import made as omade
+    from oracle import transformers as otr
+    cfg = flow_configs()[name]
+    sd = sub(flows_npz, f'{name}/sd/')
+    layers = []
+    for li, c in enumerate(cfg):
+        deg_in = np.asarray(c['degrees_in'])
+        tr = c['transformer']
+        deg_tr = deg_in[deg_in != -1]
+        deg_out = transformer_degrees_out(tr, deg_tr)
+        emb = c.get('embedding')
+        deg_cond = deg_in
+        if emb is not None:
+            deg_cond = otr.periodic_embedding_degrees_out(deg_in, np.asarray(emb['periodic_indices'], dtype=int),
+                                                          np.asarray(emb['nonperiodic_indices'], dtype=int))
+        masks = omade.made_masks(deg_cond, deg_out, c['hidden_layers'], dtype=dtype)
+        made = []
+        for k, m in enumerate(masks):
+            p = f'{li}._conditioner.layers.{2 * k}.'
+            layer = dict(bias=sd[p + 'bias'].astype(dtype), mask=m)
+            if c['weight_norm']:
+                layer['weight_g'] = sd[p + 'weight_g'].astype(dtype)
+                layer['weight_v'] = sd[p + 'weight_v'].astype(dtype)
+            else:
+                layer['weight'] = sd[p + 'weight'].astype(dtype)
+            made.append(layer)
+        layers.append(dict(degrees_in=deg_in, transformer=tr, embedding=emb, made=made))
+    return layers
+
+
+def transformer_degrees_out(tr, deg):
+    """get_degrees_out of each transformer type (tile by P; mixed: concatenated)."""
+    from oracle import transformers as otr
+    t = tr['type']
+    if t == 'affine':
+        return np.tile(deg, 2)
+    if t in ('volpres', 'moebius'):
+        return np.array(deg)
+    if t == 'spline':
+        P = otr.spline_n_parameters_per_feature(
+            tr['n_bins'], tr.get('circular', False), tr.get('identity_boundary_slopes', False),
+            tr.get('learn_lower_bound', False), tr.get('learn_upper_bound', False))
+        return np.tile(deg, P)
+    if t == 'mixed':
+        return np.concatenate([transformer_degrees_out(s, deg[np.asarray(i)])
+                               for s, i in zip(tr['transformers'], tr['indices'])])
+    raise ValueError(t)

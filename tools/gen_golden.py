@@ -1,0 +1,644 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under ``tests/golden/`` from the reference itself.
+
+DEV CONTAINER ONLY.  Imports the read-only reference (``/root/reference``) through
+``tools/ref_shim.py`` and dumps inputs + expected outputs as small ``.npz`` /
+``.json`` fixtures.  Only DATA is written (inputs, weights, outputs); no reference
+source travels.  Run:  ``PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py``
+
+For every floating-point case two reference outputs are stored:
+  * ``*_f64``: the reference run in float64 on the float32-rounded inputs/weights
+    (the parity target),
+  * ``*_f32``: the reference run in float32 (its own noise floor vs float64).
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ref_shim  # noqa: F401,E402
+
+from tfep.nn import masked as rmasked  # noqa: E402
+from tfep.nn.conditioners.made import MADE, generate_degrees  # noqa: E402
+from tfep.nn.embeddings.mafembed import PeriodicEmbedding  # noqa: E402
+from tfep.nn.flows.maf import MAF  # noqa: E402
+from tfep.nn.flows.sequential import SequentialFlow  # noqa: E402
+from tfep.nn.transformers.affine import AffineTransformer, VolumePreservingShiftTransformer  # noqa: E402
+from tfep.nn.transformers.mixed import MixedTransformer  # noqa: E402
+from tfep.nn.transformers.moebius import MoebiusTransformer  # noqa: E402
+from tfep.nn.transformers.spline import NeuralSplineTransformer  # noqa: E402
+from tfep.loss import BoltzmannKLDivLoss  # noqa: E402
+from tfep.analysis.estimator import fep_estimator  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def gen(seed):
+    g = torch.Generator()
+    g.manual_seed(seed)
+    return g
+
+
+class f64:
+    """Context: torch default dtype = float64."""
+    def __enter__(self):
+        self.old = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+
+    def __exit__(self, *a):
+        torch.set_default_dtype(self.old)
+
+
+def sd_to_np(sd, prefix='sd/'):
+    return {prefix + k: npy(v) for k, v in sd.items()}
+
+
+def to_double_sd(sd):
+    return {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+# -----------------------------------------------------------------------------
+# 1. integer tables: degrees, hidden degrees, masks
+# -----------------------------------------------------------------------------
+
+def gen_degrees():
+    cases = []
+    # The argument sets below are the known-answer inputs of the reference's own
+    # test (tests/nn/conditioners/test_made.py:50-67) plus docstring examples and
+    # north-star sizes; expected values are produced by running the reference here.
+    arglist = [
+        dict(n_features=3),
+        dict(n_features=7, order='descending'),
+        dict(n_features=7, order='descending', max_value=2),
+        dict(n_features=7, max_value=2, conditioning_indices=[0, 2, 3]),
+        dict(n_features=6, repeats=2),
+        dict(n_features=7, repeats=[1, 3, 2], conditioning_indices=[2]),
+        dict(n_features=5, order='ascending', conditioning_indices=[0, 1]),
+        dict(n_features=5, order='descending', conditioning_indices=[0, 3]),
+        dict(n_features=7, order='ascending', max_value=3),
+        dict(n_features=8, order='descending', repeats=2),
+        dict(n_features=8, order='ascending', repeats=3),
+        dict(n_features=9, order='descending', repeats=[2, 3, 1], max_value=2),
+        dict(n_features=10, order='ascending', repeats=2, conditioning_indices=[1, 4, 7]),
+        dict(n_features=66, order='ascending'),
+        dict(n_features=66, order='descending'),
+        dict(n_features=1024, order='ascending', repeats=2),
+    ]
+    for kw in arglist:
+        cases.append({'kwargs': kw, 'expected': generate_degrees(**kw).tolist()})
+
+    hidden_cases = []
+    hidden_args = [
+        # (degrees_in, degrees_out, hidden_layers)
+        ([0, 1, 2], [0, 1, 2] * 2, 2),
+        ([0, 1, 2, 3], [0, 0, 1, 1, 2, 2, 3, 3], 1),
+        ([-1, -1, 0, 1, 2], [0, 1, 2, 0, 1, 2], 3),
+        ([2, 1, 0], [2, 1, 0, 2, 1, 0], [4, 5]),
+        ([-1, 0, 0, 1, 1], [0, 0, 1, 1], [6]),
+        ([0, 1, 2, 3, 4], [0, 1, 2, 3, 4] * 3, [[0, 1, 2, 3], [3, 2, 1, 0, 0]]),
+        ([-1, -1], [0, 0, 0, 0], 3),
+        (generate_degrees(66).tolist(), generate_degrees(66).tile((2,)).tolist(), 2),
+        (generate_degrees(12, order='descending').tolist(),
+         generate_degrees(12, order='descending').tile((25,)).tolist(), 2),
+    ]
+    for din, dout, hl in hidden_args:
+        out = MADE._get_degrees_hidden(torch.tensor(din), torch.tensor(dout), hl)
+        hidden_cases.append({'degrees_in': din, 'degrees_out': dout, 'hidden_layers': hl,
+                             'expected': [o.tolist() for o in out]})
+
+    mask_cases = []
+    for din, dout, strict, tr in [
+        ([0, 1, 2], [0, 1, 2, 2], True, False),
+        ([0, 1, 2], [0, 1, 2, 2], False, False),
+        ([-1, 0, 1, 1], [0, 1, 2], True, True),
+        ([-1, 0, 1, 1], [1, 0, 1, 0, -1], False, True),
+        ([2, 1, 0], [2, 1, 0, 2, 1, 0], True, True),
+    ]:
+        m = rmasked.create_autoregressive_mask(np.array(din), np.array(dout), strictly_less=strict,
+                                               transpose=tr, dtype=torch.float32)
+        mask_cases.append({'degrees_in': din, 'degrees_out': dout, 'strictly_less': strict,
+                           'transpose': tr, 'expected': m.int().tolist()})
+
+    # Full MADE masks for a small net: bit-packed.
+    made = MADE(degrees_in=generate_degrees(7, conditioning_indices=[1]),
+                degrees_out=generate_degrees(6).tile((3,)), hidden_layers=2)
+    made_masks = [npy(l.mask).astype(int).tolist() for l in made.layers[::2]]
+    # Mask nnz at north-star-like structure but reduced size.
+    nnz = []
+    for D, P, order in [(66, 2, 'ascending'), (66, 2, 'descending'), (300, 25, 'ascending')]:
+        deg = generate_degrees(D, order=order)
+        m = MADE(degrees_in=deg, degrees_out=deg.tile((P,)), hidden_layers=2, weight_norm=False)
+        nnz.append({'D': D, 'P': P, 'order': order,
+                    'shapes': [list(l.mask.shape) for l in m.layers[::2]],
+                    'nnz': [int(l.mask.sum().item()) for l in m.layers[::2]]})
+
+    with open(os.path.join(OUT, 'degrees.json'), 'w') as f:
+        json.dump({'generate_degrees': cases, 'degrees_hidden': hidden_cases,
+                   'masks': mask_cases,
+                   'made_masks': {'degrees_in': generate_degrees(7, conditioning_indices=[1]).tolist(),
+                                  'degrees_out': generate_degrees(6).tile((3,)).tolist(),
+                                  'hidden_layers': 2, 'expected': made_masks},
+                   'mask_nnz': nnz}, f)
+
+
+# -----------------------------------------------------------------------------
+# 2. masked linear, weight norm, MADE
+# -----------------------------------------------------------------------------
+
+def gen_masked():
+    out = {}
+    g = gen(7)
+    B, I, O = 6, 8, 5
+    x = torch.randn(B, I, generator=g)
+    w = torch.randn(O, I, generator=g)
+    b = torch.randn(O, generator=g)
+    mask = torch.tril(torch.ones(O, I))
+    mask[2] = 0.0                                   # fully-masked row (NaN-safe path)
+    out.update(x=npy(x), weight=npy(w), bias=npy(b), mask=npy(mask))
+    out['y_f32'] = npy(rmasked.masked_linear(x, w, b, mask))
+    out['y_f64'] = npy(rmasked.masked_linear(x.double(), w.double(), b.double(), mask.double()))
+    out['y_nomask_f64'] = npy(rmasked.masked_linear(x.double(), w.double(), b.double(), None))
+
+    # Weight norm module with the fully-masked row.
+    torch.manual_seed(3)
+    lin = rmasked.MaskedLinear(I, O, bias=True, mask=mask.clone())
+    lin = rmasked.masked_weight_norm(lin, name='weight')
+    with torch.no_grad():
+        lin.weight_g.mul_(1.7)                      # make g != ||v||
+    y32 = lin(x)
+    out['wn_g'] = npy(lin.weight_g)
+    out['wn_v'] = npy(lin.weight_v)
+    out['wn_bias'] = npy(lin.bias)
+    out['wn_weight_f32'] = npy(lin.weight)
+    out['wn_y_f32'] = npy(y32)
+    with f64():
+        lin64 = rmasked.MaskedLinear(I, O, bias=True, mask=mask.double())
+        lin64 = rmasked.masked_weight_norm(lin64, name='weight')
+        lin64.load_state_dict(to_double_sd(lin.state_dict()))
+        y64 = lin64(x.double())
+        out['wn_weight_f64'] = npy(lin64.weight)
+        out['wn_y_f64'] = npy(y64)
+    out['wn_state_keys'] = np.array(sorted(lin.state_dict().keys()))
+    np.savez_compressed(os.path.join(OUT, 'masked_linear.npz'), **out)
+
+
+def run_made(kwargs, x, seed):
+    torch.manual_seed(seed)
+    m32 = MADE(**kwargs)
+    with torch.no_grad():
+        for l in m32.layers[::2]:               # decouple g from ||v|| and bias from init
+            if hasattr(l, 'weight_g'):
+                l.weight_g.mul_(torch.rand_like(l.weight_g) + 0.5)
+    y32 = m32(x)
+    with f64():
+        m64 = MADE(**kwargs)
+        m64.load_state_dict(to_double_sd(m32.state_dict()))
+        h = x.double()
+        hidden = []
+        for mod in m64.layers:
+            h = mod(h)
+            if isinstance(mod, torch.nn.ELU):
+                hidden.append(npy(h))
+        y64 = h
+    return m32, npy(y32), npy(y64), hidden
+
+
+def gen_made():
+    cases = {
+        'a': dict(degrees_in=generate_degrees(5), degrees_out=generate_degrees(5).tile((2,)),
+                  hidden_layers=2, weight_norm=True),
+        'b': dict(degrees_in=generate_degrees(7, conditioning_indices=[0, 3]),
+                  degrees_out=generate_degrees(5).tile((3,)), hidden_layers=1, weight_norm=False),
+        'c': dict(degrees_in=generate_degrees(6, order='descending'),
+                  degrees_out=generate_degrees(6, order='descending').tile((4,)),
+                  hidden_layers=[7, 9], weight_norm=True),
+        'd': dict(degrees_in=generate_degrees(8, repeats=2),
+                  degrees_out=generate_degrees(8, repeats=2).tile((2,)),
+                  hidden_layers=3, weight_norm=True),
+    }
+    out = {}
+    meta = {}
+    for name, kw in cases.items():
+        n_in = len(kw['degrees_in'])
+        x = torch.randn(9, n_in, generator=gen(11))
+        m32, y32, y64, hidden = run_made(kw, x, seed=5)
+        out.update(sd_to_np(m32.state_dict(), prefix=f'{name}/sd/'))
+        out[f'{name}/x'] = npy(x)
+        out[f'{name}/y_f32'] = y32
+        out[f'{name}/y_f64'] = y64
+        for i, h in enumerate(hidden):
+            out[f'{name}/hidden{i}_f64'] = h
+        meta[name] = dict(degrees_in=kw['degrees_in'].tolist(), degrees_out=kw['degrees_out'].tolist(),
+                          hidden_layers=kw['hidden_layers'], weight_norm=kw['weight_norm'],
+                          n_parameters=int(m32.n_parameters()))
+    out['meta'] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, 'made.npz'), **out)
+
+
+# -----------------------------------------------------------------------------
+# 3. transformers
+# -----------------------------------------------------------------------------
+
+SPLINE_VARIANTS = [
+    # (circular, identity_boundary_slopes, learn_lower, learn_upper)
+    (False, False, False, False),
+    (False, True, False, False),
+    (False, False, True, False),
+    (False, False, False, True),
+    (False, False, True, True),
+    (False, True, True, False),
+    (False, True, False, True),
+    (False, True, True, True),
+    (True, False, False, False),
+    (True, True, False, False),
+]
+
+
+def variant_name(v):
+    return 'c%d_i%d_l%d_u%d' % tuple(int(b) for b in v)
+
+
+def run_transformer(make, x, par):
+    """Run forward + inverse in f32 and f64; return dict of arrays."""
+    out = {}
+    t32 = make(torch.float32)
+    y32, l32 = t32(x, par)
+    out['y_f32'], out['ldj_f32'] = npy(y32), npy(l32)
+    with f64():
+        t64 = make(torch.float64)
+        y64, l64 = t64(x.double(), par.double())
+        xi, li = t64.inverse(y64, par.double())
+        out['y_f64'], out['ldj_f64'] = npy(y64), npy(l64)
+        out['xinv_f64'], out['ldjinv_f64'] = npy(xi), npy(li)
+    return out
+
+
+def gen_transformers():
+    out = {}
+    B, D = 16, 6
+
+    # ---- affine
+    g = gen(21)
+    x = torch.randn(B, D, generator=g)
+    par = torch.randn(B, 2 * D, generator=g) * 0.7
+    res = run_transformer(lambda dt: AffineTransformer(), x, par)
+    out.update({'affine/x': npy(x), 'affine/par': npy(par)})
+    out.update({'affine/' + k: v for k, v in res.items()})
+
+    # ---- volume preserving shift (with periodic wrap)
+    g = gen(22)
+    x = torch.rand(B, D, generator=g) * 2 - 1
+    par = torch.randn(B, D, generator=g)
+    pidx = torch.tensor([1, 4])
+    plim = torch.tensor([-1.0, 1.0])
+    res = run_transformer(lambda dt: VolumePreservingShiftTransformer(
+        periodic_indices=pidx, periodic_limits=plim.to(dt)), x, par)
+    out.update({'volpres/x': npy(x), 'volpres/par': npy(par),
+                'volpres/periodic_indices': npy(pidx), 'volpres/periodic_limits': npy(plim)})
+    out.update({'volpres/' + k: v for k, v in res.items()})
+
+    # ---- splines: all legal flag combinations, K = 8 and a K = 3 case with y-domain != x-domain
+    spl_meta = {}
+    for K, dom in [(8, 'sym'), (3, 'asym')]:
+        for v in SPLINE_VARIANTS:
+            circ, ident, ll, lu = v
+            name = f'spline/K{K}_{dom}_{variant_name(v)}'
+            if dom == 'sym':
+                x0 = torch.full((D,), -5.0)
+                xf = torch.full((D,), 5.0)
+                y0 = yf = None
+            else:
+                x0 = torch.tensor([-2.0, -1.0, 0.0, -3.0, -0.5, 1.0])
+                xf = torch.tensor([0.0, 1.5, 2.0, 3.0, 0.5, 4.0])
+                if circ:
+                    y0 = yf = None
+                else:
+                    y0 = x0 + 1.0
+                    yf = y0 + (xf - x0) * 1.5
+            kw = dict(n_bins=K, circular=circ, identity_boundary_slopes=ident,
+                      learn_lower_bound=ll, learn_upper_bound=lu)
+
+            def make(dt, x0=x0, xf=xf, y0=y0, yf=yf, kw=kw):
+                return NeuralSplineTransformer(
+                    x0=x0.to(dt), xf=xf.to(dt),
+                    y0=None if y0 is None else y0.to(dt),
+                    yf=None if yf is None else yf.to(dt), **kw)
+
+            t = make(torch.float32)
+            P = int(t.n_parameters_per_feature)
+            g = gen(100 + K + 7 * SPLINE_VARIANTS.index(v))
+            par = torch.randn(B, P * D, generator=g)
+            if ll or lu:
+                # Keep the learnable-domain scale/shift moderate.
+                pv = par.reshape(B, P, D)
+                pv[:, -1] *= 0.2
+                if ll and lu:
+                    pv[:, -2] *= 0.5
+                par = pv.reshape(B, P * D).contiguous()
+            # Inputs: rows 0..B-5 in-domain randoms, then out-of-domain on both sides,
+            # then exactly-on-knot values (filled below).
+            width = xf - x0
+            if circ:
+                x = torch.rand(B, D, generator=g) * width + x0
+            else:
+                x = (torch.rand(B, D, generator=g) * 0.96 + 0.02) * width + x0
+                x[-4] = x0 - 0.37 * width          # below the domain
+                x[-3] = xf + 0.21 * width          # above the domain
+            # Exactly-on-knot inputs (strict '>' puts them in the lower bin): use the f32 knots.
+            nx0, ny0, w_, h_, s_, sh_ = t._get_parameters(par)
+            base = nx0 if nx0.dim() == 1 else nx0.unsqueeze(1)
+            knots = base + torch.cumsum(w_, dim=1)          # (B, K, D) upper knots of each bin
+            if not circ:
+                x[-2] = knots[-2, 1]                         # an interior knot
+                x[-1] = (nx0 if nx0.dim() == 1 else nx0[-1])  # the first knot x0
+            res = run_transformer(make, x, par)
+            with f64():
+                t64 = make(torch.float64)
+                nx0, ny0, w_, h_, s_, sh_ = t64._get_parameters(par.double())
+                res['gp_x0_f64'] = npy(nx0 if nx0.dim() == 2 else nx0.expand(B, D))
+                res['gp_y0_f64'] = npy(ny0 if ny0.dim() == 2 else ny0.expand(B, D))
+                res['gp_widths_f64'], res['gp_heights_f64'], res['gp_slopes_f64'] = npy(w_), npy(h_), npy(s_)
+                if sh_ is not None:
+                    res['gp_shifts_f64'] = npy(sh_)
+            out.update({name + '/x': npy(x), name + '/par': npy(par)})
+            out.update({name + '/' + k: vv for k, vv in res.items()})
+            spl_meta[name] = dict(x0=x0.tolist(), xf=xf.tolist(),
+                                  y0=None if y0 is None else y0.tolist(),
+                                  yf=None if yf is None else yf.tolist(),
+                                  P=P, **kw)
+    out['spline/meta'] = np.array(json.dumps(spl_meta))
+
+    # ---- Moebius, d = 2 and 3, unit_sphere both
+    mo_meta = {}
+    for d in (2, 3):
+        for unit in (False, True):
+            name = f'moebius/d{d}_u{int(unit)}'
+            g = gen(300 + d + int(unit))
+            nv = 4
+            x = torch.randn(B, nv * d, generator=g)
+            if unit:
+                xv = x.reshape(B, nv, d)
+                x = (xv / torch.linalg.norm(xv, dim=-1, keepdim=True)).reshape(B, nv * d)
+                x = x.double().float()
+            par = torch.randn(B, nv * d, generator=g)
+            res = run_transformer(lambda dt: MoebiusTransformer(dimension=d, unit_sphere=unit), x, par)
+            out.update({name + '/x': npy(x), name + '/par': npy(par)})
+            out.update({name + '/' + k: vv for k, vv in res.items()})
+            mo_meta[name] = dict(dimension=d, unit_sphere=unit, max_radius=0.99)
+    out['moebius/meta'] = np.array(json.dumps(mo_meta))
+
+    # ---- Mixed: spline on [0,2,5], affine on [1,3], moebius(d=2, unit) on... keep simple 2+: affine+spline+volpres
+    g = gen(41)
+    Dm = 7
+    ind = [[0, 2, 5], [1, 3], [4, 6]]
+    x = torch.rand(B, Dm, generator=g) * 1.6 - 0.8
+
+    def make_mixed(dt):
+        return MixedTransformer(
+            transformers=[
+                NeuralSplineTransformer(x0=torch.full((3,), -1.0).to(dt), xf=torch.full((3,), 1.0).to(dt), n_bins=4),
+                AffineTransformer(),
+                NeuralSplineTransformer(x0=torch.full((2,), -1.0).to(dt), xf=torch.full((2,), 1.0).to(dt),
+                                        n_bins=3, circular=True),
+            ], indices=ind)
+    tm = make_mixed(torch.float32)
+    npar = len(tm.get_identity_parameters(Dm))
+    par = torch.randn(B, npar, generator=g)
+    res = run_transformer(make_mixed, x, par)
+    out.update({'mixed/x': npy(x), 'mixed/par': npy(par)})
+    out.update({'mixed/' + k: v for k, v in res.items()})
+    out['mixed/degrees_out'] = npy(tm.get_degrees_out(torch.arange(Dm)))
+    out['mixed/split'] = npy(tm._parameters_split_indices)
+
+    # ---- periodic embedding
+    g = gen(51)
+    x = torch.rand(B, 6, generator=g)
+    emb = PeriodicEmbedding(n_features_in=6, limits=[0.0, 1.0], periodic_indices=[1, 2, 5])
+    out['pemb/x'] = npy(x)
+    out['pemb/y_f32'] = npy(emb(x))
+    with f64():
+        emb64 = PeriodicEmbedding(n_features_in=6, limits=[0.0, 1.0], periodic_indices=[1, 2, 5])
+        out['pemb/y_f64'] = npy(emb64(x.double()))
+    out['pemb/degrees_in'] = np.array([0, 1, 2, 3, 4, 5])
+    out['pemb/degrees_out'] = npy(emb.get_degrees_out(torch.arange(6)))
+    out['pemb/periodic_indices'] = npy(emb._periodic_indices)
+    out['pemb/nonperiodic_indices'] = npy(emb._nonperiodic_indices)
+
+    np.savez_compressed(os.path.join(OUT, 'transformers.npz'), **out)
+
+
+# -----------------------------------------------------------------------------
+# 4. flows (end to end)
+# -----------------------------------------------------------------------------
+
+def perturb_weight_g(flow, seed):
+    g = gen(seed)
+    with torch.no_grad():
+        for n, p in flow.named_parameters():
+            if n.endswith('weight_g'):
+                p.mul_(torch.rand(p.shape, generator=g) + 0.5)
+
+
+def run_flow(make_flow, x, seed, out, name, inverse=True, store_masks=False):
+    torch.manual_seed(seed)
+    f32 = make_flow(torch.float32)
+    perturb_weight_g(f32, seed + 1)
+    y32, l32 = f32(x)
+    with f64():
+        f64m = make_flow(torch.float64)
+        f64m.load_state_dict(to_double_sd(f32.state_dict()))
+        y64, l64 = f64m(x.double())
+        out[f'{name}/y_f64'], out[f'{name}/ldj_f64'] = npy(y64), npy(l64)
+        if inverse:
+            # Inverse of the float32-rounded forward output, in float64.
+            yin = y32.detach().double()
+            xi, li = f64m.inverse(yin)
+            out[f'{name}/inv_in'] = npy(y32)
+            out[f'{name}/xinv_f64'], out[f'{name}/ldjinv_f64'] = npy(xi), npy(li)
+    out[f'{name}/x'] = npy(x)
+    out[f'{name}/y_f32'], out[f'{name}/ldj_f32'] = npy(y32), npy(l32)
+    for k, v in f32.state_dict().items():
+        if k.endswith('.mask') and not store_masks:
+            continue
+        if k.endswith('.mask'):
+            out[f'{name}/sdmask/{k}'] = np.packbits(npy(v).astype(bool), axis=None)
+            out[f'{name}/sdmaskshape/{k}'] = np.array(v.shape)
+        else:
+            out[f'{name}/sd/{k}'] = npy(v)
+    out[f'{name}/n_parameters'] = np.array(int(f32.n_parameters()))
+    return f32
+
+
+def gen_flows():
+    out = {}
+
+    # cfg1 exactly: 2-layer MAF + affine, D=66, B=1024, weight_norm, no identity init.
+    D = 66
+    x = torch.randn(1024, D, generator=gen(1234))
+
+    def make_cfg1(dt):
+        return SequentialFlow(
+            MAF(degrees_in=generate_degrees(D, order='ascending'), initialize_identity=False),
+            MAF(degrees_in=generate_degrees(D, order='descending'), initialize_identity=False),
+        )
+    run_flow(make_cfg1, x, 0, out, 'cfg1', inverse=False, store_masks=True)
+    # inverse on a small slice (D sequential passes)
+    torch.manual_seed(0)
+
+    # 4-layer RQ-8, D=66, hidden [96, 96]; in-domain and tail inputs.
+    def make_rq(dt):
+        layers = []
+        for i in range(4):
+            layers.append(MAF(
+                degrees_in=generate_degrees(D, order='ascending' if i % 2 == 0 else 'descending'),
+                transformer=NeuralSplineTransformer(x0=torch.full((D,), -5.0).to(dt),
+                                                    xf=torch.full((D,), 5.0).to(dt), n_bins=8),
+                hidden_layers=[96, 96], initialize_identity=False))
+        return SequentialFlow(*layers)
+    x_in = torch.randn(192, D, generator=gen(1234)).clamp(-4.9, 4.9)
+    x_tail = 1.5 * torch.randn(64, D, generator=gen(4321)) * 2.0
+    x = torch.cat([x_in, x_tail])
+    run_flow(make_rq, x, 0, out, 'rq4', inverse=True)
+
+    # Conditioning DOFs + repeats + default hidden width, affine; D=10.
+    def make_cond(dt):
+        deg = generate_degrees(10, conditioning_indices=[0, 7], repeats=2)
+        return SequentialFlow(
+            MAF(degrees_in=deg, initialize_identity=False),
+            MAF(degrees_in=generate_degrees(10, order='descending', conditioning_indices=[0, 7], repeats=2),
+                transformer=NeuralSplineTransformer(x0=torch.full((8,), -4.0).to(dt),
+                                                    xf=torch.full((8,), 4.0).to(dt), n_bins=5,
+                                                    identity_boundary_slopes=True),
+                initialize_identity=False, weight_norm=False),
+        )
+    x = torch.randn(40, 10, generator=gen(99))
+    run_flow(make_cond, x, 2, out, 'cond', inverse=True, store_masks=True)
+
+    # Circular spline + periodic embedding on 8 angles in [0, 1) (cfg4-i recipe, reduced).
+    def make_circ(dt):
+        layers = []
+        for i in range(2):
+            layers.append(MAF(
+                degrees_in=generate_degrees(8, order='ascending' if i % 2 == 0 else 'descending'),
+                transformer=NeuralSplineTransformer(x0=torch.zeros(8).to(dt), xf=torch.ones(8).to(dt),
+                                                    n_bins=8, circular=True),
+                embedding=PeriodicEmbedding(n_features_in=8, limits=[0.0, 1.0]),
+                initialize_identity=False))
+        return SequentialFlow(*layers)
+    x = torch.rand(48, 8, generator=gen(77))
+    run_flow(make_circ, x, 4, out, 'circ', inverse=True)
+
+    # Moebius d=2 unit sphere on 6 angles -> 12 features, repeats=2 (cfg4-ii recipe, reduced).
+    def make_moeb(dt):
+        layers = []
+        for i in range(2):
+            layers.append(MAF(
+                degrees_in=generate_degrees(12, order='ascending' if i % 2 == 0 else 'descending', repeats=2),
+                transformer=MoebiusTransformer(dimension=2, unit_sphere=True),
+                initialize_identity=False))
+        return SequentialFlow(*layers)
+    ang = torch.rand(32, 6, generator=gen(78)) * 2 * np.pi
+    x = torch.stack([torch.cos(ang), torch.sin(ang)], dim=2).reshape(32, 12)
+    run_flow(make_moeb, x, 6, out, 'moeb', inverse=True)
+
+    # Mixed transformer inside a MAF: spline on even, affine on odd features; D=6.
+    def make_mixflow(dt):
+        return SequentialFlow(MAF(
+            degrees_in=generate_degrees(6),
+            transformer=MixedTransformer(
+                transformers=[
+                    NeuralSplineTransformer(x0=torch.full((3,), -3.0).to(dt), xf=torch.full((3,), 3.0).to(dt), n_bins=4),
+                    AffineTransformer()],
+                indices=[[0, 2, 4], [1, 3, 5]]),
+            initialize_identity=False))
+    x = torch.randn(24, 6, generator=gen(79))
+    run_flow(make_mixflow, x, 8, out, 'mixflow', inverse=True)
+
+    # Identity initialisation: y == x, ldj == 0 (tests/nn/flows/test_maf.py:221-223).
+    def make_ident(dt):
+        return SequentialFlow(MAF(
+            degrees_in=generate_degrees(5),
+            transformer=NeuralSplineTransformer(x0=torch.full((5,), -2.0).to(dt), xf=torch.full((5,), 2.0).to(dt), n_bins=4),
+            initialize_identity=True))
+    x = torch.randn(8, 5, generator=gen(80))
+    torch.manual_seed(10)
+    fid = make_ident(torch.float32)
+    y, l = fid(x)
+    out['ident/x'] = npy(x)
+    out['ident/y_f32'], out['ident/ldj_f32'] = npy(y), npy(l)
+    for k, v in fid.state_dict().items():
+        if not k.endswith('.mask'):
+            out[f'ident/sd/{k}'] = npy(v)
+
+    np.savez_compressed(os.path.join(OUT, 'flows.npz'), **out)
+
+
+# -----------------------------------------------------------------------------
+# 5. loss + estimator
+# -----------------------------------------------------------------------------
+
+def gen_loss():
+    out = {}
+    g = gen(5)
+    N = 257
+    uB = torch.randn(N, generator=g) * 3 + 10
+    ldj = torch.randn(N, generator=g)
+    lw = torch.randn(N, generator=g)
+    uA = torch.randn(N, generator=g) * 2 + 8
+    out.update(uB=npy(uB), ldj=npy(ldj), lw=npy(lw), uA=npy(uA))
+    import warnings
+    warnings.simplefilter('ignore')
+    for dt, tag in [(torch.float32, 'f32'), (torch.float64, 'f64')]:
+        # The estimator takes log(N) in the torch DEFAULT dtype (estimator.py:75-77), so the
+        # float64 goldens are produced under default dtype float64, like the reference's tests.
+        torch.set_default_dtype(dt)
+        a, b_, c, d = uB.to(dt), ldj.to(dt), lw.to(dt), uA.to(dt)
+        L = BoltzmannKLDivLoss()
+        out[f'loss_plain_{tag}'] = npy(L(a, b_))
+        out[f'loss_ref_{tag}'] = npy(L(a, b_, ref_potentials=d))
+        out[f'loss_weighted_{tag}'] = npy(L(a, b_, log_weights=c))
+        out[f'loss_all_{tag}'] = npy(L(a, b_, log_weights=c, ref_potentials=d))
+        out[f'loss_noldj_{tag}'] = npy(L(a))
+        an = a.clone()
+        an[[3, 77]] = float('nan')
+        Ln = BoltzmannKLDivLoss(ignore_nan=True)
+        out[f'loss_nan_plain_{tag}'] = npy(Ln(an, b_))
+        out[f'loss_nan_weighted_{tag}'] = npy(Ln(an, b_, log_weights=c))
+        out[f'loss_nan_propagates_{tag}'] = npy(L(an, b_))
+        work = a - b_ - d
+        out[f'fep_plain_{tag}'] = npy(fep_estimator(work))
+        out[f'fep_kT_{tag}'] = npy(fep_estimator(work * 2.5, kT=2.5))
+        out[f'fep_biased_{tag}'] = npy(fep_estimator(torch.stack([work, c], dim=1)))
+        boot = torch.stack([work[torch.randint(0, N, (N,), generator=gen(s))] for s in range(4)])
+        out[f'fep_vec_in_{tag}'] = npy(boot)
+        out[f'fep_vec_{tag}'] = npy(fep_estimator(boot, vectorized=True))
+        wts = torch.rand(4, N, generator=gen(9)).to(dt)
+        wts = wts / wts.sum(dim=1, keepdim=True)
+        out[f'fep_bayes_w_{tag}'] = npy(wts)
+        out[f'fep_bayes_{tag}'] = npy(fep_estimator(work.expand(4, N), weights=wts, vectorized=True))
+        bootb = torch.stack([torch.stack([work, c], dim=1)[torch.randint(0, N, (N,), generator=gen(s))]
+                             for s in range(3)])
+        out[f'fep_vecb_in_{tag}'] = npy(bootb)
+        out[f'fep_vecb_{tag}'] = npy(fep_estimator(bootb, vectorized=True))
+    torch.set_default_dtype(torch.float32)
+    np.savez_compressed(os.path.join(OUT, 'loss.npz'), **out)
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(4)
+    gen_degrees()
+    gen_masked()
+    gen_made()
+    gen_transformers()
+    gen_flows()
+    gen_loss()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
