@@ -1,0 +1,249 @@
+/*
+ * tfep_hip.h -- C ABI of libtfep_hip.so: the MI355X (gfx950) kernels of the
+ * tfep.nn normalizing-flow hot path.
+ *
+ * The reference (andrrizzi/tfep @ 2024-12-20) is pure Python on PyTorch and has
+ * no FFI of its own; each entry point below replaces one reference function of
+ * the path (cited as file:line relative to the reference root) and is what a
+ * ctypes / cffi binding added to that function would call.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to float32 / int32 unless marked "host";
+ *   - tensors are dense row-major; `ld*` arguments are row strides in elements;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every
+ *     call only enqueues work on that stream and never synchronises;
+ *   - every function returns 0 on success, a negative tfep_status otherwise, and
+ *     never throws; tfep_last_error() returns a host string for the calling thread;
+ *   - "parameters" follow the reference's conditioner-output layout unless a
+ *     tfep_param_layout says otherwise: column p*D + f of a (B, P*D) matrix is
+ *     parameter p of feature f (transformers/spline.py:351-352, affine.py:138-141);
+ *   - log_det_J outputs are (B,) float32; with accumulate != 0 the kernel ADDS to
+ *     the existing values (the `cumulative_log_det_J += log_det_J` of
+ *     flows/sequential.py:66), otherwise it overwrites them.
+ */
+#ifndef TFEP_HIP_H
+#define TFEP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFEP_HIP_ABI_VERSION 1
+
+typedef enum tfep_status {
+    TFEP_OK = 0,
+    TFEP_ERR_INVALID_ARGUMENT = -1,
+    TFEP_ERR_UNSUPPORTED = -2,
+    TFEP_ERR_LAUNCH = -3
+} tfep_status;
+
+/* ABI version of the loaded library (== TFEP_HIP_ABI_VERSION it was built with). */
+int tfep_hip_abi_version(void);
+/* Host string describing the last error on the calling thread ("" if none). */
+const char* tfep_last_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Layout of transformer parameters in memory.                                */
+/*   parameter p of feature f of sample b lives at                            */
+/*       params[b * ld + p * stride_p + f * stride_f]                         */
+/*   reference layout: ld = P*D, stride_p = D, stride_f = 1.                  */
+/* ------------------------------------------------------------------------- */
+typedef struct tfep_param_layout {
+    int64_t ld;
+    int64_t stride_p;
+    int64_t stride_f;
+} tfep_param_layout;
+
+/* ------------------------------------------------------------------------- */
+/* Masked linear layers (tfep/nn/masked.py)                                   */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Effective masked weight, recomputed from its parametrisation.
+ *   weight_g != NULL :  W[o,i] = mask[o,i] != 0 ? v[o,i] * (g[o] / ||v[o,:]||_2) : 0
+ *                       replaces MaskedWeightNorm.compute_weight + _ApplyMask
+ *                       (masked.py:369-371, :433-439; NaN-safe for fully-masked rows)
+ *   weight_g == NULL :  W[o,i] = v[o,i] * mask[o,i]      (masked.py:270; mask may be NULL)
+ * The result is written permuted and zero-padded for the GEMM kernels:
+ *   w_out[row_of_out[o] * ldw + col_of_in[i]] = W[o,i]
+ * row_of_out / col_of_in may be NULL (identity).  Padding rows/cols of w_out
+ * (n_rows_padded x ldw) that no (o,i) maps to are set to 0.
+ */
+int tfep_masked_weight_prepare(const float* weight_v, const float* weight_g, const float* mask,
+                               int out_features, int in_features,
+                               const int32_t* row_of_out, const int32_t* col_of_in,
+                               float* w_out, int n_rows_padded, int64_t ldw, void* stream);
+
+/*
+ * Per column-tile bounding range of the mask non-zeros, in PACKED coordinates:
+ *   k_ranges[2*t], k_ranges[2*t+1] = [k_begin, k_end) over packed rows t*tile_n .. (t+1)*tile_n - 1,
+ * rounded outwards to multiples of tile_k (k_end clipped to k_padded); an all-zero tile gets [0, 0).
+ * The GEMM skips everything outside the range: the autoregressive masks of MADE are block
+ * triangular once the hidden units are sorted by degree (conditioners/made.py:286-329,
+ * masked.py:90-99).  The ranges depend on the mask buffer only -- compute once, reuse.
+ * row_of_out / col_of_in: the same permutations given to tfep_masked_weight_prepare (or NULL).
+ */
+int tfep_mask_k_ranges(const float* mask, int out_features, int in_features,
+                       const int32_t* row_of_out, const int32_t* col_of_in,
+                       int tile_n, int tile_k, int n_tiles, int k_padded,
+                       int32_t* k_ranges, void* stream);
+
+/*
+ * y = act(x W^T + b)      replaces MaskedLinearFunc.forward + F.linear (masked.py:265-277)
+ *                         and the ELU of MADE (conditioners/made.py:320).
+ *   x (B, >= k_padded) row stride ldx, columns [K, k_padded) must be ZERO (k_padded = K rounded
+ *   up to tfep_masked_linear_tile_k());  w (n_rows_w, >= k_padded) row stride ldw, packed by
+ *   tfep_masked_weight_prepare;  bias (N) in packed row order or NULL;  y (B, .) row stride ldy.
+ *   k_ranges: output of tfep_mask_k_ranges with tile_n = tfep_masked_linear_tile_n(),
+ *   tile_k = tfep_masked_linear_tile_k(), or NULL for the full K range.
+ *   col_map: optional (N) int32; packed output column j is stored at y[:, col_map[j]], skipped if
+ *   col_map[j] < 0; NULL = identity.   act: 0 = identity, 1 = ELU(alpha = 1).
+ *   Both operands must be 16-byte aligned with row strides that are multiples of 4 floats.
+ * fp32 MFMA (v_mfma_f32_16x16x4_f32): exact fp32 products, fp32 accumulation.
+ */
+int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw,
+                               const float* bias, const int32_t* k_ranges, const int32_t* col_map,
+                               float* y, int64_t ldy, int B, int N, int n_rows_w, int k_padded,
+                               int act, void* stream);
+int tfep_masked_linear_tile_n(void);
+int tfep_masked_linear_tile_k(void);
+int tfep_masked_linear_tile_m(void);
+
+/* ------------------------------------------------------------------------- */
+/* Transformers (tfep/nn/transformers)                                        */
+/* ------------------------------------------------------------------------- */
+
+/* y = x * exp(a) + b, ldj = sum_f a     (affine.py:321-323; inverse :361-363)
+ * parameter 0 = shift b, parameter 1 = log-scale a (affine.py:136-141). */
+int tfep_affine_forward(const float* x, int64_t ldx, const float* params, tfep_param_layout layout,
+                        float* y, int64_t ldy, float* log_det_J, int accumulate,
+                        int B, int D, void* stream);
+int tfep_affine_inverse(const float* y, int64_t ldy, const float* params, tfep_param_layout layout,
+                        float* x, int64_t ldx, float* log_det_J, int accumulate,
+                        int B, int D, void* stream);
+
+/* y = x + b with optional periodic wrap, ldj = 0  (affine.py:366-456).
+ * periodic_mask: (D) int32, non-zero for wrapped features, or NULL.
+ * sign = +1 forward, -1 inverse. */
+int tfep_volume_preserving_shift(const float* x, int64_t ldx, const float* shift, int64_t ldp,
+                                 const int32_t* periodic_mask, float lower, float upper, int sign,
+                                 float* y, int64_t ldy, int B, int D, void* stream);
+
+/* Rational-quadratic neural spline (transformers/spline.py:29-650). */
+typedef struct tfep_spline_desc {
+    const float* x0;      /* (D) first knot of the input domain   (spline.py:153)  */
+    const float* xf;      /* (D) last knot of the input domain    (spline.py:154)  */
+    const float* y0;      /* (D) first knot of the output domain  (spline.py:156)  */
+    const float* yf;      /* (D) last knot of the output domain   (spline.py:157)  */
+    int32_t n_bins;       /* K                                                      */
+    int32_t circular;                 /* spline.py:158, :236-238, :257-259          */
+    int32_t identity_boundary_slopes; /* spline.py:159, :378-380                    */
+    int32_t learn_lower_bound;        /* spline.py:160, :387-410                    */
+    int32_t learn_upper_bound;        /* spline.py:161                              */
+    float min_bin_size;               /* spline.py:162, :394-395                    */
+    float min_slope;                  /* spline.py:163, :414-415                    */
+} tfep_spline_desc;
+
+/* Parameters per feature for a descriptor (spline.py:165-182). */
+int tfep_spline_n_parameters_per_feature(const tfep_spline_desc* desc);
+
+/* NeuralSplineTransformer.forward / .inverse (spline.py:184-261): parameter split and
+ * normalisation (_get_parameters :319-417), circular shift, strict-'>' bin search
+ * (_assign_bins :567-650), RQ evaluation (:478-494 / :521-536) and log|det J| (:546-564).
+ * Outside the spline domain the map is linear along the boundary slope. */
+int tfep_spline_forward(const float* x, int64_t ldx, const float* params, tfep_param_layout layout,
+                        const tfep_spline_desc* desc, float* y, int64_t ldy,
+                        float* log_det_J, int accumulate, int B, int D, void* stream);
+int tfep_spline_inverse(const float* y, int64_t ldy, const float* params, tfep_param_layout layout,
+                        const tfep_spline_desc* desc, float* x, int64_t ldx,
+                        float* log_det_J, int accumulate, int B, int D, void* stream);
+
+/* Moebius transformer on `dimension`-vectors (moebius.py:374-478); inverse = forward with
+ * -w (moebius.py:142-147): pass sign = -1.  D = n_vectors * dimension, dimension <= 8. */
+int tfep_moebius_forward(const float* x, int64_t ldx, const float* params, int64_t ldp,
+                         int dimension, float max_radius, int unit_sphere, int sign,
+                         float* y, int64_t ldy, float* log_det_J, int accumulate,
+                         int B, int D, void* stream);
+
+/* PeriodicEmbedding.forward (embeddings/mafembed.py:112-145):
+ * out = [x[:, nonperiodic]..., cos t0, sin t0, cos t1, sin t1, ...], t = (x - lower) * 2pi/(upper-lower). */
+int tfep_periodic_embedding(const float* x, int64_t ldx, const int32_t* periodic_indices, int n_periodic,
+                            const int32_t* nonperiodic_indices, int n_nonperiodic,
+                            float lower, float upper, float* out, int64_t ldo, int B, void* stream);
+
+/* Column gather / scatter used by AutoregressiveFlow / MixedTransformer for fixed and
+ * conditioning features (flows/autoregressive.py:164-173, transformers/mixed.py:178-186):
+ *   gather : dst[b, j] = src[b, idx[j]]      scatter: dst[b, idx[j]] = src[b, j]   (j < n_idx) */
+int tfep_gather_columns(const float* src, int64_t lds, const int32_t* idx, int n_idx,
+                        float* dst, int64_t ldd, int B, void* stream);
+int tfep_scatter_columns(const float* src, int64_t lds, const int32_t* idx, int n_idx,
+                         float* dst, int64_t ldd, int B, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Fused MADE output layer + transformer (the headline kernel)                */
+/* ------------------------------------------------------------------------- */
+
+typedef enum tfep_fused_kind {
+    TFEP_FUSED_AFFINE = 0,   /* P = 2                                         */
+    TFEP_FUSED_SPLINE = 1    /* plain or circular RQ spline, no learnable bounds */
+} tfep_fused_kind;
+
+/* Feature slots per 16-wide MFMA column group (16). */
+int tfep_fused_tile_features(void);
+/* 1 if (kind, desc) is supported by the fused kernel. */
+int tfep_fused_supported(int kind, const tfep_spline_desc* desc);
+/* Packed weight rows per column tile of the fused kernel (= tile_n for tfep_mask_k_ranges):
+ * P * FT * 16 where FT feature groups of 16 slots share a tile (spline K=8: 25*1*16, affine: 2*8*16).
+ * Packed row of (slot s, parameter p):  tile = s / (16*FT), ft = (s / 16) % FT, j = s % 16,
+ *   row = tile * (P*FT*16) + (ft * P + p) * 16 + j. */
+int tfep_fused_tile_columns(int kind, const tfep_spline_desc* desc);
+
+/*
+ * params = h W^T + b is formed tile by tile in MFMA accumulators and consumed in registers by
+ * the transformer: the (B, P*D) parameter tensor never reaches HBM.
+ *   h (B, >= k_padded) hidden activations (zero padded), w / bias_packed packed as above
+ *   (already masked), k_ranges per column tile (tile_n = tfep_fused_tile_columns()).
+ *   x, y (B, .): transformer input / output; feature slot s reads x[:, feat_index[s]] and writes
+ *   y[:, feat_index[s]] (feat_index[s] < 0: padding slot, nothing read or written);
+ *   feat_tr[s] indexes desc->x0/xf/y0/yf (spline only).  n_feature_slots: multiple of 16*FT.
+ *   ldj_partial: (n_feature_slots/16, B) float64 workspace; log_det_J (B,) is reduced from it.
+ * Replaces MaskedLinear (last layer, masked.py:188-208) + NeuralSplineTransformer.forward
+ * (spline.py:184-241) / AffineTransformer.forward (affine.py:51-77).
+ */
+int tfep_fused_output_transformer_forward(const float* h, int64_t ldh, const float* w, int64_t ldw,
+                                          const float* bias_packed, const int32_t* k_ranges,
+                                          int kind, const tfep_spline_desc* desc,
+                                          const float* x, int64_t ldx, float* y, int64_t ldy,
+                                          const int32_t* feat_index, const int32_t* feat_tr,
+                                          int n_feature_slots, double* ldj_partial,
+                                          float* log_det_J, int accumulate,
+                                          int B, int n_rows_w, int k_padded, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* TFEP reductions (tfep/loss.py, tfep/analysis/estimator.py)                 */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * One pass over the local shard producing the sufficient statistics of
+ * BoltzmannKLDivLoss.forward (loss.py:125-140) and fep_estimator (estimator.py:73-86):
+ *   r_i = u_B[i] - ldj[i] - u_A[i]                (ldj / u_A may be NULL)
+ *   out[0] = count of non-NaN r_i (or all, if !ignore_nan)     out[1] = sum r_i
+ *   out[2] = m_w = max_i log_w[i]       out[3] = sum exp(log_w - m_w)
+ *   out[4] = sum exp(log_w - m_w) r_i                           (log_w may be NULL)
+ *   out[5] = m_e = max_i (-r_i/kT + bias_i/kT)    out[6] = sum exp(-r_i/kT + bias_i/kT - m_e)
+ *   out[7] = m_b = max_i bias_i/kT      out[8] = sum exp(bias_i/kT - m_b)   (bias may be NULL)
+ * out is (9) float64 on the device; workspace: tfep_tfep_reduce_workspace_doubles(N) float64.  Statistics combine across shards / GPUs by
+ * max + rescaled sum (one all-reduce of <= 9 scalars).
+ */
+int tfep_tfep_reduce(const float* target_potentials, const float* log_det_J,
+                     const float* ref_potentials, const float* log_weights, const float* bias,
+                     float kT, int ignore_nan, int N, double* workspace, double* out, void* stream);
+/* Size (in doubles) of the device workspace tfep_tfep_reduce needs for N samples. */
+int tfep_tfep_reduce_workspace_doubles(int N);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFEP_HIP_H */

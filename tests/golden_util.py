@@ -147,3 +147,67 @@ def transformer_degrees_out(tr, deg):
         return np.concatenate([transformer_degrees_out(s, deg[np.asarray(i)])
                                for s, i in zip(tr['transformers'], tr['indices'])])
     raise ValueError(t)
+
+
+# ---------------------------------------------------------------------------
+# tfep_amd module builders for the golden flows (the product under test)
+# ---------------------------------------------------------------------------
+
+def build_transformer(tr):
+    import torch
+    from tfep_amd.nn import transformers as T
+    t = tr['type']
+    if t == 'affine':
+        return T.AffineTransformer()
+    if t == 'moebius':
+        return T.MoebiusTransformer(dimension=tr['dimension'], unit_sphere=tr.get('unit_sphere', False))
+    if t == 'spline':
+        kw = {k: v for k, v in tr.items() if k not in ('type', 'x0', 'xf', 'n_bins', 'y0', 'yf')}
+        f32 = lambda a: None if a is None else torch.tensor(np.asarray(a), dtype=torch.float32)
+        return T.NeuralSplineTransformer(x0=f32(tr['x0']), xf=f32(tr['xf']), n_bins=tr['n_bins'],
+                                         y0=f32(tr.get('y0')), yf=f32(tr.get('yf')), **kw)
+    if t == 'mixed':
+        return T.MixedTransformer([build_transformer(s) for s in tr['transformers']], tr['indices'])
+    raise ValueError(t)
+
+
+def build_flow(name, flows_npz=None, device='cuda'):
+    """SequentialFlow of tfep_amd MAF layers configured like golden flow ``name``; weights
+    loaded from the fixture through ``load_state_dict`` (reference state_dict schema)."""
+    import torch
+    from tfep_amd.nn.embeddings import PeriodicEmbedding
+    from tfep_amd.nn.flows import MAF, SequentialFlow
+    layers = []
+    for c in flow_configs()[name]:
+        emb = c.get('embedding')
+        embedding = None
+        if emb is not None:
+            embedding = PeriodicEmbedding(n_features_in=len(c['degrees_in']), limits=list(emb['limits']),
+                                          periodic_indices=emb['periodic_indices'])
+        layers.append(MAF(degrees_in=torch.as_tensor(np.asarray(c['degrees_in'])),
+                          transformer=build_transformer(c['transformer']),
+                          hidden_layers=c['hidden_layers'], embedding=embedding,
+                          weight_norm=c['weight_norm'], initialize_identity=False))
+    flow = SequentialFlow(*layers)
+    if flows_npz is not None:
+        sd = flow.state_dict()
+        gold = sub(flows_npz, f'{name}/sd/')
+        missing = [k for k in sd if k not in gold and not k.endswith('.mask')]
+        assert not missing, f'state_dict keys absent from the reference fixture: {missing}'
+        extra = [k for k in gold if k not in sd]
+        assert not extra, f'reference state_dict keys unknown to tfep_amd: {extra}'
+        for k, v in gold.items():
+            t = torch.from_numpy(np.asarray(v))
+            assert tuple(t.shape) == tuple(sd[k].shape), (k, t.shape, sd[k].shape)
+            assert t.dtype == sd[k].dtype, (k, t.dtype, sd[k].dtype)
+            sd[k] = t
+        flow.load_state_dict(sd, strict=True)
+    return flow.to(device) if device is not None else flow
+
+
+def err_stats(got, ref):
+    """(relative L2 error, max abs error) of ``got`` against the float64 reference."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    d = got - ref
+    return float(np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-300)), float(np.abs(d).max())

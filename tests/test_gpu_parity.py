@@ -1,0 +1,303 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference's golden vectors
+and the CPU oracle.  Run with ``-m gpu`` on an MI355X.
+
+Tolerances (north star: <= 1e-5 relative on mapped coordinates and log|det J|):
+  * given identical transformer parameters: relative L2 error of y <= 1e-5 and per-sample
+    |d ldj| <= 1e-5 * max(1, |ldj|) against the reference run in float64;
+  * end to end through the fp32 GEMMs: relative L2 of y <= 1e-5 and the log-det error no worse
+    than 4x the reference's own float32-vs-float64 error on the same data (floor 2e-5 absolute).
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-5
+
+
+def dev(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda()
+
+
+def check_y(got, ref, rel=REL, what='y'):
+    r, m = gu.err_stats(got.cpu().numpy(), ref)
+    assert r <= rel, f'{what}: relative L2 error {r:.3e} > {rel:.1e} (max abs {m:.3e})'
+    return r, m
+
+
+def check_ldj(got, ref, rel=REL, floor=0.0):
+    got = got.cpu().numpy().astype(np.float64)
+    tol = np.maximum(rel * np.maximum(1.0, np.abs(ref)), floor)
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), f'ldj: max abs error {np.abs(got - ref).max():.3e}, {bad.sum()} samples out of tolerance'
+
+
+# ------------------------------------------------------------------ transformers (identical parameters)
+
+def test_affine_volpres():
+    from tfep_amd.nn.transformers import AffineTransformer, VolumePreservingShiftTransformer
+    g = gu.load('transformers.npz')
+    t = AffineTransformer()
+    y, l = t(dev(g['affine/x']), dev(g['affine/par']))
+    check_y(y, g['affine/y_f64']); check_ldj(l, g['affine/ldj_f64'])
+    x, l = t.inverse(dev(g['affine/y_f64']), dev(g['affine/par']))
+    check_y(x, g['affine/xinv_f64'], what='x'); check_ldj(l, g['affine/ldjinv_f64'])
+
+    t = VolumePreservingShiftTransformer(torch.from_numpy(g['volpres/periodic_indices']),
+                                         torch.from_numpy(g['volpres/periodic_limits']))
+    y, l = t(dev(g['volpres/x']), dev(g['volpres/par']))
+    # float32 wrap of a float32 sum: compare against the reference's own float32 result exactly-ish
+    np.testing.assert_allclose(y.cpu().numpy(), g['volpres/y_f32'], rtol=0, atol=1e-6)
+    assert torch.all(l == 0)
+    x, _ = t.inverse(dev(g['volpres/y_f32']), dev(g['volpres/par']))
+    assert x.shape == y.shape
+
+
+def _spline_names():
+    return sorted(json.loads(str(gu.load('transformers.npz')['spline/meta'])).keys())
+
+
+@pytest.mark.parametrize('name', _spline_names())
+def test_spline_variants(name):
+    g = gu.load('transformers.npz')
+    meta = json.loads(str(g['spline/meta']))[name]
+    t = gu.build_transformer(dict(type='spline', x0=meta['x0'], xf=meta['xf'], n_bins=meta['n_bins'],
+                                  y0=meta['y0'], yf=meta['yf'], circular=meta['circular'],
+                                  identity_boundary_slopes=meta['identity_boundary_slopes'],
+                                  learn_lower_bound=meta['learn_lower_bound'],
+                                  learn_upper_bound=meta['learn_upper_bound'])).cuda()
+    par = dev(g[name + '/par'])
+    y, l = t(dev(g[name + '/x']), par)
+    check_y(y, g[name + '/y_f64']); check_ldj(l, g[name + '/ldj_f64'])
+    x, l = t.inverse(dev(g[name + '/y_f64']), par)
+    check_y(x, g[name + '/xinv_f64'], what='x'); check_ldj(l, g[name + '/ldjinv_f64'])
+
+
+@pytest.mark.parametrize('name', ['moebius/d2_u0', 'moebius/d2_u1', 'moebius/d3_u0', 'moebius/d3_u1'])
+def test_moebius(name):
+    from tfep_amd.nn.transformers import MoebiusTransformer
+    g = gu.load('transformers.npz')
+    meta = json.loads(str(g['moebius/meta']))[name]
+    t = MoebiusTransformer(meta['dimension'], meta['max_radius'], meta['unit_sphere'])
+    par = dev(g[name + '/par'])
+    y, l = t(dev(g[name + '/x']), par)
+    check_y(y, g[name + '/y_f64']); check_ldj(l, g[name + '/ldj_f64'])
+    x, l = t.inverse(dev(g[name + '/y_f64']), par)
+    check_y(x, g[name + '/xinv_f64'], what='x'); check_ldj(l, g[name + '/ldjinv_f64'])
+
+
+def test_mixed_and_periodic_embedding():
+    from tfep_amd.nn.embeddings import PeriodicEmbedding
+    g = gu.load('transformers.npz')
+    spec = dict(type='mixed',
+                transformers=[dict(type='spline', x0=np.full(3, -1.0), xf=np.full(3, 1.0), n_bins=4),
+                              dict(type='affine'),
+                              dict(type='spline', x0=np.full(2, -1.0), xf=np.full(2, 1.0), n_bins=3, circular=True)],
+                indices=[[0, 2, 5], [1, 3], [4, 6]])
+    t = gu.build_transformer(spec).cuda()
+    assert t._parameters_split_indices.tolist() == g['mixed/split'].tolist()
+    assert t.get_degrees_out(torch.arange(7)).tolist() == g['mixed/degrees_out'].tolist()
+    par = dev(g['mixed/par'])
+    y, l = t(dev(g['mixed/x']), par)
+    check_y(y, g['mixed/y_f64']); check_ldj(l, g['mixed/ldj_f64'])
+    x, l = t.inverse(dev(g['mixed/y_f64']), par)
+    check_y(x, g['mixed/xinv_f64'], what='x'); check_ldj(l, g['mixed/ldjinv_f64'])
+
+    emb = PeriodicEmbedding(6, [0.0, 1.0], periodic_indices=[1, 2, 5]).cuda()
+    out = emb(dev(g['pemb/x']))
+    np.testing.assert_allclose(out.cpu().numpy(), g['pemb/y_f64'], rtol=0, atol=2e-6)
+    assert emb.get_degrees_out(torch.arange(6)).tolist() == g['pemb/degrees_out'].tolist()
+
+
+def test_empty_and_ragged_batches():
+    from tfep_amd.nn.transformers import AffineTransformer
+    t = AffineTransformer()
+    y, l = t(torch.empty(0, 5, device='cuda'), torch.empty(0, 10, device='cuda'))
+    assert y.shape == (0, 5) and l.shape == (0,)
+    for B in (1, 3, 5, 257):                  # not multiples of the 4-rows-per-block launch shape
+        x = torch.randn(B, 7, device='cuda')
+        p = torch.randn(B, 14, device='cuda') * 0.3
+        y, l = t(x, p)
+        ref = x.double() * torch.exp(p[:, 7:].double()) + p[:, :7].double()
+        assert torch.allclose(y.double(), ref, rtol=1e-6, atol=1e-6)
+        assert torch.allclose(l.double(), p[:, 7:].double().sum(1), rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError, match='must have shape'):
+        t(torch.randn(4, 7, device='cuda'), torch.randn(4, 13, device='cuda'))
+    with pytest.raises(TypeError):
+        t(torch.randn(4, 7, device='cuda', dtype=torch.float64), torch.randn(4, 14, device='cuda'))
+
+
+# ------------------------------------------------------------------ masked linear / MADE
+
+def test_masked_linear_and_weight_norm():
+    from tfep_amd.nn import masked
+    g = gu.load('masked_linear.npz')
+    x, w, b, m = dev(g['x']), dev(g['weight']), dev(g['bias']), dev(g['mask'])
+    check_y(masked.masked_linear(x, w, b, m), g['y_f64'], rel=2e-6)
+    check_y(masked.masked_linear(x, w, b, None), g['y_nomask_f64'], rel=2e-6)
+    lin = masked.masked_weight_norm(masked.MaskedLinear(8, 5, mask=torch.from_numpy(g['mask'])))
+    lin.load_state_dict({'bias': torch.from_numpy(g['wn_bias']), 'weight_g': torch.from_numpy(g['wn_g']),
+                         'weight_v': torch.from_numpy(g['wn_v']), 'mask': torch.from_numpy(g['mask'])})
+    lin = lin.cuda()
+    weff = lin.weight
+    assert torch.all(torch.isfinite(weff)) and torch.all(weff[2] == 0)       # fully-masked row: 0, not NaN
+    check_y(weff, g['wn_weight_f64'], rel=1e-6, what='W')
+    check_y(lin(x), g['wn_y_f64'], rel=2e-6)
+    # extra leading dimensions, like F.linear
+    y3 = lin(x.reshape(2, 3, 8))
+    assert y3.shape == (2, 3, 5)
+
+
+@pytest.mark.parametrize('name', ['a', 'b', 'c', 'd'])
+def test_made_forward(name):
+    from tfep_amd.nn.conditioners import MADE
+    g = gu.load('made.npz')
+    meta = json.loads(str(g['meta']))[name]
+    made = MADE(torch.tensor(meta['degrees_in']), torch.tensor(meta['degrees_out']), meta['hidden_layers'],
+                meta['weight_norm'])
+    sd = {k: torch.from_numpy(v) for k, v in gu.sub(g, f'{name}/sd/').items()}
+    made.load_state_dict(sd, strict=True)
+    assert int(made.n_parameters()) == meta['n_parameters']
+    made = made.cuda()
+    y = made(dev(g[f'{name}/x']))
+    check_y(y, g[f'{name}/y_f64'], rel=2e-6, what='params')
+
+
+# ------------------------------------------------------------------ flows end to end
+
+def _flow_check(name, fused):
+    g = gu.load('flows.npz')
+    flow = gu.build_flow(name, g)
+    for layer in flow:
+        layer.fused = fused
+    x = dev(g[f'{name}/x'])
+    x_before = x.clone()
+    y, l = flow(x)
+    assert torch.equal(x, x_before), 'input modified'
+    assert y.shape == x.shape and l.shape == (x.shape[0],)
+    ry, my = check_y(y, g[f'{name}/y_f64'])
+    ref_noise = np.abs(g[f'{name}/ldj_f32'].astype(np.float64) - g[f'{name}/ldj_f64']).max()
+    check_ldj(l, g[f'{name}/ldj_f64'], floor=max(4 * ref_noise, 2e-5))
+    return flow, g
+
+
+@pytest.mark.parametrize('fused', [True, False])
+@pytest.mark.parametrize('name', ['cfg1', 'rq4', 'cond', 'circ', 'moeb', 'mixflow'])
+def test_flow_forward(name, fused):
+    _flow_check(name, fused)
+
+
+def test_fused_path_is_taken_where_expected():
+    g = gu.load('flows.npz')
+    assert gu.build_flow('cfg1', g)[0]._fused_kind() == 0
+    assert gu.build_flow('rq4', g)[0]._fused_kind() == 1
+    assert gu.build_flow('circ', g)[0]._fused_kind() == 1
+    assert gu.build_flow('cond', g)[0]._fused_kind() == 0
+    assert gu.build_flow('cond', g)[1]._fused_kind() is None      # identity slopes, K=5: generic path
+    assert gu.build_flow('moeb', g)[0]._fused_kind() is None
+
+
+@pytest.mark.parametrize('name', ['cond', 'circ', 'moeb', 'mixflow', 'rq4'])
+def test_flow_inverse(name):
+    g = gu.load('flows.npz')
+    flow = gu.build_flow(name, g)
+    yin = dev(g[f'{name}/inv_in'])
+    x, l = flow.inverse(yin)
+    rel = 1e-5 if name != 'rq4' else 5e-5       # 66 sequential passes x 4 layers amplify fp32 GEMM noise
+    check_y(x, g[f'{name}/xinv_f64'], rel=rel, what='x')
+    ref_noise = np.abs(g[f'{name}/ldj_f32'].astype(np.float64) - g[f'{name}/ldj_f64']).max()
+    check_ldj(l, g[f'{name}/ldjinv_f64'], floor=max(8 * ref_noise, 5e-5))
+    # round trip: forward(inverse(y)) == y and the log-dets cancel (tests/nn/flows/test_maf.py:283-285)
+    y2, l2 = flow(x)
+    assert torch.allclose(y2, yin, atol=1e-4)
+    assert torch.allclose(l + l2, torch.zeros_like(l), atol=1e-3)
+
+
+def test_identity_initialisation():
+    g = gu.load('flows.npz')
+    flow = gu.build_flow('ident', g)
+    x = dev(g['ident/x'])
+    for fused in (True, False):
+        for layer in flow:
+            layer.fused = fused
+        y, l = flow(x)
+        assert torch.allclose(y, x, atol=1e-6)
+        assert torch.allclose(l, torch.zeros_like(l), atol=1e-5)
+    xi, li = flow.inverse(y)
+    assert torch.allclose(xi, x, atol=1e-6) and torch.allclose(li, torch.zeros_like(li), atol=1e-5)
+
+
+def test_flow_vs_oracle_medium_size():
+    """Seeded D=300, 4-layer RQ-8 with the default hidden width (multi-tile GEMMs, ragged batch)
+    against the CPU oracle in float64 on the same float32 weights."""
+    from oracle import flows as oflows, made as omade
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF, SequentialFlow
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    D, B = 300, 777
+    torch.manual_seed(0)
+    layers = [MAF(generate_degrees(D, 'ascending' if i % 2 == 0 else 'descending'),
+                  transformer=NeuralSplineTransformer(torch.full((D,), -5.), torch.full((D,), 5.), 8),
+                  initialize_identity=False) for i in range(2)]
+    flow = SequentialFlow(*layers)
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(1234)).clamp(-4.9, 4.9)
+    x[5] *= 1.3                                     # a few out-of-domain values
+    sd = {k: v.numpy() for k, v in flow.state_dict().items()}
+    olayers = []
+    for i in range(2):
+        made = omade.made_layers_from_state({k: (v.astype(np.float64) if v.dtype == np.float32 else v)
+                                             for k, v in sd.items()}, prefix=f'{i}._conditioner.')
+        olayers.append(dict(degrees_in=omade.generate_degrees(D, 'ascending' if i % 2 == 0 else 'descending'),
+                            transformer=dict(type='spline', x0=np.full(D, -5.), xf=np.full(D, 5.), n_bins=8),
+                            embedding=None, made=made))
+    y_ref, l_ref = oflows.sequential_forward(x.numpy().astype(np.float64), olayers)
+    flow = flow.cuda()
+    for fused in (True, False):
+        for layer in flow:
+            layer.fused = fused
+        y, l = flow(x.cuda())
+        check_y(y, y_ref)
+        check_ldj(l, l_ref, floor=5e-5)
+
+
+# ------------------------------------------------------------------ loss / estimator
+
+def test_loss_and_estimator():
+    from tfep_amd.analysis import fep_estimator
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    g = gu.load('loss.npz')
+    uB, ldj, lw, uA = (dev(g[k]) for k in ('uB', 'ldj', 'lw', 'uA'))
+    L = BoltzmannKLDivLoss()
+
+    def close(a, key, rtol=2e-6):
+        np.testing.assert_allclose(float(a), float(g[key]), rtol=rtol, atol=1e-6)
+    close(L(uB, ldj), 'loss_plain_f64')
+    close(L(uB, ldj, ref_potentials=uA), 'loss_ref_f64')
+    close(L(uB, ldj, log_weights=lw), 'loss_weighted_f64')
+    close(L(uB, ldj, log_weights=lw, ref_potentials=uA), 'loss_all_f64')
+    close(L(uB), 'loss_noldj_f64')
+    un = uB.clone(); un[[3, 77]] = float('nan')
+    Ln = BoltzmannKLDivLoss(ignore_nan=True)
+    close(Ln(un, ldj), 'loss_nan_plain_f64')
+    close(Ln(un, ldj, log_weights=lw), 'loss_nan_weighted_f64')
+    assert torch.isnan(L(un, ldj))                                  # NaNs propagate unless ignored (tests/test_loss.py)
+
+    work = uB - ldj - uA
+    close(fep_estimator(work), 'fep_plain_f64')
+    close(fep_estimator(work * 2.5, kT=2.5), 'fep_kT_f64')
+    close(fep_estimator(torch.stack([work, lw], dim=1)), 'fep_biased_f64')
+    np.testing.assert_allclose(fep_estimator(dev(g['fep_vec_in_f64']), vectorized=True).cpu().numpy(),
+                               g['fep_vec_f64'], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(fep_estimator(work.expand(4, -1), weights=dev(g['fep_bayes_w_f64']),
+                                             vectorized=True).cpu().numpy(), g['fep_bayes_f64'], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(fep_estimator(dev(g['fep_vecb_in_f64']), vectorized=True).cpu().numpy(),
+                               g['fep_vecb_f64'], rtol=2e-6, atol=1e-6)
+    # statistical sanity of the reference's own test (tests/analysis/test_bootstrap.py:178-190):
+    # work ~ N(0, 1)  ->  dF ~ -0.5
+    w = torch.randn(200000, generator=torch.Generator().manual_seed(0)).cuda()
+    assert abs(float(fep_estimator(w)) + 0.5) < 0.02

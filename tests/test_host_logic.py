@@ -1,0 +1,178 @@
+"""CPU tests of the host side of tfep_amd: constructors, degrees / masks, state_dict schema,
+error conventions, the C ABI symbol table.  No kernel is launched (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from tfep_amd import _lib
+from tfep_amd.nn import masked
+from tfep_amd.nn.conditioners import MADE, generate_degrees
+from tfep_amd.nn.flows import MAF, AutoregressiveFlow, SequentialFlow
+from tfep_amd.nn.transformers import (AffineTransformer, MixedTransformer, MoebiusTransformer,
+                                      NeuralSplineTransformer)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ C ABI
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, 'include', 'tfep_hip.h')).read()
+    declared = set(re.findall(r'\b(tfep_[a-z0-9_]+)\s*\(', header))
+    declared -= {'tfep_param_layout', 'tfep_spline_desc'}
+    assert declared, 'no declarations parsed'
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} declared in tfep_hip.h but not exported'
+    # the ctypes binding covers exactly the declared entry points
+    assert set(_lib.EXPORTED_SYMBOLS) == declared
+    assert _lib.load().tfep_hip_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    D = 4
+    flow = SequentialFlow(MAF(generate_degrees(D)))
+    with pytest.raises(_lib.TfepHipError, match='no CPU fallback'):
+        flow(torch.randn(2, D))
+    with pytest.raises(_lib.TfepHipError, match='no CPU fallback'):
+        AffineTransformer()(torch.randn(2, D), torch.randn(2, 2 * D))
+
+
+# ------------------------------------------------------------------ degrees / masks (known-answer tables)
+
+def test_generate_degrees_table():
+    for case in gu.load_json('degrees.json')['generate_degrees']:
+        assert generate_degrees(**case['kwargs']).tolist() == case['expected'], case['kwargs']
+    with pytest.raises(ValueError, match="Accepted string values"):
+        generate_degrees(4, order='sideways')
+
+
+def test_degrees_hidden_table():
+    for case in gu.load_json('degrees.json')['degrees_hidden']:
+        got = MADE._get_degrees_hidden(torch.tensor(case['degrees_in']), torch.tensor(case['degrees_out']),
+                                       case['hidden_layers'])
+        assert [g.tolist() for g in got] == case['expected']
+    with pytest.raises(ValueError, match='too small'):
+        MADE(degrees_in=[0, 1, 2, 3, 4], degrees_out=[0, 1, 2, 3, 4], hidden_layers=[3])
+    with pytest.raises(ValueError, match='ignored'):
+        MADE(degrees_in=[0, 1, 2], degrees_out=[0, 1, 2], hidden_layers=[[0, 1, 2]])
+
+
+def test_mask_table_and_made_masks():
+    j = gu.load_json('degrees.json')
+    for case in j['masks']:
+        m = masked.create_autoregressive_mask(np.array(case['degrees_in']), np.array(case['degrees_out']),
+                                              strictly_less=case['strictly_less'], transpose=case['transpose'])
+        assert m.dtype == torch.get_default_dtype()
+        assert m.int().tolist() == case['expected']
+    mm = j['made_masks']
+    made = MADE(mm['degrees_in'], mm['degrees_out'], mm['hidden_layers'])
+    assert [l.mask.int().tolist() for l in made.layers[::2]] == mm['expected']
+    for case in j['mask_nnz'][:2]:
+        deg = generate_degrees(case['D'], case['order'])
+        made = MADE(deg, deg.tile((case['P'],)), 2, weight_norm=False)
+        assert [list(l.mask.shape) for l in made.layers[::2]] == case['shapes']
+        assert [int(l.mask.sum()) for l in made.layers[::2]] == case['nnz']
+
+
+# ------------------------------------------------------------------ state_dict schema == reference's
+
+@pytest.mark.parametrize('name', ['cfg1', 'rq4', 'cond', 'circ', 'moeb', 'mixflow', 'ident'])
+def test_state_dict_schema_matches_reference(name):
+    g = gu.load('flows.npz')
+    flow = gu.build_flow(name, g, device=None)      # asserts keys / shapes / dtypes both ways
+    n_par = g[f'{name}/n_parameters'] if f'{name}/n_parameters' in g.files else None
+    if n_par is not None:
+        assert int(flow.n_parameters()) == int(n_par)
+    if name in ('cfg1', 'cond'):
+        sd = flow.state_dict()
+        for k in sd:
+            if k.endswith('.mask'):
+                shape = tuple(g[f'{name}/sdmaskshape/{k}'])
+                bits = np.unpackbits(g[f'{name}/sdmask/{k}'])[:shape[0] * shape[1]].reshape(shape)
+                assert np.array_equal(bits.astype(bool), sd[k].numpy() != 0), k
+
+
+def test_masked_linear_module_schema():
+    mask = torch.tril(torch.ones(5, 8))
+    mask[2] = 0
+    lin = masked.MaskedLinear(8, 5, mask=mask)
+    assert torch.all(lin.weight[mask == 0] == 0)
+    assert int(lin.n_parameters()) == int(mask.sum()) + 5
+    lin = masked.masked_weight_norm(lin)
+    assert sorted(lin.state_dict().keys()) == ['bias', 'mask', 'weight_g', 'weight_v']
+    assert lin.weight_g.shape == (5, 1) and lin.weight_v.shape == (5, 8)
+    with pytest.raises(RuntimeError, match='two weight_norm'):
+        masked.masked_weight_norm(lin)
+    # weight norm init: g = row norm of the masked weight (masked.py:391)
+    np.testing.assert_allclose(lin.weight_g[:, 0].detach().numpy(),
+                               np.linalg.norm(lin.weight_v.detach().numpy(), axis=1), rtol=1e-6)
+    g = gu.load('masked_linear.npz')
+    assert sorted(lin.state_dict().keys()) == list(g['wn_state_keys'])
+    masked.remove_masked_weight_norm(lin)
+    assert 'weight' in lin._parameters and 'weight_g' not in lin._parameters
+    assert torch.all(torch.isfinite(lin.weight)) and torch.all(lin.weight[2] == 0)
+
+
+# ------------------------------------------------------------------ constructor error conventions
+
+def test_error_conventions():
+    with pytest.raises(ValueError, match='consecutive values'):
+        MAF(degrees_in=[0, 2, 3])
+    with pytest.raises(ValueError, match='consecutive values'):
+        MAF(degrees_in=[1, 2, 3])
+    with pytest.raises(ValueError, match='0 <= i < n_features_in'):
+        AutoregressiveFlow(3, [[0], [5]], MADE([0, 1, 2], [0, 1, 2] * 2), AffineTransformer())
+    x0 = torch.zeros(3)
+    with pytest.raises(ValueError, match='circular spline with learnable limits'):
+        NeuralSplineTransformer(x0, x0 + 1, 4, circular=True, learn_lower_bound=True)
+    with pytest.raises(ValueError, match='x0==y0 and xf==yf'):
+        NeuralSplineTransformer(x0, x0 + 1, 4, y0=x0 + 0.5, circular=True)
+    with pytest.raises(ValueError, match='minimum bin size'):
+        NeuralSplineTransformer(x0, x0 + 1, 4, min_bin_size=0.0)
+    with pytest.raises(ValueError, match='minimum slope'):
+        NeuralSplineTransformer(x0, x0 + 1, 4, min_slope=1.0)
+    with pytest.raises(ValueError, match='greater than 1'):
+        MixedTransformer([AffineTransformer()], [[0, 1]])
+    with pytest.raises(ValueError, match='must equal'):
+        MixedTransformer([AffineTransformer(), AffineTransformer()], [[0, 1]])
+    with pytest.raises(ValueError, match='only if x0=y0'):
+        NeuralSplineTransformer(x0, x0 + 1, 4, y0=x0 + 0.5).get_identity_parameters(3)
+
+
+@pytest.mark.parametrize('circular,identity,ll,lu', gu.SPLINE_VARIANTS)
+def test_spline_parameter_count_and_degrees(circular, identity, ll, lu):
+    K, D = 5, 3
+    t = NeuralSplineTransformer(torch.zeros(D), torch.ones(D), K, circular=circular,
+                                identity_boundary_slopes=identity, learn_lower_bound=ll, learn_upper_bound=lu)
+    n = (3 * K + 1) + (int(circular) - 2) * int(identity) + int(ll) + int(lu)
+    assert t.n_parameters_per_feature == n
+    assert len(t.get_identity_parameters(D)) == n * D
+    assert t.get_degrees_out(torch.arange(D)).tolist() == list(range(D)) * n
+    # the library agrees with the module (no launch involved)
+    desc = _lib.SplineDesc(0, 0, 0, 0, K, int(circular), int(identity), int(ll), int(lu), 1e-4, 1e-4)
+    assert _lib.load().tfep_spline_n_parameters_per_feature(ctypes.byref(desc)) == n
+
+
+def test_identity_initialisation_sets_conditioner_output():
+    D = 5
+    maf = MAF(generate_degrees(D), transformer=NeuralSplineTransformer(torch.full((D,), -2.), torch.full((D,), 2.), 4))
+    last = maf._conditioner.layers[-1]
+    assert torch.all(last.weight_g == 0) and torch.all(last.bias == 0)
+    maf = MAF(generate_degrees(D), weight_norm=False)
+    assert torch.all(maf._conditioner.layers[-1]._parameters['weight'] == 0)
+    assert MoebiusTransformer(2).get_identity_parameters(6).shape == (6,)
+
+
+def test_inverse_masks_and_indices_buffers():
+    maf = MAF(degrees_in=[-1, 0, 0, 1, -1, 2])
+    assert maf._fixed_indices.tolist() == [0, 4]
+    assert maf._transformer_indices.tolist() == [1, 2, 3, 5]
+    assert maf._inverse_masks.int().tolist() == [[0, 1, 1, 0, 0, 0], [0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 1]]
+    maf = MAF(degrees_in=[0, 1, 2])
+    assert maf._transformer_indices.numel() == 0 and not maf.has_fixed_indices

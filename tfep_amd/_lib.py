@@ -1,0 +1,141 @@
+"""ctypes binding of libtfep_hip.so (the C ABI declared in include/tfep_hip.h).
+
+There is NO CPU fallback: if the library is missing or a tensor is not a float32
+HIP tensor, calls raise.  ``import torch`` happens first so that the library binds
+to the HIP runtime PyTorch-ROCm already loaded (same ``libamdhip64.so.7`` soname),
+which is what makes ``tensor.data_ptr()`` and the current stream valid on our side.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libtfep_hip.so')
+ABI_VERSION = 1
+
+_lib = None
+
+
+class ParamLayout(Structure):
+    _fields_ = [('ld', c_int64), ('stride_p', c_int64), ('stride_f', c_int64)]
+
+
+class SplineDesc(Structure):
+    _fields_ = [('x0', c_void_p), ('xf', c_void_p), ('y0', c_void_p), ('yf', c_void_p),
+                ('n_bins', c_int32), ('circular', c_int32), ('identity_boundary_slopes', c_int32),
+                ('learn_lower_bound', c_int32), ('learn_upper_bound', c_int32),
+                ('min_bin_size', c_float), ('min_slope', c_float)]
+
+
+_P = c_void_p
+_SIGNATURES = {
+    'tfep_hip_abi_version': (c_int, []),
+    'tfep_last_error': (c_char_p, []),
+    'tfep_masked_weight_prepare': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int64, _P]),
+    'tfep_mask_k_ranges': (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    'tfep_masked_linear_forward': (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64,
+                                           c_int, c_int, c_int, c_int, c_int, _P]),
+    'tfep_masked_linear_tile_n': (c_int, []),
+    'tfep_masked_linear_tile_k': (c_int, []),
+    'tfep_masked_linear_tile_m': (c_int, []),
+    'tfep_affine_forward': (c_int, [_P, c_int64, _P, ParamLayout, _P, c_int64, _P, c_int, c_int, c_int, _P]),
+    'tfep_affine_inverse': (c_int, [_P, c_int64, _P, ParamLayout, _P, c_int64, _P, c_int, c_int, c_int, _P]),
+    'tfep_volume_preserving_shift': (c_int, [_P, c_int64, _P, c_int64, _P, c_float, c_float, c_int,
+                                             _P, c_int64, c_int, c_int, _P]),
+    'tfep_spline_n_parameters_per_feature': (c_int, [POINTER(SplineDesc)]),
+    'tfep_spline_forward': (c_int, [_P, c_int64, _P, ParamLayout, POINTER(SplineDesc), _P, c_int64,
+                                    _P, c_int, c_int, c_int, _P]),
+    'tfep_spline_inverse': (c_int, [_P, c_int64, _P, ParamLayout, POINTER(SplineDesc), _P, c_int64,
+                                    _P, c_int, c_int, c_int, _P]),
+    'tfep_moebius_forward': (c_int, [_P, c_int64, _P, c_int64, c_int, c_float, c_int, c_int,
+                                     _P, c_int64, _P, c_int, c_int, c_int, _P]),
+    'tfep_periodic_embedding': (c_int, [_P, c_int64, _P, c_int, _P, c_int, c_float, c_float,
+                                        _P, c_int64, c_int, _P]),
+    'tfep_gather_columns': (c_int, [_P, c_int64, _P, c_int, _P, c_int64, c_int, _P]),
+    'tfep_scatter_columns': (c_int, [_P, c_int64, _P, c_int, _P, c_int64, c_int, _P]),
+    'tfep_fused_tile_features': (c_int, []),
+    'tfep_fused_supported': (c_int, [c_int, POINTER(SplineDesc)]),
+    'tfep_fused_tile_columns': (c_int, [c_int, POINTER(SplineDesc)]),
+    'tfep_fused_output_transformer_forward': (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int,
+                                                      POINTER(SplineDesc), _P, c_int64, _P, c_int64,
+                                                      _P, _P, c_int, _P, _P, c_int,
+                                                      c_int, c_int, c_int, _P]),
+    'tfep_tfep_reduce': (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P]),
+    'tfep_tfep_reduce_workspace_doubles': (c_int, [c_int]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))
+
+
+class TfepHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once) and bind every declared entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TfepHipError(
+            f'{LIB_PATH} not found: build it with `python -m tfep_amd.build` '
+            '(tfep_amd has no CPU fallback).')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.tfep_hip_abi_version()
+    if v != ABI_VERSION:
+        raise TfepHipError(f'libtfep_hip.so ABI version {v} != expected {ABI_VERSION}; rebuild it.')
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.tfep_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)
+        raise TfepHipError(f'{name} failed ({rc}): {msg}')
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def check_device_tensor(t, name, dtype=torch.float32):
+    """The kernels take float32 HIP tensors only; anything else is an error (no fallback)."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name} must be a torch.Tensor')
+    if not t.is_cuda:
+        raise TfepHipError(
+            f'{name} is on {t.device}: tfep_amd runs on a HIP device only (there is no CPU fallback).')
+    if t.dtype != dtype:
+        raise TypeError(f'{name} must be {dtype}, got {t.dtype}')
+    return t
+
+
+def rows(t, name):
+    """A 2-D float32 HIP tensor with unit column stride (copied if needed); returns (tensor, row stride)."""
+    check_device_tensor(t, name)
+    if t.dim() != 2:
+        raise ValueError(f'{name} must be 2-D (batch, features), got shape {tuple(t.shape)}')
+    B, D = t.shape
+    ok = (D <= 1 or t.stride(1) == 1) and (B <= 1 or t.stride(0) >= max(D, 1))
+    if not ok:
+        t = t.contiguous()
+    ld = t.stride(0) if (B > 1 and D > 0) else max(D, 1)
+    return t, ld

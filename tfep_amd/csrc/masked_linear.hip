@@ -1,0 +1,485 @@
+// MADE conditioner kernels for gfx950: masked weight preparation, mask k-ranges, and the
+// fp32-MFMA masked-linear GEMM with three epilogues (bias, bias+ELU, fused transformer).
+//
+// GEMM shape:  Y[b, n] = sum_k X[b, k] * W[n, k]      (both operands K-contiguous, "NT")
+//
+// Tiling (one workgroup = 8 wavefronts = 512 threads, one workgroup per CU):
+//   workgroup tile  BM x BN = (8 * 16 * MREP) x (16 * NREP),  BK = 16
+//   wave w owns rows [w*16*MREP, (w+1)*16*MREP) and ALL BN columns, as MREP x NREP tiles of
+//   v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate; 4 accumulator VGPRs each).
+//   Operands are staged global -> LDS by the LDS-DMA (global_load_lds_dwordx4, no staging
+//   VGPRs) into a double buffer: the DMA of k-tile t+1 flies under the MFMAs of k-tile t.
+//   Each lane reads its fragments with ONE ds_read_b128 per 16-deep k-tile: lane l takes
+//   floats [4q, 4q+4) (q = l >> 4) of row (l & 15) and uses element s in MFMA step s; A and B
+//   use the same k permutation so the dot product is unchanged.
+//
+// Mask sparsity: the weights are stored already masked (zeros materialised) and, per column
+// tile, a [k_begin, k_end) range bounds the non-zeros.  After sorting hidden units by degree the
+// MADE masks are block triangular (reference conditioners/made.py:286-329), so ~half of the
+// k-tiles are skipped without touching them.
+#include "common.h"
+#include "spline.h"
+
+namespace tfep {
+
+constexpr int BK = 16;
+constexpr int WAVES = 8;
+constexpr int THREADS = WAVES * 64;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum Epilogue { EPI_LINEAR = 0, EPI_ELU = 1, EPI_AFFINE = 2, EPI_SPLINE = 3 };
+
+// ------------------------------------------------------------------------------------------
+// Weight preparation (reference masked.py:369-371, :433-439, :270)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) weight_prepare_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                             const float* __restrict__ mask, int N, int K,
+                                                             const int32_t* __restrict__ row_of_out,
+                                                             const int32_t* __restrict__ col_of_in,
+                                                             float* __restrict__ w_out, int64_t ldw) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= N) return;
+    const int lane = threadIdx.x & 63;
+    const float* vr = v + (int64_t)o * K;
+    const float* mr = mask ? mask + (int64_t)o * K : nullptr;
+    float scale = 1.0f;
+    if (g) {
+        float ss = 0.f;
+        for (int i = lane; i < K; i += 64) ss += vr[i] * vr[i];
+        ss = wave_sum(ss);
+        scale = g[o] / sqrtf(ss);          // may be inf/NaN for a fully-masked row: never used below
+    }
+    const int64_t orow = row_of_out ? row_of_out[o] : o;
+    float* wr = w_out + orow * ldw;
+    for (int i = lane; i < K; i += 64) {
+        float val;
+        if (mr && mr[i] == 0.0f)
+            val = 0.0f;                    // _ApplyMask: exact zero, also where v*scale is NaN
+        else
+            val = g ? vr[i] * scale : (mr ? vr[i] * mr[i] : vr[i]);
+        wr[col_of_in ? col_of_in[i] : i] = val;
+    }
+}
+
+// Bounding k-range of the mask non-zeros per tile of `tile_n` packed rows.
+__global__ void __launch_bounds__(256) mask_k_ranges_kernel(const float* __restrict__ mask, int N, int K,
+                                                            const int32_t* __restrict__ row_of_out,
+                                                            const int32_t* __restrict__ col_of_in, int tile_n,
+                                                            int32_t* __restrict__ lo_hi) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= N) return;
+    const int lane = threadIdx.x & 63;
+    const float* mr = mask + (int64_t)o * K;
+    int lo = 0x7fffffff, hi = -1;
+    for (int i = lane; i < K; i += 64) {
+        if (mr[i] != 0.0f) {
+            const int c = col_of_in ? col_of_in[i] : i;
+            lo = min(lo, c);
+            hi = max(hi, c);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off, 64));
+        hi = max(hi, __shfl_xor(hi, off, 64));
+    }
+    if (lane == 0 && hi >= 0) {
+        const int t = (row_of_out ? row_of_out[o] : o) / tile_n;
+        atomicMin(&lo_hi[2 * t], lo);
+        atomicMax(&lo_hi[2 * t + 1], hi);
+    }
+}
+
+__global__ void init_k_ranges_kernel(int32_t* __restrict__ lo_hi, int n_tiles) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_tiles) {
+        lo_hi[2 * t] = 0x7fffffff;
+        lo_hi[2 * t + 1] = -1;
+    }
+}
+
+__global__ void finish_k_ranges_kernel(int32_t* __restrict__ lo_hi, int n_tiles, int tile_k, int k_padded) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    int lo = lo_hi[2 * t], hi = lo_hi[2 * t + 1];
+    if (hi < 0) {
+        lo = 0;
+        hi = 0;                            // empty tile: no k-tiles at all
+    } else {
+        lo = (lo / tile_k) * tile_k;
+        hi = min(((hi + tile_k) / tile_k) * tile_k, k_padded);
+    }
+    lo_hi[2 * t] = lo;
+    lo_hi[2 * t + 1] = hi;
+}
+
+// ------------------------------------------------------------------------------------------
+// GEMM
+// ------------------------------------------------------------------------------------------
+struct FusedArgs {
+    const float* x;            // transformer input  (B, ldx)
+    int64_t ldx;
+    float* y;                  // transformer output (B, ldy)
+    int64_t ldy;
+    const int32_t* feat_index; // packed feature slot -> column of x / y, -1 = padding slot
+    const int32_t* feat_tr;    // packed feature slot -> index among the transformed features (x0/xf/...)
+    double* ldj_partial;       // (n_col_tiles, B)
+    const float *x0, *xf, *y0, *yf;
+    SplineFlags sf;
+};
+
+struct GemmArgs {
+    const float* a;            // activations (B, lda), zero padded up to k_padded columns
+    int64_t lda;
+    const float* w;            // packed masked weights (n_padded, ldw)
+    int64_t ldw;
+    const float* bias;         // packed bias (n_padded) or NULL
+    const int32_t* k_ranges;   // per column tile [begin, end) or NULL
+    const int32_t* col_map;    // linear epilogues: packed column -> output column, -1 = drop; NULL = identity
+    float* y;
+    int64_t ldy;
+    int B, N, k_padded;
+    FusedArgs fu;
+};
+
+template <int MREP, int NREP>
+struct Tile {
+    static constexpr int BM = WAVES * 16 * MREP;
+    static constexpr int BN = 16 * NREP;
+    static constexpr int A_FLOATS = BM * BK;
+    static constexpr int B_FLOATS = BN * BK;
+    static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
+    static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
+    // 1 KiB (16 rows x 64 B) per LDS-DMA wave instruction
+    static constexpr int A_CHUNKS = BM / 16;
+    static constexpr int B_CHUNKS = BN / 16;
+};
+
+// Issue the LDS-DMA of one k-tile.  Chunk c (16 rows) is issued by wave (c % WAVES); inside a
+// chunk lane l covers row (l >> 2), floats [4*(l&3), +4): the LDS image is [row][16] linear,
+// exactly base + 16*lane as the DMA requires.  Rows past the end of the matrix are clamped to
+// the last valid row (their results are never stored).
+template <int MREP, int NREP>
+__device__ inline void stage_tile(const GemmArgs& g, float* lds_stage, int m0, int n0, int k0, int wave, int lane,
+                                  int n_rows_w) {
+    using T = Tile<MREP, NREP>;
+    const int r = lane >> 2, q = lane & 3;
+#pragma unroll
+    for (int c = wave; c < T::A_CHUNKS + T::B_CHUNKS; c += WAVES) {
+        const float* src;
+        float* dst;
+        if (c < T::A_CHUNKS) {
+            int row = m0 + c * 16 + r;
+            row = row < g.B ? row : g.B - 1;
+            src = g.a + (int64_t)row * g.lda + k0 + 4 * q;
+            dst = lds_stage + c * 16 * BK;
+        } else {
+            const int cb = c - T::A_CHUNKS;
+            int row = n0 + cb * 16 + r;
+            row = row < n_rows_w ? row : n_rows_w - 1;
+            src = g.w + (int64_t)row * g.ldw + k0 + 4 * q;
+            dst = lds_stage + T::A_FLOATS + cb * 16 * BK;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+
+__device__ inline float elu_f(float v) { return v > 0.f ? v : expm1f(v); }
+
+// P parameters x FT feature groups per column tile (NREP = P * FT) for the fused epilogues.
+template <int MREP, int NREP, int EPI, int P, int KSPL>
+__global__ void __launch_bounds__(THREADS) gemm_kernel(GemmArgs g, int n_rows_w) {
+    using T = Tile<MREP, NREP>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int mt = blockIdx.x, nt = blockIdx.y;
+    const int m0 = mt * T::BM, n0 = nt * T::BN;
+
+    int kb = 0, ke = g.k_padded;
+    if (g.k_ranges) {
+        kb = g.k_ranges[2 * nt];
+        ke = g.k_ranges[2 * nt + 1];
+    }
+
+    f32x4 acc[NREP][MREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (ke - kb) / BK;
+    if (nk > 0) stage_tile<MREP, NREP>(g, lds, m0, n0, kb, wave, lane, n_rows_w);
+
+    const int frag_off = (lane & 15) * BK + (lane >> 4) * 4;   // row (l&15), floats [4q, 4q+4)
+    for (int t = 0; t < nk; ++t) {
+        __syncthreads();   // DMA of tile t landed (vmcnt(0) + barrier); everyone is done with the other buffer
+        float* cur = lds + (t & 1) * T::STAGE_FLOATS;
+        if (t + 1 < nk)
+            stage_tile<MREP, NREP>(g, lds + ((t + 1) & 1) * T::STAGE_FLOATS, m0, n0, kb + (t + 1) * BK, wave, lane,
+                                   n_rows_w);
+
+        const float* As = cur + (wave * 16 * MREP) * BK + frag_off;
+        const float* Bs = cur + T::A_FLOATS + frag_off;
+        f32x4 af[MREP];
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) af[m] = *(const f32x4*)(As + m * 16 * BK);
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+            const f32x4 bf = *(const f32x4*)(Bs + n * 16 * BK);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < MREP; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s], bf[s], acc[n][m], 0, 0, 0);
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogues
+    // C layout of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + reg.
+    const int cj = lane & 15, rq = (lane >> 4) * 4;
+    const int wrow0 = m0 + wave * 16 * MREP;
+
+    if constexpr (EPI == EPI_LINEAR || EPI == EPI_ELU) {
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+            const int col = n0 + n * 16 + cj;
+            if (col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.f;
+            const int ocol = g.col_map ? g.col_map[col] : col;
+            if (ocol < 0) continue;
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = wrow0 + m * 16 + rq + i;
+                    if (row < g.B) {
+                        float v = acc[n][m][i] + bv;
+                        if (EPI == EPI_ELU) v = elu_f(v);
+                        g.y[(int64_t)row * g.ldy + ocol] = v;
+                    }
+                }
+        }
+    } else {
+        // Fused transformer: packed column (ft*P + p)*16 + j of this tile is parameter p of
+        // feature slot (nt*FT + ft)*16 + j; the lane owns that feature for 4*MREP samples.
+        constexpr int FT = NREP / P;
+        const FusedArgs& fu = g.fu;
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+            const int slot = (nt * FT + ft) * 16 + cj;
+            const int fcol = fu.feat_index[slot];
+            const bool live = fcol >= 0;
+            float bias_p[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) bias_p[p] = g.bias ? g.bias[n0 + (ft * P + p) * 16 + cj] : 0.f;
+            float x0 = 0.f, xf = 1.f, y0 = 0.f, yf = 1.f;
+            if (EPI == EPI_SPLINE && live) {
+                const int ftr = fu.feat_tr[slot];
+                x0 = fu.x0[ftr];
+                xf = fu.xf[ftr];
+                y0 = fu.y0[ftr];
+                yf = fu.yf[ftr];
+            }
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = wrow0 + m * 16 + rq + i;
+                    const bool ok = live && row < g.B;
+                    double ld = 0.0;
+                    if (ok) {
+                        const float xv = fu.x[(int64_t)row * fu.ldx + fcol];
+                        float out;
+                        if constexpr (EPI == EPI_AFFINE) {
+                            const float shift = acc[ft * P + 0][m][i] + bias_p[0];
+                            const float ls = acc[ft * P + 1][m][i] + bias_p[1];
+                            out = xv * expf(ls) + shift;           // affine.py:321-323
+                            ld = (double)ls;
+                        } else {
+                            float w[KSPL], h[KSPL], sraw[KSPL + 1];
+#pragma unroll
+                            for (int k = 0; k < KSPL; ++k) {
+                                w[k] = acc[ft * P + k][m][i] + bias_p[k];
+                                h[k] = acc[ft * P + KSPL + k][m][i] + bias_p[KSPL + k];
+                            }
+                            // plain: K+1 slopes; circular: K slopes, slope_K := slope_0, last = shift
+#pragma unroll
+                            for (int k = 0; k < KSPL; ++k) sraw[k] = acc[ft * P + 2 * KSPL + k][m][i] + bias_p[2 * KSPL + k];
+                            const float lastp = acc[ft * P + 3 * KSPL][m][i] + bias_p[3 * KSPL];
+                            sraw[KSPL] = fu.sf.circular ? sraw[0] : lastp;
+                            out = (float)rq_spline_element<KSPL, false>(w, h, sraw, lastp, 0.f, fu.sf, x0, xf, y0, yf, xv, &ld);
+                        }
+                        fu.y[(int64_t)row * fu.ldy + fcol] = out;
+                    }
+                    // sum over the 16 features held by lanes with the same (lane >> 4)
+#pragma unroll
+                    for (int off = 8; off > 0; off >>= 1) ld += __shfl_xor(ld, off, 64);
+                    if (cj == 0 && row < g.B) {
+                        double* dst = fu.ldj_partial + (int64_t)(nt * FT + ft) * g.B + row;
+                        *dst = ld;
+                    }
+                }
+        }
+    }
+}
+
+// ldj[b] (+)= sum_t partial[t][b]
+__global__ void __launch_bounds__(256) ldj_reduce_kernel(const double* __restrict__ partial, int n_tiles, int B,
+                                                         float* __restrict__ ldj, int accumulate) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double s = 0.0;
+    for (int t = 0; t < n_tiles; ++t) s += partial[(int64_t)t * B + b];
+    ldj[b] = accumulate ? (float)((double)ldj[b] + s) : (float)s;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+constexpr int LIN_MREP = 2, LIN_NREP = 16;          // 256 x 256 tile for the hidden layers
+constexpr int FUSED_TILE_FEATURES = 16;
+
+template <int MREP, int NREP, int EPI, int P, int KSPL>
+static int launch_gemm(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStream_t s) {
+    using T = Tile<MREP, NREP>;
+    auto kern = gemm_kernel<MREP, NREP, EPI, P, KSPL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%d): %s", T::LDS_BYTES, hipGetErrorString(e));
+        attr_set = true;
+    }
+    dim3 grid((unsigned)((g.B + T::BM - 1) / T::BM), (unsigned)n_col_tiles);
+    kern<<<grid, THREADS, T::LDS_BYTES, s>>>(g, n_rows_w);
+    return check_launch("gemm_kernel");
+}
+
+static int check_gemm_operands(const float* a, int64_t lda, const float* w, int64_t ldw, int k_padded) {
+    TFEP_REQUIRE(a && w, "masked_linear: NULL operand");
+    TFEP_REQUIRE(k_padded > 0 && k_padded % BK == 0, "masked_linear: k_padded=%d must be a positive multiple of %d", k_padded, BK);
+    TFEP_REQUIRE(lda >= k_padded && ldw >= k_padded, "masked_linear: lda=%lld / ldw=%lld smaller than k_padded=%d",
+                 (long long)lda, (long long)ldw, k_padded);
+    TFEP_REQUIRE(lda % 4 == 0 && ldw % 4 == 0, "masked_linear: row strides must be multiples of 4 floats");
+    TFEP_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)w % 16 == 0), "masked_linear: operands must be 16-byte aligned");
+    return TFEP_OK;
+}
+
+}  // namespace tfep
+
+using namespace tfep;
+
+extern "C" {
+
+int tfep_masked_linear_tile_m(void) { return Tile<LIN_MREP, LIN_NREP>::BM; }
+int tfep_masked_linear_tile_n(void) { return Tile<LIN_MREP, LIN_NREP>::BN; }
+int tfep_masked_linear_tile_k(void) { return BK; }
+int tfep_fused_tile_features(void) { return FUSED_TILE_FEATURES; }
+
+int tfep_masked_weight_prepare(const float* weight_v, const float* weight_g, const float* mask, int out_features,
+                               int in_features, const int32_t* row_of_out, const int32_t* col_of_in, float* w_out,
+                               int n_rows_padded, int64_t ldw, void* stream) {
+    TFEP_REQUIRE(weight_v && w_out, "masked_weight_prepare: NULL pointer");
+    TFEP_REQUIRE(out_features >= 0 && in_features >= 0, "masked_weight_prepare: negative size");
+    TFEP_REQUIRE(n_rows_padded >= out_features && ldw >= in_features, "masked_weight_prepare: output too small");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(w_out, 0, (size_t)n_rows_padded * (size_t)ldw * sizeof(float), s);
+    if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    if (out_features == 0 || in_features == 0) return TFEP_OK;
+    weight_prepare_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, s>>>(weight_v, weight_g, mask, out_features,
+                                                                              in_features, row_of_out, col_of_in, w_out, ldw);
+    return check_launch("weight_prepare_kernel");
+}
+
+int tfep_mask_k_ranges(const float* mask, int out_features, int in_features, const int32_t* row_of_out,
+                       const int32_t* col_of_in, int tile_n, int tile_k, int n_tiles, int k_padded,
+                       int32_t* k_ranges, void* stream) {
+    TFEP_REQUIRE(k_ranges, "mask_k_ranges: NULL output");
+    TFEP_REQUIRE(tile_n > 0 && tile_k > 0 && n_tiles >= 0, "mask_k_ranges: bad tile sizes");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_tiles == 0) return TFEP_OK;
+    TFEP_REQUIRE(mask, "mask_k_ranges: mask is NULL (pass k_ranges = NULL to the GEMM for dense weights)");
+    init_k_ranges_kernel<<<(unsigned)((n_tiles + 255) / 256), 256, 0, s>>>(k_ranges, n_tiles);
+    if (out_features > 0 && in_features > 0)
+        mask_k_ranges_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, s>>>(mask, out_features, in_features,
+                                                                                 row_of_out, col_of_in, tile_n, k_ranges);
+    finish_k_ranges_kernel<<<(unsigned)((n_tiles + 255) / 256), 256, 0, s>>>(k_ranges, n_tiles, tile_k, k_padded);
+    return check_launch("mask_k_ranges");
+}
+
+int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
+                               const int32_t* k_ranges, const int32_t* col_map, float* y, int64_t ldy, int B, int N,
+                               int n_rows_w, int k_padded, int act, void* stream) {
+    int rc = check_gemm_operands(x, ldx, w, ldw, k_padded);
+    if (rc) return rc;
+    TFEP_REQUIRE(y, "masked_linear: y is NULL");
+    TFEP_REQUIRE(B >= 0 && N >= 0 && n_rows_w >= N, "masked_linear: bad sizes B=%d N=%d rows=%d", B, N, n_rows_w);
+    TFEP_REQUIRE(act == 0 || act == 1, "masked_linear: act must be 0 (identity) or 1 (ELU)");
+    if (B == 0 || N == 0) return TFEP_OK;
+    GemmArgs g = {};
+    g.a = x; g.lda = ldx; g.w = w; g.ldw = ldw; g.bias = bias; g.k_ranges = k_ranges; g.col_map = col_map;
+    g.y = y; g.ldy = ldy; g.B = B; g.N = N; g.k_padded = k_padded;
+    const int n_tiles = (N + Tile<LIN_MREP, LIN_NREP>::BN - 1) / Tile<LIN_MREP, LIN_NREP>::BN;
+    if (act == 1) return launch_gemm<LIN_MREP, LIN_NREP, EPI_ELU, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);
+    return launch_gemm<LIN_MREP, LIN_NREP, EPI_LINEAR, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);
+}
+
+int tfep_fused_supported(int kind, const tfep_spline_desc* d) {
+    if (kind == TFEP_FUSED_AFFINE) return 1;
+    if (kind == TFEP_FUSED_SPLINE && d)
+        return d->n_bins == 8 && !d->identity_boundary_slopes && !d->learn_lower_bound && !d->learn_upper_bound;
+    return 0;
+}
+
+int tfep_fused_tile_columns(int kind, const tfep_spline_desc* d) {
+    if (kind == TFEP_FUSED_AFFINE) return 16 * 16;      // P = 2, FT = 8
+    if (kind == TFEP_FUSED_SPLINE && tfep_fused_supported(kind, d)) return 16 * 25;   // P = 25, FT = 1
+    return fail(TFEP_ERR_UNSUPPORTED, "fused: unsupported transformer configuration");
+}
+
+int tfep_fused_output_transformer_forward(const float* h, int64_t ldh, const float* w, int64_t ldw,
+                                          const float* bias_packed, const int32_t* k_ranges, int kind,
+                                          const tfep_spline_desc* desc, const float* x, int64_t ldx, float* y,
+                                          int64_t ldy, const int32_t* feat_index, const int32_t* feat_tr,
+                                          int n_feature_slots, double* ldj_partial, float* log_det_J, int accumulate,
+                                          int B, int n_rows_w, int k_padded, void* stream) {
+    int rc = check_gemm_operands(h, ldh, w, ldw, k_padded);
+    if (rc) return rc;
+    TFEP_REQUIRE(x && y && feat_index && ldj_partial && log_det_J, "fused: NULL pointer");
+    TFEP_REQUIRE(n_feature_slots > 0 && n_feature_slots % FUSED_TILE_FEATURES == 0,
+                 "fused: n_feature_slots=%d must be a positive multiple of %d", n_feature_slots, FUSED_TILE_FEATURES);
+    if (!tfep_fused_supported(kind, desc)) return fail(TFEP_ERR_UNSUPPORTED, "fused: unsupported transformer configuration");
+    if (B == 0) return TFEP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs g = {};
+    g.a = h; g.lda = ldh; g.w = w; g.ldw = ldw; g.bias = bias_packed; g.k_ranges = k_ranges;
+    g.B = B; g.k_padded = k_padded;
+    g.fu.x = x; g.fu.ldx = ldx; g.fu.y = y; g.fu.ldy = ldy; g.fu.feat_index = feat_index; g.fu.feat_tr = feat_tr;
+    g.fu.ldj_partial = ldj_partial;
+    const int n_groups = n_feature_slots / FUSED_TILE_FEATURES;
+    if (kind == TFEP_FUSED_AFFINE) {
+        constexpr int P = 2, FT = 8;
+        TFEP_REQUIRE(n_groups % FT == 0, "fused affine: feature slots must be a multiple of %d", FT * 16);
+        TFEP_REQUIRE(n_rows_w >= n_feature_slots * P, "fused: weight has too few rows");
+        g.N = n_feature_slots * P;
+        rc = launch_gemm<2, P * FT, EPI_AFFINE, P, 1>(g, n_rows_w, n_groups / FT, s);
+    } else {
+        constexpr int P = 25, KS = 8;
+        TFEP_REQUIRE(feat_tr && desc->x0 && desc->xf && desc->y0 && desc->yf, "fused spline: NULL descriptor arrays");
+        TFEP_REQUIRE(n_rows_w >= n_feature_slots * P, "fused: weight has too few rows");
+        g.N = n_feature_slots * P;
+        g.fu.x0 = desc->x0; g.fu.xf = desc->xf; g.fu.y0 = desc->y0; g.fu.yf = desc->yf;
+        g.fu.sf.K = KS; g.fu.sf.circular = desc->circular != 0; g.fu.sf.identity = false;
+        g.fu.sf.learn_lower = false; g.fu.sf.learn_upper = false;
+        g.fu.sf.min_bin = desc->min_bin_size; g.fu.sf.min_slope = desc->min_slope;
+        g.fu.sf.slope_offset = (float)log(exp(1.0 - (double)desc->min_slope) - 1.0);
+        rc = launch_gemm<2, P, EPI_SPLINE, P, KS>(g, n_rows_w, n_groups, s);
+    }
+    if (rc) return rc;
+    ldj_reduce_kernel<<<(unsigned)((B + 255) / 256), 256, 0, s>>>(ldj_partial, n_groups, B, log_det_J, accumulate);
+    return check_launch("ldj_reduce_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+// Rational-quadratic neural spline, one element per call, shared by the standalone
+// transformer kernels and the fused MADE-output epilogue.
+//
+// Follows NeuralSplineTransformer (reference transformers/spline.py):
+//   _get_parameters  :319-417   softmax widths/heights, softplus slopes, learnable bounds
+//   _assign_bins     :567-650   bin = #{knots < x} - 1 with STRICT '>', linear tails
+//   forward/inverse  :478-494 / :521-536, log-det :546-564, circular shift :236-238 / :257-259
+//
+// Numerics: exp / log / softplus in fp32 (<= 1 ulp libm), everything geometric
+// (knot prefix sums, epsilon, the rational quadratic, the log-derivative sum) in fp64,
+// so the result tracks the fp64 reference to ~1e-7 relative instead of inheriting the
+// fp32 cancellation of (x - x_k)/w.  The two sentinel knots of the
+// reference are algebraically a linear map with the boundary slope; it is evaluated directly.
+#pragma once
+
+#include "common.h"
+
+namespace tfep {
+
+struct SplineFlags {
+    int K;
+    bool circular, identity, learn_lower, learn_upper;
+    float min_bin, min_slope;
+    float slope_offset;   // log(exp(1 - min_slope) - 1), spline.py:414
+};
+
+__device__ inline float softplus_f(float z) {
+    // torch softplus, beta = 1, threshold = 20 (spline.py:415).
+    return z > 20.0f ? z : log1pf(expf(z));
+}
+
+// Raw-slope accessor position for knot j (0..K) in the per-feature parameter vector
+// (spline.py:359-380).  Returns -1 when the raw slope is the constant 0 (identity boundary).
+__device__ __host__ inline int spline_slope_param(int j, int K, bool circular, bool identity) {
+    if (identity) {
+        if (j == 0 || j == K) return -1;
+        return 2 * K + j - 1;
+    }
+    if (circular && j == K) return 2 * K;
+    return 2 * K + j;
+}
+
+__host__ __device__ inline int spline_n_params(int K, bool circular, bool identity, bool ll, bool lu) {
+    int n = 3 * K + 1;          // spline.py:165-182
+    if (ll) n += 1;
+    if (lu) n += 1;
+    if (identity) n -= circular ? 1 : 2;
+    return n;
+}
+
+// Evaluate one element.
+//   w[k], h[k]   raw (pre-softmax) widths / heights, k < K
+//   sraw[j]      raw (pre-softplus) slopes of the K+1 knots, already expanded
+//   last, last2  parameters P-1 and P-2 (shift / log-scale / domain shift), 0 if unused
+//   x0,xf,y0,yf  the registered domain of the feature
+// Returns the mapped value; *logd receives log(dy/dx) of the FORWARD map evaluated at the
+// point (the caller negates for the inverse, spline.py:562-564).
+template <int KMAX, bool INVERSE>
+__device__ inline double rq_spline_element(const float (&w)[KMAX], const float (&h)[KMAX],
+                                           const float (&sraw)[KMAX + 1], float last, float last2,
+                                           const SplineFlags& f, float x0f, float xff, float y0f,
+                                           float yff, float vin, double* logd) {
+    const int K = f.K;
+    const double mb = (double)f.min_bin;
+
+    // ---- domain (spline.py:384-410)
+    double x0 = x0f, y0 = y0f;
+    double W = (double)xff - (double)x0f - K * mb;
+    double H = (double)yff - (double)y0f - K * mb;
+    if (f.learn_lower || f.learn_upper) {
+        double scale = (double)expf(last);
+        W *= scale;
+        H *= scale;
+        if (f.learn_lower && f.learn_upper) {
+            x0 += (double)last2;
+            y0 += (double)last2;
+        } else if (f.learn_lower) {
+            x0 = (double)xff - W - K * mb;
+            y0 = (double)yff - H - K * mb;
+        }
+    }
+
+    double v = vin;
+    if (f.circular && !INVERSE) {
+        // spline.py:236-238 (xf fixed for circular splines)
+        v = py_mod(v - x0 + (double)last, (double)xff - x0) + x0;
+    }
+
+    // ---- softmax normalisation (spline.py:394-395)
+    float mw = -INFINITY, mh = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+            mw = fmaxf(mw, w[k]);
+            mh = fmaxf(mh, h[k]);
+        }
+    float ew[KMAX], eh[KMAX];
+    float sw = 0.f, sh = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        ew[k] = 0.f;
+        eh[k] = 0.f;
+        if (k < K) {
+            ew[k] = expf(w[k] - mw);
+            eh[k] = expf(h[k] - mh);
+            sw += ew[k];
+            sh += eh[k];
+        }
+    }
+    const double iw = W / (double)sw, ih = H / (double)sh;
+
+    // ---- bin search: strict '>' (spline.py:622-625).  v <= first knot -> lower tail.
+    double kx = x0, ky = y0;          // lower knot of the current bin
+    double bw = 0.0, bh = 0.0;        // width / height of the found bin
+    float rs0 = sraw[0], rs1 = sraw[0];
+    bool found = false;
+    const double ref0 = INVERSE ? y0 : x0;
+    const bool lower_tail = !(v > ref0);
+    float rs_last = sraw[0];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+            const double wk = (double)ew[k] * iw + mb;
+            const double hk = (double)eh[k] * ih + mb;
+            if (!found) {
+                const double upper = INVERSE ? (ky + hk) : (kx + wk);
+                if (v > upper) {
+                    kx += wk;
+                    ky += hk;
+                } else {
+                    found = true;
+                    bw = wk;
+                    bh = hk;
+                    rs0 = sraw[k];
+                    rs1 = sraw[k + 1];
+                }
+            }
+            if (k == K - 1) rs_last = sraw[k + 1];
+        }
+    }
+
+    double out, ld;
+    if (lower_tail || !found) {
+        // Linear continuation with the boundary slope (spline.py:599-614; reference
+        // NumPy oracle tests/nn/transformers/test_spline.py:83-87).
+        const float rs = lower_tail ? sraw[0] : rs_last;
+        const double d = (double)(softplus_f(rs + f.slope_offset) + f.min_slope);
+        const double bx = lower_tail ? x0 : kx, by = lower_tail ? y0 : ky;
+        out = INVERSE ? (bx + (v - by) / d) : (by + d * (v - bx));
+        ld = (double)logf((float)d);
+    } else {
+        const double dk = (double)(softplus_f(rs0 + f.slope_offset) + f.min_slope);
+        const double dk1 = (double)(softplus_f(rs1 + f.slope_offset) + f.min_slope);
+        const double s = bh / bw;                                  // spline.py:643
+        const double t = dk1 + dk - 2.0 * s;
+        double eps;
+        if (INVERSE) {                                             // spline.py:521-536
+            const double ym = v - ky;
+            const double a = bh * (s - dk) + ym * t;
+            const double b = bh * dk - ym * t;
+            const double c = -s * ym;
+            eps = 2.0 * c / (-b - sqrt(b * b - 4.0 * a * c));
+            out = eps * bw + kx;
+        } else {                                                   // spline.py:485-494
+            eps = (v - kx) / bw;
+            const double e1 = eps * (1.0 - eps);
+            out = ky + bh * (s * eps * eps + dk * e1) / (s + t * e1);
+        }
+        const double e1 = eps * (1.0 - eps);                       // spline.py:556-558
+        const double om = 1.0 - eps;
+        const double num = s * s * (dk1 * eps * eps + 2.0 * s * e1 + dk * om * om);
+        const double den = s + t * e1;
+        ld = (double)logf((float)(num / (den * den)));
+    }
+
+    if (f.circular && INVERSE) {
+        // spline.py:257-259
+        out = py_mod(out - x0 - (double)last, (double)xff - x0) + x0;
+    }
+    *logd = ld;
+    return out;
+}
+
+}  // namespace tfep

@@ -1,0 +1,399 @@
+// Standalone (unfused) transformer kernels: affine, volume-preserving shift, RQ spline,
+// Moebius, periodic embedding, column gather/scatter.  HBM-bound elementwise work with a
+// per-sample log|det J| reduction: one wavefront owns one sample (row), its 64 lanes walk the
+// features with unit stride (coalesced 256-B segments per parameter row) and the log-derivative
+// is summed in fp64 with a wave butterfly -- no atomics, bit-reproducible.
+#include "common.h"
+#include "spline.h"
+
+#include <stdarg.h>
+
+namespace tfep {
+
+std::string& last_error() {
+    static thread_local std::string s;
+    return s;
+}
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+constexpr int ROWS_PER_BLOCK = 4;   // 4 waves = 256 threads
+
+__device__ inline void store_ldj(float* ldj, int b, double total, int accumulate) {
+    if ((threadIdx.x & 63) == 0) {
+        if (accumulate)
+            ldj[b] = (float)((double)ldj[b] + total);
+        else
+            ldj[b] = (float)total;
+    }
+}
+
+// ---------------------------------------------------------------- affine (affine.py:321-323, :361-363)
+template <bool INVERSE>
+__global__ void __launch_bounds__(256) affine_kernel(const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ params, tfep_param_layout L,
+                                                     float* __restrict__ y, int64_t ldy, float* __restrict__ ldj,
+                                                     int accumulate, int B, int D) {
+    const int b = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (int64_t)b * ldx;
+    const float* pr = params + (int64_t)b * L.ld;
+    float* yr = y + (int64_t)b * ldy;
+    double acc = 0.0;
+    for (int f = lane; f < D; f += 64) {
+        const float shift = pr[f * L.stride_f];
+        const float ls = pr[L.stride_p + f * L.stride_f];
+        const float v = xr[f];
+        if (INVERSE)
+            yr[f] = (v - shift) * expf(-ls);
+        else
+            yr[f] = v * expf(ls) + shift;
+        acc += (double)ls;
+    }
+    acc = wave_sum(acc);
+    if (ldj) store_ldj(ldj, b, INVERSE ? -acc : acc, accumulate);
+}
+
+// ---------------------------------------------------------------- volume preserving shift (affine.py:366-456)
+__global__ void __launch_bounds__(256) volpres_kernel(const float* __restrict__ x, int64_t ldx,
+                                                      const float* __restrict__ shift, int64_t ldp,
+                                                      const int32_t* __restrict__ periodic, float lower,
+                                                      float upper, float sign, float* __restrict__ y,
+                                                      int64_t ldy, int B, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * D) return;
+    const int b = (int)(i / D), f = (int)(i % D);
+    float v = x[(int64_t)b * ldx + f] + sign * shift[(int64_t)b * ldp + f];
+    if (periodic && periodic[f]) {
+        // float32 `%` with Python semantics, then + lower (affine.py:409, :454)
+        const float period = upper - lower;
+        float r = fmodf(v, period);
+        if (r != 0.f && ((r < 0.f) != (period < 0.f))) r += period;
+        v = r + lower;
+    }
+    y[(int64_t)b * ldy + f] = v;
+}
+
+// ---------------------------------------------------------------- RQ spline (spline.py)
+struct SplineArgs {
+    const float *x0, *xf, *y0, *yf;
+    SplineFlags f;
+    int P;
+};
+
+template <int KMAX, bool INVERSE>
+__global__ void __launch_bounds__(256) spline_kernel(const float* __restrict__ x, int64_t ldx,
+                                                     const float* __restrict__ params, tfep_param_layout L,
+                                                     SplineArgs a, float* __restrict__ y, int64_t ldy,
+                                                     float* __restrict__ ldj, int accumulate, int B, int D) {
+    const int b = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const float* xr = x + (int64_t)b * ldx;
+    const float* pr = params + (int64_t)b * L.ld;
+    float* yr = y + (int64_t)b * ldy;
+    const int K = a.f.K;
+    double acc = 0.0;
+    for (int f = lane; f < D; f += 64) {
+        const float* pf = pr + f * L.stride_f;
+        float w[KMAX], h[KMAX], sraw[KMAX + 1];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            w[k] = 0.f;
+            h[k] = 0.f;
+            if (k < K) {
+                w[k] = pf[k * L.stride_p];
+                h[k] = pf[(K + k) * L.stride_p];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j <= KMAX; ++j) {
+            sraw[j] = 0.f;
+            if (j <= K) {
+                const int pi = spline_slope_param(j, K, a.f.circular, a.f.identity);
+                if (pi >= 0) sraw[j] = pf[pi * L.stride_p];
+            }
+        }
+        float last = 0.f, last2 = 0.f;
+        if (a.f.circular || a.f.learn_lower || a.f.learn_upper) last = pf[(a.P - 1) * L.stride_p];
+        if (a.f.learn_lower && a.f.learn_upper) last2 = pf[(a.P - 2) * L.stride_p];
+        double ld;
+        const double out = rq_spline_element<KMAX, INVERSE>(w, h, sraw, last, last2, a.f, a.x0[f], a.xf[f],
+                                                            a.y0[f], a.yf[f], xr[f], &ld);
+        yr[f] = (float)out;
+        acc += ld;
+    }
+    acc = wave_sum(acc);
+    if (ldj) store_ldj(ldj, b, INVERSE ? -acc : acc, accumulate);
+}
+
+// ---------------------------------------------------------------- Moebius (moebius.py:374-478)
+// One lane per d-vector.  log|det J| in closed form: with c = N/|x-w|^2 and the reflection
+// R = I - 2 dd^T/|d|^2 (d = x - w) the unit-sphere Jacobian is c R, so log|det| = dim*log|c|;
+// the general Jacobian is c R (I - xx^T/|x|^2) + y x^T/|x|^2 whose determinant is
+// -(c^(dim-1)/|x|) * xhat . (R y)   (matrix-determinant lemma for a rank-(dim-1) + rank-1 sum).
+constexpr int MOEBIUS_MAX_DIM = 8;
+
+__global__ void __launch_bounds__(256) moebius_kernel(const float* __restrict__ x, int64_t ldx,
+                                                      const float* __restrict__ params, int64_t ldp, int dim,
+                                                      float max_radius, int unit_sphere, float sign,
+                                                      float* __restrict__ y, int64_t ldy, float* __restrict__ ldj,
+                                                      int accumulate, int B, int D) {
+    const int b = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int nvec = D / dim;
+    const float* xr = x + (int64_t)b * ldx;
+    const float* pr = params + (int64_t)b * ldp;
+    float* yr = y + (int64_t)b * ldy;
+    double acc = 0.0;
+    for (int v = lane; v < nvec; v += 64) {
+        double xv[MOEBIUS_MAX_DIM], wv[MOEBIUS_MAX_DIM], dv[MOEBIUS_MAX_DIM], yv[MOEBIUS_MAX_DIM];
+        double wn2 = 0.0, xn2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+            if (i < dim) {
+                xv[i] = (double)xr[v * dim + i];
+                wv[i] = (double)(sign * pr[v * dim + i]);
+                wn2 += wv[i] * wv[i];
+                xn2 += xv[i] * xv[i];
+            }
+        const double wn = sqrt(wn2), xn = sqrt(xn2);
+        double resc = (double)max_radius / (1.0 + wn);             // moebius.py:437-441
+        if (!unit_sphere) resc *= xn;
+        const double wns = resc * wn;
+        const double numer = (unit_sphere ? 1.0 : xn2) - wns * wns;   // moebius.py:446-449
+        double dn2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+            if (i < dim) {
+                wv[i] *= resc;
+                dv[i] = xv[i] - wv[i];
+                dn2 += dv[i] * dv[i];
+            }
+        const double c = numer / dn2;
+        double dy = 0.0;   // d . y
+        double xy = 0.0;   // x . y
+#pragma unroll
+        for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+            if (i < dim) {
+                yv[i] = c * dv[i] - wv[i];                         // moebius.py:452
+                yr[v * dim + i] = (float)yv[i];
+                dy += dv[i] * yv[i];
+                xy += xv[i] * yv[i];
+            }
+        double ld;
+        if (unit_sphere) {
+            ld = dim * log(fabs(c));
+        } else {
+            double xd = 0.0;
+#pragma unroll
+            for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+                if (i < dim) xd += xv[i] * dv[i];
+            const double xRy = xy - 2.0 * xd * dy / dn2;           // x . (R y)
+            ld = (dim - 1) * log(fabs(c)) - 2.0 * log(xn) + log(fabs(xRy));
+        }
+        acc += ld;
+    }
+    acc = wave_sum(acc);
+    if (ldj) store_ldj(ldj, b, acc, accumulate);
+}
+
+// ---------------------------------------------------------------- periodic embedding (mafembed.py:112-145)
+__global__ void __launch_bounds__(256) periodic_embedding_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                 const int32_t* __restrict__ pidx, int n_per,
+                                                                 const int32_t* __restrict__ nidx, int n_non,
+                                                                 float lower, float scale,
+                                                                 float* __restrict__ out, int64_t ldo, int B) {
+    const int n_out = n_non + n_per;     // one thread per (row, source feature)
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * n_out) return;
+    const int b = (int)(i / n_out), j = (int)(i % n_out);
+    if (j < n_non) {
+        out[(int64_t)b * ldo + j] = x[(int64_t)b * ldx + nidx[j]];
+    } else {
+        const int q = j - n_non;
+        const float t = (x[(int64_t)b * ldx + pidx[q]] - lower) * scale;
+        float s, c;
+        sincosf(t, &s, &c);
+        out[(int64_t)b * ldo + n_non + 2 * q] = c;
+        out[(int64_t)b * ldo + n_non + 2 * q + 1] = s;
+    }
+}
+
+// ---------------------------------------------------------------- column gather / scatter
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) columns_kernel(const float* __restrict__ src, int64_t lds,
+                                                      const int32_t* __restrict__ idx, int n_idx,
+                                                      float* __restrict__ dst, int64_t ldd, int B) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * n_idx) return;
+    const int b = (int)(i / n_idx), j = (int)(i % n_idx);
+    if (SCATTER)
+        dst[(int64_t)b * ldd + idx[j]] = src[(int64_t)b * lds + j];
+    else
+        dst[(int64_t)b * ldd + j] = src[(int64_t)b * lds + idx[j]];
+}
+
+static inline unsigned row_blocks(int B) { return (unsigned)((B + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
+
+static int make_spline_args(const tfep_spline_desc* d, SplineArgs* a) {
+    TFEP_REQUIRE(d != nullptr, "spline descriptor is NULL");
+    TFEP_REQUIRE(d->x0 && d->xf && d->y0 && d->yf, "spline descriptor: x0/xf/y0/yf must be non-NULL");
+    TFEP_REQUIRE(d->n_bins >= 1 && d->n_bins <= 32, "spline: n_bins=%d unsupported (1..32)", d->n_bins);
+    TFEP_REQUIRE(!(d->circular && (d->learn_lower_bound || d->learn_upper_bound)),
+                 "Cannot instantiate a circular spline with learnable limits.");
+    TFEP_REQUIRE(d->min_bin_size > 0.f, "The minimum bin size should be positive.");
+    TFEP_REQUIRE(d->min_slope > 0.f && d->min_slope < 1.f, "The minimum slope should be between 0 and 1.");
+    a->x0 = d->x0;
+    a->xf = d->xf;
+    a->y0 = d->y0;
+    a->yf = d->yf;
+    a->f.K = d->n_bins;
+    a->f.circular = d->circular != 0;
+    a->f.identity = d->identity_boundary_slopes != 0;
+    a->f.learn_lower = d->learn_lower_bound != 0;
+    a->f.learn_upper = d->learn_upper_bound != 0;
+    a->f.min_bin = d->min_bin_size;
+    a->f.min_slope = d->min_slope;
+    a->f.slope_offset = (float)log(exp(1.0 - (double)d->min_slope) - 1.0);
+    a->P = spline_n_params(a->f.K, a->f.circular, a->f.identity, a->f.learn_lower, a->f.learn_upper);
+    return TFEP_OK;
+}
+
+template <bool INVERSE>
+static int launch_spline(const float* x, int64_t ldx, const float* params, tfep_param_layout L,
+                         const tfep_spline_desc* desc, float* y, int64_t ldy, float* ldj, int accumulate,
+                         int B, int D, void* stream) {
+    SplineArgs a;
+    int rc = make_spline_args(desc, &a);
+    if (rc) return rc;
+    TFEP_REQUIRE(x && params && y, "spline: x/params/y must be non-NULL");
+    TFEP_REQUIRE(B >= 0 && D >= 0, "spline: negative size");
+    if (B == 0) return TFEP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (a.f.K <= 8)
+        spline_kernel<8, INVERSE><<<row_blocks(B), 256, 0, s>>>(x, ldx, params, L, a, y, ldy, ldj, accumulate, B, D);
+    else if (a.f.K <= 16)
+        spline_kernel<16, INVERSE><<<row_blocks(B), 256, 0, s>>>(x, ldx, params, L, a, y, ldy, ldj, accumulate, B, D);
+    else
+        spline_kernel<32, INVERSE><<<row_blocks(B), 256, 0, s>>>(x, ldx, params, L, a, y, ldy, ldj, accumulate, B, D);
+    return check_launch("spline_kernel");
+}
+
+}  // namespace tfep
+
+using namespace tfep;
+
+extern "C" {
+
+int tfep_hip_abi_version(void) { return TFEP_HIP_ABI_VERSION; }
+const char* tfep_last_error(void) { return last_error().c_str(); }
+
+int tfep_affine_forward(const float* x, int64_t ldx, const float* params, tfep_param_layout layout, float* y,
+                        int64_t ldy, float* log_det_J, int accumulate, int B, int D, void* stream) {
+    TFEP_REQUIRE(x && params && y, "affine: x/params/y must be non-NULL");
+    TFEP_REQUIRE(B >= 0 && D >= 0, "affine: negative size");
+    if (B == 0) return TFEP_OK;
+    affine_kernel<false><<<row_blocks(B), 256, 0, (hipStream_t)stream>>>(x, ldx, params, layout, y, ldy, log_det_J,
+                                                                         accumulate, B, D);
+    return check_launch("affine_kernel");
+}
+
+int tfep_affine_inverse(const float* y, int64_t ldy, const float* params, tfep_param_layout layout, float* x,
+                        int64_t ldx, float* log_det_J, int accumulate, int B, int D, void* stream) {
+    TFEP_REQUIRE(x && params && y, "affine: x/params/y must be non-NULL");
+    TFEP_REQUIRE(B >= 0 && D >= 0, "affine: negative size");
+    if (B == 0) return TFEP_OK;
+    affine_kernel<true><<<row_blocks(B), 256, 0, (hipStream_t)stream>>>(y, ldy, params, layout, x, ldx, log_det_J,
+                                                                        accumulate, B, D);
+    return check_launch("affine_kernel");
+}
+
+int tfep_volume_preserving_shift(const float* x, int64_t ldx, const float* shift, int64_t ldp,
+                                 const int32_t* periodic_mask, float lower, float upper, int sign, float* y,
+                                 int64_t ldy, int B, int D, void* stream) {
+    TFEP_REQUIRE(x && shift && y, "volume_preserving_shift: x/shift/y must be non-NULL");
+    TFEP_REQUIRE(sign == 1 || sign == -1, "volume_preserving_shift: sign must be +1 or -1");
+    if ((int64_t)B * D == 0) return TFEP_OK;
+    const int64_t n = (int64_t)B * D;
+    volpres_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, ldx, shift, ldp, periodic_mask,
+                                                                                 lower, upper, (float)sign, y, ldy, B, D);
+    return check_launch("volpres_kernel");
+}
+
+int tfep_spline_n_parameters_per_feature(const tfep_spline_desc* d) {
+    if (!d) return fail(TFEP_ERR_INVALID_ARGUMENT, "spline descriptor is NULL");
+    return spline_n_params(d->n_bins, d->circular != 0, d->identity_boundary_slopes != 0, d->learn_lower_bound != 0,
+                           d->learn_upper_bound != 0);
+}
+
+int tfep_spline_forward(const float* x, int64_t ldx, const float* params, tfep_param_layout layout,
+                        const tfep_spline_desc* desc, float* y, int64_t ldy, float* log_det_J, int accumulate, int B,
+                        int D, void* stream) {
+    return launch_spline<false>(x, ldx, params, layout, desc, y, ldy, log_det_J, accumulate, B, D, stream);
+}
+
+int tfep_spline_inverse(const float* y, int64_t ldy, const float* params, tfep_param_layout layout,
+                        const tfep_spline_desc* desc, float* x, int64_t ldx, float* log_det_J, int accumulate, int B,
+                        int D, void* stream) {
+    return launch_spline<true>(y, ldy, params, layout, desc, x, ldx, log_det_J, accumulate, B, D, stream);
+}
+
+int tfep_moebius_forward(const float* x, int64_t ldx, const float* params, int64_t ldp, int dimension,
+                         float max_radius, int unit_sphere, int sign, float* y, int64_t ldy, float* log_det_J,
+                         int accumulate, int B, int D, void* stream) {
+    TFEP_REQUIRE(x && params && y, "moebius: x/params/y must be non-NULL");
+    TFEP_REQUIRE(dimension >= 1 && dimension <= MOEBIUS_MAX_DIM, "moebius: dimension=%d unsupported (1..%d)", dimension,
+                 MOEBIUS_MAX_DIM);
+    TFEP_REQUIRE(D % dimension == 0, "moebius: n_features=%d is not a multiple of dimension=%d", D, dimension);
+    TFEP_REQUIRE(sign == 1 || sign == -1, "moebius: sign must be +1 or -1");
+    if (B == 0) return TFEP_OK;
+    moebius_kernel<<<row_blocks(B), 256, 0, (hipStream_t)stream>>>(x, ldx, params, ldp, dimension, max_radius,
+                                                                   unit_sphere, (float)sign, y, ldy, log_det_J,
+                                                                   accumulate, B, D);
+    return check_launch("moebius_kernel");
+}
+
+int tfep_periodic_embedding(const float* x, int64_t ldx, const int32_t* periodic_indices, int n_periodic,
+                            const int32_t* nonperiodic_indices, int n_nonperiodic, float lower, float upper,
+                            float* out, int64_t ldo, int B, void* stream) {
+    TFEP_REQUIRE(x && out, "periodic_embedding: x/out must be non-NULL");
+    TFEP_REQUIRE(n_periodic == 0 || periodic_indices, "periodic_embedding: periodic_indices is NULL");
+    TFEP_REQUIRE(n_nonperiodic == 0 || nonperiodic_indices, "periodic_embedding: nonperiodic_indices is NULL");
+    const int64_t n = (int64_t)B * (n_periodic + n_nonperiodic);
+    if (n == 0) return TFEP_OK;
+    const float scale = (float)(2.0 * 3.14159265358979323846 / ((double)upper - (double)lower));
+    periodic_embedding_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        x, ldx, periodic_indices, n_periodic, nonperiodic_indices, n_nonperiodic, lower, scale, out, ldo, B);
+    return check_launch("periodic_embedding_kernel");
+}
+
+int tfep_gather_columns(const float* src, int64_t lds, const int32_t* idx, int n_idx, float* dst, int64_t ldd, int B,
+                        void* stream) {
+    TFEP_REQUIRE(src && dst && (idx || n_idx == 0), "gather_columns: NULL pointer");
+    const int64_t n = (int64_t)B * n_idx;
+    if (n == 0) return TFEP_OK;
+    columns_kernel<false><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, lds, idx, n_idx, dst, ldd, B);
+    return check_launch("gather_columns");
+}
+
+int tfep_scatter_columns(const float* src, int64_t lds, const int32_t* idx, int n_idx, float* dst, int64_t ldd, int B,
+                         void* stream) {
+    TFEP_REQUIRE(src && dst && (idx || n_idx == 0), "scatter_columns: NULL pointer");
+    const int64_t n = (int64_t)B * n_idx;
+    if (n == 0) return TFEP_OK;
+    columns_kernel<true><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, lds, idx, n_idx, dst, ldd, B);
+    return check_launch("scatter_columns");
+}
+
+}  // extern "C"

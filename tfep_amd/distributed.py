@@ -1,0 +1,49 @@
+"""Multi-GPU plumbing: one process per GPU, ``torch.distributed`` (backend ``nccl`` = RCCL over xGMI).
+
+The flow is row-wise independent, so the batch shards across ranks with NO collective on the
+data path.  The only cross-sample coupling is in the TFEP reductions; their sufficient statistics
+(9 float64, see tfep_hip.h: counts, sums and (max, rescaled-sum) pairs) combine with a single
+all-gather of 9 scalars per rank followed by a local (max, rescale, sum) combine -- latency only.
+"""
+import torch
+import torch.distributed as dist
+
+# layout of the statistics vector (tfep_hip.h)
+_PLAIN = (0, 1)                       # count, sum r
+_PAIRS = ((2, (3, 4)), (5, (6,)), (7, (8,)))   # (max index, indices of sums rescaled by exp(max - global max))
+
+
+def combine_stats(stats_list):
+    """Combine per-shard statistics ``(n_shards, 9)`` into the statistics of the union."""
+    s = torch.stack(list(stats_list)) if not torch.is_tensor(stats_list) else stats_list
+    out = torch.empty(9, dtype=s.dtype, device=s.device)
+    for i in _PLAIN:
+        out[i] = s[:, i].sum()
+    for mi, sums in _PAIRS:
+        m = s[:, mi]
+        gm = torch.where(torch.isnan(m).any(), torch.full_like(m[0], float('nan')), m.max())
+        scale = torch.exp(m - gm)
+        scale = torch.where(torch.isinf(m) & (m < 0), torch.zeros_like(scale), scale)   # empty shard
+        out[mi] = gm
+        for si in sums:
+            out[si] = (s[:, si] * scale).sum()
+    return out
+
+
+def allreduce_stats(stats, group=None):
+    """All ranks get the statistics of the global batch (no-op without an initialised group)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return stats
+    world = dist.get_world_size(group)
+    if world == 1:
+        return stats
+    gathered = [torch.empty_like(stats) for _ in range(world)]
+    dist.all_gather(gathered, stats, group=group)
+    return combine_stats(gathered)
+
+
+def shard_rows(n_rows, rank, world_size):
+    """Contiguous row block ``[begin, end)`` of this rank (remainder spread over the first ranks)."""
+    base, rem = divmod(n_rows, world_size)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)

@@ -1,0 +1,332 @@
+"""MADE conditioner with the ``tfep.nn.conditioners.made`` API on gfx950 kernels.
+
+Mirrors reference ``tfep/nn/conditioners/made.py``: ``generate_degrees`` (:32-145) and
+``MADE`` (:152-434) -- same constructor, ``state_dict`` keys (``layers.{0,2,4,..}.{bias,
+weight_g, weight_v | weight, mask}``), ``set_output`` and ``n_parameters``.
+
+Execution plan (built lazily per device, host-side integer work only):
+  * hidden units are SORTED BY DEGREE (a permutation of hidden units leaves the network
+    function unchanged); with sorted units every mask of the network becomes block lower
+    triangular, so the GEMM skips ~half of its k-tiles through per-column-tile k-ranges
+    computed from the actual mask buffers (``tfep_mask_k_ranges``);
+  * weights are re-packed (weight norm + mask + permutation + zero padding) by
+    ``tfep_masked_weight_prepare`` on EVERY forward, like the reference's pre-hook;
+  * three launches of the fp32-MFMA GEMM, the ELU fused in the first two.
+"""
+from typing import Literal, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from ... import ops
+from ...utils.misc import ensure_tensor_sequence
+from .. import masked
+from .conditioner import Conditioner
+
+
+# =============================================================================
+# UTILS
+# =============================================================================
+
+def _round_robin(x, length, err_msg=None):
+    """Tile ``x`` to ``length`` elements (reference made.py:441-461)."""
+    n_rounds, n_rem = divmod(length, len(x))
+    if n_rounds == 0:
+        if err_msg is None:
+            err_msg = f'Length {length} is smaller than the array (len={len(x)}).'
+        raise ValueError(err_msg)
+    out = x.repeat(n_rounds)
+    if n_rem != 0:
+        out = torch.cat([out, x[:n_rem]])
+    return out
+
+
+def generate_degrees(
+        n_features: int,
+        order: Literal['ascending', 'descending', 'random'] = 'ascending',
+        max_value: Optional[int] = None,
+        conditioning_indices: Optional[Sequence[int]] = None,
+        repeats: Union[int, Sequence[int]] = 1,
+) -> torch.Tensor:
+    """Generate node degrees for MADE layers (reference made.py:32-145).
+
+    Degrees run from 0 to ``max_value``; conditioning features get -1.
+
+    >>> generate_degrees(n_features=3).tolist()
+    [0, 1, 2]
+    >>> generate_degrees(7, order='descending', max_value=2).tolist()
+    [2, 1, 0, 2, 1, 0, 2]
+    >>> generate_degrees(7, max_value=2, conditioning_indices=[0, 2, 3]).tolist()
+    [-1, 0, -1, -1, 1, 2, 0]
+    >>> generate_degrees(7, repeats=[1, 3, 2], conditioning_indices=[2]).tolist()
+    [0, 1, -1, 1, 1, 2, 2]
+    """
+    n_free = n_features
+    if conditioning_indices is not None:
+        n_free -= len(conditioning_indices)
+
+    if max_value is None:
+        try:
+            max_value = len(repeats) - 1
+        except TypeError:
+            max_value = int(np.ceil(n_free / repeats)) - 1
+
+    if order == 'ascending':
+        degrees = torch.arange(max_value + 1)
+    elif order == 'descending':
+        degrees = torch.arange(max_value, -1, -1)
+    elif order == 'random':
+        degrees = torch.randperm(max_value + 1)
+    else:
+        raise ValueError("Accepted string values for 'order' "
+                         "are 'ascending', 'descending', and 'random'.")
+
+    repeats = ensure_tensor_sequence(repeats, dtype=int)
+    degrees = torch.repeat_interleave(degrees, repeats)[:n_free]
+    degrees = _round_robin(degrees, length=n_free)
+
+    if conditioning_indices is not None:
+        try:
+            conditioning_indices = conditioning_indices.tolist()
+        except AttributeError:
+            pass
+        cond = set(conditioning_indices)
+        free_idx = [i for i in range(n_features) if i not in cond]
+        out = torch.empty(n_features, dtype=degrees.dtype)
+        out[list(conditioning_indices)] = -1
+        out[free_idx] = degrees
+        degrees = out
+    return degrees
+
+
+# =============================================================================
+# MADE
+# =============================================================================
+
+class MADE(Conditioner):
+    """Masked autoencoder conditioner: ``[MaskedLinear, ELU] * n_hidden + MaskedLinear``.
+
+    Arguments as reference made.py:246-284.  Output column ``p*D + f`` is parameter ``p``
+    of feature ``f`` when ``degrees_out = transformer.get_degrees_out(degrees)``.
+    """
+
+    def __init__(
+            self,
+            degrees_in: Sequence[int],
+            degrees_out: Sequence[int],
+            hidden_layers: Union[int, Sequence[int], Sequence[Sequence[int]]] = 2,
+            weight_norm: bool = True,
+    ):
+        super().__init__()
+        degrees_in = ensure_tensor_sequence(degrees_in, dtype=int)
+        degrees_out = ensure_tensor_sequence(degrees_out, dtype=int)
+        degrees_hidden = self._get_degrees_hidden(degrees_in, degrees_out, hidden_layers)
+        n_hidden = len(degrees_hidden)
+
+        layers = []
+        prev = degrees_in
+        for layer_idx in range(n_hidden + 1):
+            is_output = layer_idx == n_hidden
+            cur = degrees_out if is_output else degrees_hidden[layer_idx]
+            # hidden layers '>=', output layer strict '>' (reference made.py:308-309)
+            mask = masked.create_autoregressive_mask(prev, cur, strictly_less=is_output, transpose=True)
+            lin = masked.MaskedLinear(in_features=len(prev), out_features=len(cur), bias=True, mask=mask)
+            if weight_norm:
+                lin = masked.masked_weight_norm(lin, name='weight')
+            layers.extend([lin, torch.nn.ELU()])
+            prev = cur
+        layers.pop()
+        self.layers = torch.nn.Sequential(*layers)
+
+        # Host-side copy of the degrees (drives the degree sort of the execution plan).
+        self._degrees = [degrees_in.clone()] + [d.clone() for d in degrees_hidden] + [degrees_out.clone()]
+        self._plans = {}
+        self._frozen = False
+
+    # ------------------------------------------------------------------ reference API
+    @property
+    def dimension_in(self) -> int:
+        return self.layers[0].in_features
+
+    @property
+    def dimension_out(self) -> int:
+        return self.layers[-1].out_features
+
+    @property
+    def dimensions_hidden(self) -> torch.Tensor:
+        return torch.tensor([l.out_features for l in self.layers[:-1:2]])
+
+    @property
+    def weight_norm(self):
+        return self.layers[-1].has_weight_norm
+
+    def n_parameters(self) -> int:
+        """The total number of (unmasked) parameters."""
+        return sum(l.n_parameters() for l in self.layers[::2])
+
+    def set_output(self, output: torch.Tensor):
+        """Make the conditioner return ``output`` for any input (reference made.py:358-364)."""
+        last = self.layers[-1]
+        if self.weight_norm:
+            last.weight_g.data.fill_(0.0)
+        else:
+            last._parameters['weight'].data.fill_(0.0)
+        last.bias.data = output.to(last.bias.data)
+
+    @classmethod
+    def _get_degrees_hidden(cls, degrees_in, degrees_out, hidden_layers):
+        """Degrees of the hidden nodes (reference made.py:366-434)."""
+        try:
+            hidden_layers = hidden_layers.tolist()
+        except AttributeError:
+            pass
+        max_degree_out = degrees_out.max()
+        relevant = degrees_in < max_degree_out
+
+        if isinstance(hidden_layers, int):
+            n_rel = int(relevant.sum())
+            n_out = len(degrees_out)
+            width = max(int(np.ceil((n_rel * n_out) ** 0.5)), n_rel)
+            hidden_layers = [width] * hidden_layers
+
+        if isinstance(hidden_layers[0], int):
+            motif = degrees_in[relevant]
+            return [
+                _round_robin(motif, width, err_msg=(
+                    f'Hidden layer {idx} is too small for the number'
+                    ' of input features. Increase the size of the layer or'
+                    ' explicitly pass the degrees for the hidden layers.'))
+                for idx, width in enumerate(hidden_layers)
+            ]
+
+        degrees_hidden = [ensure_tensor_sequence(x) for x in hidden_layers]
+        for idx, deg in enumerate(degrees_hidden):
+            if torch.any(deg >= max_degree_out):
+                raise ValueError(f'The {idx}-th hidden layer contain '
+                                 'nodes with degrees that will be ignored '
+                                 'by the output layer.')
+        return degrees_hidden
+
+    # ------------------------------------------------------------------ execution plan
+    def _linears(self):
+        return list(self.layers[::2])
+
+    def invalidate_plan(self):
+        """Drop cached permutations / k-ranges (call after replacing a ``mask`` buffer)."""
+        self._plans = {}
+
+    def _apply(self, fn, *args, **kwargs):
+        self._plans = {}
+        return super()._apply(fn, *args, **kwargs)
+
+    def plan(self, device):
+        """Per-device plan: hidden-unit permutations, padded sizes, k-ranges, work buffers."""
+        key = str(device)
+        if key in self._plans:
+            return self._plans[key]
+        tm, tn, tk = ops.tile_sizes()
+        lins = self._linears()
+        n_lin = len(lins)
+        plan = {'row_of_out': [], 'col_of_in': [], 'n_pad': [], 'k_pad': [], 'k_ranges': [],
+                'w': [None] * n_lin, 'bias': [None] * n_lin}
+        col_of_in = None
+        for li, lin in enumerate(lins):
+            is_out = li == n_lin - 1
+            k_pad = ops.round_up(lin.in_features, tk)
+            if is_out:
+                row_of_out = None
+                n_pad = lin.out_features
+            else:
+                deg = self._degrees[li + 1]
+                order = torch.argsort(deg, stable=True)              # packed position -> hidden unit
+                row = torch.empty_like(order)
+                row[order] = torch.arange(len(order))                # hidden unit -> packed position
+                row_of_out = row.to(device=device, dtype=torch.int32)
+                n_pad = ops.round_up(lin.out_features, tk)
+            plan['row_of_out'].append(row_of_out)
+            plan['col_of_in'].append(col_of_in)
+            plan['n_pad'].append(n_pad)
+            plan['k_pad'].append(k_pad)
+            n_tiles = (n_pad + tn - 1) // tn
+            plan['k_ranges'].append(ops.mask_k_ranges(lin.mask, tn, n_tiles, k_pad, row_of_out, col_of_in))
+            col_of_in = row_of_out
+        self._plans[key] = plan
+        return plan
+
+    def _pack_layer(self, plan, li, lin, row_of_out=None, n_rows=None):
+        """Weight norm + mask + permutation + padding of layer ``li`` (every forward)."""
+        row_of_out = plan['row_of_out'][li] if row_of_out is None else row_of_out
+        n_rows = plan['n_pad'][li] if n_rows is None else n_rows
+        if lin.has_weight_norm:
+            v, g = lin.weight_v.detach(), lin.weight_g.detach()
+        else:
+            v, g = lin._parameters['weight'].detach(), None
+        key = ('w', li, n_rows)
+        if self._frozen and ('packed', li, n_rows) in plan:
+            return plan[('packed', li, n_rows)]
+        buf = plan.get(key)
+        if buf is None or buf.shape != (n_rows, plan['k_pad'][li]):
+            buf = torch.empty(n_rows, plan['k_pad'][li], dtype=torch.float32, device=v.device)
+            plan[key] = buf
+        ops.masked_weight_prepare(v, g, lin.mask, row_of_out, plan['col_of_in'][li], n_rows, plan['k_pad'][li], out=buf)
+        bias = torch.zeros(1, n_rows, dtype=torch.float32, device=v.device)
+        if row_of_out is None:
+            bias[0, :lin.out_features] = lin.bias.detach()
+        else:
+            ops.scatter_columns(lin.bias.detach()[None, :], row_of_out, bias)
+        if self._frozen:
+            plan[('packed', li, n_rows)] = (buf, bias[0])
+        return buf, bias[0]
+
+    def _embed(self, x):
+        return x
+
+    def frozen_weights(self):
+        """Context manager: pack the weights once and reuse them for every forward inside the
+        block (the D sequential passes of the autoregressive inverse share one set of weights)."""
+        return _FrozenWeights(self)
+
+    def forward_hidden(self, x):
+        """Run every layer but the last; returns the last hidden activations (zero padded,
+        units sorted by degree) and the plan."""
+        ops.check_device_tensor(x, 'x')
+        x = self._embed(x)
+        plan = self.plan(x.device)
+        lins = self._linears()
+        h = ops.pad_columns(x, plan['k_pad'][0])
+        for li, lin in enumerate(lins[:-1]):
+            w, b = self._pack_layer(plan, li, lin)
+            h = ops.masked_linear_packed(h, w, b, plan['n_pad'][li], k_ranges=plan['k_ranges'][li], act=1)
+        return h, plan
+
+    def forward(self, x):
+        lead = x.shape[:-1]
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.shape[1] != self.dimension_in:
+            raise ValueError(f'expected {self.dimension_in} input features, got {x2.shape[1]}')
+        h, plan = self.forward_hidden(x2)
+        li = len(plan['n_pad']) - 1
+        lin = self.layers[-1]
+        w, b = self._pack_layer(plan, li, lin)
+        out = ops.masked_linear_packed(h, w, b, lin.out_features, k_ranges=plan['k_ranges'][li], act=0)
+        return out.reshape(*lead, lin.out_features)
+
+
+class _FrozenWeights:
+    def __init__(self, made):
+        self.made = made
+
+    def _drop(self):
+        for plan in self.made._plans.values():
+            for k in [k for k in plan if isinstance(k, tuple) and k[0] == 'packed']:
+                del plan[k]
+
+    def __enter__(self):
+        self._drop()
+        self.made._frozen = True
+        return self.made
+
+    def __exit__(self, *a):
+        self.made._frozen = False
+        self._drop()
+        return False

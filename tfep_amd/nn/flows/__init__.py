@@ -1,0 +1,3 @@
+from .autoregressive import AutoregressiveFlow  # noqa: F401
+from .maf import MAF  # noqa: F401
+from .sequential import SequentialFlow  # noqa: F401

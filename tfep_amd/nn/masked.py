@@ -1,0 +1,188 @@
+"""Masked linear layers with the ``tfep.nn.masked`` API, computing on gfx950 kernels.
+
+Mirrors reference ``tfep/nn/masked.py``: ``create_autoregressive_mask`` (:36-108),
+``MaskedLinear`` (:115-213), ``masked_linear`` (:305), ``masked_weight_norm`` (:312-330),
+``remove_masked_weight_norm`` (:333-348).  Same constructor arguments, parameter / buffer
+names (``weight`` | ``weight_g`` + ``weight_v``, ``bias``, ``mask``) and error behaviour.
+
+The arithmetic runs in ``libtfep_hip.so``: the effective weight ``mask o g v/||v||`` is
+rebuilt by ``tfep_masked_weight_prepare`` on every forward (the reference does the same in
+a forward pre-hook, masked.py:397-398) and the product by the fp32-MFMA GEMM.  There is no
+CPU path: calling ``forward`` on CPU tensors raises.
+"""
+import numpy as np
+import torch
+from torch.nn.parameter import Parameter
+
+from .. import ops
+
+
+# =============================================================================
+# CREATE AUTOREGRESSIVE MASKS
+# =============================================================================
+
+def create_autoregressive_mask(degrees_in, degrees_out, strictly_less=True, transpose=False, dtype=None):
+    """0/1 mask connecting inputs to outputs of (strictly) greater degree.
+
+    Same semantics as reference masked.py:36-108: with ``transpose=True`` the mask has
+    shape ``(n_out, n_in)`` and ``mask[o, i] = deg_out[o] > deg_in[i]`` (``>=`` if
+    ``strictly_less`` is False).
+    """
+    degrees_in = torch.as_tensor(np.asarray(degrees_in) if not torch.is_tensor(degrees_in) else degrees_in)
+    degrees_out = torch.as_tensor(np.asarray(degrees_out) if not torch.is_tensor(degrees_out) else degrees_out)
+    if transpose:
+        a, b = degrees_out[:, None], degrees_in[None, :]
+    else:
+        a, b = degrees_out[None, :], degrees_in[:, None]
+    mask = (a > b) if strictly_less else (a >= b)
+    if dtype is None:
+        dtype = torch.get_default_dtype()
+    return mask.to(dtype)
+
+
+# =============================================================================
+# FUNCTIONAL API
+# =============================================================================
+
+def masked_linear(input, weight, bias=None, mask=None):
+    r"""``y = x (M o A)^T + b`` (reference masked.py:265-277), on the HIP GEMM.
+
+    ``input`` may have extra leading dimensions ``(batch, *, in_features)``.
+    """
+    lead = input.shape[:-1]
+    x2 = input.reshape(-1, input.shape[-1])
+    n_out, k = weight.shape
+    tm, tn, tk = ops.tile_sizes()
+    k_padded = ops.round_up(k, tk)
+    w = ops.masked_weight_prepare(weight, None, mask, k_padded=k_padded)
+    y = ops.masked_linear_packed(ops.pad_columns(x2, k_padded), w, bias, n_out)
+    return y.reshape(*lead, n_out)
+
+
+# =============================================================================
+# MODULE API
+# =============================================================================
+
+class MaskedLinear(torch.nn.Linear):
+    r"""Masked linear transformation :math:`y = x \cdot (M \circ A)^T + b`.
+
+    Constructor, attributes and ``state_dict`` keys as reference masked.py:115-213.
+    """
+
+    def __init__(self, in_features, out_features, bias=True, mask=None):
+        super().__init__(in_features, out_features, bias=bias)
+        self.register_buffer('mask', mask)
+        # Masked weights start at exactly 0 (masked.py:172-176).
+        if self.mask is not None:
+            self.weight.data = self.weight.data * self.mask
+
+    def n_parameters(self):
+        """int: The total number of (unmasked) parameters (masked.py:178-186)."""
+        if self.mask is None:
+            n = self._weight_numel()
+        else:
+            n = (self.mask != 0).sum()
+        if self.bias is not None:
+            n = n + self.bias.numel()
+        return n
+
+    def _weight_numel(self):
+        return self.out_features * self.in_features
+
+    @property
+    def has_weight_norm(self):
+        return 'weight_g' in self._parameters
+
+    def effective_weight(self):
+        """The masked (and weight-normalised) weight as a dense ``(out, in)`` HIP tensor."""
+        if self.has_weight_norm:
+            w = ops.masked_weight_prepare(self.weight_v.detach(), self.weight_g.detach(), self.mask,
+                                          k_padded=self.in_features)
+        else:
+            w = ops.masked_weight_prepare(self._parameters['weight'].detach(), None, self.mask,
+                                          k_padded=self.in_features)
+        return w
+
+    def __getattr__(self, name):
+        # With weight norm the reference exposes ``module.weight`` as the recomputed tensor
+        # (masked.py:395); here it is computed on demand.
+        if name == 'weight' and 'weight_g' in self.__dict__.get('_parameters', {}):
+            return self.effective_weight()
+        return super().__getattr__(name)
+
+    def forward(self, input):
+        lead = input.shape[:-1]
+        x2 = input.reshape(-1, input.shape[-1])
+        tm, tn, tk = ops.tile_sizes()
+        k_padded = ops.round_up(self.in_features, tk)
+        if self.has_weight_norm:
+            w = ops.masked_weight_prepare(self.weight_v.detach(), self.weight_g.detach(), self.mask,
+                                          k_padded=k_padded)
+        else:
+            w = ops.masked_weight_prepare(self._parameters['weight'].detach(), None, self.mask, k_padded=k_padded)
+        bias = None if self.bias is None else self.bias.detach()
+        y = ops.masked_linear_packed(ops.pad_columns(x2, k_padded), w, bias, self.out_features)
+        return y.reshape(*lead, self.out_features)
+
+    def extra_repr(self):
+        return 'in_features={}, out_features={}, bias={}, weight_norm={}'.format(
+            self.in_features, self.out_features, self.bias is not None, self.has_weight_norm)
+
+
+# =============================================================================
+# WEIGHT NORMALIZATION
+# =============================================================================
+
+def masked_weight_norm(module, name='weight', dim=0):
+    """NaN-free weight normalisation of a (masked) linear module (reference masked.py:312-404).
+
+    Replaces parameter ``name`` with ``name_g`` (per-row norm, shape ``(out, 1)``) and
+    ``name_v`` (direction).  Gradient hooks keep masked entries of ``v`` and fully-masked
+    rows of ``g`` at zero gradient (masked.py:401-402), for optimisers run by the caller.
+    """
+    if name + '_g' in module._parameters:
+        raise RuntimeError("Cannot register two weight_norm hooks on the same parameter {}".format(name))
+    if dim != 0:
+        raise ValueError('masked_weight_norm supports dim=0 (one norm per output row) only.')
+    mask = getattr(module, 'mask', None)
+    weight = module._parameters[name]
+    del module._parameters[name]
+    g = Parameter(torch.linalg.vector_norm(weight.data, ord=2, dim=1, keepdim=True))
+    v = Parameter(weight.data)
+    module.register_parameter(name + '_g', g)
+    module.register_parameter(name + '_v', v)
+    if mask is not None:
+        zero_rows = (torch.linalg.vector_norm(mask, ord=2, dim=1) == 0.0)
+        zero_entries = mask == 0.0
+
+        def _g_hook(grad, zero_rows=zero_rows):
+            grad = grad.clone()
+            grad[zero_rows.to(grad.device)] = 0.0
+            return grad
+
+        def _v_hook(grad, zero_entries=zero_entries):
+            grad = grad.clone()
+            grad[zero_entries.to(grad.device)] = 0.0
+            return grad
+
+        module._tfep_wn_hooks = (g.register_hook(_g_hook), v.register_hook(_v_hook))
+    return module
+
+
+def remove_masked_weight_norm(module, name='weight'):
+    """Fold ``g``/``v`` back into a plain ``weight`` parameter (reference masked.py:333-348)."""
+    if name + '_g' not in module._parameters:
+        raise ValueError("weight_norm of '{}' not found in {}".format(name, module))
+    g = module._parameters[name + '_g']
+    v = module._parameters[name + '_v']
+    norm = torch.linalg.vector_norm(v.data, ord=2, dim=1, keepdim=True)
+    w = v.data * (g.data / norm)
+    mask = getattr(module, 'mask', None)
+    if mask is not None:
+        w[mask == 0.0] = 0.0
+    for h in getattr(module, '_tfep_wn_hooks', ()):
+        h.remove()
+    del module._parameters[name + '_g']
+    del module._parameters[name + '_v']
+    module.register_parameter(name, Parameter(w))
+    return module

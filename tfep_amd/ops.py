@@ -1,0 +1,225 @@
+"""Tensor-level wrappers of the C ABI (one function per entry point of include/tfep_hip.h).
+
+Every function takes float32 HIP tensors, launches on the current HIP stream of the
+tensor's device and returns fresh output tensors (inputs are never modified, like the
+reference: flows/autoregressive.py:165-166).  No autograd, no CPU path.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ParamLayout, SplineDesc, call, check_device_tensor, ptr, rows, stream_of
+
+
+def _ldj_out(log_det_J, B, like):
+    """Return (tensor, accumulate flag): accumulate into ``log_det_J`` if given."""
+    if log_det_J is None:
+        return torch.empty(B, dtype=torch.float32, device=like.device), 0
+    check_device_tensor(log_det_J, 'log_det_J')
+    if log_det_J.shape != (B,) or not log_det_J.is_contiguous():
+        raise ValueError('log_det_J must be a contiguous (batch,) tensor')
+    return log_det_J, 1
+
+
+def _check_params(parameters, B, n, name='parameters'):
+    parameters, ld = rows(parameters, name)
+    if parameters.shape[0] != B or parameters.shape[1] != n:
+        raise ValueError(f'{name} must have shape ({B}, {n}), got {tuple(parameters.shape)}')
+    return parameters, ld
+
+
+def _layout(ld, D, layout=None):
+    if layout is not None:
+        return ParamLayout(*layout)
+    return ParamLayout(ld, D, 1)                          # reference layout: column p*D + f
+
+
+# ----------------------------------------------------------------------------- affine
+
+def affine(x, parameters, inverse=False, log_det_J=None):
+    """AffineTransformer.forward / .inverse (reference affine.py:51-106)."""
+    x, ldx = rows(x, 'x')
+    B, D = x.shape
+    parameters, ldp = _check_params(parameters, B, 2 * D)
+    y = torch.empty(B, D, dtype=x.dtype, device=x.device)
+    ldj, acc = _ldj_out(log_det_J, B, x)
+    fn = 'tfep_affine_inverse' if inverse else 'tfep_affine_forward'
+    call(fn, ptr(x), ldx, ptr(parameters), _layout(ldp, D), ptr(y), max(D, 1), ptr(ldj), acc, B, D, stream_of(x))
+    return y, ldj
+
+
+def volume_preserving_shift(x, shift, periodic_mask=None, limits=(0.0, 1.0), inverse=False):
+    """VolumePreservingShiftTransformer (reference affine.py:366-456); log-det is zero."""
+    x, ldx = rows(x, 'x')
+    B, D = x.shape
+    shift, lds = _check_params(shift, B, D, 'shift')
+    y = torch.empty(B, D, dtype=x.dtype, device=x.device)
+    if periodic_mask is not None:
+        check_device_tensor(periodic_mask, 'periodic_mask', torch.int32)
+    call('tfep_volume_preserving_shift', ptr(x), ldx, ptr(shift), lds,
+         ptr(periodic_mask), float(limits[0]), float(limits[1]), -1 if inverse else 1,
+         ptr(y), max(D, 1), B, D, stream_of(x))
+    return y, torch.zeros(B, dtype=x.dtype, device=x.device)
+
+
+# ----------------------------------------------------------------------------- spline
+
+class SplineConfig:
+    """Host mirror of tfep_spline_desc; keeps the (D,) device arrays alive."""
+
+    def __init__(self, x0, xf, y0, yf, n_bins, circular=False, identity_boundary_slopes=False,
+                 learn_lower_bound=False, learn_upper_bound=False, min_bin_size=1e-4, min_slope=1e-4):
+        self.x0, self.xf, self.y0, self.yf = (check_device_tensor(t.contiguous(), n)
+                                              for t, n in ((x0, 'x0'), (xf, 'xf'), (y0, 'y0'), (yf, 'yf')))
+        self.desc = SplineDesc(self.x0.data_ptr(), self.xf.data_ptr(), self.y0.data_ptr(), self.yf.data_ptr(),
+                               int(n_bins), int(bool(circular)), int(bool(identity_boundary_slopes)),
+                               int(bool(learn_lower_bound)), int(bool(learn_upper_bound)),
+                               float(min_bin_size), float(min_slope))
+        self.n_parameters_per_feature = _lib.load().tfep_spline_n_parameters_per_feature(ctypes.byref(self.desc))
+
+
+def spline(x, parameters, cfg, inverse=False, log_det_J=None, layout=None):
+    """NeuralSplineTransformer.forward / .inverse (reference spline.py:184-261)."""
+    x, ldx = rows(x, 'x')
+    B, D = x.shape
+    P = cfg.n_parameters_per_feature
+    if cfg.x0.numel() != D:
+        raise ValueError(f'spline domain has {cfg.x0.numel()} features, input has {D}')
+    parameters, ldp = _check_params(parameters, B, P * D)
+    y = torch.empty(B, D, dtype=x.dtype, device=x.device)
+    ldj, acc = _ldj_out(log_det_J, B, x)
+    fn = 'tfep_spline_inverse' if inverse else 'tfep_spline_forward'
+    call(fn, ptr(x), ldx, ptr(parameters), _layout(ldp, D, layout), ctypes.byref(cfg.desc),
+         ptr(y), max(D, 1), ptr(ldj), acc, B, D, stream_of(x))
+    return y, ldj
+
+
+# ----------------------------------------------------------------------------- moebius
+
+def moebius(x, parameters, dimension, max_radius=0.99, unit_sphere=False, inverse=False, log_det_J=None):
+    """MoebiusTransformer.forward / .inverse (reference moebius.py:104-147, :374-478)."""
+    x, ldx = rows(x, 'x')
+    B, D = x.shape
+    parameters, ldp = _check_params(parameters, B, D)
+    y = torch.empty(B, D, dtype=x.dtype, device=x.device)
+    ldj, acc = _ldj_out(log_det_J, B, x)
+    call('tfep_moebius_forward', ptr(x), ldx, ptr(parameters), ldp,
+         int(dimension), float(max_radius), int(bool(unit_sphere)), -1 if inverse else 1,
+         ptr(y), max(D, 1), ptr(ldj), acc, B, D, stream_of(x))
+    return y, ldj
+
+
+# ----------------------------------------------------------------------------- embedding / index helpers
+
+def periodic_embedding(x, periodic_indices, nonperiodic_indices, lower, upper):
+    """PeriodicEmbedding.forward (reference mafembed.py:112-145)."""
+    x, ldx = rows(x, 'x')
+    B = x.shape[0]
+    n_per, n_non = periodic_indices.numel(), nonperiodic_indices.numel()
+    out = torch.empty(B, n_non + 2 * n_per, dtype=x.dtype, device=x.device)
+    call('tfep_periodic_embedding', ptr(x), ldx, ptr(periodic_indices), n_per, ptr(nonperiodic_indices), n_non,
+         float(lower), float(upper), ptr(out), n_non + 2 * n_per, B, stream_of(x))
+    return out
+
+
+def gather_columns(src, idx):
+    src, lds = rows(src, 'src')
+    B, n = src.shape[0], idx.numel()
+    dst = torch.empty(B, n, dtype=src.dtype, device=src.device)
+    call('tfep_gather_columns', ptr(src), lds, ptr(idx), n, ptr(dst), n, B, stream_of(src))
+    return dst
+
+
+def scatter_columns(src, idx, dst):
+    """dst[:, idx[j]] = src[:, j] (in place on ``dst``, which the caller owns)."""
+    src, lds = rows(src, 'src')
+    B, n = src.shape[0], idx.numel()
+    if not dst.is_contiguous():
+        raise ValueError('dst must be contiguous')
+    call('tfep_scatter_columns', ptr(src), lds, ptr(idx), n, ptr(dst), dst.shape[1], B, stream_of(src))
+    return dst
+
+
+# ----------------------------------------------------------------------------- masked linear
+
+def tile_sizes():
+    lib = _lib.load()
+    return lib.tfep_masked_linear_tile_m(), lib.tfep_masked_linear_tile_n(), lib.tfep_masked_linear_tile_k()
+
+
+def round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+def pad_columns(x, k_padded):
+    """Return ``x`` as a (B, k_padded) buffer with zero padding (GEMM operand contract)."""
+    x, _ = rows(x, 'x')
+    B, K = x.shape
+    if K == k_padded and x.stride(0) == K and x.data_ptr() % 16 == 0:
+        return x
+    out = torch.zeros(B, k_padded, dtype=x.dtype, device=x.device)
+    out[:, :K] = x
+    return out
+
+
+def masked_weight_prepare(weight_v, weight_g=None, mask=None, row_of_out=None, col_of_in=None,
+                          n_rows_padded=None, k_padded=None, out=None):
+    """Effective masked weight, permuted + zero padded (reference masked.py:369-371, :433-439, :270)."""
+    check_device_tensor(weight_v, 'weight')
+    N, K = weight_v.shape
+    tk = tile_sizes()[2]
+    n_rows_padded = N if n_rows_padded is None else n_rows_padded
+    k_padded = round_up(K, tk) if k_padded is None else k_padded
+    if out is None:
+        out = torch.empty(n_rows_padded, k_padded, dtype=torch.float32, device=weight_v.device)
+    call('tfep_masked_weight_prepare', ptr(weight_v.contiguous()),
+         ptr(None if weight_g is None else weight_g.contiguous()),
+         ptr(None if mask is None else mask.contiguous()), N, K, ptr(row_of_out), ptr(col_of_in),
+         ptr(out), n_rows_padded, k_padded, stream_of(weight_v))
+    return out
+
+
+def mask_k_ranges(mask, tile_n, n_tiles, k_padded, row_of_out=None, col_of_in=None):
+    check_device_tensor(mask, 'mask')
+    N, K = mask.shape
+    out = torch.empty(n_tiles, 2, dtype=torch.int32, device=mask.device)
+    call('tfep_mask_k_ranges', ptr(mask.contiguous()), N, K, ptr(row_of_out), ptr(col_of_in), tile_n,
+         tile_sizes()[2], n_tiles, k_padded, ptr(out), stream_of(mask))
+    return out
+
+
+def masked_linear_packed(x_padded, w_packed, bias, n_out, k_ranges=None, col_map=None, act=0, out=None,
+                         out_cols=None):
+    """y = act(x W^T + b) on packed operands (reference masked.py:265-277 + made.py:320)."""
+    B = x_padded.shape[0]
+    n_rows_w, k_padded = w_packed.shape
+    if out is None:
+        out = torch.empty(B, n_out if out_cols is None else out_cols, dtype=torch.float32, device=x_padded.device)
+    call('tfep_masked_linear_forward', ptr(x_padded), x_padded.shape[1], ptr(w_packed), k_padded,
+         ptr(bias), ptr(k_ranges), ptr(col_map), ptr(out), out.shape[1], B, n_out, n_rows_w, k_padded, int(act),
+         stream_of(x_padded))
+    return out
+
+
+# ----------------------------------------------------------------------------- reductions
+
+def tfep_reduce(target_potentials, log_det_J=None, ref_potentials=None, log_weights=None, bias=None,
+                kT=1.0, ignore_nan=False):
+    """The 9 float64 sufficient statistics of the TFEP loss / estimator (see tfep_hip.h)."""
+    t = check_device_tensor(target_potentials.contiguous(), 'target_potentials')
+    N = t.numel()
+    opt = []
+    for v, n in ((log_det_J, 'log_det_J'), (ref_potentials, 'ref_potentials'), (log_weights, 'log_weights'),
+                 (bias, 'bias')):
+        if v is not None:
+            v = check_device_tensor(v.contiguous(), n)
+            if v.numel() != N:
+                raise ValueError(f'{n} must have {N} elements')
+        opt.append(v)
+    nws = _lib.load().tfep_tfep_reduce_workspace_doubles(N)
+    ws = torch.empty(nws, dtype=torch.float64, device=t.device)
+    out = torch.empty(9, dtype=torch.float64, device=t.device)
+    call('tfep_tfep_reduce', ptr(t), ptr(opt[0]), ptr(opt[1]), ptr(opt[2]), ptr(opt[3]), float(kT),
+         int(bool(ignore_nan)), N, ptr(ws), ptr(out), stream_of(t))
+    return out
