@@ -45,7 +45,7 @@ def test_affine_volpres():
     t = AffineTransformer()
     y, l = t(dev(g['affine/x']), dev(g['affine/par']))
     check_y(y, g['affine/y_f64']); check_ldj(l, g['affine/ldj_f64'])
-    x, l = t.inverse(dev(g['affine/y_f64']), dev(g['affine/par']))
+    x, l = t.inverse(dev(g['affine/inv_in']), dev(g['affine/par']))
     check_y(x, g['affine/xinv_f64'], what='x'); check_ldj(l, g['affine/ldjinv_f64'])
 
     t = VolumePreservingShiftTransformer(torch.from_numpy(g['volpres/periodic_indices']),
@@ -74,7 +74,7 @@ def test_spline_variants(name):
     par = dev(g[name + '/par'])
     y, l = t(dev(g[name + '/x']), par)
     check_y(y, g[name + '/y_f64']); check_ldj(l, g[name + '/ldj_f64'])
-    x, l = t.inverse(dev(g[name + '/y_f64']), par)
+    x, l = t.inverse(dev(g[name + '/inv_in']), par)
     check_y(x, g[name + '/xinv_f64'], what='x'); check_ldj(l, g[name + '/ldjinv_f64'])
 
 
@@ -87,7 +87,7 @@ def test_moebius(name):
     par = dev(g[name + '/par'])
     y, l = t(dev(g[name + '/x']), par)
     check_y(y, g[name + '/y_f64']); check_ldj(l, g[name + '/ldj_f64'])
-    x, l = t.inverse(dev(g[name + '/y_f64']), par)
+    x, l = t.inverse(dev(g[name + '/inv_in']), par)
     check_y(x, g[name + '/xinv_f64'], what='x'); check_ldj(l, g[name + '/ldjinv_f64'])
 
 
@@ -99,19 +99,20 @@ def test_mixed_and_periodic_embedding():
                               dict(type='affine'),
                               dict(type='spline', x0=np.full(2, -1.0), xf=np.full(2, 1.0), n_bins=3, circular=True)],
                 indices=[[0, 2, 5], [1, 3], [4, 6]])
-    t = gu.build_transformer(spec).cuda()
+    t = gu.build_transformer(spec)
     assert t._parameters_split_indices.tolist() == g['mixed/split'].tolist()
     assert t.get_degrees_out(torch.arange(7)).tolist() == g['mixed/degrees_out'].tolist()
+    t = t.cuda()
     par = dev(g['mixed/par'])
     y, l = t(dev(g['mixed/x']), par)
     check_y(y, g['mixed/y_f64']); check_ldj(l, g['mixed/ldj_f64'])
-    x, l = t.inverse(dev(g['mixed/y_f64']), par)
+    x, l = t.inverse(dev(g['mixed/inv_in']), par)
     check_y(x, g['mixed/xinv_f64'], what='x'); check_ldj(l, g['mixed/ldjinv_f64'])
 
-    emb = PeriodicEmbedding(6, [0.0, 1.0], periodic_indices=[1, 2, 5]).cuda()
-    out = emb(dev(g['pemb/x']))
-    np.testing.assert_allclose(out.cpu().numpy(), g['pemb/y_f64'], rtol=0, atol=2e-6)
+    emb = PeriodicEmbedding(6, [0.0, 1.0], periodic_indices=[1, 2, 5])
     assert emb.get_degrees_out(torch.arange(6)).tolist() == g['pemb/degrees_out'].tolist()
+    out = emb.cuda()(dev(g['pemb/x']))
+    np.testing.assert_allclose(out.cpu().numpy(), g['pemb/y_f64'], rtol=0, atol=2e-6)
 
 
 def test_empty_and_ragged_batches():

@@ -6,8 +6,8 @@
 //   _assign_bins     :567-650   bin = #{knots < x} - 1 with STRICT '>', linear tails
 //   forward/inverse  :478-494 / :521-536, log-det :546-564, circular shift :236-238 / :257-259
 //
-// Numerics: exp / log / softplus in fp32 (<= 1 ulp libm), everything geometric
-// (knot prefix sums, epsilon, the rational quadratic, the log-derivative sum) in fp64,
+// Numerics: the softmax of widths / heights and everything geometric (knot prefix sums,
+// epsilon, the rational quadratic, the log-derivative sum) in fp64; softplus / log in fp32,
 // so the result tracks the fp64 reference to ~1e-7 relative instead of inheriting the
 // fp32 cancellation of (x - x_k)/w.  The two sentinel knots of the
 // reference are algebraically a linear map with the boundary slope; it is evaluated directly.
@@ -68,7 +68,7 @@ __device__ inline double rq_spline_element(const float (&w)[KMAX], const float (
     double W = (double)xff - (double)x0f - K * mb;
     double H = (double)yff - (double)y0f - K * mb;
     if (f.learn_lower || f.learn_upper) {
-        double scale = (double)expf(last);
+        double scale = exp((double)last);
         W *= scale;
         H *= scale;
         if (f.learn_lower && f.learn_upper) {
@@ -94,20 +94,22 @@ __device__ inline double rq_spline_element(const float (&w)[KMAX], const float (
             mw = fmaxf(mw, w[k]);
             mh = fmaxf(mh, h[k]);
         }
-    float ew[KMAX], eh[KMAX];
-    float sw = 0.f, sh = 0.f;
+    // exp in fp64: a 1-ulp fp32 softmax moves the knots by ~2e-7 of the domain, which a narrow
+    // bin amplifies to > 1e-5 in the log-derivative.
+    double ew[KMAX], eh[KMAX];
+    double sw = 0.0, sh = 0.0;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
-        ew[k] = 0.f;
-        eh[k] = 0.f;
+        ew[k] = 0.0;
+        eh[k] = 0.0;
         if (k < K) {
-            ew[k] = expf(w[k] - mw);
-            eh[k] = expf(h[k] - mh);
+            ew[k] = exp((double)w[k] - (double)mw);
+            eh[k] = exp((double)h[k] - (double)mh);
             sw += ew[k];
             sh += eh[k];
         }
     }
-    const double iw = W / (double)sw, ih = H / (double)sh;
+    const double iw = W / sw, ih = H / sh;
 
     // ---- bin search: strict '>' (spline.py:622-625).  v <= first knot -> lower tail.
     double kx = x0, ky = y0;          // lower knot of the current bin
@@ -120,8 +122,8 @@ __device__ inline double rq_spline_element(const float (&w)[KMAX], const float (
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         if (k < K) {
-            const double wk = (double)ew[k] * iw + mb;
-            const double hk = (double)eh[k] * ih + mb;
+            const double wk = ew[k] * iw + mb;
+            const double hk = eh[k] * ih + mb;
             if (!found) {
                 const double upper = INVERSE ? (ky + hk) : (kx + wk);
                 if (v > upper) {

@@ -277,9 +277,9 @@ static int launch_spline(const float* x, int64_t ldx, const float* params, tfep_
     SplineArgs a;
     int rc = make_spline_args(desc, &a);
     if (rc) return rc;
-    TFEP_REQUIRE(x && params && y, "spline: x/params/y must be non-NULL");
     TFEP_REQUIRE(B >= 0 && D >= 0, "spline: negative size");
     if (B == 0) return TFEP_OK;
+    TFEP_REQUIRE(x && params && y, "spline: x/params/y must be non-NULL");
     hipStream_t s = (hipStream_t)stream;
     if (a.f.K <= 8)
         spline_kernel<8, INVERSE><<<row_blocks(B), 256, 0, s>>>(x, ldx, params, L, a, y, ldy, ldj, accumulate, B, D);
@@ -301,9 +301,9 @@ const char* tfep_last_error(void) { return last_error().c_str(); }
 
 int tfep_affine_forward(const float* x, int64_t ldx, const float* params, tfep_param_layout layout, float* y,
                         int64_t ldy, float* log_det_J, int accumulate, int B, int D, void* stream) {
-    TFEP_REQUIRE(x && params && y, "affine: x/params/y must be non-NULL");
     TFEP_REQUIRE(B >= 0 && D >= 0, "affine: negative size");
     if (B == 0) return TFEP_OK;
+    TFEP_REQUIRE(x && params && y, "affine: x/params/y must be non-NULL");
     affine_kernel<false><<<row_blocks(B), 256, 0, (hipStream_t)stream>>>(x, ldx, params, layout, y, ldy, log_det_J,
                                                                          accumulate, B, D);
     return check_launch("affine_kernel");
@@ -311,9 +311,9 @@ int tfep_affine_forward(const float* x, int64_t ldx, const float* params, tfep_p
 
 int tfep_affine_inverse(const float* y, int64_t ldy, const float* params, tfep_param_layout layout, float* x,
                         int64_t ldx, float* log_det_J, int accumulate, int B, int D, void* stream) {
-    TFEP_REQUIRE(x && params && y, "affine: x/params/y must be non-NULL");
     TFEP_REQUIRE(B >= 0 && D >= 0, "affine: negative size");
     if (B == 0) return TFEP_OK;
+    TFEP_REQUIRE(x && params && y, "affine: x/params/y must be non-NULL");
     affine_kernel<true><<<row_blocks(B), 256, 0, (hipStream_t)stream>>>(y, ldy, params, layout, x, ldx, log_det_J,
                                                                         accumulate, B, D);
     return check_launch("affine_kernel");
@@ -322,9 +322,9 @@ int tfep_affine_inverse(const float* y, int64_t ldy, const float* params, tfep_p
 int tfep_volume_preserving_shift(const float* x, int64_t ldx, const float* shift, int64_t ldp,
                                  const int32_t* periodic_mask, float lower, float upper, int sign, float* y,
                                  int64_t ldy, int B, int D, void* stream) {
-    TFEP_REQUIRE(x && shift && y, "volume_preserving_shift: x/shift/y must be non-NULL");
     TFEP_REQUIRE(sign == 1 || sign == -1, "volume_preserving_shift: sign must be +1 or -1");
     if ((int64_t)B * D == 0) return TFEP_OK;
+    TFEP_REQUIRE(x && shift && y, "volume_preserving_shift: x/shift/y must be non-NULL");
     const int64_t n = (int64_t)B * D;
     volpres_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, ldx, shift, ldp, periodic_mask,
                                                                                  lower, upper, (float)sign, y, ldy, B, D);
@@ -352,7 +352,7 @@ int tfep_spline_inverse(const float* y, int64_t ldy, const float* params, tfep_p
 int tfep_moebius_forward(const float* x, int64_t ldx, const float* params, int64_t ldp, int dimension,
                          float max_radius, int unit_sphere, int sign, float* y, int64_t ldy, float* log_det_J,
                          int accumulate, int B, int D, void* stream) {
-    TFEP_REQUIRE(x && params && y, "moebius: x/params/y must be non-NULL");
+    TFEP_REQUIRE(B == 0 || (x && params && y), "moebius: x/params/y must be non-NULL");
     TFEP_REQUIRE(dimension >= 1 && dimension <= MOEBIUS_MAX_DIM, "moebius: dimension=%d unsupported (1..%d)", dimension,
                  MOEBIUS_MAX_DIM);
     TFEP_REQUIRE(D % dimension == 0, "moebius: n_features=%d is not a multiple of dimension=%d", D, dimension);
@@ -367,7 +367,7 @@ int tfep_moebius_forward(const float* x, int64_t ldx, const float* params, int64
 int tfep_periodic_embedding(const float* x, int64_t ldx, const int32_t* periodic_indices, int n_periodic,
                             const int32_t* nonperiodic_indices, int n_nonperiodic, float lower, float upper,
                             float* out, int64_t ldo, int B, void* stream) {
-    TFEP_REQUIRE(x && out, "periodic_embedding: x/out must be non-NULL");
+    TFEP_REQUIRE(B == 0 || (x && out), "periodic_embedding: x/out must be non-NULL");
     TFEP_REQUIRE(n_periodic == 0 || periodic_indices, "periodic_embedding: periodic_indices is NULL");
     TFEP_REQUIRE(n_nonperiodic == 0 || nonperiodic_indices, "periodic_embedding: nonperiodic_indices is NULL");
     const int64_t n = (int64_t)B * (n_periodic + n_nonperiodic);
@@ -380,18 +380,18 @@ int tfep_periodic_embedding(const float* x, int64_t ldx, const int32_t* periodic
 
 int tfep_gather_columns(const float* src, int64_t lds, const int32_t* idx, int n_idx, float* dst, int64_t ldd, int B,
                         void* stream) {
-    TFEP_REQUIRE(src && dst && (idx || n_idx == 0), "gather_columns: NULL pointer");
     const int64_t n = (int64_t)B * n_idx;
     if (n == 0) return TFEP_OK;
+    TFEP_REQUIRE(src && dst && idx, "gather_columns: NULL pointer");
     columns_kernel<false><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, lds, idx, n_idx, dst, ldd, B);
     return check_launch("gather_columns");
 }
 
 int tfep_scatter_columns(const float* src, int64_t lds, const int32_t* idx, int n_idx, float* dst, int64_t ldd, int B,
                          void* stream) {
-    TFEP_REQUIRE(src && dst && (idx || n_idx == 0), "scatter_columns: NULL pointer");
     const int64_t n = (int64_t)B * n_idx;
     if (n == 0) return TFEP_OK;
+    TFEP_REQUIRE(src && dst && idx, "scatter_columns: NULL pointer");
     columns_kernel<true><<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, lds, idx, n_idx, dst, ldd, B);
     return check_launch("scatter_columns");
 }

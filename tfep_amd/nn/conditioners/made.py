@@ -291,6 +291,8 @@ class MADE(Conditioner):
         units sorted by degree) and the plan."""
         ops.check_device_tensor(x, 'x')
         x = self._embed(x)
+        if x.shape[1] != self.dimension_in:
+            raise ValueError(f'expected {self.dimension_in} input features, got {x.shape[1]}')
         plan = self.plan(x.device)
         lins = self._linears()
         h = ops.pad_columns(x, plan['k_pad'][0])
@@ -302,8 +304,6 @@ class MADE(Conditioner):
     def forward(self, x):
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
-        if x2.shape[1] != self.dimension_in:
-            raise ValueError(f'expected {self.dimension_in} input features, got {x2.shape[1]}')
         h, plan = self.forward_hidden(x2)
         li = len(plan['n_pad']) - 1
         lin = self.layers[-1]

@@ -275,8 +275,13 @@ def run_transformer(make, x, par):
     with f64():
         t64 = make(torch.float64)
         y64, l64 = t64(x.double(), par.double())
-        xi, li = t64.inverse(y64, par.double())
+        # The inverse is evaluated on a float32-representable input (the rounded forward output):
+        # where the map is flat, x = f^-1(y) amplifies the rounding of y by 1/f', so a float32
+        # implementation can only be compared on inputs it can represent.
+        yin = y64.detach().float()
+        xi, li = t64.inverse(yin.double(), par.double())
         out['y_f64'], out['ldj_f64'] = npy(y64), npy(l64)
+        out['inv_in'] = npy(yin)
         out['xinv_f64'], out['ldjinv_f64'] = npy(xi), npy(li)
     return out
 
