@@ -139,7 +139,7 @@ class MADE(Conditioner):
         self.layers = torch.nn.Sequential(*layers)
 
         # Host-side copy of the degrees (drives the degree sort of the execution plan).
-        self._degrees = [degrees_in.clone()] + [d.clone() for d in degrees_hidden] + [degrees_out.clone()]
+        self._degrees = [d.detach().cpu().clone() for d in (degrees_in, *degrees_hidden, degrees_out)]
         self._plans = {}
         self._frozen = False
 
@@ -237,10 +237,10 @@ class MADE(Conditioner):
                 row_of_out = None
                 n_pad = lin.out_features
             else:
-                deg = self._degrees[li + 1]
+                deg = self._degrees[li + 1].cpu()
                 order = torch.argsort(deg, stable=True)              # packed position -> hidden unit
                 row = torch.empty_like(order)
-                row[order] = torch.arange(len(order))                # hidden unit -> packed position
+                row[order] = torch.arange(len(order), device='cpu')                # hidden unit -> packed position
                 row_of_out = row.to(device=device, dtype=torch.int32)
                 n_pad = ops.round_up(lin.out_features, tk)
             plan['row_of_out'].append(row_of_out)

@@ -89,23 +89,31 @@ class AutoregressiveFlow(torch.nn.Module):
             return t
         i32 = dict(device=device, dtype=torch.int32)
         n_in = self._inverse_masks.shape[1]
-        tr = self._transformer_indices if self.has_fixed_indices else torch.arange(n_in)
-        tr = tr.cpu()
+        tr = self._transformer_indices.cpu() if self.has_fixed_indices else torch.arange(n_in, device='cpu')
         t = {
             'tr': tr.to(**i32), 'fixed': self._fixed_indices.to(**i32),
             'cond': self._conditioner_indices.to(**i32),
             'n_tr': len(tr),
         }
-        # inverse: per pass, columns of x to commit and their position among transformer features
-        pos = torch.full((n_in,), -1, dtype=torch.long)
-        pos[tr] = torch.arange(len(tr))
-        steps = []
-        for m in self._inverse_masks.cpu():
-            cols = torch.nonzero(m).flatten()
-            steps.append((cols.to(**i32), pos[cols].to(**i32)))
-        t['inverse_steps'] = steps
         self._dev[key] = t
         return t
+
+    def _inverse_steps(self, device):
+        """Per inverse pass: the columns of x to commit and their position among the transformer
+        features (reference autoregressive.py:203-227)."""
+        t = self._tables(device)
+        if 'inverse_steps' not in t:
+            i32 = dict(device=device, dtype=torch.int32)
+            n_in = self._inverse_masks.shape[1]
+            tr = t['tr'].cpu().long()
+            pos = torch.full((n_in,), -1, dtype=torch.long, device='cpu')
+            pos[tr] = torch.arange(len(tr), device='cpu')
+            steps = []
+            for m in self._inverse_masks.cpu():
+                cols = torch.nonzero(m).flatten()
+                steps.append((cols.to(**i32), pos[cols].to(**i32)))
+            t['inverse_steps'] = steps
+        return t['inverse_steps']
 
     # ------------------------------------------------------------------ fused path
     def _fused_kind(self):
@@ -136,16 +144,16 @@ class AutoregressiveFlow(torch.nn.Module):
         tile_cols = lib.tfep_fused_tile_columns(kind, ctypes.byref(desc) if desc is not None else None)
         FT = tile_cols // (16 * P)
         n_slots = ops.round_up(n_tr, 16 * FT)
-        deg_tr = made._degrees[-1][:n_tr]
+        deg_tr = made._degrees[-1][:n_tr].cpu()
         order = torch.argsort(deg_tr, stable=True)                 # slot -> transformed feature
         slot_of = torch.empty_like(order)
-        slot_of[order] = torch.arange(n_tr)
-        feat_tr = torch.zeros(n_slots, dtype=torch.long)
+        slot_of[order] = torch.arange(n_tr, device='cpu')
+        feat_tr = torch.zeros(n_slots, dtype=torch.long, device='cpu')
         feat_tr[:n_tr] = order
-        feat_index = torch.full((n_slots,), -1, dtype=torch.long)
+        feat_index = torch.full((n_slots,), -1, dtype=torch.long, device='cpu')
         feat_index[:n_tr] = tables['tr'].cpu().long()[order]
         s = slot_of.repeat(P)                                      # slot of output row o = p*n_tr + t
-        p = torch.arange(P).repeat_interleave(n_tr)
+        p = torch.arange(P, device='cpu').repeat_interleave(n_tr)
         row_of_out = (s // (16 * FT)) * tile_cols + (((s // 16) % FT) * P + p) * 16 + (s % 16)
         n_tiles = n_slots // (16 * FT)
         i32 = dict(device=device, dtype=torch.int32)
@@ -172,10 +180,17 @@ class AutoregressiveFlow(torch.nn.Module):
         ldj = torch.empty(B, dtype=torch.float32, device=x.device)
         ws = torch.empty(fp['n_slots'] // 16, B, dtype=torch.float64, device=x.device)
         desc = self._transformer.config(x.device).desc if kind == _FUSED_SPLINE else None
+        prof = getattr(self, '_profile_events', None)
+        if prof is not None:                     # bench.py: HIP events around the fused launch
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream(x.device))
         _lib.call('tfep_fused_output_transformer_forward', _lib.ptr(h), h.shape[1], _lib.ptr(w), w.shape[1],
                   _lib.ptr(b), _lib.ptr(fp['k_ranges']), kind, ctypes.byref(desc) if desc is not None else None,
                   _lib.ptr(x), ldx, _lib.ptr(y), D, _lib.ptr(fp['feat_index']), _lib.ptr(fp['feat_tr']),
                   fp['n_slots'], _lib.ptr(ws), _lib.ptr(ldj), 0, B, fp['n_rows'], w.shape[1], _lib.stream_of(x))
+        if prof is not None:
+            ev1.record(torch.cuda.current_stream(x.device))
+            prof.append((ev0, ev1))
         return y, ldj
 
     # ------------------------------------------------------------------ reference API
@@ -208,7 +223,7 @@ class AutoregressiveFlow(torch.nn.Module):
         freeze = getattr(self._conditioner, 'frozen_weights', None)
         ctx = freeze() if freeze is not None else _null_context()
         with ctx:
-            for cols, pos in t['inverse_steps']:
+            for cols, pos in self._inverse_steps(y.device):
                 parameters = self.get_transformer_parameters(x)
                 x_temp, log_det_J = self._transformer.inverse(y, parameters)
                 ops.scatter_columns(ops.gather_columns(x_temp, pos), cols, x)
