@@ -1,0 +1,115 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU reduction path: per-rank sufficient statistics
+-> all-gather -> combine must reproduce the oracle's whole-batch loss / free-energy estimate."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_util as gu
+from oracle import loss as oloss
+from tfep_amd.distributed import allreduce_stats, combine_stats, shard_rows
+
+
+def shard_stats(uB, ldj, uA, lw, bias, kT=1.0, ignore_nan=False):
+    """numpy restatement of the 9 statistics tfep_tfep_reduce emits for one shard (tfep_hip.h)."""
+    r = (uB - ldj - uA).astype(np.float32).astype(np.float64)
+    isn = np.isnan(r)
+    keep = ~isn if ignore_nan else np.ones_like(isn)
+    out = np.zeros(9)
+    out[0] = keep.sum()
+    out[1] = r[keep].sum() if ignore_nan else r.sum()
+    if lw is not None:
+        m = lw.max()
+        e = np.exp(lw - m)
+        out[2], out[3] = m, e.sum()
+        out[4] = (e * np.where(isn & ignore_nan, 0.0, r)).sum()
+    else:
+        out[2] = -np.inf
+    e_arg = -r / kT + (bias / kT if bias is not None else 0.0)
+    out[5] = e_arg.max()
+    out[6] = np.exp(e_arg - out[5]).sum()
+    if bias is not None:
+        out[7] = (bias / kT).max()
+        out[8] = np.exp(bias / kT - out[7]).sum()
+    else:
+        out[7] = -np.inf
+    return out
+
+
+def finalize(stats, weighted, biased, kT=1.0):
+    loss = stats[4] / stats[3] if weighted else stats[1] / stats[0]
+    lse = stats[5] + np.log(stats[6])
+    lse -= (stats[7] + np.log(stats[8])) if biased else np.log(stats[0])
+    return loss, -kT * lse
+
+
+def test_shard_rows_partition():
+    for n, w in [(10, 3), (65536, 8), (7, 8), (0, 2)]:
+        spans = [shard_rows(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(e - b for b, e in spans) - min(e - b for b, e in spans) <= 1
+
+
+def test_combine_stats_matches_whole_batch_oracle():
+    g = gu.load('loss.npz')
+    uB, ldj, lw, uA = (g[k].astype(np.float64) for k in ('uB', 'ldj', 'lw', 'uA'))
+    N = uB.size
+    for world in (1, 2, 3, 8):
+        shards = [shard_stats(*(a[b:e] for a in (uB, ldj, uA, lw, lw)))
+                  for b, e in (shard_rows(N, r, world) for r in range(world))]
+        comb = combine_stats(torch.tensor(np.stack(shards))).numpy()
+        loss, df = finalize(comb, weighted=True, biased=True)
+        np.testing.assert_allclose(loss, oloss.boltzmann_kl_div_loss(uB, ldj, lw, uA), rtol=1e-6)
+        np.testing.assert_allclose(df, oloss.fep_estimator(np.stack([uB - ldj - uA, lw], axis=1)), rtol=1e-6)
+    # an empty shard (max = -inf) must not poison the combination
+    shards.append(np.array([0, 0, -np.inf, 0, 0, -np.inf, 0, -np.inf, 0]))
+    comb2 = combine_stats(torch.tensor(np.stack(shards))).numpy()
+    np.testing.assert_allclose(comb2, comb, rtol=1e-12)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = gu.load('loss.npz')
+        uB, ldj, lw, uA = (g[k].astype(np.float64) for k in ('uB', 'ldj', 'lw', 'uA'))
+        b, e = shard_rows(uB.size, rank, world)
+        local = torch.tensor(shard_stats(uB[b:e], ldj[b:e], uA[b:e], None, None))
+        glob = allreduce_stats(local)                       # all_gather + combine (the RCCL path, on gloo)
+        loss, df = finalize(glob.numpy(), weighted=False, biased=False)
+        q.put((rank, float(loss), float(df)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allreduce_of_tfep_statistics():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = gu.load('loss.npz')
+    uB, ldj, uA = (g[k].astype(np.float64) for k in ('uB', 'ldj', 'uA'))
+    for _, loss, df in res:                                 # every rank holds the GLOBAL answer
+        np.testing.assert_allclose(loss, oloss.boltzmann_kl_div_loss(uB, ldj, None, uA), rtol=1e-6)
+        np.testing.assert_allclose(df, oloss.fep_estimator(uB - ldj - uA), rtol=1e-6)
+    assert res[0][1:] == res[1][1:]
