@@ -98,15 +98,17 @@ int tfep_mask_k_ranges(const float* mask, int out_features, int in_features,
  *   tfep_masked_weight_prepare;  bias (N) in packed row order or NULL;  y (B, .) row stride ldy.
  *   k_ranges: output of tfep_mask_k_ranges with tile_n = tfep_masked_linear_tile_n(),
  *   tile_k = tfep_masked_linear_tile_k(), or NULL for the full K range.
+ *   tile_order: optional (n_tiles) int32 permutation of the column tiles: workgroups are launched in
+ *   this order (pass the tiles sorted by descending k-range so the longest run first); NULL = 0..n-1.
  *   col_map: optional (N) int32; packed output column j is stored at y[:, col_map[j]], skipped if
  *   col_map[j] < 0; NULL = identity.   act: 0 = identity, 1 = ELU(alpha = 1).
  *   Both operands must be 16-byte aligned with row strides that are multiples of 4 floats.
  * fp32 MFMA (v_mfma_f32_16x16x4_f32): exact fp32 products, fp32 accumulation.
  */
 int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw,
-                               const float* bias, const int32_t* k_ranges, const int32_t* col_map,
-                               float* y, int64_t ldy, int B, int N, int n_rows_w, int k_padded,
-                               int act, void* stream);
+                               const float* bias, const int32_t* k_ranges, const int32_t* tile_order,
+                               const int32_t* col_map, float* y, int64_t ldy, int B, int N, int n_rows_w,
+                               int k_padded, int act, void* stream);
 int tfep_masked_linear_tile_n(void);
 int tfep_masked_linear_tile_k(void);
 int tfep_masked_linear_tile_m(void);
@@ -204,7 +206,8 @@ int tfep_fused_tile_columns(int kind, const tfep_spline_desc* desc);
  * params = h W^T + b is formed tile by tile in MFMA accumulators and consumed in registers by
  * the transformer: the (B, P*D) parameter tensor never reaches HBM.
  *   h (B, >= k_padded) hidden activations (zero padded), w / bias_packed packed as above
- *   (already masked), k_ranges per column tile (tile_n = tfep_fused_tile_columns()).
+ *   (already masked), k_ranges per column tile (tile_n = tfep_fused_tile_columns()), tile_order as in
+ *   tfep_masked_linear_forward.
  *   x, y (B, .): transformer input / output; feature slot s reads x[:, feat_index[s]] and writes
  *   y[:, feat_index[s]] (feat_index[s] < 0: padding slot, nothing read or written);
  *   feat_tr[s] indexes desc->x0/xf/y0/yf (spline only).  n_feature_slots: multiple of 16*FT.
@@ -214,12 +217,19 @@ int tfep_fused_tile_columns(int kind, const tfep_spline_desc* desc);
  */
 int tfep_fused_output_transformer_forward(const float* h, int64_t ldh, const float* w, int64_t ldw,
                                           const float* bias_packed, const int32_t* k_ranges,
+                                          const int32_t* tile_order,
                                           int kind, const tfep_spline_desc* desc,
                                           const float* x, int64_t ldx, float* y, int64_t ldy,
                                           const int32_t* feat_index, const int32_t* feat_tr,
                                           int n_feature_slots, double* ldj_partial,
                                           float* log_det_J, int accumulate,
                                           int B, int n_rows_w, int k_padded, void* stream);
+
+/* Diagnostic (not on the path): run `iters` x 200 register-only v_mfma_f32_16x16x4_f32 per wave on
+ * `blocks` workgroups of 512 threads -- the matrix-pipe ceiling of this device for the GEMM's own
+ * instruction mix (2*25 accumulator tiles, 2 waves per SIMD).  scratch: blocks*512 floats.
+ * flops = blocks * 8 waves * iters * 200 * 2048. */
+int tfep_diag_mfma_peak(float* scratch, int blocks, int iters, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* TFEP reductions (tfep/loss.py, tfep/analysis/estimator.py)                 */

@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libtfep_hip.so')
+LIB_PATH = os.environ.get('TFEP_HIP_LIB') or os.path.join(_HERE, 'lib', 'libtfep_hip.so')
 ABI_VERSION = 1
 
 _lib = None
@@ -35,7 +35,7 @@ _SIGNATURES = {
     'tfep_last_error': (c_char_p, []),
     'tfep_masked_weight_prepare': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int64, _P]),
     'tfep_mask_k_ranges': (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
-    'tfep_masked_linear_forward': (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, c_int64,
+    'tfep_masked_linear_forward': (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64,
                                            c_int, c_int, c_int, c_int, c_int, _P]),
     'tfep_masked_linear_tile_n': (c_int, []),
     'tfep_masked_linear_tile_k': (c_int, []),
@@ -58,10 +58,11 @@ _SIGNATURES = {
     'tfep_fused_tile_features': (c_int, []),
     'tfep_fused_supported': (c_int, [c_int, POINTER(SplineDesc)]),
     'tfep_fused_tile_columns': (c_int, [c_int, POINTER(SplineDesc)]),
-    'tfep_fused_output_transformer_forward': (c_int, [_P, c_int64, _P, c_int64, _P, _P, c_int,
+    'tfep_fused_output_transformer_forward': (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, c_int,
                                                       POINTER(SplineDesc), _P, c_int64, _P, c_int64,
                                                       _P, _P, c_int, _P, _P, c_int,
                                                       c_int, c_int, c_int, _P]),
+    'tfep_diag_mfma_peak': (c_int, [_P, c_int, c_int, _P]),
     'tfep_tfep_reduce': (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P]),
     'tfep_tfep_reduce_workspace_doubles': (c_int, [c_int]),
 }

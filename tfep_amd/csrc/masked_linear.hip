@@ -20,6 +20,8 @@
 #include "common.h"
 #include "spline.h"
 
+#include <stdlib.h>
+
 namespace tfep {
 
 constexpr int BK = 16;
@@ -140,6 +142,11 @@ struct GemmArgs {
     float* y;
     int64_t ldy;
     int B, N, k_padded;
+    const int32_t* tile_order; // optional: launch position -> column tile (heaviest k-range first), or NULL
+    int map_mode;              // 0: row-tile fastest; 1: XCD-aware 8x4 super-tiles
+    int m_tiles, n_tiles;
+    int diag;                  // diagnostics only (TFEP_DIAG): 1 = skip the epilogue, 2 = skip the MFMAs,
+                               // 4 = skip the LDS-DMA, 8 = skip the barriers (garbage results; timing only)
     FusedArgs fu;
 };
 
@@ -150,7 +157,8 @@ struct Tile {
     static constexpr int A_FLOATS = BM * BK;
     static constexpr int B_FLOATS = BN * BK;
     static constexpr int STAGE_FLOATS = A_FLOATS + B_FLOATS;
-    static constexpr int LDS_BYTES = 2 * STAGE_FLOATS * 4;
+    static constexpr int STAGES = 2;
+    static constexpr int LDS_BYTES = STAGES * STAGE_FLOATS * 4;
     // 1 KiB (16 rows x 64 B) per LDS-DMA wave instruction
     static constexpr int A_CHUNKS = BM / 16;
     static constexpr int B_CHUNKS = BN / 16;
@@ -190,12 +198,30 @@ __device__ inline float elu_f(float v) { return v > 0.f ? v : expm1f(v); }
 
 // P parameters x FT feature groups per column tile (NREP = P * FT) for the fused epilogues.
 template <int MREP, int NREP, int EPI, int P, int KSPL>
-__global__ void __launch_bounds__(THREADS) gemm_kernel(GemmArgs g, int n_rows_w) {
+__global__ void __launch_bounds__(THREADS, (MREP == 1 ? 4 : 2)) gemm_kernel(GemmArgs g, int n_rows_w) {
     using T = Tile<MREP, NREP>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int mt = blockIdx.x, nt = blockIdx.y;
+    // Workgroup -> (row tile, column tile).  Workgroups are dealt round-robin over the 8 XCDs
+    // (id % 8 labels the XCD) and each XCD has its own L2, so in mode 1 the 32 workgroups that are
+    // co-resident on one XCD form an 8 (row tiles) x 4 (column tiles) super-tile: 8 activation
+    // panels + 4 weight panels are fetched once into that L2 instead of 32 + 1.  Pure speed: any
+    // placement gives the same result.
+    int mt, ntp;
+    if (g.map_mode == 1) {
+        const int id = blockIdx.x;
+        const int xcd = id & 7, seq = id >> 3;
+        const int S = (seq >> 5) * 8 + xcd, w = seq & 31;
+        const int SM = (g.m_tiles + 7) >> 3;
+        mt = (S % SM) * 8 + (w & 7);
+        ntp = (S / SM) * 4 + (w >> 3);
+        if (mt >= g.m_tiles || ntp >= g.n_tiles) return;
+    } else {
+        mt = blockIdx.x % g.m_tiles;
+        ntp = blockIdx.x / g.m_tiles;
+    }
+    const int nt = g.tile_order ? g.tile_order[ntp] : ntp;
     const int m0 = mt * T::BM, n0 = nt * T::BN;
 
     int kb = 0, ke = g.k_padded;
@@ -210,33 +236,60 @@ __global__ void __launch_bounds__(THREADS) gemm_kernel(GemmArgs g, int n_rows_w)
 #pragma unroll
         for (int m = 0; m < MREP; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Two-stage LDS double buffer: the DMA of k-tile t+1 flies under the MFMAs of k-tile t; one
+    // barrier per k-tile.
     const int nk = (ke - kb) / BK;
     if (nk > 0) stage_tile<MREP, NREP>(g, lds, m0, n0, kb, wave, lane, n_rows_w);
-
     const int frag_off = (lane & 15) * BK + (lane >> 4) * 4;   // row (l&15), floats [4q, 4q+4)
+    // The matrix pipe is the bottleneck, so it is started first after the barrier and the ~60
+    // scalar/vector instructions that issue the next tile's LDS-DMA run in the shadow of MFMA groups.
+    // Waves w and w+4 share a SIMD and leave the barrier together: they issue their DMA at
+    // DIFFERENT column groups (N_DMA_A / N_DMA_B) so one of them always feeds the matrix pipe.
+    constexpr int N_DMA_A = 2, N_DMA_B = NREP / 2 + 1;
+    static_assert(NREP > N_DMA_B, "column groups per wave");
+    const bool late_half = wave >= WAVES / 2;
     for (int t = 0; t < nk; ++t) {
-        __syncthreads();   // DMA of tile t landed (vmcnt(0) + barrier); everyone is done with the other buffer
+        if (!(g.diag & 8)) __syncthreads();   // DMA of tile t landed (vmcnt(0) + barrier); other buffer free
         float* cur = lds + (t & 1) * T::STAGE_FLOATS;
-        if (t + 1 < nk)
-            stage_tile<MREP, NREP>(g, lds + ((t + 1) & 1) * T::STAGE_FLOATS, m0, n0, kb + (t + 1) * BK, wave, lane,
-                                   n_rows_w);
-
         const float* As = cur + (wave * 16 * MREP) * BK + frag_off;
         const float* Bs = cur + T::A_FLOATS + frag_off;
         f32x4 af[MREP];
 #pragma unroll
         for (int m = 0; m < MREP; ++m) af[m] = *(const f32x4*)(As + m * 16 * BK);
+        // B fragments are software-pipelined one column group ahead (bq[n & 1]) so a wave does not
+        // depend on its SIMD partner to cover the LDS latency of every group.
+        f32x4 bq[2];
+        bq[0] = *(const f32x4*)(Bs);
+        const bool dma = t + 1 < nk && !(g.diag & 4);
 #pragma unroll
         for (int n = 0; n < NREP; ++n) {
-            const f32x4 bf = *(const f32x4*)(Bs + n * 16 * BK);
+            if (n == N_DMA_A || n == N_DMA_B) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (dma && late_half == (n == N_DMA_B))
+                    stage_tile<MREP, NREP>(g, lds + ((t + 1) & 1) * T::STAGE_FLOATS, m0, n0, kb + (t + 1) * BK, wave,
+                                           lane, n_rows_w);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (n + 1 < NREP) bq[(n + 1) & 1] = *(const f32x4*)(Bs + (n + 1) * 16 * BK);
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch AHEAD of this group's MFMAs
+            const f32x4 bf = bq[n & 1];
+            if (!(g.diag & 2)) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int m = 0; m < MREP; ++m)
-                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s], bf[s], acc[n][m], 0, 0, 0);
+                    for (int m = 0; m < MREP; ++m)
+                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s], bf[s], acc[n][m], 0, 0, 0);
+            }
         }
     }
 
+    if (g.diag & 1) {   // timing-only build of the main loop: keep the accumulators alive, store nothing
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int m = 0; m < MREP; ++m) asm volatile("" ::"v"(acc[n][m]));
+        return;
+    }
     // ---------------------------------------------------------------- epilogues
     // C layout of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + reg.
     const int cj = lane & 15, rq = (lane >> 4) * 4;
@@ -326,6 +379,36 @@ __global__ void __launch_bounds__(THREADS) gemm_kernel(GemmArgs g, int n_rows_w)
     }
 }
 
+// Diagnostic: the matrix-pipe ceiling of THIS device for the GEMM's own instruction mix -- the same
+// 2 x NREP accumulator tiles of v_mfma_f32_16x16x4_f32 per wave, operands in registers, no memory.
+template <int MREP, int NREP>
+__global__ void __launch_bounds__(THREADS, 2) mfma_peak_kernel(float* out, int iters) {
+    f32x4 acc[NREP][MREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 af[MREP], bf;
+#pragma unroll
+    for (int m = 0; m < MREP; ++m) af[m] = (f32x4){1.0f + threadIdx.x, 0.5f, 0.25f, 2.0f};
+    bf = (f32x4){1e-3f * threadIdx.x, 1e-3f, 2e-3f, 3e-3f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int n = 0; n < NREP; ++n)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < MREP; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s], bf[s], acc[n][m], 0, 0, 0);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+        for (int m = 0; m < MREP; ++m) sum += acc[n][m][0] + acc[n][m][1] + acc[n][m][2] + acc[n][m][3];
+    out[blockIdx.x * THREADS + threadIdx.x] = sum;
+}
+
 // ldj[b] (+)= sum_t partial[t][b]
 __global__ void __launch_bounds__(256) ldj_reduce_kernel(const double* __restrict__ partial, int n_tiles, int B,
                                                          float* __restrict__ ldj, int accumulate) {
@@ -342,6 +425,14 @@ __global__ void __launch_bounds__(256) ldj_reduce_kernel(const double* __restric
 constexpr int LIN_MREP = 2, LIN_NREP = 16;          // 256 x 256 tile for the hidden layers
 constexpr int FUSED_TILE_FEATURES = 16;
 
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+// Tuning switches (A/B experiments; defaults are the measured best).
+static int block_map_mode() { static int m = env_int("TFEP_BLOCK_MAP", 1); return m; }
+static int fused_mrep() { static int m = env_int("TFEP_FUSED_MREP", 2); return m; }
+
 template <int MREP, int NREP, int EPI, int P, int KSPL>
 static int launch_gemm(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStream_t s) {
     using T = Tile<MREP, NREP>;
@@ -352,8 +443,20 @@ static int launch_gemm(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStre
         if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%d): %s", T::LDS_BYTES, hipGetErrorString(e));
         attr_set = true;
     }
-    dim3 grid((unsigned)((g.B + T::BM - 1) / T::BM), (unsigned)n_col_tiles);
-    kern<<<grid, THREADS, T::LDS_BYTES, s>>>(g, n_rows_w);
+    GemmArgs ga = g;
+    ga.m_tiles = (g.B + T::BM - 1) / T::BM;
+    ga.n_tiles = n_col_tiles;
+    ga.map_mode = block_map_mode();
+    ga.diag = env_int("TFEP_DIAG", 0);
+    long long blocks;
+    if (ga.map_mode == 1) {
+        const long long SM = (ga.m_tiles + 7) / 8, SN = (ga.n_tiles + 3) / 4;
+        blocks = ((SM * SN + 7) / 8) * 8 * 32;
+    } else {
+        blocks = (long long)ga.m_tiles * ga.n_tiles;
+    }
+    if (blocks > 0x7fffffffLL) return fail(TFEP_ERR_INVALID_ARGUMENT, "gemm: grid too large");
+    kern<<<dim3((unsigned)blocks), THREADS, T::LDS_BYTES, s>>>(ga, n_rows_w);
     return check_launch("gemm_kernel");
 }
 
@@ -410,8 +513,8 @@ int tfep_mask_k_ranges(const float* mask, int out_features, int in_features, con
 }
 
 int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
-                               const int32_t* k_ranges, const int32_t* col_map, float* y, int64_t ldy, int B, int N,
-                               int n_rows_w, int k_padded, int act, void* stream) {
+                               const int32_t* k_ranges, const int32_t* tile_order, const int32_t* col_map, float* y,
+                               int64_t ldy, int B, int N, int n_rows_w, int k_padded, int act, void* stream) {
     int rc = check_gemm_operands(x, ldx, w, ldw, k_padded);
     if (rc) return rc;
     TFEP_REQUIRE(y, "masked_linear: y is NULL");
@@ -420,10 +523,16 @@ int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int6
     if (B == 0 || N == 0) return TFEP_OK;
     GemmArgs g = {};
     g.a = x; g.lda = ldx; g.w = w; g.ldw = ldw; g.bias = bias; g.k_ranges = k_ranges; g.col_map = col_map;
-    g.y = y; g.ldy = ldy; g.B = B; g.N = N; g.k_padded = k_padded;
+    g.y = y; g.ldy = ldy; g.B = B; g.N = N; g.k_padded = k_padded; g.tile_order = tile_order;
     const int n_tiles = (N + Tile<LIN_MREP, LIN_NREP>::BN - 1) / Tile<LIN_MREP, LIN_NREP>::BN;
     if (act == 1) return launch_gemm<LIN_MREP, LIN_NREP, EPI_ELU, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);
     return launch_gemm<LIN_MREP, LIN_NREP, EPI_LINEAR, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);
+}
+
+int tfep_diag_mfma_peak(float* scratch, int blocks, int iters, void* stream) {
+    TFEP_REQUIRE(scratch && blocks > 0 && iters > 0, "diag_mfma_peak: bad arguments");
+    mfma_peak_kernel<2, 25><<<blocks, THREADS, 0, (hipStream_t)stream>>>(scratch, iters);
+    return check_launch("mfma_peak_kernel");
 }
 
 int tfep_fused_supported(int kind, const tfep_spline_desc* d) {
@@ -440,7 +549,8 @@ int tfep_fused_tile_columns(int kind, const tfep_spline_desc* d) {
 }
 
 int tfep_fused_output_transformer_forward(const float* h, int64_t ldh, const float* w, int64_t ldw,
-                                          const float* bias_packed, const int32_t* k_ranges, int kind,
+                                          const float* bias_packed, const int32_t* k_ranges,
+                                          const int32_t* tile_order, int kind,
                                           const tfep_spline_desc* desc, const float* x, int64_t ldx, float* y,
                                           int64_t ldy, const int32_t* feat_index, const int32_t* feat_tr,
                                           int n_feature_slots, double* ldj_partial, float* log_det_J, int accumulate,
@@ -455,7 +565,7 @@ int tfep_fused_output_transformer_forward(const float* h, int64_t ldh, const flo
     hipStream_t s = (hipStream_t)stream;
     GemmArgs g = {};
     g.a = h; g.lda = ldh; g.w = w; g.ldw = ldw; g.bias = bias_packed; g.k_ranges = k_ranges;
-    g.B = B; g.k_padded = k_padded;
+    g.B = B; g.k_padded = k_padded; g.tile_order = tile_order;
     g.fu.x = x; g.fu.ldx = ldx; g.fu.y = y; g.fu.ldy = ldy; g.fu.feat_index = feat_index; g.fu.feat_tr = feat_tr;
     g.fu.ldj_partial = ldj_partial;
     const int n_groups = n_feature_slots / FUSED_TILE_FEATURES;
@@ -475,7 +585,10 @@ int tfep_fused_output_transformer_forward(const float* h, int64_t ldh, const flo
         g.fu.sf.learn_lower = false; g.fu.sf.learn_upper = false;
         g.fu.sf.min_bin = desc->min_bin_size; g.fu.sf.min_slope = desc->min_slope;
         g.fu.sf.slope_offset = (float)log(exp(1.0 - (double)desc->min_slope) - 1.0);
-        rc = launch_gemm<2, P, EPI_SPLINE, P, KS>(g, n_rows_w, n_groups, s);
+        if (fused_mrep() == 1)
+            rc = launch_gemm<1, P, EPI_SPLINE, P, KS>(g, n_rows_w, n_groups, s);
+        else
+            rc = launch_gemm<2, P, EPI_SPLINE, P, KS>(g, n_rows_w, n_groups, s);
     }
     if (rc) return rc;
     ldj_reduce_kernel<<<(unsigned)((B + 255) / 256), 256, 0, s>>>(ldj_partial, n_groups, B, log_det_J, accumulate);

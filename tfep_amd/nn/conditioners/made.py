@@ -227,7 +227,7 @@ class MADE(Conditioner):
         tm, tn, tk = ops.tile_sizes()
         lins = self._linears()
         n_lin = len(lins)
-        plan = {'row_of_out': [], 'col_of_in': [], 'n_pad': [], 'k_pad': [], 'k_ranges': [],
+        plan = {'row_of_out': [], 'col_of_in': [], 'n_pad': [], 'k_pad': [], 'k_ranges': [], 'tile_order': [],
                 'w': [None] * n_lin, 'bias': [None] * n_lin}
         col_of_in = None
         for li, lin in enumerate(lins):
@@ -249,6 +249,7 @@ class MADE(Conditioner):
             plan['k_pad'].append(k_pad)
             n_tiles = (n_pad + tn - 1) // tn
             plan['k_ranges'].append(ops.mask_k_ranges(lin.mask, tn, n_tiles, k_pad, row_of_out, col_of_in))
+            plan['tile_order'].append(ops.heavy_first_order(plan['k_ranges'][-1]))
             col_of_in = row_of_out
         self._plans[key] = plan
         return plan
@@ -298,7 +299,8 @@ class MADE(Conditioner):
         h = ops.pad_columns(x, plan['k_pad'][0])
         for li, lin in enumerate(lins[:-1]):
             w, b = self._pack_layer(plan, li, lin)
-            h = ops.masked_linear_packed(h, w, b, plan['n_pad'][li], k_ranges=plan['k_ranges'][li], act=1)
+            h = ops.masked_linear_packed(h, w, b, plan['n_pad'][li], k_ranges=plan['k_ranges'][li], act=1,
+                                         tile_order=plan['tile_order'][li])
         return h, plan
 
     def forward(self, x):
@@ -308,7 +310,8 @@ class MADE(Conditioner):
         li = len(plan['n_pad']) - 1
         lin = self.layers[-1]
         w, b = self._pack_layer(plan, li, lin)
-        out = ops.masked_linear_packed(h, w, b, lin.out_features, k_ranges=plan['k_ranges'][li], act=0)
+        out = ops.masked_linear_packed(h, w, b, lin.out_features, k_ranges=plan['k_ranges'][li], act=0,
+                                       tile_order=plan['tile_order'][li])
         return out.reshape(*lead, lin.out_features)
 
 

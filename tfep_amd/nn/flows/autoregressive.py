@@ -165,6 +165,7 @@ class AutoregressiveFlow(torch.nn.Module):
         }
         fp['k_ranges'] = ops.mask_k_ranges(last.mask, tile_cols, n_tiles, mplan['k_pad'][li],
                                            fp['row_of_out'], mplan['col_of_in'][li])
+        fp['tile_order'] = ops.heavy_first_order(fp['k_ranges'])
         self._dev[key] = fp
         return fp
 
@@ -185,7 +186,8 @@ class AutoregressiveFlow(torch.nn.Module):
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record(torch.cuda.current_stream(x.device))
         _lib.call('tfep_fused_output_transformer_forward', _lib.ptr(h), h.shape[1], _lib.ptr(w), w.shape[1],
-                  _lib.ptr(b), _lib.ptr(fp['k_ranges']), kind, ctypes.byref(desc) if desc is not None else None,
+                  _lib.ptr(b), _lib.ptr(fp['k_ranges']), _lib.ptr(fp['tile_order']), kind,
+                  ctypes.byref(desc) if desc is not None else None,
                   _lib.ptr(x), ldx, _lib.ptr(y), D, _lib.ptr(fp['feat_index']), _lib.ptr(fp['feat_tr']),
                   fp['n_slots'], _lib.ptr(ws), _lib.ptr(ldj), 0, B, fp['n_rows'], w.shape[1], _lib.stream_of(x))
         if prof is not None:

@@ -189,15 +189,23 @@ def mask_k_ranges(mask, tile_n, n_tiles, k_padded, row_of_out=None, col_of_in=No
     return out
 
 
+def heavy_first_order(k_ranges):
+    """Column tiles sorted by descending k-range length (host-side, once per mask)."""
+    kr = k_ranges.cpu().long()
+    order = torch.argsort(kr[:, 1] - kr[:, 0], descending=True, stable=True)
+    return order.to(device=k_ranges.device, dtype=torch.int32)
+
+
 def masked_linear_packed(x_padded, w_packed, bias, n_out, k_ranges=None, col_map=None, act=0, out=None,
-                         out_cols=None):
+                         out_cols=None, tile_order=None):
     """y = act(x W^T + b) on packed operands (reference masked.py:265-277 + made.py:320)."""
     B = x_padded.shape[0]
     n_rows_w, k_padded = w_packed.shape
     if out is None:
         out = torch.empty(B, n_out if out_cols is None else out_cols, dtype=torch.float32, device=x_padded.device)
     call('tfep_masked_linear_forward', ptr(x_padded), x_padded.shape[1], ptr(w_packed), k_padded,
-         ptr(bias), ptr(k_ranges), ptr(col_map), ptr(out), out.shape[1], B, n_out, n_rows_w, k_padded, int(act),
+         ptr(bias), ptr(k_ranges), ptr(tile_order), ptr(col_map), ptr(out), out.shape[1], B, n_out, n_rows_w,
+         k_padded, int(act),
          stream_of(x_padded))
     return out
 
