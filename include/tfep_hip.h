@@ -102,14 +102,18 @@ int tfep_mask_k_ranges(const float* mask, int out_features, int in_features,
  *   this order (pass the tiles sorted by descending k-range so the longest run first); NULL = 0..n-1.
  *   col_map: optional (N) int32; packed output column j is stored at y[:, col_map[j]], skipped if
  *   col_map[j] < 0; NULL = identity.   act: 0 = identity, 1 = ELU(alpha = 1).
+ *   tile_n: column-tile width, 0 / tfep_masked_linear_tile_n() (default) or
+ *   tfep_masked_linear_narrow_tile_n() for few output rows (the per-degree row slices of the blocked
+ *   autoregressive inverse, flows/autoregressive.py:179-229); k_ranges must use the same tile_n.
  *   Both operands must be 16-byte aligned with row strides that are multiples of 4 floats.
  * fp32 MFMA (v_mfma_f32_16x16x4_f32): exact fp32 products, fp32 accumulation.
  */
 int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw,
                                const float* bias, const int32_t* k_ranges, const int32_t* tile_order,
                                const int32_t* col_map, float* y, int64_t ldy, int B, int N, int n_rows_w,
-                               int k_padded, int act, void* stream);
+                               int k_padded, int act, int tile_n, void* stream);
 int tfep_masked_linear_tile_n(void);
+int tfep_masked_linear_narrow_tile_n(void);
 int tfep_masked_linear_tile_k(void);
 int tfep_masked_linear_tile_m(void);
 

@@ -36,7 +36,8 @@ _SIGNATURES = {
     'tfep_masked_weight_prepare': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int, c_int64, _P]),
     'tfep_mask_k_ranges': (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     'tfep_masked_linear_forward': (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64,
-                                           c_int, c_int, c_int, c_int, c_int, _P]),
+                                           c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    'tfep_masked_linear_narrow_tile_n': (c_int, []),
     'tfep_masked_linear_tile_n': (c_int, []),
     'tfep_masked_linear_tile_k': (c_int, []),
     'tfep_masked_linear_tile_m': (c_int, []),

@@ -245,8 +245,8 @@ __global__ void __launch_bounds__(THREADS, (MREP == 1 ? 4 : 2)) gemm_kernel(Gemm
     // scalar/vector instructions that issue the next tile's LDS-DMA run in the shadow of MFMA groups.
     // Waves w and w+4 share a SIMD and leave the barrier together: they issue their DMA at
     // DIFFERENT column groups (N_DMA_A / N_DMA_B) so one of them always feeds the matrix pipe.
-    constexpr int N_DMA_A = 2, N_DMA_B = NREP / 2 + 1;
-    static_assert(NREP > N_DMA_B, "column groups per wave");
+    constexpr int N_DMA_A = NREP >= 4 ? 2 : 0, N_DMA_B = NREP >= 4 ? NREP / 2 + 1 : NREP - 1;
+    static_assert(NREP >= 2 && NREP > N_DMA_B && N_DMA_A != N_DMA_B, "column groups per wave");
     const bool late_half = wave >= WAVES / 2;
     for (int t = 0; t < nk; ++t) {
         if (!(g.diag & 8)) __syncthreads();   // DMA of tile t landed (vmcnt(0) + barrier); other buffer free
@@ -423,6 +423,7 @@ __global__ void __launch_bounds__(256) ldj_reduce_kernel(const double* __restric
 // host side
 // ------------------------------------------------------------------------------------------
 constexpr int LIN_MREP = 2, LIN_NREP = 16;          // 256 x 256 tile for the hidden layers
+constexpr int NARROW_NREP = 2;                      // 256 x 32 tile: row slices of the blocked inverse
 constexpr int FUSED_TILE_FEATURES = 16;
 
 static int env_int(const char* name, int dflt) {
@@ -479,6 +480,7 @@ extern "C" {
 int tfep_masked_linear_tile_m(void) { return Tile<LIN_MREP, LIN_NREP>::BM; }
 int tfep_masked_linear_tile_n(void) { return Tile<LIN_MREP, LIN_NREP>::BN; }
 int tfep_masked_linear_tile_k(void) { return BK; }
+int tfep_masked_linear_narrow_tile_n(void) { return Tile<LIN_MREP, NARROW_NREP>::BN; }
 int tfep_fused_tile_features(void) { return FUSED_TILE_FEATURES; }
 
 int tfep_masked_weight_prepare(const float* weight_v, const float* weight_g, const float* mask, int out_features,
@@ -514,7 +516,8 @@ int tfep_mask_k_ranges(const float* mask, int out_features, int in_features, con
 
 int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias,
                                const int32_t* k_ranges, const int32_t* tile_order, const int32_t* col_map, float* y,
-                               int64_t ldy, int B, int N, int n_rows_w, int k_padded, int act, void* stream) {
+                               int64_t ldy, int B, int N, int n_rows_w, int k_padded, int act, int tile_n,
+                               void* stream) {
     int rc = check_gemm_operands(x, ldx, w, ldw, k_padded);
     if (rc) return rc;
     TFEP_REQUIRE(y, "masked_linear: y is NULL");
@@ -524,6 +527,15 @@ int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int6
     GemmArgs g = {};
     g.a = x; g.lda = ldx; g.w = w; g.ldw = ldw; g.bias = bias; g.k_ranges = k_ranges; g.col_map = col_map;
     g.y = y; g.ldy = ldy; g.B = B; g.N = N; g.k_padded = k_padded; g.tile_order = tile_order;
+    constexpr int WIDE_BN = Tile<LIN_MREP, LIN_NREP>::BN, NARROW_BN = Tile<LIN_MREP, NARROW_NREP>::BN;
+    TFEP_REQUIRE(tile_n == 0 || tile_n == WIDE_BN || tile_n == NARROW_BN,
+                 "masked_linear: tile_n=%d unsupported (0, %d or %d)", tile_n, WIDE_BN, NARROW_BN);
+    if (tile_n == NARROW_BN) {
+        // narrow column tile for the row slices of the blocked autoregressive inverse
+        const int n_tiles = (N + tile_n - 1) / tile_n;
+        if (act == 1) return launch_gemm<LIN_MREP, NARROW_NREP, EPI_ELU, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);
+        return launch_gemm<LIN_MREP, NARROW_NREP, EPI_LINEAR, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);
+    }
     const int n_tiles = (N + Tile<LIN_MREP, LIN_NREP>::BN - 1) / Tile<LIN_MREP, LIN_NREP>::BN;
     if (act == 1) return launch_gemm<LIN_MREP, LIN_NREP, EPI_ELU, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);
     return launch_gemm<LIN_MREP, LIN_NREP, EPI_LINEAR, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);

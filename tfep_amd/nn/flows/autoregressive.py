@@ -18,6 +18,7 @@ from ... import _lib, ops
 from ...utils.misc import ensure_tensor_sequence
 from ..conditioners.made import MADE
 from ..transformers.affine import AffineTransformer
+from ..transformers.moebius import MoebiusTransformer
 from ..transformers.spline import NeuralSplineTransformer
 
 _FUSED_AFFINE, _FUSED_SPLINE = 0, 1
@@ -66,7 +67,8 @@ class AutoregressiveFlow(torch.nn.Module):
         self.register_buffer('_fixed_indices', fixed_indices)
         self.register_buffer('_conditioner_indices', conditioner_indices)
         self._dev = {}
-        self.fused = True      # set False to force the generic (unfused) path
+        self.fused = True             # set False to force the generic (unfused) forward path
+        self.blocked_inverse = True   # set False to force the reference's one-full-pass-per-degree inverse
 
         if initialize_identity:
             identity_parameters = self._transformer.get_identity_parameters(n_transformer_indices)
@@ -213,9 +215,18 @@ class AutoregressiveFlow(torch.nn.Module):
         return y, log_det_J
 
     def inverse(self, y: torch.Tensor):
-        """``(x, log_det_J)`` of the inverse map: one conditioner pass per autoregressive degree
-        (reference autoregressive.py:179-229); the last pass' log-det is the total."""
+        """``(x, log_det_J)`` of the inverse map (reference autoregressive.py:179-229).
+
+        With a MADE conditioner the inverse runs as a blocked forward substitution: pass ``k``
+        evaluates only the rows of the three masked linears that belong to degree ``k`` (contiguous
+        row slices of the degree-sorted packed weights), so the whole inverse costs about one forward
+        in flops instead of ``n_degrees`` forwards.  Otherwise (user conditioner, embedding, mixed
+        transformer, ``blocked_inverse=False``): one full conditioner pass per degree, like the
+        reference; the last pass' log-det is the total.
+        """
         ops.check_device_tensor(y, 'y')
+        if self._blocked_ok():
+            return self._inverse_blocked(y)
         t = self._tables(y.device)
         x = torch.zeros(y.shape, dtype=y.dtype, device=y.device)
         if self.has_fixed_indices:
@@ -230,6 +241,150 @@ class AutoregressiveFlow(torch.nn.Module):
                 x_temp, log_det_J = self._transformer.inverse(y, parameters)
                 ops.scatter_columns(ops.gather_columns(x_temp, pos), cols, x)
         return x, log_det_J
+
+    # ------------------------------------------------------------------ blocked inverse
+    def _blocked_ok(self):
+        made = self._conditioner
+        if not self.blocked_inverse or not isinstance(made, MADE) or len(self._conditioner_indices) > 0:
+            return False
+        if getattr(made, 'embedding', None) is not None or len(made._linears()) < 2:
+            return False
+        tr = self._transformer
+        if type(tr) in (AffineTransformer, NeuralSplineTransformer):
+            return True
+        if type(tr) is MoebiusTransformer:
+            # every vector must live inside one degree (e.g. generate_degrees(..., repeats=dimension))
+            deg = made._degrees[0]
+            deg = deg[deg != -1]
+            d = tr.dimension
+            return len(deg) % d == 0 and bool((deg.reshape(-1, d) == deg.reshape(-1, d)[:, :1]).all())
+        return False
+
+    def _sub_transformer(self, sel, device):
+        """The transformer restricted to the transformed features ``sel`` (a degree group)."""
+        tr = self._transformer
+        if type(tr) is NeuralSplineTransformer:
+            cfg = tr.config(device)
+            return ('spline', ops.SplineConfig(
+                cfg.x0[sel], cfg.xf[sel], cfg.y0[sel], cfg.yf[sel], int(tr.n_bins), bool(tr._circular),
+                bool(tr._identity_boundary_slopes), bool(tr._learn_lower_bound), bool(tr._learn_upper_bound),
+                float(tr._min_bin_size), float(tr._min_slope)))
+        if type(tr) is MoebiusTransformer:
+            return ('moebius', tr)
+        return ('affine', tr)
+
+    def _blocked_plan(self, device):
+        key = ('blocked', str(device))
+        bp = self._dev.get(key)
+        if bp is not None:
+            return bp
+        lib = _lib.load()
+        made = self._conditioner
+        mplan = made.plan(device)
+        lins = made._linears()
+        L = len(lins) - 1
+        tk = lib.tfep_masked_linear_tile_k()
+        narrow = lib.tfep_masked_linear_narrow_tile_n()
+        tables = self._tables(device)
+        deg_in = made._degrees[0].cpu()
+        tr_idx = tables['tr'].cpu().long()
+        deg_tr = deg_in[tr_idx]
+        n_tr = len(tr_idx)
+        P = lins[-1].out_features // n_tr
+        max_deg = int(deg_tr.max())
+        hid_sorted = [torch.sort(made._degrees[l + 1].cpu()).values for l in range(L)]
+
+        def up(v):
+            return (v + tk - 1) // tk * tk
+
+        kr, steps = [], []
+        row_inv = torch.empty(P * n_tr, dtype=torch.long, device='cpu')
+        base = 0
+        i32 = dict(device=device, dtype=torch.int32)
+
+        def add_ranges(kb, ke, n_rows):
+            off = len(kr)
+            kr.extend([(kb, ke)] * ((n_rows + narrow - 1) // narrow))
+            return off
+
+        for d in range(max_deg + 1):
+            e = d - 1
+            hidden = []
+            for l in range(L):
+                r0 = int(torch.searchsorted(hid_sorted[l], e, right=False))
+                r1 = int(torch.searchsorted(hid_sorted[l], e, right=True))
+                if r1 > r0:
+                    if l == 0:
+                        pos = torch.nonzero(deg_in <= e).flatten()
+                        kb, ke = ((int(pos.min()) // tk) * tk, up(int(pos.max()) + 1)) if len(pos) else (0, 0)
+                    else:
+                        kb, ke = 0, up(int(torch.searchsorted(hid_sorted[l - 1], e, right=True)))
+                    ke = min(ke, mplan['k_pad'][l])
+                    hidden.append((l, r0, r1 - r0, add_ranges(kb, ke, r1 - r0)))
+            sel = torch.nonzero(deg_tr == d).flatten()
+            n_d = len(sel)
+            ke = min(up(int(torch.searchsorted(hid_sorted[L - 1], e, right=True))), mplan['k_pad'][L])
+            for p in range(P):
+                row_inv[p * n_tr + sel] = base + p * n_d + torch.arange(n_d, device='cpu')
+            steps.append(dict(hidden=hidden, out=(base, P * n_d, add_ranges(0, ke, P * n_d)), n_d=n_d,
+                              sel=sel.to(**i32), cols=tr_idx[sel].to(**i32),
+                              sub=self._sub_transformer(sel.to(device), device)))
+            base += P * n_d
+        bp = dict(steps=steps, P=P, L=L, row_inv=row_inv.to(**i32),
+                  k_ranges=torch.tensor(kr, dtype=torch.int32).reshape(-1, 2).to(device), n_rows_out=P * n_tr)
+        self._dev[key] = bp
+        return bp
+
+    def _inverse_blocked(self, y):
+        y, _ = _lib.rows(y, 'y')
+        B, D = y.shape
+        dev = y.device
+        tables = self._tables(dev)
+        bp = self._blocked_plan(dev)
+        made = self._conditioner
+        mplan = made.plan(dev)
+        lins = made._linears()
+        L = bp['L']
+        f32 = dict(dtype=torch.float32, device=dev)
+        with made.frozen_weights():
+            packs = [made._pack_layer(mplan, l, lins[l]) for l in range(L)]
+            w_out, b_out = made._pack_layer(mplan, L, lins[L], row_of_out=bp['row_inv'], n_rows=bp['n_rows_out'])
+            x = torch.zeros(B, D, **f32)
+            xpad = torch.zeros(B, mplan['k_pad'][0], **f32)          # conditioner input, zero padded
+            if self.has_fixed_indices:
+                fixed = ops.gather_columns(y, tables['fixed'])
+                ops.scatter_columns(fixed, tables['fixed'], x)
+                ops.scatter_columns(fixed, tables['fixed'], xpad)
+                y_tr = ops.gather_columns(y, tables['tr'])
+            else:
+                y_tr = y
+            h = [torch.zeros(B, mplan['n_pad'][l], **f32) for l in range(L)]
+            ldj = torch.zeros(B, **f32)
+            par_bufs = {}
+            kr = bp['k_ranges']
+            for st in bp['steps']:
+                for l, r0, n_rows, off in st['hidden']:
+                    ops.gemm_slice(xpad if l == 0 else h[l - 1], packs[l][0], r0, n_rows, packs[l][1], kr, off,
+                                   h[l], r0, act=1)
+                if st['n_d'] == 0:
+                    continue
+                base, n_rows, off = st['out']
+                par = par_bufs.get(n_rows)
+                if par is None:
+                    par = par_bufs[n_rows] = torch.empty(B, n_rows, **f32)
+                ops.gemm_slice(h[L - 1], w_out, base, n_rows, b_out, kr, off, par, 0, act=0)
+                y_d = ops.gather_columns(y_tr, st['sel'])
+                kind, sub = st['sub']
+                if kind == 'spline':
+                    x_d, _ = ops.spline(y_d, par, sub, inverse=True, log_det_J=ldj)
+                elif kind == 'moebius':
+                    x_d, _ = ops.moebius(y_d, par, sub.dimension, sub.max_radius, sub.unit_sphere, inverse=True,
+                                         log_det_J=ldj)
+                else:
+                    x_d, _ = ops.affine(y_d, par, inverse=True, log_det_J=ldj)
+                ops.scatter_columns(x_d, st['cols'], x)
+                ops.scatter_columns(x_d, st['cols'], xpad)
+        return x, ldj
 
     def get_transformer_parameters(self, x: torch.Tensor) -> torch.Tensor:
         """Run the conditioner (reference autoregressive.py:231-247)."""

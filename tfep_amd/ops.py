@@ -205,9 +205,24 @@ def masked_linear_packed(x_padded, w_packed, bias, n_out, k_ranges=None, col_map
         out = torch.empty(B, n_out if out_cols is None else out_cols, dtype=torch.float32, device=x_padded.device)
     call('tfep_masked_linear_forward', ptr(x_padded), x_padded.shape[1], ptr(w_packed), k_padded,
          ptr(bias), ptr(k_ranges), ptr(tile_order), ptr(col_map), ptr(out), out.shape[1], B, n_out, n_rows_w,
-         k_padded, int(act),
+         k_padded, int(act), 0,
          stream_of(x_padded))
     return out
+
+
+def gemm_slice(x_padded, w_packed, row0, n_rows, bias, k_ranges, kr_offset, out, col0, act):
+    """Row slice of a packed masked linear layer with the narrow column tile:
+    ``out[:, col0:col0+n_rows] = act(x W[row0:row0+n_rows]^T + bias[row0:row0+n_rows])``.
+    ``k_ranges[kr_offset:]`` holds the [k_begin, k_end) of the slice's 32-row tiles."""
+    B = x_padded.shape[0]
+    k_padded = w_packed.shape[1]
+    esz = 4
+    call('tfep_masked_linear_forward', ptr(x_padded), x_padded.shape[1],
+         ctypes.c_void_p(w_packed.data_ptr() + row0 * k_padded * esz), k_padded,
+         ctypes.c_void_p(bias.data_ptr() + row0 * esz),
+         ctypes.c_void_p(k_ranges.data_ptr() + kr_offset * 2 * 4), None, None,
+         ctypes.c_void_p(out.data_ptr() + col0 * esz), out.shape[1], B, n_rows, n_rows, k_padded, int(act),
+         _lib.load().tfep_masked_linear_narrow_tile_n(), stream_of(x_padded))
 
 
 # ----------------------------------------------------------------------------- reductions
