@@ -111,8 +111,8 @@ def main():
     fused_layers = [l for l in flow if l._fused_kind() is not None]
     assert len(fused_layers) == len(flow), 'bench expects the fused HIP path on every layer'
     # algorithmic flops of the fused output kernel: 2 * nnz(mask_out) per sample
-    nnz_out = [float(l._conditioner.layers[-1].mask.sum()) for l in flow]
-    nnz_all = [sum(float(m.mask.sum()) for m in l._conditioner.layers[::2]) for l in flow]
+    nnz_out = [float(torch.count_nonzero(l._conditioner.layers[-1].mask)) for l in flow]
+    nnz_all = [sum(float(torch.count_nonzero(m.mask)) for m in l._conditioner.layers[::2]) for l in flow]
 
     def step():
         y, ldj = flow(x)

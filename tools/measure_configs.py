@@ -1,0 +1,90 @@
+#!/usr/bin/env python
+"""Throughput of the other BASELINE.json configurations (parity-test cases, not the bench line) and of
+the inverse, for DESIGN.md.  Prints one JSON line per measurement.  Run on an MI355X."""
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tfep_amd.nn.conditioners import generate_degrees  # noqa: E402
+from tfep_amd.nn.embeddings import PeriodicEmbedding  # noqa: E402
+from tfep_amd.nn.flows import MAF, SequentialFlow  # noqa: E402
+from tfep_amd.nn.transformers import MoebiusTransformer, NeuralSplineTransformer  # noqa: E402
+
+dev = torch.device('cuda')
+
+
+def timeit(fn, warmup=1, steps=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps, out
+
+
+def report(name, B, dt, **kw):
+    print(json.dumps(dict(config=name, batch=B, ms=round(dt * 1e3, 3), samples_per_s=round(B / dt, 1), **kw)), flush=True)
+
+
+def order(i):
+    return 'ascending' if i % 2 == 0 else 'descending'
+
+
+which = set(sys.argv[1:]) or {'cfg1', 'cfg2inv', 'cfg4'}
+torch.manual_seed(0)
+
+if 'cfg1' in which:
+    D, B = 66, 1024
+    with torch.device(dev):
+        flow = SequentialFlow(*[MAF(generate_degrees(D, order(i)), initialize_identity=False) for i in range(2)])
+    x = torch.randn(B, D, device=dev)
+    dt, (y, _) = timeit(lambda: flow(x), 3, 20)
+    report('cfg1 forward: 2-layer MAF + affine, D=66', B, dt)
+    dt, (xi, _) = timeit(lambda: flow.inverse(y), 1, 5)
+    report('cfg1 inverse (blocked)', B, dt, roundtrip_max_abs=float((xi - x).abs().max()))
+    for l in flow:
+        l.blocked_inverse = False
+    dt, _ = timeit(lambda: flow.inverse(y), 1, 3)
+    report('cfg1 inverse (one full pass per degree, reference algorithm)', B, dt)
+
+if 'cfg2inv' in which:
+    D = 3000
+    B = int(os.environ.get('INV_BATCH', 8192))
+    with torch.device(dev):
+        flow = SequentialFlow(MAF(generate_degrees(D, 'ascending'),
+                                  transformer=NeuralSplineTransformer(torch.full((D,), -5.0), torch.full((D,), 5.0), 8),
+                                  initialize_identity=False))
+    x = torch.randn(B, D, device=dev).clamp_(-4.9, 4.9)
+    dt, (y, lf) = timeit(lambda: flow(x), 1, 2)
+    report('cfg2 ONE layer forward', B, dt)
+    dt, (xi, li) = timeit(lambda: flow.inverse(y), 1, 1)
+    report('cfg2 ONE layer inverse (blocked, 3000 degrees)', B, dt,
+           roundtrip_rel_l2=float((xi - x).norm() / x.norm()), ldj_cancel_max_abs=float((lf + li).abs().max()))
+
+if 'cfg4' in which:
+    D, B = 512, 131072
+    with torch.device(dev):
+        flow = SequentialFlow(*[MAF(generate_degrees(D, order(i)),
+                                    transformer=NeuralSplineTransformer(torch.zeros(D), torch.ones(D), 8, circular=True),
+                                    embedding=PeriodicEmbedding(D, limits=[0.0, 1.0]), initialize_identity=False)
+                                for i in range(4)])
+    x = torch.rand(B, D, device=dev)
+    dt, (y, _) = timeit(lambda: flow(x), 1, 3)
+    report('cfg4-i forward: 4-layer MAF + circular RQ-8 + periodic embedding, 512 torsions', B, dt,
+           y_in_domain=bool(((y >= 0) & (y <= 1)).all()))
+    with torch.device(dev):
+        flow = SequentialFlow(*[MAF(generate_degrees(2 * D, order(i), repeats=2),
+                                    transformer=MoebiusTransformer(dimension=2, unit_sphere=True),
+                                    initialize_identity=False) for i in range(4)])
+    ang = torch.rand(B, D, device=dev) * 2 * math.pi
+    x = torch.stack([torch.cos(ang), torch.sin(ang)], dim=2).reshape(B, 2 * D)
+    dt, (y, _) = timeit(lambda: flow(x), 1, 3)
+    report('cfg4-ii forward: 4-layer MAF + Moebius(d=2, unit sphere), 512 torsions as 1024 features', B, dt,
+           max_norm_error=float((y.reshape(B, D, 2).norm(dim=2) - 1).abs().max()))
