@@ -114,6 +114,31 @@ int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int6
                                int k_padded, int act, int tile_n, void* stream);
 int tfep_masked_linear_tile_n(void);
 int tfep_masked_linear_narrow_tile_n(void);
+
+/*
+ * General form of the same GEMM, used by the backward pass (MaskedLinearFunc.backward,
+ * masked.py:279-302: grad_input = g W_masked, grad_weight = (g^T x) o mask):
+ *   y (+)= act(x w^T + bias) [* elu'(elu_grad_of)]
+ *   elu_grad_of: optional saved ELU OUTPUT h with the layout of y; the result is multiplied by
+ *     elu'(z) = h > 0 ? 1 : h + 1   (ELU backward of conditioners/made.py:320 fused into grad_input);
+ *   accumulate: add into y (gradient accumulation over batch chunks);
+ *   tile_live: optional (ceil(B/tile_m) x ceil(N/tile_n)) bytes, 0 = output tile entirely masked, skipped
+ *     (grad_weight of a block-triangular mask).
+ * Other fields as in tfep_masked_linear_forward (wide column tile).
+ */
+typedef struct tfep_gemm_desc {
+    const float* x; int64_t ldx;
+    const float* w; int64_t ldw;
+    const float* bias;
+    const int32_t* k_ranges;
+    const int32_t* tile_order;
+    const int32_t* col_map;
+    float* y; int64_t ldy;
+    int32_t B, N, n_rows_w, k_padded, act, accumulate;
+    const float* elu_grad_of; int64_t ld_elu_grad_of;
+    const uint8_t* tile_live;
+} tfep_gemm_desc;
+int tfep_masked_linear_gemm(const tfep_gemm_desc* desc, void* stream);
 int tfep_masked_linear_tile_k(void);
 int tfep_masked_linear_tile_m(void);
 
@@ -228,6 +253,48 @@ int tfep_fused_output_transformer_forward(const float* h, int64_t ldh, const flo
                                           int n_feature_slots, double* ldj_partial,
                                           float* log_det_J, int accumulate,
                                           int B, int n_rows_w, int k_padded, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Backward (training step, app/base.py:780-840 calls loss.backward())         */
+/* ------------------------------------------------------------------------- */
+
+/* out (C x R, row stride ld_out >= R) = in^T for in (R x C, row stride ld_in).  Layout helper of the
+ * backward GEMMs: grad_input = g W needs W^T K-contiguous, grad_weight = g^T x needs g^T and x^T. */
+int tfep_transpose(const float* in, int64_t ld_in, int R, int C, float* out, int64_t ld_out, void* stream);
+/* out[c] (+)= sum_r in[r, c]      grad_bias = grad_output.sum(0)  (masked.py:299-300) */
+int tfep_column_sums(const float* in, int64_t ld, int R, int C, float* out, int accumulate, void* stream);
+/* out[b, c] += in[b, c] */
+int tfep_add_inplace(const float* in, int64_t ld_in, float* out, int64_t ld_out, int B, int C, void* stream);
+
+/* Vector-Jacobian products of the transformers' FORWARD maps.  Given gy (B, D) = dL/dy and
+ * g_log_det_J (B,) = dL/d log_det_J (may be NULL) they write gparams (layout glayout, every parameter
+ * of every feature) and gx (B, D) = the DIRECT dL/dx (not through the conditioner).
+ * Reference: eager autograd through affine.py:321-323 / spline.py:184-241, :319-417, :424-650.
+ * The spline version supports plain, circular and identity-boundary-slope splines (fixed bounds). */
+int tfep_affine_backward(const float* x, int64_t ldx, const float* params, tfep_param_layout layout,
+                         const float* gy, int64_t ldgy, const float* g_log_det_J,
+                         float* gparams, tfep_param_layout glayout, float* gx, int64_t ldgx,
+                         int B, int D, void* stream);
+int tfep_spline_backward(const float* x, int64_t ldx, const float* params, tfep_param_layout layout,
+                         const tfep_spline_desc* desc, const float* gy, int64_t ldgy,
+                         const float* g_log_det_J, float* gparams, tfep_param_layout glayout,
+                         float* gx, int64_t ldgx, int B, int D, void* stream);
+
+/* Gradient of the masked weight-norm parametrisation from the gradient of the PACKED effective weight
+ * (as written by tfep_masked_weight_prepare with the same permutations):
+ *   weight_g != NULL: grad_v (out, in), grad_g (out); masked entries of grad_v and fully-masked rows of
+ *   grad_g are zero (the reference's gradient hooks, masked.py:401-402, :429);
+ *   weight_g == NULL: grad_v = grad_weight = gW o mask (masked.py:293-297), grad_g unused. */
+int tfep_weight_norm_backward(const float* gw_packed, int64_t ldw, const float* weight_v,
+                              const float* weight_g, const float* mask, int out_features, int in_features,
+                              const int32_t* row_of_out, const int32_t* col_of_in,
+                              float* grad_v, float* grad_g, void* stream);
+
+/* Backward of tfep_periodic_embedding: gx[:, f] for every input feature (periodic and not). */
+int tfep_periodic_embedding_backward(const float* x, int64_t ldx, const int32_t* periodic_indices,
+                                     int n_periodic, const int32_t* nonperiodic_indices, int n_nonperiodic,
+                                     float lower, float upper, const float* gout, int64_t ldg,
+                                     float* gx, int64_t ldgx, int B, void* stream);
 
 /* Diagnostic (not on the path): run `iters` x 200 register-only v_mfma_f32_16x16x4_f32 per wave on
  * `blocks` workgroups of 512 threads -- the matrix-pipe ceiling of this device for the GEMM's own

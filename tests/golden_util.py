@@ -171,14 +171,14 @@ def build_transformer(tr):
     raise ValueError(t)
 
 
-def build_flow(name, flows_npz=None, device='cuda'):
+def build_flow(name, flows_npz=None, device='cuda', configs=None):
     """SequentialFlow of tfep_amd MAF layers configured like golden flow ``name``; weights
     loaded from the fixture through ``load_state_dict`` (reference state_dict schema)."""
     import torch
     from tfep_amd.nn.embeddings import PeriodicEmbedding
     from tfep_amd.nn.flows import MAF, SequentialFlow
     layers = []
-    for c in flow_configs()[name]:
+    for c in (configs or flow_configs())[name]:
         emb = c.get('embedding')
         embedding = None
         if emb is not None:
@@ -211,3 +211,26 @@ def err_stats(got, ref):
     ref = np.asarray(ref, dtype=np.float64)
     d = got - ref
     return float(np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-300)), float(np.abs(d).max())
+
+
+def grad_flow_configs():
+    """Flows of tests/golden/grads.npz (tools/gen_golden.py:gen_grads)."""
+    from oracle.made import generate_degrees as gd
+    D = 10
+    emb = dict(type='periodic', limits=(0.0, 1.0), periodic_indices=list(range(D)), nonperiodic_indices=[])
+    return {
+        'affine': [
+            dict(degrees_in=gd(D, 'ascending'), transformer=dict(type='affine'), hidden_layers=2, weight_norm=True),
+            dict(degrees_in=gd(D, 'descending', conditioning_indices=[2, 5]), transformer=dict(type='affine'),
+                 hidden_layers=2, weight_norm=False)],
+        'spline': [
+            dict(degrees_in=gd(D, 'ascending'), transformer=_spl(D, -4.0, 4.0, 8), hidden_layers=2, weight_norm=True),
+            dict(degrees_in=gd(D, 'descending'), transformer=_spl(D, -4.0, 4.0, 8), hidden_layers=[24, 24],
+                 weight_norm=True)],
+        'circular': [
+            dict(degrees_in=gd(D, 'ascending'), transformer=_spl(D, 0.0, 1.0, 8, circular=True), embedding=emb,
+                 hidden_layers=2, weight_norm=True)],
+        'identslopes': [
+            dict(degrees_in=gd(D, 'ascending'), transformer=_spl(D, -2.0, 2.0, 5, identity_boundary_slopes=True),
+                 hidden_layers=2, weight_norm=True)],
+    }

@@ -25,13 +25,13 @@ def dev(a, dtype=torch.float32):
 
 
 def check_y(got, ref, rel=REL, what='y'):
-    r, m = gu.err_stats(got.cpu().numpy(), ref)
+    r, m = gu.err_stats(got.detach().cpu().numpy(), ref)
     assert r <= rel, f'{what}: relative L2 error {r:.3e} > {rel:.1e} (max abs {m:.3e})'
     return r, m
 
 
 def check_ldj(got, ref, rel=REL, floor=0.0):
-    got = got.cpu().numpy().astype(np.float64)
+    got = got.detach().cpu().numpy().astype(np.float64)
     tol = np.maximum(rel * np.maximum(1.0, np.abs(ref)), floor)
     bad = np.abs(got - ref) > tol
     assert not bad.any(), f'ldj: max abs error {np.abs(got - ref).max():.3e}, {bad.sum()} samples out of tolerance'

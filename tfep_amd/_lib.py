@@ -22,6 +22,15 @@ class ParamLayout(Structure):
     _fields_ = [('ld', c_int64), ('stride_p', c_int64), ('stride_f', c_int64)]
 
 
+class GemmDesc(Structure):
+    _fields_ = [('x', c_void_p), ('ldx', c_int64), ('w', c_void_p), ('ldw', c_int64), ('bias', c_void_p),
+                ('k_ranges', c_void_p), ('tile_order', c_void_p), ('col_map', c_void_p),
+                ('y', c_void_p), ('ldy', c_int64),
+                ('B', c_int32), ('N', c_int32), ('n_rows_w', c_int32), ('k_padded', c_int32),
+                ('act', c_int32), ('accumulate', c_int32),
+                ('elu_grad_of', c_void_p), ('ld_elu_grad_of', c_int64), ('tile_live', c_void_p)]
+
+
 class SplineDesc(Structure):
     _fields_ = [('x0', c_void_p), ('xf', c_void_p), ('y0', c_void_p), ('yf', c_void_p),
                 ('n_bins', c_int32), ('circular', c_int32), ('identity_boundary_slopes', c_int32),
@@ -64,6 +73,17 @@ _SIGNATURES = {
                                                       _P, _P, c_int, _P, _P, c_int,
                                                       c_int, c_int, c_int, _P]),
     'tfep_diag_mfma_peak': (c_int, [_P, c_int, c_int, _P]),
+    'tfep_masked_linear_gemm': (c_int, [POINTER(GemmDesc), _P]),
+    'tfep_transpose': (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, _P]),
+    'tfep_column_sums': (c_int, [_P, c_int64, c_int, c_int, _P, c_int, _P]),
+    'tfep_add_inplace': (c_int, [_P, c_int64, _P, c_int64, c_int, c_int, _P]),
+    'tfep_affine_backward': (c_int, [_P, c_int64, _P, ParamLayout, _P, c_int64, _P, _P, ParamLayout, _P, c_int64,
+                                     c_int, c_int, _P]),
+    'tfep_spline_backward': (c_int, [_P, c_int64, _P, ParamLayout, POINTER(SplineDesc), _P, c_int64, _P, _P,
+                                     ParamLayout, _P, c_int64, c_int, c_int, _P]),
+    'tfep_weight_norm_backward': (c_int, [_P, c_int64, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    'tfep_periodic_embedding_backward': (c_int, [_P, c_int64, _P, c_int, _P, c_int, c_float, c_float, _P, c_int64,
+                                                 _P, c_int64, c_int, _P]),
     'tfep_tfep_reduce': (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P]),
     'tfep_tfep_reduce_workspace_doubles': (c_int, [c_int]),
 }

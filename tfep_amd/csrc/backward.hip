@@ -1,0 +1,463 @@
+// Backward (training) kernels of the flow path: transformer gradients, weight-norm gradient,
+// layout helpers for the backward GEMMs.  Reference semantics: the reference relies on eager
+// autograd through spline.py / affine.py / mafembed.py and on MaskedLinearFunc.backward
+// (masked.py:279-302) + the weight-norm gradient hooks (masked.py:401-402, :429).
+//
+// Launch shape as the forward transformer kernels: one wavefront per sample row, lanes walk the
+// features (coalesced per parameter row); all derivative arithmetic in fp64.
+#include "common.h"
+#include "spline.h"
+
+namespace tfep {
+
+constexpr int ROWS_PER_BLOCK_B = 4;
+static inline unsigned row_blocks_b(int B) { return (unsigned)((B + ROWS_PER_BLOCK_B - 1) / ROWS_PER_BLOCK_B); }
+
+// ---------------------------------------------------------------- transpose (LDS tiled, 32 x 32)
+__global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict__ in, int64_t ld_in, int R, int C,
+                                                        float* __restrict__ out, int64_t ld_out) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int r = r0 + ty + i, c = c0 + tx;
+        tile[ty + i][tx] = (r < R && c < C) ? in[(int64_t)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int c = c0 + ty + i, r = r0 + tx;                  // out[c][r]
+        if (c < C && r < R) out[(int64_t)c * ld_out + r] = tile[tx][ty + i];
+    }
+}
+
+// out[c] (+)= sum_r in[r, c]   (bias gradient, masked.py:299-300)
+__global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ in, int64_t ld, int R, int C,
+                                                     float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int r = 0; r < R; ++r) s += (double)in[(int64_t)r * ld + c];
+    out[c] = accumulate ? (float)((double)out[c] + s) : (float)s;
+}
+
+// ---------------------------------------------------------------- affine backward (affine.py:321-323)
+__global__ void __launch_bounds__(256) affine_backward_kernel(const float* __restrict__ x, int64_t ldx,
+                                                              const float* __restrict__ params, tfep_param_layout L,
+                                                              const float* __restrict__ gy, int64_t ldgy,
+                                                              const float* __restrict__ gldj,
+                                                              float* __restrict__ gparams, tfep_param_layout GL,
+                                                              float* __restrict__ gx, int64_t ldgx, int B, int D) {
+    const int b = blockIdx.x * ROWS_PER_BLOCK_B + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const float gl = gldj ? gldj[b] : 0.f;
+    for (int f = lane; f < D; f += 64) {
+        const float ls = params[(int64_t)b * L.ld + L.stride_p + f * L.stride_f];
+        const float g = gy[(int64_t)b * ldgy + f];
+        const float e = expf(ls);
+        const float xv = x[(int64_t)b * ldx + f];
+        gparams[(int64_t)b * GL.ld + f * GL.stride_f] = g;                                   // d/d shift
+        gparams[(int64_t)b * GL.ld + GL.stride_p + f * GL.stride_f] = g * xv * e + gl;       // d/d log_scale
+        gx[(int64_t)b * ldgx + f] = g * e;
+    }
+}
+
+// ---------------------------------------------------------------- RQ spline backward
+struct SplineArgsB {
+    const float *x0, *xf, *y0, *yf;
+    SplineFlags f;
+    int P;
+};
+
+__device__ inline double sigmoid_d(double z) { return z > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-z)); }
+
+// Reverse mode through rq_spline_element (spline.h), FORWARD direction only, fixed bounds.
+template <int KMAX>
+__device__ inline void rq_spline_backward(const float (&w)[KMAX], const float (&h)[KMAX], const float (&sraw)[KMAX + 1],
+                                          float last, const SplineFlags& f, float x0f, float xff, float y0f, float yff,
+                                          float vin, double gy, double gl, double (&guw)[KMAX], double (&guh)[KMAX],
+                                          double (&gus)[KMAX + 1], double* glast, double* gxin) {
+    const int K = f.K;
+    const double mb = (double)f.min_bin;
+    const double x0 = x0f, y0 = y0f;
+    const double W = (double)xff - x0 - K * mb, H = (double)yff - y0 - K * mb;
+    double v = vin;
+    if (f.circular) v = py_mod(v - x0 + (double)last, (double)xff - x0) + x0;
+
+    float mw = -INFINITY, mh = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+            mw = fmaxf(mw, w[k]);
+            mh = fmaxf(mh, h[k]);
+        }
+    double pw[KMAX], ph[KMAX];
+    double sw = 0.0, sh = 0.0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        pw[k] = 0.0;
+        ph[k] = 0.0;
+        if (k < K) {
+            pw[k] = exp((double)w[k] - (double)mw);
+            ph[k] = exp((double)h[k] - (double)mh);
+            sw += pw[k];
+            sh += ph[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        pw[k] /= sw;
+        ph[k] /= sh;
+    }
+
+    double kx = x0, ky = y0, bw = 0.0, bh = 0.0;
+    int kbin = -1;
+    bool found = false;
+    const bool lower_tail = !(v > x0);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K && !found) {
+            const double wk = pw[k] * W + mb, hk = ph[k] * H + mb;
+            if (v > kx + wk) {
+                kx += wk;
+                ky += hk;
+            } else {
+                found = true;
+                bw = wk;
+                bh = hk;
+                kbin = k;
+            }
+        }
+
+    double gw[KMAX], gh[KMAX], gd[KMAX + 1];      // grads wrt widths, heights, slopes (values)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        gw[k] = 0.0;
+        gh[k] = 0.0;
+        gd[k] = 0.0;
+    }
+    gd[KMAX] = 0.0;
+    double gv;
+
+    auto slope = [&](float r) { return (double)(softplus_f(r + f.slope_offset) + f.min_slope); };
+    if (lower_tail || !found) {
+        // y = y_b + d (v - x_b), ld = log d; the boundary knot is a constant of the softmax outputs
+        float rs = sraw[0];
+        int jb = 0;
+        if (!lower_tail) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k == K - 1) rs = sraw[k + 1];
+            jb = K;
+        }
+        const double d = slope(rs);
+        const double bx = lower_tail ? x0 : kx;
+        const double gdb = gy * (v - bx) + gl / d;
+#pragma unroll
+        for (int j = 0; j <= KMAX; ++j)
+            if (j == jb) gd[j] = gdb;
+        gv = gy * d;
+    } else {
+        float rs0 = sraw[0], rs1 = sraw[0];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k == kbin) {
+                rs0 = sraw[k];
+                rs1 = sraw[k + 1];
+            }
+        const double dk = slope(rs0), dk1 = slope(rs1);
+        const double s = bh / bw, t = dk1 + dk - 2.0 * s;
+        const double eps = (v - kx) / bw, om = 1.0 - eps, e1 = eps * om;
+        const double A = s * eps * eps + dk * e1;
+        const double Dn = s + t * e1;
+        const double Q = dk1 * eps * eps + 2.0 * s * e1 + dk * om * om;
+        const double dy_dA = bh / Dn, dy_dDn = -bh * A / (Dn * Dn);
+        const double gs = gy * (dy_dA * eps * eps + dy_dDn * (1.0 - 2.0 * e1)) +
+                          gl * (2.0 / s + 2.0 * e1 / Q - 2.0 * (1.0 - 2.0 * e1) / Dn);
+        const double geps = gy * (dy_dA * (2.0 * s * eps + dk * (1.0 - 2.0 * eps)) + dy_dDn * t * (1.0 - 2.0 * eps)) +
+                            gl * ((2.0 * dk1 * eps + 2.0 * s * (1.0 - 2.0 * eps) - 2.0 * dk * om) / Q -
+                                  2.0 * t * (1.0 - 2.0 * eps) / Dn);
+        const double gdk = gy * (dy_dA * e1 + dy_dDn * e1) + gl * (om * om / Q - 2.0 * e1 / Dn);
+        const double gdk1 = gy * (dy_dDn * e1) + gl * (eps * eps / Q - 2.0 * e1 / Dn);
+        const double gh_bin = gy * A / Dn + gs / bw;
+        const double gw_bin = -gs * s / bw - geps * eps / bw;
+        const double gxk = -geps / bw;
+        gv = geps / bw;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            if (k < kbin) {
+                gw[k] = gxk;
+                gh[k] = gy;
+            } else if (k == kbin) {
+                gw[k] = gw_bin;
+                gh[k] = gh_bin;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j <= KMAX; ++j) {
+            if (j == kbin) gd[j] = gdk;
+            if (j == kbin + 1) gd[j] = gdk1;
+        }
+    }
+
+    // softmax backward: w_k = p_k W + mb
+    double dotw = 0.0, doth = 0.0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        dotw += pw[k] * gw[k];
+        doth += ph[k] * gh[k];
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        guw[k] = pw[k] * W * (gw[k] - dotw);
+        guh[k] = ph[k] * H * (gh[k] - doth);
+    }
+    // softplus backward
+#pragma unroll
+    for (int j = 0; j <= KMAX; ++j) gus[j] = (j <= K) ? gd[j] * sigmoid_d((double)sraw[j] + (double)f.slope_offset) : 0.0;
+    *glast = f.circular ? gv : 0.0;
+    *gxin = gv;
+}
+
+template <int KMAX>
+__global__ void __launch_bounds__(256) spline_backward_kernel(const float* __restrict__ x, int64_t ldx,
+                                                              const float* __restrict__ params, tfep_param_layout L,
+                                                              SplineArgsB a, const float* __restrict__ gy, int64_t ldgy,
+                                                              const float* __restrict__ gldj,
+                                                              float* __restrict__ gparams, tfep_param_layout GL,
+                                                              float* __restrict__ gx, int64_t ldgx, int B, int D) {
+    const int b = blockIdx.x * ROWS_PER_BLOCK_B + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int K = a.f.K;
+    const double gl = gldj ? (double)gldj[b] : 0.0;
+    for (int f = lane; f < D; f += 64) {
+        const float* pf = params + (int64_t)b * L.ld + f * L.stride_f;
+        float* gp = gparams + (int64_t)b * GL.ld + f * GL.stride_f;
+        float w[KMAX], h[KMAX], sraw[KMAX + 1];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            w[k] = 0.f;
+            h[k] = 0.f;
+            if (k < K) {
+                w[k] = pf[k * L.stride_p];
+                h[k] = pf[(K + k) * L.stride_p];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j <= KMAX; ++j) {
+            sraw[j] = 0.f;
+            if (j <= K) {
+                const int pi = spline_slope_param(j, K, a.f.circular, a.f.identity);
+                if (pi >= 0) sraw[j] = pf[pi * L.stride_p];
+            }
+        }
+        const float last = a.f.circular ? pf[(a.P - 1) * L.stride_p] : 0.f;
+        double guw[KMAX], guh[KMAX], gus[KMAX + 1], glast, gxin;
+        rq_spline_backward<KMAX>(w, h, sraw, last, a.f, a.x0[f], a.xf[f], a.y0[f], a.yf[f], x[(int64_t)b * ldx + f],
+                                 (double)gy[(int64_t)b * ldgy + f], gl, guw, guh, gus, &glast, &gxin);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) {
+                gp[k * GL.stride_p] = (float)guw[k];
+                gp[(K + k) * GL.stride_p] = (float)guh[k];
+            }
+        // slopes: knot K of a circular spline shares the parameter of knot 0; identity boundary
+        // slopes have no parameter.
+        double g0 = gus[0];
+#pragma unroll
+        for (int j = 0; j <= KMAX; ++j)
+            if (j == K && a.f.circular && !a.f.identity) g0 += gus[j];
+#pragma unroll
+        for (int j = 0; j <= KMAX; ++j) {
+            if (j > K) continue;
+            if (a.f.circular && !a.f.identity && j == K) continue;
+            const int pi = spline_slope_param(j, K, a.f.circular, a.f.identity);
+            if (pi >= 0) gp[pi * GL.stride_p] = (float)(j == 0 ? g0 : gus[j]);
+        }
+        if (a.f.circular) gp[(a.P - 1) * GL.stride_p] = (float)glast;
+        gx[(int64_t)b * ldgx + f] = (float)gxin;
+    }
+}
+
+// ---------------------------------------------------------------- weight-norm backward
+// W[o,i] = M[o,i] v[o,i] g[o]/n_o, n_o = ||v[o,:]||.  Given gW (packed coordinates):
+//   gg[o]   = sum_i gW M v / n
+//   gv[o,i] = M (g/n) gW - g v / n^3 * sum_j gW M v
+// with the reference's hooks: gv = 0 where M == 0, gg = 0 for fully-masked rows (masked.py:401-402, :429).
+// Without weight norm (g == NULL): gweight = gW o M (masked.py:293-297).
+__global__ void __launch_bounds__(256) weight_norm_backward_kernel(const float* __restrict__ gw_packed, int64_t ldw,
+                                                                   const float* __restrict__ v,
+                                                                   const float* __restrict__ g,
+                                                                   const float* __restrict__ mask, int N, int K,
+                                                                   const int32_t* __restrict__ row_of_out,
+                                                                   const int32_t* __restrict__ col_of_in,
+                                                                   float* __restrict__ gv, float* __restrict__ gg) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= N) return;
+    const int lane = threadIdx.x & 63;
+    const float* vr = v + (int64_t)o * K;
+    const float* mr = mask ? mask + (int64_t)o * K : nullptr;
+    const float* gr = gw_packed + (int64_t)(row_of_out ? row_of_out[o] : o) * ldw;
+    float* gvr = gv + (int64_t)o * K;
+    if (!g) {
+        for (int i = lane; i < K; i += 64) {
+            const float gwv = gr[col_of_in ? col_of_in[i] : i];
+            gvr[i] = (mr && mr[i] == 0.f) ? 0.f : gwv;
+        }
+        return;
+    }
+    double ss = 0.0, dot = 0.0, msum = 0.0;
+    for (int i = lane; i < K; i += 64) {
+        const double vv = vr[i];
+        ss += vv * vv;
+        const bool live = !mr || mr[i] != 0.f;
+        if (live) {
+            dot += (double)gr[col_of_in ? col_of_in[i] : i] * vv;
+            msum += 1.0;
+        }
+    }
+    ss = wave_sum(ss);
+    dot = wave_sum(dot);
+    msum = wave_sum(msum);
+    const double n = sqrt(ss);
+    const bool dead = msum == 0.0 || n == 0.0;
+    const double gg_o = dead ? 0.0 : dot / n;
+    const double go = (double)g[o];
+    for (int i = lane; i < K; i += 64) {
+        const bool live = !mr || mr[i] != 0.f;
+        double out = 0.0;
+        if (live && !dead) out = go / n * (double)gr[col_of_in ? col_of_in[i] : i] - go * (double)vr[i] * dot / (n * n * n);
+        gvr[i] = (float)out;
+    }
+    if (lane == 0) gg[o] = (float)gg_o;
+}
+
+// ---------------------------------------------------------------- periodic embedding backward
+// out = [x_non..., cos t, sin t, ...], t = (x - lower) * scale  ->  gx[p] = (-sin t g_cos + cos t g_sin) * scale
+__global__ void __launch_bounds__(256) periodic_embedding_backward_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                          const int32_t* __restrict__ pidx, int n_per,
+                                                                          const int32_t* __restrict__ nidx, int n_non,
+                                                                          float lower, float scale,
+                                                                          const float* __restrict__ gout, int64_t ldg,
+                                                                          float* __restrict__ gx, int64_t ldgx, int B) {
+    const int n_src = n_non + n_per;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * n_src) return;
+    const int b = (int)(i / n_src), j = (int)(i % n_src);
+    if (j < n_non) {
+        gx[(int64_t)b * ldgx + nidx[j]] = gout[(int64_t)b * ldg + j];
+    } else {
+        const int q = j - n_non;
+        const float t = (x[(int64_t)b * ldx + pidx[q]] - lower) * scale;
+        float sn, cs;
+        sincosf(t, &sn, &cs);
+        const float gc = gout[(int64_t)b * ldg + n_non + 2 * q], gs = gout[(int64_t)b * ldg + n_non + 2 * q + 1];
+        gx[(int64_t)b * ldgx + pidx[q]] = (-sn * gc + cs * gs) * scale;
+    }
+}
+
+// out[b, c] += in[b, c]   (gx = direct + through-the-conditioner)
+__global__ void __launch_bounds__(256) add_inplace_kernel(const float* __restrict__ in, int64_t ldi,
+                                                          float* __restrict__ out, int64_t ldo, int B, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * C) return;
+    const int b = (int)(i / C), c = (int)(i % C);
+    out[(int64_t)b * ldo + c] += in[(int64_t)b * ldi + c];
+}
+
+}  // namespace tfep
+
+using namespace tfep;
+
+extern "C" {
+
+int tfep_transpose(const float* in, int64_t ld_in, int R, int C, float* out, int64_t ld_out, void* stream) {
+    TFEP_REQUIRE(R >= 0 && C >= 0 && ld_in >= C && ld_out >= R, "transpose: bad sizes");
+    if (R == 0 || C == 0) return TFEP_OK;
+    TFEP_REQUIRE(in && out, "transpose: NULL pointer");
+    dim3 grid((unsigned)((C + 31) / 32), (unsigned)((R + 31) / 32));
+    transpose_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, ld_in, R, C, out, ld_out);
+    return check_launch("transpose_kernel");
+}
+
+int tfep_column_sums(const float* in, int64_t ld, int R, int C, float* out, int accumulate, void* stream) {
+    TFEP_REQUIRE(R >= 0 && C >= 0, "column_sums: bad sizes");
+    if (C == 0) return TFEP_OK;
+    TFEP_REQUIRE(out && (in || R == 0), "column_sums: NULL pointer");
+    colsum_kernel<<<(unsigned)((C + 255) / 256), 256, 0, (hipStream_t)stream>>>(in, ld, R, C, out, accumulate);
+    return check_launch("colsum_kernel");
+}
+
+int tfep_add_inplace(const float* in, int64_t ld_in, float* out, int64_t ld_out, int B, int C, void* stream) {
+    const int64_t n = (int64_t)B * C;
+    if (n <= 0) return TFEP_OK;
+    TFEP_REQUIRE(in && out, "add_inplace: NULL pointer");
+    add_inplace_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(in, ld_in, out, ld_out, B, C);
+    return check_launch("add_inplace_kernel");
+}
+
+int tfep_affine_backward(const float* x, int64_t ldx, const float* params, tfep_param_layout layout, const float* gy,
+                         int64_t ldgy, const float* g_log_det_J, float* gparams, tfep_param_layout glayout, float* gx,
+                         int64_t ldgx, int B, int D, void* stream) {
+    TFEP_REQUIRE(B >= 0 && D >= 0, "affine_backward: negative size");
+    if (B == 0 || D == 0) return TFEP_OK;
+    TFEP_REQUIRE(x && params && gy && gparams && gx, "affine_backward: NULL pointer");
+    affine_backward_kernel<<<row_blocks_b(B), 256, 0, (hipStream_t)stream>>>(x, ldx, params, layout, gy, ldgy, g_log_det_J,
+                                                                            gparams, glayout, gx, ldgx, B, D);
+    return check_launch("affine_backward_kernel");
+}
+
+int tfep_spline_backward(const float* x, int64_t ldx, const float* params, tfep_param_layout layout,
+                         const tfep_spline_desc* d, const float* gy, int64_t ldgy, const float* g_log_det_J,
+                         float* gparams, tfep_param_layout glayout, float* gx, int64_t ldgx, int B, int D, void* stream) {
+    TFEP_REQUIRE(d != nullptr, "spline_backward: descriptor is NULL");
+    TFEP_REQUIRE(d->n_bins >= 1 && d->n_bins <= 32, "spline_backward: n_bins=%d unsupported (1..32)", d->n_bins);
+    if (d->learn_lower_bound || d->learn_upper_bound)
+        return fail(TFEP_ERR_UNSUPPORTED, "spline_backward: learnable domain bounds are not supported yet");
+    TFEP_REQUIRE(B >= 0 && D >= 0, "spline_backward: negative size");
+    if (B == 0 || D == 0) return TFEP_OK;
+    TFEP_REQUIRE(x && params && gy && gparams && gx && d->x0 && d->xf && d->y0 && d->yf, "spline_backward: NULL pointer");
+    SplineArgsB a;
+    a.x0 = d->x0; a.xf = d->xf; a.y0 = d->y0; a.yf = d->yf;
+    a.f.K = d->n_bins; a.f.circular = d->circular != 0; a.f.identity = d->identity_boundary_slopes != 0;
+    a.f.learn_lower = false; a.f.learn_upper = false;
+    a.f.min_bin = d->min_bin_size; a.f.min_slope = d->min_slope;
+    a.f.slope_offset = (float)log(exp(1.0 - (double)d->min_slope) - 1.0);
+    a.P = spline_n_params(a.f.K, a.f.circular, a.f.identity, false, false);
+    hipStream_t s = (hipStream_t)stream;
+    if (a.f.K <= 8)
+        spline_backward_kernel<8><<<row_blocks_b(B), 256, 0, s>>>(x, ldx, params, layout, a, gy, ldgy, g_log_det_J, gparams, glayout, gx, ldgx, B, D);
+    else if (a.f.K <= 16)
+        spline_backward_kernel<16><<<row_blocks_b(B), 256, 0, s>>>(x, ldx, params, layout, a, gy, ldgy, g_log_det_J, gparams, glayout, gx, ldgx, B, D);
+    else
+        spline_backward_kernel<32><<<row_blocks_b(B), 256, 0, s>>>(x, ldx, params, layout, a, gy, ldgy, g_log_det_J, gparams, glayout, gx, ldgx, B, D);
+    return check_launch("spline_backward_kernel");
+}
+
+int tfep_weight_norm_backward(const float* gw_packed, int64_t ldw, const float* weight_v, const float* weight_g,
+                              const float* mask, int out_features, int in_features, const int32_t* row_of_out,
+                              const int32_t* col_of_in, float* grad_v, float* grad_g, void* stream) {
+    TFEP_REQUIRE(out_features >= 0 && in_features >= 0, "weight_norm_backward: negative size");
+    if (out_features == 0 || in_features == 0) return TFEP_OK;
+    TFEP_REQUIRE(gw_packed && weight_v && grad_v && (!weight_g || grad_g), "weight_norm_backward: NULL pointer");
+    weight_norm_backward_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+        gw_packed, ldw, weight_v, weight_g, mask, out_features, in_features, row_of_out, col_of_in, grad_v, grad_g);
+    return check_launch("weight_norm_backward_kernel");
+}
+
+int tfep_periodic_embedding_backward(const float* x, int64_t ldx, const int32_t* periodic_indices, int n_periodic,
+                                     const int32_t* nonperiodic_indices, int n_nonperiodic, float lower, float upper,
+                                     const float* gout, int64_t ldg, float* gx, int64_t ldgx, int B, void* stream) {
+    const int64_t n = (int64_t)B * (n_periodic + n_nonperiodic);
+    if (n == 0) return TFEP_OK;
+    TFEP_REQUIRE(x && gout && gx, "periodic_embedding_backward: NULL pointer");
+    const float scale = (float)(2.0 * 3.14159265358979323846 / ((double)upper - (double)lower));
+    periodic_embedding_backward_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(
+        x, ldx, periodic_indices, n_periodic, nonperiodic_indices, n_nonperiodic, lower, scale, gout, ldg, gx, ldgx, B);
+    return check_launch("periodic_embedding_backward_kernel");
+}
+
+}  // extern "C"

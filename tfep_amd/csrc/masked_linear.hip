@@ -145,6 +145,10 @@ struct GemmArgs {
     const int32_t* tile_order; // optional: launch position -> column tile (heaviest k-range first), or NULL
     int map_mode;              // 0: row-tile fastest; 1: XCD-aware 8x4 super-tiles
     int m_tiles, n_tiles;
+    const float* aux;          // linear epilogue: if set, y = acc * elu'(aux) with elu'(h) = h > 0 ? 1 : h + 1
+    int64_t ldaux;             //   (ELU backward from the saved activation h; same indexing as y)
+    int accumulate;            // linear epilogue: y += value instead of y = value
+    const uint8_t* tile_live;  // optional (m_tiles x n_tiles): 0 = the whole output tile is masked, skip it
     int diag;                  // diagnostics only (TFEP_DIAG): 1 = skip the epilogue, 2 = skip the MFMAs,
                                // 4 = skip the LDS-DMA, 8 = skip the barriers (garbage results; timing only)
     FusedArgs fu;
@@ -222,6 +226,7 @@ __global__ void __launch_bounds__(THREADS, (MREP == 1 ? 4 : 2)) gemm_kernel(Gemm
         ntp = blockIdx.x / g.m_tiles;
     }
     const int nt = g.tile_order ? g.tile_order[ntp] : ntp;
+    if (g.tile_live && !g.tile_live[(int64_t)mt * g.n_tiles + nt]) return;
     const int m0 = mt * T::BM, n0 = nt * T::BN;
 
     int kb = 0, ke = g.k_padded;
@@ -311,7 +316,12 @@ __global__ void __launch_bounds__(THREADS, (MREP == 1 ? 4 : 2)) gemm_kernel(Gemm
                     if (row < g.B) {
                         float v = acc[n][m][i] + bv;
                         if (EPI == EPI_ELU) v = elu_f(v);
-                        g.y[(int64_t)row * g.ldy + ocol] = v;
+                        if (g.aux) {
+                            const float h = g.aux[(int64_t)row * g.ldaux + ocol];
+                            v *= h > 0.f ? 1.f : h + 1.f;
+                        }
+                        float* dst = g.y + (int64_t)row * g.ldy + ocol;
+                        *dst = g.accumulate ? *dst + v : v;
                     }
                 }
         }
@@ -539,6 +549,24 @@ int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int6
     const int n_tiles = (N + Tile<LIN_MREP, LIN_NREP>::BN - 1) / Tile<LIN_MREP, LIN_NREP>::BN;
     if (act == 1) return launch_gemm<LIN_MREP, LIN_NREP, EPI_ELU, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);
     return launch_gemm<LIN_MREP, LIN_NREP, EPI_LINEAR, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);
+}
+
+int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
+    TFEP_REQUIRE(d != nullptr, "masked_linear_gemm: NULL descriptor");
+    int rc = check_gemm_operands(d->x, d->ldx, d->w, d->ldw, d->k_padded);
+    if (rc) return rc;
+    TFEP_REQUIRE(d->y, "masked_linear_gemm: y is NULL");
+    TFEP_REQUIRE(d->B >= 0 && d->N >= 0 && d->n_rows_w >= 1, "masked_linear_gemm: bad sizes");
+    TFEP_REQUIRE(d->act == 0 || d->act == 1, "masked_linear_gemm: act must be 0 or 1");
+    if (d->B == 0 || d->N == 0) return TFEP_OK;
+    GemmArgs g = {};
+    g.a = d->x; g.lda = d->ldx; g.w = d->w; g.ldw = d->ldw; g.bias = d->bias; g.k_ranges = d->k_ranges;
+    g.col_map = d->col_map; g.y = d->y; g.ldy = d->ldy; g.B = d->B; g.N = d->N; g.k_padded = d->k_padded;
+    g.tile_order = d->tile_order; g.aux = d->elu_grad_of; g.ldaux = d->ld_elu_grad_of; g.accumulate = d->accumulate;
+    g.tile_live = d->tile_live;
+    const int n_tiles = (d->N + Tile<LIN_MREP, LIN_NREP>::BN - 1) / Tile<LIN_MREP, LIN_NREP>::BN;
+    if (d->act == 1) return launch_gemm<LIN_MREP, LIN_NREP, EPI_ELU, 1, 1>(g, d->n_rows_w, n_tiles, (hipStream_t)stream);
+    return launch_gemm<LIN_MREP, LIN_NREP, EPI_LINEAR, 1, 1>(g, d->n_rows_w, n_tiles, (hipStream_t)stream);
 }
 
 int tfep_diag_mfma_peak(float* scratch, int blocks, int iters, void* stream) {

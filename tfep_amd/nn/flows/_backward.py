@@ -1,0 +1,279 @@
+"""Backward pass of one MAF layer on the HIP kernels (training step, reference app/base.py:780-840).
+
+The reference differentiates the flow with eager autograd plus ``MaskedLinearFunc.backward``
+(masked.py:279-302) and the weight-norm gradient hooks (masked.py:401-402, :429).  Here one
+``torch.autograd.Function`` per MAF layer wraps the (fused) HIP forward; its backward
+
+  1. recomputes the hidden activations and the transformer parameters for a chunk of the batch
+     (so the ``(B, P*D)`` parameter tensor only ever exists for a chunk),
+  2. runs the transformer VJP kernel (``tfep_affine_backward`` / ``tfep_spline_backward``),
+  3. walks the three masked linears backwards with the SAME fp32-MFMA GEMM kernel:
+     ``grad_input = g W`` on a transposed packed weight (ELU derivative fused in the epilogue),
+     ``grad_weight += g^T x`` on transposed activations, skipping output tiles that the block-triangular
+     mask kills, ``grad_bias += column sums``,
+  4. converts the packed weight gradients to ``weight_v`` / ``weight_g`` / ``weight`` gradients
+     (``tfep_weight_norm_backward``).
+
+PyTorch's role is the autograd graph between layers, the loss and the optimiser.
+"""
+import ctypes
+
+import torch
+
+from ... import _lib, ops
+from ..conditioners.made import MADE
+from ..embeddings.mafembed import PeriodicEmbedding
+from ..transformers.affine import AffineTransformer
+from ..transformers.spline import NeuralSplineTransformer
+
+# ~2 GiB of transformer parameters per chunk
+_CHUNK_BYTES = 1 << 31
+
+
+def supported(layer):
+    made = layer._conditioner
+    if not isinstance(made, MADE) or len(layer._conditioner_indices) > 0:
+        return False
+    emb = getattr(made, 'embedding', None)
+    if emb is not None and type(emb) is not PeriodicEmbedding:
+        return False
+    tr = layer._transformer
+    if type(tr) is AffineTransformer:
+        return True
+    if type(tr) is NeuralSplineTransformer:
+        return not bool(tr._learn_lower_bound) and not bool(tr._learn_upper_bound)
+    return False
+
+
+def trainable_tensors(layer):
+    """The conditioner parameters, in a fixed order shared by forward() and backward()."""
+    out = []
+    for lin in layer._conditioner._linears():
+        if lin.has_weight_norm:
+            out += [lin.weight_g, lin.weight_v]
+        else:
+            out += [lin._parameters['weight']]
+        out.append(lin.bias)
+    return out
+
+
+class MAFLayerFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, layer, x, *params):
+        with torch.no_grad():
+            y, ldj = layer._forward_impl(x)
+        ctx.layer = layer
+        ctx.save_for_backward(x)
+        return y, ldj
+
+    @staticmethod
+    def backward(ctx, gy, gldj):
+        layer = ctx.layer
+        (x,) = ctx.saved_tensors
+        with torch.no_grad():
+            gx, gparams = layer_backward(layer, x, gy, gldj)
+        return (None, gx, *gparams)
+
+
+class UnsupportedBackward(torch.autograd.Function):
+    """Forward works for every configuration; differentiating an unsupported one fails loudly."""
+
+    @staticmethod
+    def forward(ctx, layer, x, *params):
+        with torch.no_grad():
+            return layer._forward_impl(x)
+
+    @staticmethod
+    def backward(ctx, gy, gldj):
+        raise NotImplementedError(
+            'tfep_amd: backward is implemented for MAF layers with a MADE conditioner (optionally with a '
+            'PeriodicEmbedding) and an affine or fixed-bound neural-spline transformer.')
+
+
+def _gemm(x, w, y, B, N, n_rows_w, bias=None, k_ranges=None, act=0, accumulate=0, elu_grad_of=None, tile_live=None):
+    d = _lib.GemmDesc()
+    d.x, d.ldx = x.data_ptr(), x.shape[1]
+    d.w, d.ldw = w.data_ptr(), w.shape[1]
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.k_ranges = k_ranges.data_ptr() if k_ranges is not None else None
+    d.tile_order, d.col_map = None, None
+    d.y, d.ldy = y.data_ptr(), y.shape[1]
+    d.B, d.N, d.n_rows_w, d.k_padded, d.act, d.accumulate = B, N, n_rows_w, w.shape[1], act, accumulate
+    if elu_grad_of is not None:
+        d.elu_grad_of, d.ld_elu_grad_of = elu_grad_of.data_ptr(), elu_grad_of.shape[1]
+    d.tile_live = tile_live.data_ptr() if tile_live is not None else None
+    _lib.call('tfep_masked_linear_gemm', ctypes.byref(d), _lib.stream_of(x))
+    return y
+
+
+def _transpose(src, rows, cols, out):
+    """out (cols_pad x rows_pad, zero filled by the caller) <- src[:rows, :cols]^T."""
+    _lib.call('tfep_transpose', _lib.ptr(src), src.shape[1], rows, cols, _lib.ptr(out), out.shape[1], _lib.stream_of(src))
+    return out
+
+
+def _backward_plan(layer, device):
+    key = ('bwd', str(device))
+    bp = layer._dev.get(key)
+    if bp is not None:
+        return bp
+    made = layer._conditioner
+    mplan = made.plan(device)
+    tm, tn, tk = ops.tile_sizes()
+    lins = made._linears()
+    dx_ranges, live = [], []
+    for li, lin in enumerate(lins):
+        kr = mplan['k_ranges'][li].cpu().long()                   # per 256-row tile of W: [kb, ke)
+        is_out = li == len(lins) - 1
+        n_pad = ops.round_up(lin.out_features, tk) if is_out else mplan['n_pad'][li]
+        k_pad = mplan['k_pad'][li]
+        n_row_tiles = kr.shape[0]
+        n_col_tiles = (k_pad + tn - 1) // tn
+        lo = torch.arange(n_col_tiles) * tn
+        hi = lo + tn
+        hit = (kr[:, 0:1] < hi[None, :]) & (kr[:, 1:2] > lo[None, :])          # (row tiles, col tiles)
+        live.append(hit.to(torch.uint8).contiguous().to(device))
+        # grad_input GEMM: output column tile j (over k) needs the rows n of the tiles that touch it
+        rng = torch.zeros(n_col_tiles, 2, dtype=torch.int32)
+        for j in range(n_col_tiles):
+            rows = torch.nonzero(hit[:, j]).flatten()
+            if len(rows):
+                rng[j, 0] = int(rows.min()) * tn
+                rng[j, 1] = min((int(rows.max()) + 1) * tn, n_pad)
+        dx_ranges.append(rng.to(device))
+    bp = dict(dx_ranges=dx_ranges, live=live)
+    layer._dev[key] = bp
+    return bp
+
+
+def layer_backward(layer, x, gy, gldj):
+    """Returns (gx, [grads in trainable_tensors() order])."""
+    if not supported(layer):
+        raise NotImplementedError(
+            'tfep_amd: backward is implemented for MAF layers with a MADE conditioner (optionally with a '
+            'PeriodicEmbedding) and an affine or fixed-bound neural-spline transformer.')
+    x, _ = _lib.rows(x, 'x')
+    gy = gy.contiguous().float()
+    gldj = gldj.contiguous().float() if gldj is not None else None
+    dev = x.device
+    B, D = x.shape
+    made = layer._conditioner
+    emb = getattr(made, 'embedding', None)
+    tr = layer._transformer
+    tables = layer._tables(dev)
+    mplan = made.plan(dev)
+    bplan = _backward_plan(layer, dev)
+    lins = made._linears()
+    L = len(lins) - 1
+    tm, tn, tk = ops.tile_sizes()
+    f32 = dict(dtype=torch.float32, device=dev)
+    n_tr = tables['n_tr']
+    n_out = lins[-1].out_features
+    n_out_pad = ops.round_up(n_out, tk)
+    P = n_out // n_tr
+    is_spline = type(tr) is NeuralSplineTransformer
+    stream = _lib.stream_of(x)
+
+    # ---- weights: packed (degree sorted, padded) and their transposes, once per backward
+    n_pad = [mplan['n_pad'][l] for l in range(L)] + [n_out_pad]
+    k_pad = list(mplan['k_pad'])
+    W, WT, bias = [], [], []
+    for l, lin in enumerate(lins):
+        w, b = made._pack_layer(mplan, l, lin, n_rows=n_pad[l])
+        W.append(w)
+        bias.append(b)
+        wt = torch.zeros(k_pad[l], n_pad[l], **f32)
+        WT.append(_transpose(w, n_pad[l], k_pad[l], wt))
+    gW = [torch.zeros(n_pad[l], k_pad[l], **f32) for l in range(L + 1)]
+    gb = [torch.zeros(n_pad[l], **f32) for l in range(L + 1)]
+    gx = torch.empty(B, D, **f32)
+
+    chunk = max(tm, min(B, (_CHUNK_BYTES // (4 * n_out_pad)) // tm * tm))
+    for b0 in range(0, B, chunk):
+        b1 = min(B, b0 + chunk)
+        Bc = b1 - b0
+        Bc_pad = ops.round_up(Bc, tk)
+        xc, gyc = x[b0:b1], gy[b0:b1]
+        glc = gldj[b0:b1] if gldj is not None else None
+
+        # ---- recompute the conditioner forward for the chunk
+        cin = emb(xc) if emb is not None else xc
+        h = [ops.pad_columns(cin, k_pad[0])]
+        for l in range(L):
+            h.append(ops.masked_linear_packed(h[-1], W[l], bias[l], n_pad[l], k_ranges=mplan['k_ranges'][l], act=1))
+        theta = torch.empty(Bc, n_out_pad, **f32)
+        _gemm(h[-1], W[L], theta, Bc, n_out_pad, n_pad[L], bias=bias[L], k_ranges=mplan['k_ranges'][L])
+
+        # ---- transformer VJP: gtheta (reference parameter layout, zero padded columns), direct gx
+        if layer.has_fixed_indices:
+            x_tr, gy_tr = ops.gather_columns(xc, tables['tr']), ops.gather_columns(gyc, tables['tr'])
+        else:
+            x_tr, gy_tr = xc, gyc
+        gtheta = torch.zeros(Bc, n_out_pad, **f32)
+        gx_dir = torch.empty(Bc, n_tr, **f32)
+        lay = _lib.ParamLayout(n_out_pad, n_tr, 1)
+        if is_spline:
+            _lib.call('tfep_spline_backward', _lib.ptr(x_tr), x_tr.shape[1] if Bc > 1 else n_tr, _lib.ptr(theta), lay,
+                      ctypes.byref(tr.config(dev).desc), _lib.ptr(gy_tr), gy_tr.shape[1] if Bc > 1 else n_tr,
+                      _lib.ptr(glc), _lib.ptr(gtheta), lay, _lib.ptr(gx_dir), n_tr, Bc, n_tr, stream)
+        else:
+            _lib.call('tfep_affine_backward', _lib.ptr(x_tr), x_tr.shape[1] if Bc > 1 else n_tr, _lib.ptr(theta), lay,
+                      _lib.ptr(gy_tr), gy_tr.shape[1] if Bc > 1 else n_tr, _lib.ptr(glc), _lib.ptr(gtheta), lay,
+                      _lib.ptr(gx_dir), n_tr, Bc, n_tr, stream)
+        del theta
+
+        # ---- masked linears, last to first.  g = gradient w.r.t. the layer's pre-activation output.
+        g = gtheta
+        for l in range(L, -1, -1):
+            _lib.call('tfep_column_sums', _lib.ptr(g), g.shape[1], Bc, n_pad[l], _lib.ptr(gb[l]), 1, stream)
+            gT = _transpose(g, Bc, n_pad[l], torch.zeros(n_pad[l], Bc_pad, **f32))
+            hT = _transpose(h[l], Bc, k_pad[l], torch.zeros(k_pad[l], Bc_pad, **f32))
+            # grad_weight (packed) += g^T h   [rows n, cols k], masked tiles skipped
+            _gemm(gT, hT, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=1, tile_live=bplan['live'][l])
+            del gT, hT
+            # grad_input = g W  (x ELU'(h) for hidden inputs)
+            gin = torch.empty(Bc, k_pad[l], **f32)
+            _gemm(g, WT[l], gin, Bc, k_pad[l], k_pad[l], k_ranges=bplan['dx_ranges'][l],
+                  elu_grad_of=h[l] if l > 0 else None)
+            g = gin
+
+        # ---- gradient w.r.t. the layer input: through the conditioner + direct
+        if emb is not None:
+            per, non = emb._i32[str(dev)]
+            gxc = torch.zeros(Bc, D, **f32)
+            _lib.call('tfep_periodic_embedding_backward', _lib.ptr(xc), xc.shape[1] if Bc > 1 else D, _lib.ptr(per),
+                      per.numel(), _lib.ptr(non), non.numel(), float(emb.limits[0]), float(emb.limits[1]),
+                      _lib.ptr(g), g.shape[1], _lib.ptr(gxc), D, Bc, stream)
+        else:
+            gxc = g[:, :D].contiguous()
+        if layer.has_fixed_indices:
+            direct = gyc.clone()                                  # fixed features: y = x
+            ops.scatter_columns(gx_dir, tables['tr'], direct)
+        else:
+            direct = gx_dir
+        _lib.call('tfep_add_inplace', _lib.ptr(direct), direct.shape[1], _lib.ptr(gxc), D, Bc, D, stream)
+        gx[b0:b1] = gxc
+
+    # ---- packed weight / bias gradients -> parameter gradients
+    grads = []
+    for l, lin in enumerate(lins):
+        row_of_out = mplan['row_of_out'][l]
+        col_of_in = mplan['col_of_in'][l]
+        if lin.has_weight_norm:
+            gv = torch.empty_like(lin.weight_v)
+            gg = torch.empty(lin.out_features, 1, **f32)
+            _lib.call('tfep_weight_norm_backward', _lib.ptr(gW[l]), k_pad[l], _lib.ptr(lin.weight_v.detach()),
+                      _lib.ptr(lin.weight_g.detach()), _lib.ptr(lin.mask), lin.out_features, lin.in_features,
+                      _lib.ptr(row_of_out), _lib.ptr(col_of_in), _lib.ptr(gv), _lib.ptr(gg), stream)
+            grads += [gg, gv]
+        else:
+            gw = torch.empty_like(lin._parameters['weight'])
+            _lib.call('tfep_weight_norm_backward', _lib.ptr(gW[l]), k_pad[l], _lib.ptr(lin._parameters['weight'].detach()),
+                      None, _lib.ptr(lin.mask), lin.out_features, lin.in_features, _lib.ptr(row_of_out),
+                      _lib.ptr(col_of_in), _lib.ptr(gw), None, stream)
+            grads.append(gw)
+        if row_of_out is None:
+            grads.append(gb[l][:lin.out_features].clone())
+        else:
+            grads.append(ops.gather_columns(gb[l][None, :], row_of_out)[0])
+    return gx, grads

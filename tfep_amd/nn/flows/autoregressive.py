@@ -199,8 +199,24 @@ class AutoregressiveFlow(torch.nn.Module):
 
     # ------------------------------------------------------------------ reference API
     def forward(self, x: torch.Tensor):
-        """``(y, log_det_J)`` of the push-forward (reference autoregressive.py:144-177)."""
+        """``(y, log_det_J)`` of the push-forward (reference autoregressive.py:144-177).
+
+        Under autograd (grad mode on and the input or a conditioner parameter requires grad) the
+        call is recorded as ONE graph node whose backward runs on the HIP kernels
+        (``flows/_backward.py``); otherwise it is the plain forward.
+        """
         ops.check_device_tensor(x, 'x')
+        if torch.is_grad_enabled():
+            from . import _backward
+            params = _backward.trainable_tensors(self) if isinstance(self._conditioner, MADE) else \
+                [p for p in self._conditioner.parameters()]
+            if x.requires_grad or any(p.requires_grad for p in params):
+                if _backward.supported(self):
+                    return _backward.MAFLayerFunction.apply(self, x, *params)
+                return _backward.UnsupportedBackward.apply(self, x, *params)
+        return self._forward_impl(x)
+
+    def _forward_impl(self, x: torch.Tensor):
         kind = self._fused_kind()
         if kind is not None:
             return self._forward_fused(x, kind)

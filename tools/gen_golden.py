@@ -587,6 +587,89 @@ def gen_flows():
 
 
 # -----------------------------------------------------------------------------
+# 4b. gradients of one training step (reference autograd, float64)
+# -----------------------------------------------------------------------------
+
+def gen_grads():
+    """loss = BoltzmannKLDivLoss()(u_B(y), log_det_J) with the synthetic potential
+    u_B(y) = sum_f (c_f y_f^2 + d_f y_f), backward through the reference flow in float64.
+    Stores d loss / d(every trainable parameter) and d loss / d x."""
+    from tfep.nn.conditioners.made import generate_degrees as gd
+    out = {}
+    D = 10
+
+    def quad(y, c, d):
+        return (c * y ** 2 + d * y).sum(dim=1)
+
+    flows = {
+        'affine': lambda dt: SequentialFlow(
+            MAF(degrees_in=gd(D, 'ascending'), initialize_identity=False),
+            MAF(degrees_in=gd(D, 'descending', conditioning_indices=[2, 5]), weight_norm=False,
+                initialize_identity=False)),
+        'spline': lambda dt: SequentialFlow(
+            MAF(degrees_in=gd(D, 'ascending'),
+                transformer=NeuralSplineTransformer(x0=torch.full((D,), -4.0).to(dt), xf=torch.full((D,), 4.0).to(dt), n_bins=8),
+                initialize_identity=False),
+            MAF(degrees_in=gd(D, 'descending'),
+                transformer=NeuralSplineTransformer(x0=torch.full((D,), -4.0).to(dt), xf=torch.full((D,), 4.0).to(dt), n_bins=8),
+                hidden_layers=[24, 24], initialize_identity=False)),
+        'circular': lambda dt: SequentialFlow(
+            MAF(degrees_in=gd(D, 'ascending'),
+                transformer=NeuralSplineTransformer(x0=torch.zeros(D).to(dt), xf=torch.ones(D).to(dt), n_bins=8, circular=True),
+                embedding=PeriodicEmbedding(n_features_in=D, limits=[0.0, 1.0]), initialize_identity=False)),
+        'identslopes': lambda dt: SequentialFlow(
+            MAF(degrees_in=gd(D, 'ascending'),
+                transformer=NeuralSplineTransformer(x0=torch.full((D,), -2.0).to(dt), xf=torch.full((D,), 2.0).to(dt), n_bins=5,
+                                                    identity_boundary_slopes=True),
+                initialize_identity=False)),
+    }
+    for name, make in flows.items():
+        torch.manual_seed(20)
+        f32 = make(torch.float32)
+        perturb_weight_g(f32, 21)
+        B = 48
+        g = gen(22)
+        if name == 'circular':
+            x = torch.rand(B, D, generator=g)
+        else:
+            x = torch.randn(B, D, generator=g) * 1.5
+            x[-1] = 6.0            # out-of-domain rows (both tails)
+            x[-2] = -5.5
+        c = torch.rand(D, generator=g) * 0.3
+        d = torch.randn(D, generator=g) * 0.2
+        with f64():
+            m = make(torch.float64)
+            m.load_state_dict(to_double_sd(f32.state_dict()))
+            xd = x.double().requires_grad_(True)
+            y, ldj = m(xd)
+            loss = BoltzmannKLDivLoss()(quad(y, c.double(), d.double()), ldj)
+            loss.backward()
+            out[f'{name}/loss_f64'] = npy(loss)
+            out[f'{name}/gx_f64'] = npy(xd.grad)
+            out[f'{name}/y_f64'], out[f'{name}/ldj_f64'] = npy(y), npy(ldj)
+            for k, p in m.named_parameters():
+                out[f'{name}/grad/{k}'] = npy(p.grad)
+        out[f'{name}/x'] = npy(x)
+        out[f'{name}/c'], out[f'{name}/d'] = npy(c), npy(d)
+        for k, v in f32.state_dict().items():
+            if not k.endswith('.mask'):
+                out[f'{name}/sd/{k}'] = npy(v)
+
+    # masked linear alone (reference gradcheck target, tests/nn/test_masked.py:150-170)
+    g = gen(30)
+    x = torch.randn(7, 6, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(5, 6, generator=g, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(5, generator=g, dtype=torch.float64, requires_grad=True)
+    mask = torch.tril(torch.ones(5, 6, dtype=torch.float64))
+    gy = torch.randn(7, 5, generator=g, dtype=torch.float64)
+    yy = rmasked.masked_linear(x, w, b, mask)
+    yy.backward(gy)
+    out.update({'ml/x': npy(x), 'ml/w': npy(w), 'ml/b': npy(b), 'ml/mask': npy(mask), 'ml/gy': npy(gy),
+                'ml/gx': npy(x.grad), 'ml/gw': npy(w.grad), 'ml/gb': npy(b.grad)})
+    np.savez_compressed(os.path.join(OUT, 'grads.npz'), **out)
+
+
+# -----------------------------------------------------------------------------
 # 5. loss + estimator
 # -----------------------------------------------------------------------------
 
@@ -644,6 +727,7 @@ if __name__ == '__main__':
     gen_made()
     gen_transformers()
     gen_flows()
+    gen_grads()
     gen_loss()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
