@@ -51,7 +51,7 @@ def test_training_step_gradients_match_reference_autograd(name):
     assert y.requires_grad and ldj.requires_grad
     u_b = (c * y ** 2 + d * y).sum(dim=1)            # the (external) target potential: plain torch
     loss = BoltzmannKLDivLoss()(u_b, ldj)
-    np.testing.assert_allclose(float(loss), float(g[f'{name}/loss_f64']), rtol=2e-5)
+    np.testing.assert_allclose(float(loss.detach()), float(g[f'{name}/loss_f64']), rtol=2e-5)
     loss.backward()
     assert rel(x.grad.cpu(), g[f'{name}/gx_f64']) < 5e-5, rel(x.grad.cpu(), g[f'{name}/gx_f64'])
     worst = 0.0
@@ -84,7 +84,7 @@ def test_optimizer_step_runs_and_lowers_the_loss():
         loss = BoltzmannKLDivLoss()((c * y ** 2 + d * y).sum(dim=1), ldj)
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < losses[0]
 
 

@@ -68,6 +68,31 @@ if 'cfg2inv' in which:
     report('cfg2 ONE layer inverse (blocked, 3000 degrees)', B, dt,
            roundtrip_rel_l2=float((xi - x).norm() / x.norm()), ldj_cancel_max_abs=float((lf + li).abs().max()))
 
+if 'train' in which:
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    D = 3000
+    B = int(os.environ.get('TRAIN_BATCH', 16384))
+    with torch.device(dev):
+        flow = SequentialFlow(MAF(generate_degrees(D, 'ascending'),
+                                  transformer=NeuralSplineTransformer(torch.full((D,), -5.0), torch.full((D,), 5.0), 8),
+                                  initialize_identity=False))
+    x = torch.randn(B, D, device=dev).clamp_(-4.9, 4.9)
+    c = torch.rand(D, device=dev) * 0.3
+
+    def train_step():
+        for p in flow.parameters():
+            p.grad = None
+        y, ldj = flow(x)
+        loss = BoltzmannKLDivLoss()((c * y ** 2).sum(dim=1), ldj)
+        loss.backward()
+        return loss.detach()
+    with torch.no_grad():
+        dtf, _ = timeit(lambda: flow(x), 1, 2)
+    dt, loss = timeit(train_step, 1, 2)
+    report('cfg2 ONE layer forward (no grad)', B, dtf)
+    report('cfg2 ONE layer training step (forward + backward of all parameters)', B, dt, loss=float(loss),
+           peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
+
 if 'cfg4' in which:
     D, B = 512, 131072
     with torch.device(dev):
