@@ -98,11 +98,11 @@ def flow_configs():
     return cfgs
 
 
-def oracle_layers(flows_npz, name, dtype=np.float64):
+def oracle_layers(flows_npz, name, dtype=np.float64, configs=None):
     """Build the oracle's layer dicts (weights from the fixture, masks regenerated)."""
     from oracle import made as omade
     from oracle import transformers as otr
-    cfg = flow_configs()[name]
+    cfg = (configs or flow_configs())[name]
     sd = sub(flows_npz, f'{name}/sd/')
     layers = []
     for li, c in enumerate(cfg):

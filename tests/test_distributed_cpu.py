@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 
 import golden_util as gu
 from oracle import loss as oloss
-from tfep_amd.distributed import allreduce_stats, combine_stats, shard_rows
+from tfep_amd.distributed import allreduce_gradients, allreduce_stats, combine_stats, shard_rows
 
 
 def shard_stats(uB, ldj, uA, lw, bias, kT=1.0, ignore_nan=False):
@@ -91,7 +91,13 @@ def _worker(rank, world, port, q):
         local = torch.tensor(shard_stats(uB[b:e], ldj[b:e], uA[b:e], None, None))
         glob = allreduce_stats(local)                       # all_gather + combine (the RCCL path, on gloo)
         loss, df = finalize(glob.numpy(), weighted=False, biased=False)
-        q.put((rank, float(loss), float(df)))
+        # gradient averaging of a replicated module (two small buckets)
+        lin = torch.nn.Linear(5, 3)
+        for i, p in enumerate(lin.parameters()):
+            p.grad = torch.full_like(p, float(rank + 1 + i))
+        allreduce_gradients(lin, bucket_bytes=40)
+        gavg = [float(p.grad.flatten()[0]) for p in lin.parameters()]
+        q.put((rank, float(loss), float(df), gavg))
     finally:
         dist.destroy_process_group()
 
@@ -109,7 +115,8 @@ def test_two_rank_gloo_allreduce_of_tfep_statistics():
         assert p.exitcode == 0
     g = gu.load('loss.npz')
     uB, ldj, uA = (g[k].astype(np.float64) for k in ('uB', 'ldj', 'uA'))
-    for _, loss, df in res:                                 # every rank holds the GLOBAL answer
+    for _, loss, df, gavg in res:                           # every rank holds the GLOBAL answer
         np.testing.assert_allclose(loss, oloss.boltzmann_kl_div_loss(uB, ldj, None, uA), rtol=1e-6)
         np.testing.assert_allclose(df, oloss.fep_estimator(uB - ldj - uA), rtol=1e-6)
+        assert gavg == [1.5, 2.5]                           # mean over ranks of (rank + 1 + i)
     assert res[0][1:] == res[1][1:]
