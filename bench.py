@@ -94,8 +94,10 @@ def main():
     import torch.distributed as dist
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
-    if world > 1:
+    use_dist = world > 1 or 'RANK' in os.environ          # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', device_id=device)
 
     from tfep_amd.analysis import fep_estimator
@@ -117,10 +119,10 @@ def main():
     def step():
         y, ldj = flow(x)
         work = u_B - ldj - u_A                       # reduced work of the mapped samples
-        return y, ldj, fep_estimator(work, distributed=(world > 1))
+        return y, ldj, fep_estimator(work, distributed=use_dist)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -135,7 +137,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t)
 
@@ -178,7 +180,7 @@ def main():
                 res['cpu_baseline'] = {'value': None, 'unit': 'samples/s', 'cores': os.cpu_count(), 'kind': 'port',
                                        'sample': f'failed: {type(e).__name__}: {e}'}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

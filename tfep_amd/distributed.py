@@ -35,8 +35,6 @@ def allreduce_stats(stats, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return stats
     world = dist.get_world_size(group)
-    if world == 1:
-        return stats
     gathered = [torch.empty_like(stats) for _ in range(world)]
     dist.all_gather(gathered, stats, group=group)
     return combine_stats(gathered)
