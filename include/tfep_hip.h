@@ -280,6 +280,16 @@ int tfep_spline_backward(const float* x, int64_t ldx, const float* params, tfep_
                          const float* g_log_det_J, float* gparams, tfep_param_layout glayout,
                          float* gx, int64_t ldgx, int B, int D, void* stream);
 
+/* VJP of tfep_moebius_forward (moebius.py:374-478): gparams / gx (B, D), same `sign` as the forward. */
+int tfep_moebius_backward(const float* x, int64_t ldx, const float* params, int64_t ldp,
+                          int dimension, float max_radius, int unit_sphere, int sign,
+                          const float* gy, int64_t ldgy, const float* g_log_det_J,
+                          float* gparams, int64_t ldgp, float* gx, int64_t ldgx,
+                          int B, int D, void* stream);
+/* dst[b, c] = src[b, c] for a (B, C) block with row strides (VJP of the volume-preserving shift,
+ * affine.py:366-411: gparams = gx = gy; and sub-blocks of MixedTransformer parameters). */
+int tfep_copy_2d(const float* src, int64_t lds, float* dst, int64_t ldd, int B, int C, void* stream);
+
 /* Gradient of the masked weight-norm parametrisation from the gradient of the PACKED effective weight
  * (as written by tfep_masked_weight_prepare with the same permutations):
  *   weight_g != NULL: grad_v (out, in), grad_g (out); masked entries of grad_v and fully-masked rows of

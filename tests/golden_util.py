@@ -161,6 +161,8 @@ def build_transformer(tr):
         return T.AffineTransformer()
     if t == 'moebius':
         return T.MoebiusTransformer(dimension=tr['dimension'], unit_sphere=tr.get('unit_sphere', False))
+    if t == 'volpres':
+        return T.VolumePreservingShiftTransformer()
     if t == 'spline':
         kw = {k: v for k, v in tr.items() if k not in ('type', 'x0', 'xf', 'n_bins', 'y0', 'yf')}
         f32 = lambda a: None if a is None else torch.tensor(np.asarray(a), dtype=torch.float32)
@@ -232,5 +234,16 @@ def grad_flow_configs():
                  hidden_layers=2, weight_norm=True)],
         'identslopes': [
             dict(degrees_in=gd(D, 'ascending'), transformer=_spl(D, -2.0, 2.0, 5, identity_boundary_slopes=True),
+                 hidden_layers=2, weight_norm=True)],
+        'moebius': [
+            dict(degrees_in=gd(12, 'ascending', repeats=2), transformer=dict(type='moebius', dimension=2, unit_sphere=True),
+                 hidden_layers=2, weight_norm=True),
+            dict(degrees_in=gd(12, 'descending', repeats=3), transformer=dict(type='moebius', dimension=3, unit_sphere=False),
+                 hidden_layers=2, weight_norm=True)],
+        'mixed': [
+            dict(degrees_in=gd(D, 'ascending'),
+                 transformer=dict(type='mixed',
+                                  transformers=[_spl(4, -3.0, 3.0, 4), dict(type='affine'), dict(type='volpres')],
+                                  indices=[[0, 2, 4, 6], [1, 3, 5], [7, 8, 9]], par_lengths=[13 * 4, 2 * 3, 3]),
                  hidden_layers=2, weight_norm=True)],
     }

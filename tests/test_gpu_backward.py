@@ -40,7 +40,7 @@ def test_masked_linear_function_gradients():
     assert rel(gw.cpu(), g['ml/gw']) < 1e-6
 
 
-@pytest.mark.parametrize('name', ['affine', 'spline', 'circular', 'identslopes'])
+@pytest.mark.parametrize('name', ['affine', 'spline', 'circular', 'identslopes', 'moebius', 'mixed'])
 def test_training_step_gradients_match_reference_autograd(name):
     from tfep_amd.loss import BoltzmannKLDivLoss
     g = gu.load('grads.npz')
@@ -91,8 +91,9 @@ def test_optimizer_step_runs_and_lowers_the_loss():
 def test_unsupported_backward_fails_loudly():
     from tfep_amd.nn.conditioners import generate_degrees
     from tfep_amd.nn.flows import MAF
-    from tfep_amd.nn.transformers import MoebiusTransformer
-    maf = MAF(generate_degrees(4, repeats=2), transformer=MoebiusTransformer(2, unit_sphere=True),
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    maf = MAF(generate_degrees(4), transformer=NeuralSplineTransformer(torch.zeros(4), torch.ones(4), 4,
+                                                                         learn_upper_bound=True),
               initialize_identity=False).cuda()
     y, ldj = maf(torch.randn(3, 4, device='cuda'))
     with pytest.raises(NotImplementedError, match='backward is implemented for'):

@@ -81,6 +81,9 @@ _SIGNATURES = {
                                      c_int, c_int, _P]),
     'tfep_spline_backward': (c_int, [_P, c_int64, _P, ParamLayout, POINTER(SplineDesc), _P, c_int64, _P, _P,
                                      ParamLayout, _P, c_int64, c_int, c_int, _P]),
+    'tfep_moebius_backward': (c_int, [_P, c_int64, _P, c_int64, c_int, c_float, c_int, c_int, _P, c_int64, _P,
+                                      _P, c_int64, _P, c_int64, c_int, c_int, _P]),
+    'tfep_copy_2d': (c_int, [_P, c_int64, _P, c_int64, c_int, c_int, _P]),
     'tfep_weight_norm_backward': (c_int, [_P, c_int64, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
     'tfep_periodic_embedding_backward': (c_int, [_P, c_int64, _P, c_int, _P, c_int, c_float, c_float, _P, c_int64,
                                                  _P, c_int64, c_int, _P]),

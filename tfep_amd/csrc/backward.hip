@@ -359,6 +359,122 @@ __global__ void __launch_bounds__(256) periodic_embedding_backward_kernel(const 
     }
 }
 
+// ---------------------------------------------------------------- Moebius VJP (moebius.py:374-478)
+// Reverse mode through the closed-form forward of moebius_kernel (transformers.hip); one lane per vector.
+constexpr int MOEBIUS_MAX_DIM_B = 8;
+
+__global__ void __launch_bounds__(256) moebius_backward_kernel(const float* __restrict__ x, int64_t ldx,
+                                                               const float* __restrict__ params, int64_t ldp, int dim,
+                                                               float max_radius, int unit_sphere, float sign,
+                                                               const float* __restrict__ gy, int64_t ldgy,
+                                                               const float* __restrict__ gldj,
+                                                               float* __restrict__ gparams, int64_t ldgp,
+                                                               float* __restrict__ gx, int64_t ldgx, int B, int D) {
+    const int b = blockIdx.x * ROWS_PER_BLOCK_B + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int nvec = D / dim;
+    const double gl = gldj ? (double)gldj[b] : 0.0;
+    for (int v = lane; v < nvec; v += 64) {
+        double xv[MOEBIUS_MAX_DIM_B], wv[MOEBIUS_MAX_DIM_B], uv[MOEBIUS_MAX_DIM_B], dv[MOEBIUS_MAX_DIM_B],
+            yv[MOEBIUS_MAX_DIM_B], gyv[MOEBIUS_MAX_DIM_B], xb[MOEBIUS_MAX_DIM_B], ub[MOEBIUS_MAX_DIM_B],
+            db[MOEBIUS_MAX_DIM_B];
+        double nw2 = 0.0, nx2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < MOEBIUS_MAX_DIM_B; ++i)
+            if (i < dim) {
+                xv[i] = (double)x[(int64_t)b * ldx + v * dim + i];
+                wv[i] = (double)(sign * params[(int64_t)b * ldp + v * dim + i]);
+                gyv[i] = (double)gy[(int64_t)b * ldgy + v * dim + i];
+                nw2 += wv[i] * wv[i];
+                nx2 += xv[i] * xv[i];
+            }
+        const double nw = sqrt(nw2), nx = sqrt(nx2);
+        const double s = (double)max_radius / (1.0 + nw) * (unit_sphere ? 1.0 : nx);
+        double nu2 = 0.0, Dd = 0.0;
+#pragma unroll
+        for (int i = 0; i < MOEBIUS_MAX_DIM_B; ++i)
+            if (i < dim) {
+                uv[i] = s * wv[i];
+                dv[i] = xv[i] - uv[i];
+                nu2 += uv[i] * uv[i];
+                Dd += dv[i] * dv[i];
+            }
+        const double N = (unit_sphere ? 1.0 : nx2) - nu2;
+        const double c = N / Dd;
+        double xd = 0.0, dy = 0.0, xy = 0.0;
+#pragma unroll
+        for (int i = 0; i < MOEBIUS_MAX_DIM_B; ++i)
+            if (i < dim) {
+                yv[i] = c * dv[i] - uv[i];
+                xd += xv[i] * dv[i];
+                dy += dv[i] * yv[i];
+                xy += xv[i] * yv[i];
+            }
+        // ---- reverse
+        double cb, Db = 0.0;
+        double ybar[MOEBIUS_MAX_DIM_B];
+#pragma unroll
+        for (int i = 0; i < MOEBIUS_MAX_DIM_B; ++i) {
+            ybar[i] = i < dim ? gyv[i] : 0.0;
+            xb[i] = 0.0;
+            db[i] = 0.0;
+        }
+        if (unit_sphere) {
+            cb = gl * dim / c;
+        } else {
+            // ld = (dim-1) log|c| - 2 log|x| + log|q|,  q = x.y - 2 (x.d)(d.y)/D
+            const double q = xy - 2.0 * xd * dy / Dd;
+            const double qb = gl / q;
+#pragma unroll
+            for (int i = 0; i < MOEBIUS_MAX_DIM_B; ++i)
+                if (i < dim) {
+                    ybar[i] += qb * (xv[i] - 2.0 * xd * dv[i] / Dd);
+                    xb[i] += qb * (yv[i] - 2.0 * dy * dv[i] / Dd) - gl * 2.0 * xv[i] / nx2;
+                    db[i] += qb * (-2.0 / Dd) * (dy * xv[i] + xd * yv[i]);
+                }
+            Db += qb * 2.0 * xd * dy / (Dd * Dd);
+            cb = gl * (dim - 1) / c;
+        }
+        double yd = 0.0;
+#pragma unroll
+        for (int i = 0; i < MOEBIUS_MAX_DIM_B; ++i)
+            if (i < dim) yd += ybar[i] * dv[i];
+        cb += yd;
+        const double Nb = cb / Dd;
+        Db += -cb * N / (Dd * Dd);
+        double sb = 0.0;
+#pragma unroll
+        for (int i = 0; i < MOEBIUS_MAX_DIM_B; ++i)
+            if (i < dim) {
+                db[i] += c * ybar[i] + 2.0 * Db * dv[i];
+                ub[i] = -ybar[i] - db[i] - 2.0 * Nb * uv[i];
+                xb[i] += db[i] + (unit_sphere ? 0.0 : 2.0 * Nb * xv[i]);
+                sb += ub[i] * wv[i];
+            }
+        const double nwb = -sb * s / (1.0 + nw);
+        const double nxb = unit_sphere ? 0.0 : sb * s / nx;
+#pragma unroll
+        for (int i = 0; i < MOEBIUS_MAX_DIM_B; ++i)
+            if (i < dim) {
+                double wb = s * ub[i];
+                if (nw > 0.0) wb += nwb * wv[i] / nw;
+                if (!unit_sphere) xb[i] += nxb * xv[i] / nx;
+                gparams[(int64_t)b * ldgp + v * dim + i] = (float)(sign * wb);
+                gx[(int64_t)b * ldgx + v * dim + i] = (float)xb[i];
+            }
+    }
+}
+
+// dst[b, c] = src[b, c]
+__global__ void __launch_bounds__(256) copy_2d_kernel(const float* __restrict__ src, int64_t lds,
+                                                      float* __restrict__ dst, int64_t ldd, int B, int C) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * C) return;
+    const int b = (int)(i / C), c = (int)(i % C);
+    dst[(int64_t)b * ldd + c] = src[(int64_t)b * lds + c];
+}
+
 // out[b, c] += in[b, c]   (gx = direct + through-the-conditioner)
 __global__ void __launch_bounds__(256) add_inplace_kernel(const float* __restrict__ in, int64_t ldi,
                                                           float* __restrict__ out, int64_t ldo, int B, int C) {
@@ -435,6 +551,28 @@ int tfep_spline_backward(const float* x, int64_t ldx, const float* params, tfep_
     else
         spline_backward_kernel<32><<<row_blocks_b(B), 256, 0, s>>>(x, ldx, params, layout, a, gy, ldgy, g_log_det_J, gparams, glayout, gx, ldgx, B, D);
     return check_launch("spline_backward_kernel");
+}
+
+int tfep_moebius_backward(const float* x, int64_t ldx, const float* params, int64_t ldp, int dimension,
+                          float max_radius, int unit_sphere, int sign, const float* gy, int64_t ldgy,
+                          const float* g_log_det_J, float* gparams, int64_t ldgp, float* gx, int64_t ldgx, int B, int D,
+                          void* stream) {
+    TFEP_REQUIRE(dimension >= 1 && dimension <= MOEBIUS_MAX_DIM_B, "moebius_backward: dimension=%d unsupported", dimension);
+    TFEP_REQUIRE(D % dimension == 0 && (sign == 1 || sign == -1), "moebius_backward: bad arguments");
+    if (B <= 0 || D <= 0) return TFEP_OK;
+    TFEP_REQUIRE(x && params && gy && gparams && gx, "moebius_backward: NULL pointer");
+    moebius_backward_kernel<<<row_blocks_b(B), 256, 0, (hipStream_t)stream>>>(x, ldx, params, ldp, dimension, max_radius,
+                                                                             unit_sphere, (float)sign, gy, ldgy, g_log_det_J,
+                                                                             gparams, ldgp, gx, ldgx, B, D);
+    return check_launch("moebius_backward_kernel");
+}
+
+int tfep_copy_2d(const float* src, int64_t lds, float* dst, int64_t ldd, int B, int C, void* stream) {
+    const int64_t n = (int64_t)B * C;
+    if (n <= 0) return TFEP_OK;
+    TFEP_REQUIRE(src && dst, "copy_2d: NULL pointer");
+    copy_2d_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, lds, dst, ldd, B, C);
+    return check_launch("copy_2d_kernel");
 }
 
 int tfep_weight_norm_backward(const float* gw_packed, int64_t ldw, const float* weight_v, const float* weight_g,

@@ -23,7 +23,9 @@ import torch
 from ... import _lib, ops
 from ..conditioners.made import MADE
 from ..embeddings.mafembed import PeriodicEmbedding
-from ..transformers.affine import AffineTransformer
+from ..transformers.affine import AffineTransformer, VolumePreservingShiftTransformer
+from ..transformers.mixed import MixedTransformer
+from ..transformers.moebius import MoebiusTransformer
 from ..transformers.spline import NeuralSplineTransformer
 
 # ~2 GiB of transformer parameters per chunk
@@ -37,12 +39,55 @@ def supported(layer):
     emb = getattr(made, 'embedding', None)
     if emb is not None and type(emb) is not PeriodicEmbedding:
         return False
-    tr = layer._transformer
-    if type(tr) is AffineTransformer:
+    return _transformer_supported(layer._transformer)
+
+
+def _transformer_supported(tr):
+    if type(tr) in (AffineTransformer, MoebiusTransformer, VolumePreservingShiftTransformer):
         return True
     if type(tr) is NeuralSplineTransformer:
         return not bool(tr._learn_lower_bound) and not bool(tr._learn_upper_bound)
+    if type(tr) is MixedTransformer:
+        return all(_transformer_supported(t) for t in tr._transformers)
     return False
+
+
+def _voidp(t, offset_elems=0):
+    return ctypes.c_void_p(t.data_ptr() + 4 * offset_elems)
+
+
+def transformer_vjp(tr, x, theta, th_off, ld_theta, gy, gl, gtheta, gx, stream):
+    """VJP of ``tr.forward(x, theta[:, th_off:th_off + n_par])``: writes the matching block of ``gtheta`` and
+    ``gx`` (contiguous (B, D)).  ``theta`` / ``gtheta`` have row stride ``ld_theta``."""
+    B, D = x.shape
+    dev = x.device
+    if type(tr) is MixedTransformer:
+        key = str(dev)
+        if key not in tr._i32:
+            tr._i32[key] = [ind.to(device=dev, dtype=torch.int32) for ind in tr._indices]
+        splits = [0] + tr._parameters_split_indices.tolist()
+        for sub, ind, a in zip(tr._transformers, tr._i32[key], splits):
+            xs, gys = ops.gather_columns(x, ind), ops.gather_columns(gy, ind)
+            gxs = torch.empty_like(xs)
+            transformer_vjp(sub, xs, theta, th_off + a, ld_theta, gys, gl, gtheta, gxs, stream)
+            ops.scatter_columns(gxs, ind, gx)
+        return
+    th, gth = _voidp(theta, th_off), _voidp(gtheta, th_off)
+    if type(tr) is NeuralSplineTransformer:
+        lay = _lib.ParamLayout(ld_theta, D, 1)
+        _lib.call('tfep_spline_backward', _lib.ptr(x), D, th, lay, ctypes.byref(tr.config(dev).desc), _lib.ptr(gy), D,
+                  _lib.ptr(gl), gth, lay, _lib.ptr(gx), D, B, D, stream)
+    elif type(tr) is AffineTransformer:
+        lay = _lib.ParamLayout(ld_theta, D, 1)
+        _lib.call('tfep_affine_backward', _lib.ptr(x), D, th, lay, _lib.ptr(gy), D, _lib.ptr(gl), gth, lay,
+                  _lib.ptr(gx), D, B, D, stream)
+    elif type(tr) is MoebiusTransformer:
+        _lib.call('tfep_moebius_backward', _lib.ptr(x), D, th, ld_theta, int(tr.dimension), float(tr.max_radius),
+                  int(bool(tr.unit_sphere)), 1, _lib.ptr(gy), D, _lib.ptr(gl), gth, ld_theta, _lib.ptr(gx), D, B, D,
+                  stream)
+    else:   # volume-preserving shift: y = x + b (wrap is piecewise identity), log-det = 0
+        _lib.call('tfep_copy_2d', _lib.ptr(gy), D, gth, ld_theta, B, D, stream)
+        _lib.call('tfep_copy_2d', _lib.ptr(gy), D, _lib.ptr(gx), D, B, D, stream)
 
 
 def trainable_tensors(layer):
@@ -87,7 +132,8 @@ class UnsupportedBackward(torch.autograd.Function):
     def backward(ctx, gy, gldj):
         raise NotImplementedError(
             'tfep_amd: backward is implemented for MAF layers with a MADE conditioner (optionally with a '
-            'PeriodicEmbedding) and an affine or fixed-bound neural-spline transformer.')
+            'PeriodicEmbedding) and affine / fixed-bound neural-spline / Moebius / volume-preserving / mixed '
+            'transformers.')
 
 
 def _gemm(x, w, y, B, N, n_rows_w, bias=None, k_ranges=None, act=0, accumulate=0, elu_grad_of=None, tile_live=None):
@@ -151,7 +197,8 @@ def layer_backward(layer, x, gy, gldj):
     if not supported(layer):
         raise NotImplementedError(
             'tfep_amd: backward is implemented for MAF layers with a MADE conditioner (optionally with a '
-            'PeriodicEmbedding) and an affine or fixed-bound neural-spline transformer.')
+            'PeriodicEmbedding) and affine / fixed-bound neural-spline / Moebius / volume-preserving / mixed '
+            'transformers.')
     x, _ = _lib.rows(x, 'x')
     gy = gy.contiguous().float()
     gldj = gldj.contiguous().float() if gldj is not None else None
@@ -171,7 +218,6 @@ def layer_backward(layer, x, gy, gldj):
     n_out = lins[-1].out_features
     n_out_pad = ops.round_up(n_out, tk)
     P = n_out // n_tr
-    is_spline = type(tr) is NeuralSplineTransformer
     stream = _lib.stream_of(x)
 
     # ---- weights: packed (degree sorted, padded) and their transposes, once per backward
@@ -211,15 +257,8 @@ def layer_backward(layer, x, gy, gldj):
             x_tr, gy_tr = xc, gyc
         gtheta = torch.zeros(Bc, n_out_pad, **f32)
         gx_dir = torch.empty(Bc, n_tr, **f32)
-        lay = _lib.ParamLayout(n_out_pad, n_tr, 1)
-        if is_spline:
-            _lib.call('tfep_spline_backward', _lib.ptr(x_tr), x_tr.shape[1] if Bc > 1 else n_tr, _lib.ptr(theta), lay,
-                      ctypes.byref(tr.config(dev).desc), _lib.ptr(gy_tr), gy_tr.shape[1] if Bc > 1 else n_tr,
-                      _lib.ptr(glc), _lib.ptr(gtheta), lay, _lib.ptr(gx_dir), n_tr, Bc, n_tr, stream)
-        else:
-            _lib.call('tfep_affine_backward', _lib.ptr(x_tr), x_tr.shape[1] if Bc > 1 else n_tr, _lib.ptr(theta), lay,
-                      _lib.ptr(gy_tr), gy_tr.shape[1] if Bc > 1 else n_tr, _lib.ptr(glc), _lib.ptr(gtheta), lay,
-                      _lib.ptr(gx_dir), n_tr, Bc, n_tr, stream)
+        x_tr, gy_tr = x_tr.contiguous(), gy_tr.contiguous()
+        transformer_vjp(tr, x_tr, theta, 0, n_out_pad, gy_tr, glc, gtheta, gx_dir, stream)
         del theta
 
         # ---- masked linears, last to first.  g = gradient w.r.t. the layer's pre-activation output.

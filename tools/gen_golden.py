@@ -623,20 +623,38 @@ def gen_grads():
                                                     identity_boundary_slopes=True),
                 initialize_identity=False)),
     }
+    flows['moebius'] = lambda dt: SequentialFlow(
+        MAF(degrees_in=gd(12, 'ascending', repeats=2), transformer=MoebiusTransformer(dimension=2, unit_sphere=True),
+            initialize_identity=False),
+        MAF(degrees_in=gd(12, 'descending', repeats=3), transformer=MoebiusTransformer(dimension=3, unit_sphere=False),
+            initialize_identity=False))
+    flows['mixed'] = lambda dt: SequentialFlow(
+        MAF(degrees_in=gd(D, 'ascending'),
+            transformer=MixedTransformer(
+                transformers=[
+                    NeuralSplineTransformer(x0=torch.full((4,), -3.0).to(dt), xf=torch.full((4,), 3.0).to(dt), n_bins=4),
+                    AffineTransformer(),
+                    VolumePreservingShiftTransformer()],
+                indices=[[0, 2, 4, 6], [1, 3, 5], [7, 8, 9]]),
+            initialize_identity=False))
     for name, make in flows.items():
         torch.manual_seed(20)
         f32 = make(torch.float32)
         perturb_weight_g(f32, 21)
         B = 48
         g = gen(22)
+        Dn = 12 if name == 'moebius' else D
         if name == 'circular':
-            x = torch.rand(B, D, generator=g)
+            x = torch.rand(B, Dn, generator=g)
+        elif name == 'moebius':
+            ang = torch.rand(B, 6, generator=g) * 2 * np.pi
+            x = torch.stack([torch.cos(ang), torch.sin(ang)], dim=2).reshape(B, 12)
         else:
-            x = torch.randn(B, D, generator=g) * 1.5
+            x = torch.randn(B, Dn, generator=g) * 1.5
             x[-1] = 6.0            # out-of-domain rows (both tails)
             x[-2] = -5.5
-        c = torch.rand(D, generator=g) * 0.3
-        d = torch.randn(D, generator=g) * 0.2
+        c = torch.rand(Dn, generator=g) * 0.3
+        d = torch.randn(Dn, generator=g) * 0.2
         with f64():
             m = make(torch.float64)
             m.load_state_dict(to_double_sd(f32.state_dict()))
