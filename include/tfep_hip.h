@@ -124,7 +124,9 @@ int tfep_masked_linear_narrow_tile_n(void);
  *   accumulate: add into y (gradient accumulation over batch chunks);
  *   tile_live: optional (ceil(B/tile_m) x ceil(N/tile_n)) bytes, 0 = output tile entirely masked, skipped
  *     (grad_weight of a block-triangular mask).
- * Other fields as in tfep_masked_linear_forward (wide column tile).
+ *   pre_add: partial pre-activations added before the activation (two-level blocked inverse: the block's
+ *     contribution of all earlier degrees is computed once, each degree adds only its own block's part).
+ * Other fields as in tfep_masked_linear_forward.
  */
 typedef struct tfep_gemm_desc {
     const float* x; int64_t ldx;
@@ -137,6 +139,8 @@ typedef struct tfep_gemm_desc {
     int32_t B, N, n_rows_w, k_padded, act, accumulate;
     const float* elu_grad_of; int64_t ld_elu_grad_of;
     const uint8_t* tile_live;
+    const float* pre_add; int64_t ld_pre_add;   /* optional, layout of y: y = act(x w^T + bias + pre_add) */
+    int32_t tile_n;                             /* 0 / wide (default) or tfep_masked_linear_narrow_tile_n() */
 } tfep_gemm_desc;
 int tfep_masked_linear_gemm(const tfep_gemm_desc* desc, void* stream);
 int tfep_masked_linear_tile_k(void);

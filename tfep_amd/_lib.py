@@ -28,7 +28,8 @@ class GemmDesc(Structure):
                 ('y', c_void_p), ('ldy', c_int64),
                 ('B', c_int32), ('N', c_int32), ('n_rows_w', c_int32), ('k_padded', c_int32),
                 ('act', c_int32), ('accumulate', c_int32),
-                ('elu_grad_of', c_void_p), ('ld_elu_grad_of', c_int64), ('tile_live', c_void_p)]
+                ('elu_grad_of', c_void_p), ('ld_elu_grad_of', c_int64), ('tile_live', c_void_p),
+                ('pre_add', c_void_p), ('ld_pre_add', c_int64), ('tile_n', c_int32)]
 
 
 class SplineDesc(Structure):

@@ -148,6 +148,8 @@ struct GemmArgs {
     const float* aux;          // linear epilogue: if set, y = acc * elu'(aux) with elu'(h) = h > 0 ? 1 : h + 1
     int64_t ldaux;             //   (ELU backward from the saved activation h; same indexing as y)
     int accumulate;            // linear epilogue: y += value instead of y = value
+    const float* pre_add;      // linear epilogue: added BEFORE the activation (partial pre-activations of the
+    int64_t ld_pre_add;        //   two-level blocked inverse); same indexing as y
     const uint8_t* tile_live;  // optional (m_tiles x n_tiles): 0 = the whole output tile is masked, skip it
     int diag;                  // diagnostics only (TFEP_DIAG): 1 = skip the epilogue, 2 = skip the MFMAs,
                                // 4 = skip the LDS-DMA, 8 = skip the barriers (garbage results; timing only)
@@ -315,6 +317,7 @@ __global__ void __launch_bounds__(THREADS, (MREP == 1 ? 4 : 2)) gemm_kernel(Gemm
                     const int row = wrow0 + m * 16 + rq + i;
                     if (row < g.B) {
                         float v = acc[n][m][i] + bv;
+                        if (g.pre_add) v += g.pre_add[(int64_t)row * g.ld_pre_add + ocol];
                         if (EPI == EPI_ELU) v = elu_f(v);
                         if (g.aux) {
                             const float h = g.aux[(int64_t)row * g.ldaux + ocol];
@@ -563,8 +566,16 @@ int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
     g.a = d->x; g.lda = d->ldx; g.w = d->w; g.ldw = d->ldw; g.bias = d->bias; g.k_ranges = d->k_ranges;
     g.col_map = d->col_map; g.y = d->y; g.ldy = d->ldy; g.B = d->B; g.N = d->N; g.k_padded = d->k_padded;
     g.tile_order = d->tile_order; g.aux = d->elu_grad_of; g.ldaux = d->ld_elu_grad_of; g.accumulate = d->accumulate;
-    g.tile_live = d->tile_live;
-    const int n_tiles = (d->N + Tile<LIN_MREP, LIN_NREP>::BN - 1) / Tile<LIN_MREP, LIN_NREP>::BN;
+    g.tile_live = d->tile_live; g.pre_add = d->pre_add; g.ld_pre_add = d->ld_pre_add;
+    constexpr int WIDE_BN = Tile<LIN_MREP, LIN_NREP>::BN, NARROW_BN = Tile<LIN_MREP, NARROW_NREP>::BN;
+    TFEP_REQUIRE(d->tile_n == 0 || d->tile_n == WIDE_BN || d->tile_n == NARROW_BN,
+                 "masked_linear_gemm: tile_n=%d unsupported (0, %d or %d)", d->tile_n, WIDE_BN, NARROW_BN);
+    if (d->tile_n == NARROW_BN) {
+        const int n_tiles = (d->N + NARROW_BN - 1) / NARROW_BN;
+        if (d->act == 1) return launch_gemm<LIN_MREP, NARROW_NREP, EPI_ELU, 1, 1>(g, d->n_rows_w, n_tiles, (hipStream_t)stream);
+        return launch_gemm<LIN_MREP, NARROW_NREP, EPI_LINEAR, 1, 1>(g, d->n_rows_w, n_tiles, (hipStream_t)stream);
+    }
+    const int n_tiles = (d->N + WIDE_BN - 1) / WIDE_BN;
     if (d->act == 1) return launch_gemm<LIN_MREP, LIN_NREP, EPI_ELU, 1, 1>(g, d->n_rows_w, n_tiles, (hipStream_t)stream);
     return launch_gemm<LIN_MREP, LIN_NREP, EPI_LINEAR, 1, 1>(g, d->n_rows_w, n_tiles, (hipStream_t)stream);
 }

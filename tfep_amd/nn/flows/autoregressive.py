@@ -289,8 +289,19 @@ class AutoregressiveFlow(torch.nn.Module):
             return ('moebius', tr)
         return ('affine', tr)
 
+    #: Degrees per block of the two-level blocked inverse.
+    inverse_block = 16
+
     def _blocked_plan(self, device):
-        key = ('blocked', str(device))
+        """Host-side plan of the two-level blocked forward substitution.
+
+        Degrees are processed in blocks of ``inverse_block``.  For a block, the contribution of every
+        EARLIER degree to all of the block's rows is one GEMM per layer over the (long) range of old
+        hidden units -- the activation panel is read once per block instead of once per degree.  Inside
+        the block each degree adds the (short) range of units that the block itself has produced.
+        Hidden units are stored sorted by degree, so all of these are contiguous row / column ranges.
+        """
+        key = ('blocked', str(device), self.inverse_block)
         bp = self._dev.get(key)
         if bp is not None:
             return bp
@@ -300,7 +311,6 @@ class AutoregressiveFlow(torch.nn.Module):
         lins = made._linears()
         L = len(lins) - 1
         tk = lib.tfep_masked_linear_tile_k()
-        narrow = lib.tfep_masked_linear_narrow_tile_n()
         tables = self._tables(device)
         deg_in = made._degrees[0].cpu()
         tr_idx = tables['tr'].cpu().long()
@@ -308,50 +318,80 @@ class AutoregressiveFlow(torch.nn.Module):
         n_tr = len(tr_idx)
         P = lins[-1].out_features // n_tr
         max_deg = int(deg_tr.max())
-        hid_sorted = [torch.sort(made._degrees[l + 1].cpu()).values for l in range(L)]
+        hid = [torch.sort(made._degrees[l + 1].cpu()).values for l in range(L)]
+        G = int(self.inverse_block)
 
         def up(v):
             return (v + tk - 1) // tk * tk
 
-        kr, steps = [], []
+        def r_lo(l, e):      # first packed row of layer l with degree >= e
+            return int(torch.searchsorted(hid[l], e, right=False))
+
+        def r_hi(l, e):      # one past the last packed row of layer l with degree <= e
+            return int(torch.searchsorted(hid[l], e, right=True))
+
+        # output rows grouped by degree ("inverse packing"): base[d] .. base[d+1]
+        sels = [torch.nonzero(deg_tr == d).flatten() for d in range(max_deg + 1)]
+        base = [0]
+        for sel in sels:
+            base.append(base[-1] + P * len(sel))
         row_inv = torch.empty(P * n_tr, dtype=torch.long, device='cpu')
-        base = 0
+        for d, sel in enumerate(sels):
+            n_d = len(sel)
+            for p in range(P):
+                row_inv[p * n_tr + sel] = base[d] + p * n_d + torch.arange(n_d, device='cpu')
+
+        kr = []               # all k-ranges, one entry per launch: every tile of a launch shares it
+
+        def rng(kb, ke):
+            kr.append((kb, max(kb, ke)))
+            return len(kr) - 1
+
         i32 = dict(device=device, dtype=torch.int32)
-
-        def add_ranges(kb, ke, n_rows):
-            off = len(kr)
-            kr.extend([(kb, ke)] * ((n_rows + narrow - 1) // narrow))
-            return off
-
-        for d in range(max_deg + 1):
-            e = d - 1
-            hidden = []
-            for l in range(L):
-                r0 = int(torch.searchsorted(hid_sorted[l], e, right=False))
-                r1 = int(torch.searchsorted(hid_sorted[l], e, right=True))
+        blocks = []
+        for d0 in range(0, max_deg + 1, G):
+            d1 = min(d0 + G, max_deg + 1)
+            blk = dict(wide=[], steps=[])
+            # split point between "old" and "block" inputs of layer l >= 1 / the output layer:
+            # old units of layer l-1 have degree <= d0 - 2
+            kA = [0] + [(r_hi(l - 1, d0 - 2) // tk) * tk for l in range(1, L + 1)]
+            for l in range(1, L):      # hidden layers fed by hidden layers
+                r0, r1 = r_lo(l, d0 - 1), r_hi(l, d1 - 2)
                 if r1 > r0:
-                    if l == 0:
+                    blk['wide'].append(dict(layer=l, row0=r0, n_rows=r1 - r0, kr=rng(0, kA[l])))
+            blk['out_wide'] = dict(row0=base[d0], n_rows=base[d1] - base[d0], kr=rng(0, kA[L]))
+            for d in range(d0, d1):
+                e = d - 1
+                hidden = []
+                for l in range(L):
+                    r0, r1 = r_lo(l, e), r_hi(l, e)
+                    if r1 <= r0:
+                        continue
+                    if l == 0:     # layer 0 reads x in feature order: bounding range of the known columns
                         pos = torch.nonzero(deg_in <= e).flatten()
                         kb, ke = ((int(pos.min()) // tk) * tk, up(int(pos.max()) + 1)) if len(pos) else (0, 0)
+                        ke = min(ke, mplan['k_pad'][0])
                     else:
-                        kb, ke = 0, up(int(torch.searchsorted(hid_sorted[l - 1], e, right=True)))
-                    ke = min(ke, mplan['k_pad'][l])
-                    hidden.append((l, r0, r1 - r0, add_ranges(kb, ke, r1 - r0)))
-            sel = torch.nonzero(deg_tr == d).flatten()
-            n_d = len(sel)
-            ke = min(up(int(torch.searchsorted(hid_sorted[L - 1], e, right=True))), mplan['k_pad'][L])
-            for p in range(P):
-                row_inv[p * n_tr + sel] = base + p * n_d + torch.arange(n_d, device='cpu')
-            steps.append(dict(hidden=hidden, out=(base, P * n_d, add_ranges(0, ke, P * n_d)), n_d=n_d,
-                              sel=sel.to(**i32), cols=tr_idx[sel].to(**i32),
-                              sub=self._sub_transformer(sel.to(device), device)))
-            base += P * n_d
-        bp = dict(steps=steps, P=P, L=L, row_inv=row_inv.to(**i32),
-                  k_ranges=torch.tensor(kr, dtype=torch.int32).reshape(-1, 2).to(device), n_rows_out=P * n_tr)
+                        kb, ke = kA[l], min(up(r_hi(l - 1, e)), mplan['k_pad'][l])
+                    hidden.append(dict(layer=l, row0=r0, n_rows=r1 - r0, kr=rng(kb, ke)))
+                sel = sels[d]
+                ke = min(up(r_hi(L - 1, e)), mplan['k_pad'][L])
+                blk['steps'].append(dict(hidden=hidden, out=dict(row0=base[d], n_rows=P * len(sel), kr=rng(kA[L], ke)),
+                                         n_d=len(sel), sel=sel.to(**i32), cols=tr_idx[sel].to(**i32),
+                                         sub=self._sub_transformer(sel.to(device), device)))
+            blocks.append(blk)
+        narrow = lib.tfep_masked_linear_narrow_tile_n()
+        max_rows = max([w['n_rows'] for b_ in blocks for w in b_['wide']] + [b_['out_wide']['n_rows'] for b_ in blocks] +
+                       [h_['n_rows'] for b_ in blocks for st in b_['steps'] for h_ in st['hidden']] +
+                       [st['out']['n_rows'] for b_ in blocks for st in b_['steps']])
+        bp = dict(blocks=blocks, P=P, L=L, row_inv=row_inv.to(**i32), n_rows_out=P * n_tr,
+                  max_tiles=(max_rows + narrow - 1) // narrow,
+                  k_ranges=torch.tensor(kr, dtype=torch.int32).reshape(-1, 2).to(device))
         self._dev[key] = bp
         return bp
 
     def _inverse_blocked(self, y):
+        from ._backward import _gemm
         y, _ = _lib.rows(y, 'y')
         B, D = y.shape
         dev = y.device
@@ -361,7 +401,31 @@ class AutoregressiveFlow(torch.nn.Module):
         mplan = made.plan(dev)
         lins = made._linears()
         L = bp['L']
+        narrow = _lib.load().tfep_masked_linear_narrow_tile_n()
         f32 = dict(dtype=torch.float32, device=dev)
+        kr_all = bp['k_ranges']
+
+        def launch(x_in, w, bias, desc, out, out_col0, act, pre=None, pre_col0=0, wide=False):
+            """out[:, out_col0 : +n] = act(x_in W[row0 : row0+n]^T + bias[row0:] (+ pre[:, pre_col0 : +n]))"""
+            n, row0 = desc['n_rows'], desc['row0']
+            d = _lib.GemmDesc()
+            d.x, d.ldx = x_in.data_ptr(), x_in.shape[1]
+            d.w, d.ldw = w.data_ptr() + 4 * row0 * w.shape[1], w.shape[1]
+            d.bias = (bias.data_ptr() + 4 * row0) if bias is not None else None
+            d.k_ranges = krs[desc['kr']].data_ptr()
+            d.y, d.ldy = out.data_ptr() + 4 * out_col0, out.shape[1]
+            d.B, d.N, d.n_rows_w, d.k_padded, d.act, d.accumulate = B, n, n, w.shape[1], act, 0
+            if pre is not None:
+                d.pre_add, d.ld_pre_add = pre.data_ptr() + 4 * pre_col0, pre.shape[1]
+            d.tile_n = 0 if wide else narrow
+            _lib.call('tfep_masked_linear_gemm', ctypes.byref(d), _lib.stream_of(x_in))
+
+        # every column tile of a launch shares the launch's k-range: one row-repeated table, built once
+        krs = bp.get('kr_tiles')
+        if krs is None:
+            krs = kr_all[:, None, :].expand(-1, bp['max_tiles'], 2).contiguous()
+            bp['kr_tiles'] = krs
+
         with made.frozen_weights():
             packs = [made._pack_layer(mplan, l, lins[l]) for l in range(L)]
             w_out, b_out = made._pack_layer(mplan, L, lins[L], row_of_out=bp['row_inv'], n_rows=bp['n_rows_out'])
@@ -375,31 +439,40 @@ class AutoregressiveFlow(torch.nn.Module):
             else:
                 y_tr = y
             h = [torch.zeros(B, mplan['n_pad'][l], **f32) for l in range(L)]
+            z = [None] + [torch.empty(B, mplan['n_pad'][l], **f32) for l in range(1, L)]   # partial pre-activations
+            zout = torch.empty(B, bp['n_rows_out'], **f32)
             ldj = torch.zeros(B, **f32)
-            par_bufs = {}
-            kr = bp['k_ranges']
-            for st in bp['steps']:
-                for l, r0, n_rows, off in st['hidden']:
-                    ops.gemm_slice(xpad if l == 0 else h[l - 1], packs[l][0], r0, n_rows, packs[l][1], kr, off,
-                                   h[l], r0, act=1)
-                if st['n_d'] == 0:
-                    continue
-                base, n_rows, off = st['out']
-                par = par_bufs.get(n_rows)
-                if par is None:
-                    par = par_bufs[n_rows] = torch.empty(B, n_rows, **f32)
-                ops.gemm_slice(h[L - 1], w_out, base, n_rows, b_out, kr, off, par, 0, act=0)
-                y_d = ops.gather_columns(y_tr, st['sel'])
-                kind, sub = st['sub']
-                if kind == 'spline':
-                    x_d, _ = ops.spline(y_d, par, sub, inverse=True, log_det_J=ldj)
-                elif kind == 'moebius':
-                    x_d, _ = ops.moebius(y_d, par, sub.dimension, sub.max_radius, sub.unit_sphere, inverse=True,
-                                         log_det_J=ldj)
-                else:
-                    x_d, _ = ops.affine(y_d, par, inverse=True, log_det_J=ldj)
-                ops.scatter_columns(x_d, st['cols'], x)
-                ops.scatter_columns(x_d, st['cols'], xpad)
+            for blk in bp['blocks']:
+                # ---- contribution of all earlier degrees to the whole block, once
+                for wd in blk['wide']:
+                    l = wd['layer']
+                    launch(h[l - 1], packs[l][0], packs[l][1], wd, z[l], wd['row0'], act=0)
+                ow = blk['out_wide']
+                launch(h[L - 1], w_out, b_out, ow, zout, ow['row0'], act=0, wide=ow['n_rows'] > 4 * narrow)
+                # ---- the block's own degrees, one after the other
+                for st in blk['steps']:
+                    for hd in st['hidden']:
+                        l = hd['layer']
+                        if l == 0:
+                            launch(xpad, packs[0][0], packs[0][1], hd, h[0], hd['row0'], act=1)
+                        else:   # bias is already inside z
+                            launch(h[l - 1], packs[l][0], None, hd, h[l], hd['row0'], act=1, pre=z[l], pre_col0=hd['row0'])
+                    if st['n_d'] == 0:
+                        continue
+                    od = st['out']
+                    launch(h[L - 1], w_out, None, od, zout, od['row0'], act=0, pre=zout, pre_col0=od['row0'])
+                    y_d = ops.gather_columns(y_tr, st['sel'])
+                    par = zout[:, od['row0']:od['row0'] + od['n_rows']]
+                    kind, sub = st['sub']
+                    if kind == 'spline':
+                        x_d, _ = ops.spline(y_d, par, sub, inverse=True, log_det_J=ldj)
+                    elif kind == 'moebius':
+                        x_d, _ = ops.moebius(y_d, par, sub.dimension, sub.max_radius, sub.unit_sphere, inverse=True,
+                                             log_det_J=ldj)
+                    else:
+                        x_d, _ = ops.affine(y_d, par, inverse=True, log_det_J=ldj)
+                    ops.scatter_columns(x_d, st['cols'], x)
+                    ops.scatter_columns(x_d, st['cols'], xpad)
         return x, ldj
 
     def get_transformer_parameters(self, x: torch.Tensor) -> torch.Tensor:

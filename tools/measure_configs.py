@@ -48,7 +48,7 @@ if 'cfg1' in which:
     dt, (y, _) = timeit(lambda: flow(x), 3, 20)
     report('cfg1 forward: 2-layer MAF + affine, D=66', B, dt)
     dt, (xi, _) = timeit(lambda: flow.inverse(y), 1, 5)
-    report('cfg1 inverse (blocked)', B, dt, roundtrip_max_abs=float((xi - x).abs().max()))
+    report('cfg1 inverse (blocked)', B, dt, roundtrip_max_abs=float((xi - x).detach().abs().max()))
     for l in flow:
         l.blocked_inverse = False
     dt, _ = timeit(lambda: flow.inverse(y), 1, 3)
@@ -66,7 +66,7 @@ if 'cfg2inv' in which:
     report('cfg2 ONE layer forward', B, dt)
     dt, (xi, li) = timeit(lambda: flow.inverse(y), 1, 1)
     report('cfg2 ONE layer inverse (blocked, 3000 degrees)', B, dt,
-           roundtrip_rel_l2=float((xi - x).norm() / x.norm()), ldj_cancel_max_abs=float((lf + li).abs().max()))
+           roundtrip_rel_l2=float((xi - x).detach().norm() / x.norm()), ldj_cancel_max_abs=float((lf + li).detach().abs().max()))
 
 if 'train' in which:
     from tfep_amd.loss import BoltzmannKLDivLoss
@@ -113,3 +113,33 @@ if 'cfg4' in which:
     dt, (y, _) = timeit(lambda: flow(x), 1, 3)
     report('cfg4-ii forward: 4-layer MAF + Moebius(d=2, unit sphere), 512 torsions as 1024 features', B, dt,
            max_norm_error=float((y.reshape(B, D, 2).norm(dim=2) - 1).abs().max()))
+
+if 'hbm' in which:
+    # HBM-bound kernels in isolation: algorithmic bytes / time vs the 8 TB/s HBM3E peak.
+    from tfep_amd import ops
+    D, B, K = 3000, 16384, 8
+    P = 3 * K + 1
+    x = torch.randn(B, D, device=dev).clamp_(-4.9, 4.9)
+    par = torch.randn(B, P * D, device=dev)
+    cfg = ops.SplineConfig(torch.full((D,), -5.0, device=dev), torch.full((D,), 5.0, device=dev),
+                           torch.full((D,), -5.0, device=dev), torch.full((D,), 5.0, device=dev), K)
+    for inverse in (False, True):
+        dt, _ = timeit(lambda: ops.spline(x, par, cfg, inverse=inverse), 2, 10)
+        nbytes = B * (4 * (P * D + 2 * D) + 4)
+        report(f'standalone RQ-8 spline kernel ({"inverse" if inverse else "forward"}), D=3000', B, dt,
+               algorithmic_GBps=round(nbytes / dt / 1e9, 1), frac_of_8TBps=round(nbytes / dt / 8e12, 3))
+    par2 = torch.randn(B, 2 * D, device=dev) * 0.3
+    dt, _ = timeit(lambda: ops.affine(x, par2), 2, 20)
+    nbytes = B * (4 * (2 * D + 2 * D) + 4)
+    report('standalone affine kernel, D=3000', B, dt, algorithmic_GBps=round(nbytes / dt / 1e9, 1),
+           frac_of_8TBps=round(nbytes / dt / 8e12, 3))
+    # weight re-pack of the cfg2 output layer: read v + mask, write packed (12 B per weight) + memset
+    N, Kd = 75000, 14998
+    v = torch.randn(N, Kd, device=dev)
+    g = torch.rand(N, 1, device=dev) + 0.5
+    mask = (torch.rand(N, Kd, device=dev) > 0.5).float()
+    out = torch.empty(N, 15008, device=dev)
+    dt, _ = timeit(lambda: ops.masked_weight_prepare(v, g, mask, out=out, n_rows_padded=N, k_padded=15008), 1, 5)
+    nbytes = N * Kd * 12.0
+    report('weight_prepare (weight-norm + mask + pack) 75000x14998', 1, dt, algorithmic_GBps=round(nbytes / dt / 1e9, 1),
+           frac_of_8TBps=round(nbytes / dt / 8e12, 3))
