@@ -116,6 +116,7 @@ def main():
     nnz_out = [float(torch.count_nonzero(l._conditioner.layers[-1].mask)) for l in flow]
     nnz_all = [sum(float(torch.count_nonzero(m.mask)) for m in l._conditioner.layers[::2]) for l in flow]
 
+    @torch.no_grad()                                 # the metric is the forward + log|det J| pass
     def step():
         y, ldj = flow(x)
         work = u_B - ldj - u_A                       # reduced work of the mapped samples
@@ -173,7 +174,8 @@ def main():
                 base, (xs, ys, ls) = cpu_baseline(flow, D, args.bins, args.cpu_chunk)
                 res['cpu_baseline'] = base
                 # the same chunk through layer 0 on the GPU, checked against the CPU result
-                yg, lg = flow[0](torch.from_numpy(xs).to(device))
+                with torch.no_grad():
+                    yg, lg = flow[0](torch.from_numpy(xs).to(device))
                 res['cpu_check'] = {'rel_l2_y': float(np.linalg.norm(yg.cpu().numpy() - ys) / np.linalg.norm(ys)),
                                     'max_abs_ldj': float(np.abs(lg.cpu().numpy() - ls).max())}
             except Exception as e:                              # the headline number must still print

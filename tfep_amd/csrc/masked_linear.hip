@@ -151,8 +151,8 @@ struct GemmArgs {
     const float* pre_add;      // linear epilogue: added BEFORE the activation (partial pre-activations of the
     int64_t ld_pre_add;        //   two-level blocked inverse); same indexing as y
     const uint8_t* tile_live;  // optional (m_tiles x n_tiles): 0 = the whole output tile is masked, skip it
-    int diag;                  // diagnostics only (TFEP_DIAG): 1 = skip the epilogue, 2 = skip the MFMAs,
-                               // 4 = skip the LDS-DMA, 8 = skip the barriers (garbage results; timing only)
+    int diag;                  // diagnostics only (TFEP_DIAG): 1 = skip the epilogue, 4 = skip the LDS-DMA,
+                               // 8 = skip the barriers (garbage results; timing only)
     FusedArgs fu;
 };
 
@@ -170,33 +170,52 @@ struct Tile {
     static constexpr int B_CHUNKS = BN / 16;
 };
 
-// Issue the LDS-DMA of one k-tile.  Chunk c (16 rows) is issued by wave (c % WAVES); inside a
-// chunk lane l covers row (l >> 2), floats [4*(l&3), +4): the LDS image is [row][16] linear,
-// exactly base + 16*lane as the DMA requires.  Rows past the end of the matrix are clamped to
-// the last valid row (their results are never stored).
-template <int MREP, int NREP>
-__device__ inline void stage_tile(const GemmArgs& g, float* lds_stage, int m0, int n0, int k0, int wave, int lane,
-                                  int n_rows_w) {
-    using T = Tile<MREP, NREP>;
+// LDS-DMA staging through buffer descriptors (buffer_load_dwordx4 ... offen lds).
+//
+// A workgroup owns two descriptors: the activation rows from m0 on and the weight rows from n0 on.
+// num_records ends each buffer at the last valid row, so rows past the end of a matrix read as 0 from
+// the hardware range check -- no clamping, and no access outside the allocation.  A lane needs ONE
+// VGPR per operand for all pieces of all k-tiles: its byte offset inside a 16-row piece (row l>>2,
+// floats [4*(l&3), +4)); the piece's row offset is a uniform add, the k offset rides in soffset.
+// The LDS image is [row][16 floats] linear, exactly base + 16*lane as the DMA requires.
+struct StageCtx {
+    __amdgpu_buffer_rsrc_t ra, rw;
+    uint32_t voff_a, voff_w;      // per-lane byte offset inside a piece
+    uint32_t piece_a, piece_w;    // bytes between consecutive 16-row pieces
+};
+
+__device__ inline uint32_t clamp_u32(int64_t v) { return v > 0xffffffffLL ? 0xffffffffu : (v < 0 ? 0u : (uint32_t)v); }
+
+__device__ inline StageCtx make_stage_ctx(const GemmArgs& g, int m0, int n0, int lane, int n_rows_w) {
+    StageCtx c;
+    constexpr int FLAGS = 0x00020000;     // gfx9 raw buffer, 32-bit data
+    c.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.a + (int64_t)m0 * g.lda), 0,
+                                             (int)clamp_u32((int64_t)(g.B - m0) * g.lda * 4), FLAGS);
+    c.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w + (int64_t)n0 * g.ldw), 0,
+                                             (int)clamp_u32((int64_t)(n_rows_w - n0) * g.ldw * 4), FLAGS);
     const int r = lane >> 2, q = lane & 3;
+    c.voff_a = (uint32_t)((r * g.lda + 4 * q) * 4);
+    c.voff_w = (uint32_t)((r * g.ldw + 4 * q) * 4);
+    c.piece_a = (uint32_t)(16 * g.lda * 4);
+    c.piece_w = (uint32_t)(16 * g.ldw * 4);
+    return c;
+}
+
+// Issue the LDS-DMA of one k-tile: chunk c (16 rows) is issued by wave (c % WAVES).
+template <int MREP, int NREP>
+__device__ inline void stage_tile(const StageCtx& sc, float* lds_stage, int k0, int wave) {
+    using T = Tile<MREP, NREP>;
 #pragma unroll
     for (int c = wave; c < T::A_CHUNKS + T::B_CHUNKS; c += WAVES) {
-        const float* src;
-        float* dst;
         if (c < T::A_CHUNKS) {
-            int row = m0 + c * 16 + r;
-            row = row < g.B ? row : g.B - 1;
-            src = g.a + (int64_t)row * g.lda + k0 + 4 * q;
-            dst = lds_stage + c * 16 * BK;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sc.ra, (__attribute__((address_space(3))) void*)(lds_stage + c * 16 * BK),
+                                                     16, sc.voff_a + (uint32_t)c * sc.piece_a, k0 * 4, 0, 0);
         } else {
             const int cb = c - T::A_CHUNKS;
-            int row = n0 + cb * 16 + r;
-            row = row < n_rows_w ? row : n_rows_w - 1;
-            src = g.w + (int64_t)row * g.ldw + k0 + 4 * q;
-            dst = lds_stage + T::A_FLOATS + cb * 16 * BK;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sc.rw,
+                                                     (__attribute__((address_space(3))) void*)(lds_stage + T::A_FLOATS + cb * 16 * BK),
+                                                     16, sc.voff_w + (uint32_t)cb * sc.piece_w, k0 * 4, 0, 0);
         }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
 }
 
@@ -246,7 +265,8 @@ __global__ void __launch_bounds__(THREADS, (MREP == 1 ? 4 : 2)) gemm_kernel(Gemm
     // Two-stage LDS double buffer: the DMA of k-tile t+1 flies under the MFMAs of k-tile t; one
     // barrier per k-tile.
     const int nk = (ke - kb) / BK;
-    if (nk > 0) stage_tile<MREP, NREP>(g, lds, m0, n0, kb, wave, lane, n_rows_w);
+    const StageCtx sc = make_stage_ctx(g, m0, n0, lane, n_rows_w);
+    if (nk > 0) stage_tile<MREP, NREP>(sc, lds, kb, wave);
     const int frag_off = (lane & 15) * BK + (lane >> 4) * 4;   // row (l&15), floats [4q, 4q+4)
     // The matrix pipe is the bottleneck, so it is started first after the barrier and the ~60
     // scalar/vector instructions that issue the next tile's LDS-DMA run in the shadow of MFMA groups.
@@ -273,20 +293,17 @@ __global__ void __launch_bounds__(THREADS, (MREP == 1 ? 4 : 2)) gemm_kernel(Gemm
             if (n == N_DMA_A || n == N_DMA_B) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (dma && late_half == (n == N_DMA_B))
-                    stage_tile<MREP, NREP>(g, lds + ((t + 1) & 1) * T::STAGE_FLOATS, m0, n0, kb + (t + 1) * BK, wave,
-                                           lane, n_rows_w);
+                    stage_tile<MREP, NREP>(sc, lds + ((t + 1) & 1) * T::STAGE_FLOATS, kb + (t + 1) * BK, wave);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (n + 1 < NREP) bq[(n + 1) & 1] = *(const f32x4*)(Bs + (n + 1) * 16 * BK);
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch AHEAD of this group's MFMAs
             const f32x4 bf = bq[n & 1];
-            if (!(g.diag & 2)) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                    for (int m = 0; m < MREP; ++m)
-                        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s], bf[s], acc[n][m], 0, 0, 0);
-            }
+                for (int m = 0; m < MREP; ++m)
+                    acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[m][s], bf[s], acc[n][m], 0, 0, 0);
         }
     }
 
