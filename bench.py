@@ -147,6 +147,16 @@ def main():
     kern_flops = [2.0 * nnz_out[i] * B for i, l in enumerate(flow) for _ in l._profile_events]
     achieved = sum(kern_flops) / (sum(kern_ms) * 1e-3) / 1e12
 
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
+    # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/README.md).
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    if D == 3000 and B == 65536 and args.layers == 4 and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))['hbm_bytes_per_launch']
+        except Exception:
+            traffic = None
+
     if rank == 0:
         res = {
             'metric': 'samples/s (fwd+log|detJ|) MAF+RQ-spline, 3N=3000, batch 64k',
@@ -163,7 +173,7 @@ def main():
                        'hidden_width': int(flow[0]._conditioner.dimensions_hidden[0]),
                        'parallelism': f'dp{world} (batch-sharded replicas, 9-scalar RCCL all-gather)'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                          'kernel': 'gemm_kernel<2,25,EPI_SPLINE> (fused MADE output layer + RQ spline + log-det)',
                          'flops_per_launch': kern_flops[0], 'avg_launch_ms': float(np.mean(kern_ms)),
                          'whole_step_tflops': 2.0 * sum(nnz_all) * B * args.steps / elapsed / 1e12},
