@@ -1,0 +1,110 @@
+"""GPU edge cases: odd shapes, every hidden-layer depth, large bin counts, non-contiguous inputs, and the
+C ABI's error convention (negative status + message, never a throw or a fault)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import flows as oflows, made as omade
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_flow(flow, specs, x):
+    sd = {k: (v.cpu().numpy().astype(np.float64) if v.dtype == torch.float32 else v.cpu().numpy())
+          for k, v in flow.state_dict().items()}
+    layers = [dict(degrees_in=s['degrees_in'], transformer=s['transformer'], embedding=None,
+                   made=omade.made_layers_from_state(sd, prefix=f'{i}._conditioner.')) for i, s in enumerate(specs)]
+    return oflows.sequential_forward(x.cpu().numpy().astype(np.float64), layers)
+
+
+@pytest.mark.parametrize('D,B,hidden,K', [(2, 1, 2, 3), (3, 5, 1, 2), (7, 33, 3, 20), (37, 300, 1, 8), (130, 17, 2, 12)])
+def test_odd_shapes_depths_and_bin_counts(D, B, hidden, K):
+    """D=2 (a single conditioning input; D=1 has no relevant input and fails in the reference too,
+    conditioners/made.py:447), B=1, 1-3 hidden layers, K up to 20 (the KMAX=32 kernel),
+    feature counts that are not multiples of 4 / 16 -- fused (where supported) and generic paths."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF, SequentialFlow
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    torch.manual_seed(D * 100 + K)
+    orders = ['ascending', 'descending']
+    flow = SequentialFlow(*[MAF(generate_degrees(D, o),
+                                transformer=NeuralSplineTransformer(torch.full((D,), -3.0), torch.full((D,), 3.0), K),
+                                hidden_layers=hidden, initialize_identity=False) for o in orders])
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(1)) * 1.5
+    specs = [dict(degrees_in=omade.generate_degrees(D, o),
+                  transformer=dict(type='spline', x0=np.full(D, -3.0), xf=np.full(D, 3.0), n_bins=K)) for o in orders]
+    y_ref, l_ref = oracle_flow(flow, specs, x)
+    flow = flow.cuda()
+    with torch.no_grad():
+        for fused in (True, False):
+            for layer in flow:
+                layer.fused = fused
+            y, l = flow(x.cuda())
+            assert gu.err_stats(y.cpu().numpy(), y_ref)[0] < 1e-5
+            np.testing.assert_allclose(l.cpu().numpy(), l_ref, rtol=1e-5, atol=5e-5)
+        xi, li = flow.inverse(y)
+        assert torch.allclose(xi.cpu(), x, atol=2e-4)
+        assert torch.allclose(li + l, torch.zeros_like(l), atol=2e-3)
+
+
+def test_non_contiguous_and_strided_inputs():
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    torch.manual_seed(0)
+    maf = MAF(generate_degrees(6), initialize_identity=False).cuda()
+    base = torch.randn(6, 40, device='cuda')
+    xt = base.t()                                  # (40, 6) with column stride 40
+    big = torch.randn(40, 9, device='cuda')
+    xs = big[:, 2:8]                               # row stride 9, unit column stride, offset pointer
+    with torch.no_grad():
+        for x in (xt, xs):
+            assert not x.is_contiguous()
+            y, l = maf(x)
+            y2, l2 = maf(x.contiguous())
+            assert torch.equal(y, y2) and torch.equal(l, l2)
+
+
+def test_c_abi_error_convention():
+    """Bad arguments return a negative status and set tfep_last_error(); nothing is launched."""
+    from tfep_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(4, 8, device='cuda')
+    lay = _lib.ParamLayout(16, 8, 1)
+    rc = lib.tfep_affine_forward(_lib.ptr(x), 8, None, lay, _lib.ptr(x), 8, None, 0, 4, 8, None)
+    assert rc == -1 and b'non-NULL' in lib.tfep_last_error()
+    desc = _lib.SplineDesc(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 64, 0, 0, 0, 0, 1e-4, 1e-4)
+    rc = lib.tfep_spline_forward(_lib.ptr(x), 8, _lib.ptr(x), lay, ctypes.byref(desc), _lib.ptr(x), 8, None, 0, 4, 8, None)
+    assert rc == -1 and b'n_bins=64' in lib.tfep_last_error()
+    desc = _lib.SplineDesc(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, 1, 0, 1, 0, 1e-4, 1e-4)
+    rc = lib.tfep_spline_forward(_lib.ptr(x), 8, _lib.ptr(x), lay, ctypes.byref(desc), _lib.ptr(x), 8, None, 0, 4, 8, None)
+    assert rc == -1 and b'circular spline with learnable limits' in lib.tfep_last_error()
+    # GEMM operand contract: k_padded must be a multiple of the k tile, operands 16-byte aligned
+    w = torch.zeros(16, 20, device='cuda')
+    rc = lib.tfep_masked_linear_forward(_lib.ptr(x), 8, _lib.ptr(w), 20, None, None, None, None, _lib.ptr(x), 8,
+                                        4, 8, 16, 20, 0, 0, None)
+    assert rc == -1 and b'k_padded' in lib.tfep_last_error()
+    rc = lib.tfep_moebius_forward(_lib.ptr(x), 8, _lib.ptr(x), 8, 3, 0.99, 1, 1, _lib.ptr(x), 8, None, 0, 4, 8, None)
+    assert rc == -1 and b'multiple of dimension' in lib.tfep_last_error()
+    # the Python host turns argument errors into ValueError, like the reference's constructor checks
+    from tfep_amd import ops
+    with pytest.raises(ValueError, match='must have shape'):
+        ops.moebius(x, torch.zeros(4, 7, device='cuda'), 2)
+
+
+def test_nan_inputs_propagate_without_faults():
+    """No runtime error path in forward: NaNs propagate, only to the rows that hold them."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    torch.manual_seed(0)
+    maf = MAF(generate_degrees(20), initialize_identity=False).cuda()
+    x = torch.randn(300, 20, device='cuda')
+    x[7, 3] = float('nan')
+    with torch.no_grad():
+        y, l = maf(x)
+        ok = torch.ones(300, dtype=torch.bool, device='cuda')
+        ok[7] = False
+        assert torch.isfinite(y[ok]).all() and torch.isfinite(l[ok]).all()
+        assert torch.isnan(l[7]) and torch.isnan(y[7]).any()
