@@ -100,8 +100,8 @@ __device__ inline void rq_spline_backward(const float (&w)[KMAX], const float (&
         pw[k] = 0.0;
         ph[k] = 0.0;
         if (k < K) {
-            pw[k] = exp((double)w[k] - (double)mw);
-            ph[k] = exp((double)h[k] - (double)mh);
+            pw[k] = exp_nonpos((double)w[k] - (double)mw);
+            ph[k] = exp_nonpos((double)h[k] - (double)mh);
             sw += pw[k];
             sh += ph[k];
         }
