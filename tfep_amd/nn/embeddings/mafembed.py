@@ -40,7 +40,20 @@ class PeriodicEmbedding(MAFEmbedding):
 
     def _apply(self, fn, *args, **kwargs):
         self._i32 = {}
+        self.__dict__.pop('_host_limits', None)
         return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self.__dict__.pop('_host_limits', None)
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def host_limits(self):
+        """(lower, upper) as Python floats, read from the ``limits`` buffer once (no per-call sync)."""
+        h = self.__dict__.get('_host_limits')
+        if h is None:
+            h = (float(self.limits[0]), float(self.limits[1]))
+            self.__dict__['_host_limits'] = h
+        return h
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         ops.check_device_tensor(x, 'x')
@@ -49,7 +62,7 @@ class PeriodicEmbedding(MAFEmbedding):
             self._i32[key] = (self._periodic_indices.to(device=x.device, dtype=torch.int32),
                               self._nonperiodic_indices.to(device=x.device, dtype=torch.int32))
         per, non = self._i32[key]
-        return ops.periodic_embedding(x, per, non, float(self.limits[0]), float(self.limits[1]))
+        return ops.periodic_embedding(x, per, non, *self.host_limits())
 
     def get_degrees_out(self, degrees_in: torch.Tensor) -> torch.Tensor:
         return torch.cat([degrees_in[self._nonperiodic_indices],

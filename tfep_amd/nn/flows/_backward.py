@@ -46,7 +46,7 @@ def _transformer_supported(tr):
     if type(tr) in (AffineTransformer, MoebiusTransformer, VolumePreservingShiftTransformer):
         return True
     if type(tr) is NeuralSplineTransformer:
-        return not bool(tr._learn_lower_bound) and not bool(tr._learn_upper_bound)
+        return not tr.host()['learn_lower'] and not tr.host()['learn_upper']
     if type(tr) is MixedTransformer:
         return all(_transformer_supported(t) for t in tr._transformers)
     return False
@@ -65,7 +65,7 @@ def transformer_vjp(tr, x, theta, th_off, ld_theta, gy, gl, gtheta, gx, stream):
         key = str(dev)
         if key not in tr._i32:
             tr._i32[key] = [ind.to(device=dev, dtype=torch.int32) for ind in tr._indices]
-        splits = [0] + tr._parameters_split_indices.tolist()
+        splits = tr.host_splits()
         for sub, ind, a in zip(tr._transformers, tr._i32[key], splits):
             xs, gys = ops.gather_columns(x, ind), ops.gather_columns(gy, ind)
             gxs = torch.empty_like(xs)
@@ -281,7 +281,7 @@ def layer_backward(layer, x, gy, gldj):
             per, non = emb._i32[str(dev)]
             gxc = torch.zeros(Bc, D, **f32)
             _lib.call('tfep_periodic_embedding_backward', _lib.ptr(xc), xc.shape[1] if Bc > 1 else D, _lib.ptr(per),
-                      per.numel(), _lib.ptr(non), non.numel(), float(emb.limits[0]), float(emb.limits[1]),
+                      per.numel(), _lib.ptr(non), non.numel(), *emb.host_limits(),
                       _lib.ptr(g), g.shape[1], _lib.ptr(gxc), D, Bc, stream)
         else:
             gxc = g[:, :D].contiguous()

@@ -124,9 +124,10 @@ class AutoregressiveFlow(torch.nn.Module):
         tr = self._transformer
         if type(tr) is AffineTransformer:
             return _FUSED_AFFINE
-        if type(tr) is NeuralSplineTransformer and int(tr.n_bins) == 8 and not bool(tr._identity_boundary_slopes) \
-                and not bool(tr._learn_lower_bound) and not bool(tr._learn_upper_bound):
-            return _FUSED_SPLINE
+        if type(tr) is NeuralSplineTransformer:
+            h = tr.host()
+            if h['n_bins'] == 8 and not h['identity'] and not h['learn_lower'] and not h['learn_upper']:
+                return _FUSED_SPLINE
         return None
 
     def _fused_plan(self, device, kind, tables):
@@ -280,11 +281,10 @@ class AutoregressiveFlow(torch.nn.Module):
         """The transformer restricted to the transformed features ``sel`` (a degree group)."""
         tr = self._transformer
         if type(tr) is NeuralSplineTransformer:
-            cfg = tr.config(device)
+            cfg, h = tr.config(device), tr.host()
             return ('spline', ops.SplineConfig(
-                cfg.x0[sel], cfg.xf[sel], cfg.y0[sel], cfg.yf[sel], int(tr.n_bins), bool(tr._circular),
-                bool(tr._identity_boundary_slopes), bool(tr._learn_lower_bound), bool(tr._learn_upper_bound),
-                float(tr._min_bin_size), float(tr._min_slope)))
+                cfg.x0[sel], cfg.xf[sel], cfg.y0[sel], cfg.yf[sel], h['n_bins'], h['circular'], h['identity'],
+                h['learn_lower'], h['learn_upper'], h['min_bin'], h['min_slope']))
         if type(tr) is MoebiusTransformer:
             return ('moebius', tr)
         return ('affine', tr)

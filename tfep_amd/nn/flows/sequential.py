@@ -16,7 +16,7 @@ class SequentialFlow(torch.nn.Sequential):
         return self._pass(y, inverse=True)
 
     def _pass(self, x, inverse):
-        cumulative_log_det_J = torch.zeros(x.size(0)).to(x)
+        cumulative_log_det_J = torch.zeros(x.size(0), dtype=x.dtype, device=x.device)
         flows = reversed(self) if inverse else self
         name = 'inverse' if inverse else 'forward'
         for flow in flows:

@@ -33,7 +33,16 @@ class MixedTransformer(MAFTransformer):
 
     def _apply(self, fn, *args, **kwargs):
         self._i32 = {}
+        self.__dict__.pop('_host_splits', None)
         return super()._apply(fn, *args, **kwargs)
+
+    def host_splits(self):
+        """Cumulative parameter offsets as a Python list (read from the buffer once: no per-call sync)."""
+        h = self.__dict__.get('_host_splits')
+        if h is None:
+            h = [0] + self._parameters_split_indices.tolist()
+            self.__dict__['_host_splits'] = h
+        return h
 
     @property
     def _indices(self):
@@ -60,7 +69,7 @@ class MixedTransformer(MAFTransformer):
             self._i32[key] = [ind.to(device=x.device, dtype=torch.int32) for ind in self._indices]
         y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
         ldj = None
-        splits = [0] + self._parameters_split_indices.tolist() + [parameters.shape[1]]
+        splits = self.host_splits() + [parameters.shape[1]]
         for t, ind, a, b in zip(self._transformers, self._i32[key], splits[:-1], splits[1:]):
             xg = ops.gather_columns(x, ind)
             par = parameters[:, a:b]

@@ -59,35 +59,51 @@ class NeuralSplineTransformer(MAFTransformer):
         self.register_buffer('_min_slope', torch.as_tensor(min_slope))
         self._cfg = None
 
+    def host(self):
+        """Host-side copy of the scalar buffers (``n_bins``, flags, minimum sizes).  They are registered
+        buffers like in the reference, so after ``.to('cuda')`` reading them costs a device->host sync:
+        do it once, not on every forward (and never inside a HIP-graph capture)."""
+        h = self.__dict__.get('_host_cache')
+        if h is None:
+            h = dict(n_bins=int(self.n_bins), circular=bool(self._circular),
+                     identity=bool(self._identity_boundary_slopes), learn_lower=bool(self._learn_lower_bound),
+                     learn_upper=bool(self._learn_upper_bound), min_bin=float(self._min_bin_size),
+                     min_slope=float(self._min_slope))
+            self.__dict__['_host_cache'] = h
+        return h
+
     @property
     def n_parameters_per_feature(self) -> int:
         """Parameters per feature (reference spline.py:165-182)."""
-        n = 3 * int(self.n_bins) + 1
-        if bool(self._learn_lower_bound):
+        h = self.host()
+        n = 3 * h['n_bins'] + 1
+        if h['learn_lower']:
             n += 1
-        if bool(self._learn_upper_bound):
+        if h['learn_upper']:
             n += 1
-        if bool(self._identity_boundary_slopes):
-            n -= 1 if bool(self._circular) else 2
+        if h['identity']:
+            n -= 1 if h['circular'] else 2
         return n
 
     def _apply(self, fn, *args, **kwargs):
         self._cfg = None
+        self.__dict__.pop('_host_cache', None)
         return super()._apply(fn, *args, **kwargs)
 
     def _load_from_state_dict(self, *args, **kwargs):
         self._cfg = None
+        self.__dict__.pop('_host_cache', None)
         return super()._load_from_state_dict(*args, **kwargs)
 
     def config(self, device):
         """Device descriptor handed to the kernels (rebuilt after .to() / load_state_dict)."""
         if self._cfg is None or self._cfg.x0.device != device:
+            h = self.host()
             f32 = dict(device=device, dtype=torch.float32)
             self._cfg = ops.SplineConfig(
                 self.x0.to(**f32), self.xf.to(**f32), self._y0.to(**f32), self._yf.to(**f32),
-                int(self.n_bins), bool(self._circular),
-                bool(self._identity_boundary_slopes), bool(self._learn_lower_bound),
-                bool(self._learn_upper_bound), float(self._min_bin_size), float(self._min_slope))
+                h['n_bins'], h['circular'], h['identity'], h['learn_lower'], h['learn_upper'],
+                h['min_bin'], h['min_slope'])
         return self._cfg
 
     def forward(self, x, parameters):

@@ -45,10 +45,18 @@ if 'cfg1' in which:
     with torch.device(dev):
         flow = SequentialFlow(*[MAF(generate_degrees(D, order(i)), initialize_identity=False) for i in range(2)])
     x = torch.randn(B, D, device=dev)
-    dt, (y, _) = timeit(lambda: flow(x), 3, 20)
+    with torch.no_grad():
+        dt, (y, _) = timeit(lambda: flow(x), 3, 20)
     report('cfg1 forward: 2-layer MAF + affine, D=66', B, dt)
     dt, (xi, _) = timeit(lambda: flow.inverse(y), 1, 5)
     report('cfg1 inverse (blocked)', B, dt, roundtrip_max_abs=float((xi - x).detach().abs().max()))
+    from tfep_amd.graphs import GraphedFlow
+    with torch.no_grad():
+        gf, gi = GraphedFlow(flow, B, D), GraphedFlow(flow, B, D, inverse=True)
+        dt, _ = timeit(lambda: gf(x), 3, 50)
+        report('cfg1 forward, HIP-graph replay', B, dt)
+        dt, _ = timeit(lambda: gi(y), 3, 20)
+        report('cfg1 inverse (blocked), HIP-graph replay', B, dt)
     for l in flow:
         l.blocked_inverse = False
     dt, _ = timeit(lambda: flow.inverse(y), 1, 3)
@@ -67,6 +75,12 @@ if 'cfg2inv' in which:
     dt, (xi, li) = timeit(lambda: flow.inverse(y), 1, 1)
     report('cfg2 ONE layer inverse (blocked, 3000 degrees)', B, dt,
            roundtrip_rel_l2=float((xi - x).detach().norm() / x.norm()), ldj_cancel_max_abs=float((lf + li).detach().abs().max()))
+    from tfep_amd.graphs import GraphedFlow
+    with torch.no_grad():
+        gi = GraphedFlow(flow, B, D, inverse=True, warmup=1)
+        dt, (xg, lg) = timeit(lambda: gi(y), 1, 2)
+    report('cfg2 ONE layer inverse (blocked), HIP-graph replay', B, dt, equals_eager=bool(torch.equal(xg, xi)),
+           peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
 
 if 'train' in which:
     from tfep_amd.loss import BoltzmannKLDivLoss
