@@ -98,3 +98,36 @@ def test_unsupported_backward_fails_loudly():
     y, ldj = maf(torch.randn(3, 4, device='cuda'))
     with pytest.raises(NotImplementedError, match='backward is implemented for'):
         (y.sum() + ldj.sum()).backward()
+
+
+@pytest.mark.parametrize('order,cond', [('ascending', None), ('descending', [1, 4])])
+def test_autoregressive_property_by_gradient_sparsity(order, cond):
+    """The reference's check_autoregressive_property (tests/nn/__init__.py:25-96; used by test_made.py and
+    test_maf.py:288-295): back-propagate each output-degree group and require EXACT zeros in the input
+    gradient where the autoregressive structure forbids a dependence, non-zeros where it allows one."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    D = 9
+    deg = generate_degrees(D, order, conditioning_indices=cond)
+    n_tr = int((deg != -1).sum())
+    torch.manual_seed(3)
+    maf = MAF(deg, transformer=NeuralSplineTransformer(torch.full((n_tr,), -3.0), torch.full((n_tr,), 3.0), 8),
+              initialize_identity=False).cuda()
+    x = (torch.randn(1, D, generator=torch.Generator().manual_seed(4)) * 0.8).cuda().requires_grad_(True)
+    y, ldj = maf(x)
+    deg_l = deg.tolist()
+    for d_out in sorted(set(deg_l) - {-1}):
+        idx = [i for i, d in enumerate(deg_l) if d == d_out]
+        (g,) = torch.autograd.grad(y[0, idx].sum(), x, retain_graph=True)
+        g = g[0].cpu()
+        for j, d_in in enumerate(deg_l):
+            if d_in == -1:
+                assert g[j] != 0, (d_out, j)                    # conditioning features reach every output
+            elif d_in < d_out or j in idx:
+                assert g[j] != 0, (d_out, j)                    # allowed dependence (and y_i on x_i itself)
+            else:
+                assert g[j] == 0, (d_out, j, float(g[j]))       # forbidden: exactly zero
+    # fixed (conditioning) features pass through unchanged
+    if cond:
+        assert torch.equal(y[0, cond], x[0, cond])

@@ -380,3 +380,35 @@ def test_cfg4_size_properties():
     d = torch.minimum(d, 1.0 - d)                      # distance on the circle
     assert float(d.max()) < 2e-4
     assert torch.allclose(li + l[:512], torch.zeros(512, device='cuda'), atol=5e-3)
+
+
+def test_circular_spline_fixed_points_and_periodicity():
+    """tests/nn/transformers/test_spline.py:308-352: with zero shift the period boundaries map to themselves;
+    outputs stay inside the period; first and last knot share a slope (C1 on the circle)."""
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    x0 = torch.tensor([0.0, -1.0, 2.0])
+    xf = torch.tensor([2.0, -0.5, 5.0])
+    K, B = 3, 64
+    t = NeuralSplineTransformer(x0=x0, xf=xf, n_bins=K, circular=True).cuda()
+    gen = torch.Generator().manual_seed(0)
+    eps = 1e-6
+    x = torch.cat([x0[None] + eps * (xf - x0), xf[None] - eps * (xf - x0),
+                   torch.rand(B - 2, 3, generator=gen) * (xf - x0) + x0]).cuda()
+    par = torch.randn(B, (3 * K + 1) * 3, generator=gen).cuda()
+    y, l = t(x, par)
+    assert torch.all(y > x0.cuda() - 1e-6) and torch.all(y < xf.cuda() + 1e-6)
+    xi, li = t.inverse(y, par)
+    d = (xi - x).abs()
+    d = torch.minimum(d, (xf - x0).cuda() - d)
+    assert float(d.max()) < 2e-4 and torch.allclose(l + li, torch.zeros_like(l), atol=1e-4)   # fp32 y through 1/slope
+    par0 = par.reshape(B, 3 * K + 1, 3).clone()
+    par0[:, 3 * K] = 0.0                                         # zero shift
+    y0, _ = t(x, par0.reshape(B, -1))
+    assert torch.allclose(y0[:2], x[:2], atol=2e-5)              # boundaries are fixed points
+    # derivative continuity across the period boundary: dy/dx just inside both ends agree
+    # (log-derivative of a single feature: feed one-feature transformers)
+    t1 = NeuralSplineTransformer(x0=x0[:1], xf=xf[:1], n_bins=K, circular=True).cuda()
+    p1 = par0[:1, :, :1].reshape(1, -1)
+    _, la = t1(x0[:1][None].cuda() + 1e-6, p1)
+    _, lb = t1(xf[:1][None].cuda() - 1e-6, p1)
+    assert abs(float(la - lb)) < 1e-4
