@@ -131,3 +131,45 @@ def test_autoregressive_property_by_gradient_sparsity(order, cond):
     # fixed (conditioning) features pass through unchanged
     if cond:
         assert torch.equal(y[0, cond], x[0, cond])
+
+
+def test_masked_linear_module_and_functional_autograd():
+    """tests/nn/test_masked.py:150-218 in spirit: the functional form matches the reference's analytic
+    gradients (float64 golden), and a weight-normalised MaskedLinear trains without NaNs while masked
+    weights stay exactly zero after an SGD step, including a fully-masked row."""
+    from tfep_amd.nn import masked
+    g = gu.load('grads.npz')
+    x, w, b, m, gy = (torch.from_numpy(g[f'ml/{k}']).float().cuda() for k in ('x', 'w', 'b', 'mask', 'gy'))
+    x.requires_grad_(True); w.requires_grad_(True); b.requires_grad_(True)
+    y = masked.masked_linear(x, w, b, m)
+    y.backward(gy)
+    assert rel(x.grad.cpu(), g['ml/gx']) < 1e-6 and rel(w.grad.cpu(), g['ml/gw']) < 1e-6
+    assert rel(b.grad.cpu(), g['ml/gb']) < 1e-6
+
+    mask = torch.tril(torch.ones(5, 8))
+    mask[2] = 0.0
+    torch.manual_seed(0)
+    lin = masked.masked_weight_norm(masked.MaskedLinear(8, 5, mask=mask)).cuda()
+    ref_w = lin.weight.clone()
+    opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+    xin = torch.randn(16, 8, device='cuda')
+    loss = (lin(xin) ** 2).sum()
+    loss.backward()
+    assert torch.all(lin.weight_v.grad[mask.cuda() == 0] == 0) and lin.weight_g.grad[2] == 0
+    assert torch.isfinite(lin.weight_v.grad).all() and torch.isfinite(lin.weight_g.grad).all()
+    opt.step()
+    w2 = lin.weight
+    assert torch.isfinite(w2).all() and torch.all(w2[mask.cuda() == 0] == 0) and not torch.equal(w2, ref_w)
+    # weight-norm gradients against autograd through the plain formula (float64 on the host)
+    v = lin.weight_v.detach().double().cpu().requires_grad_(True)
+    gg = lin.weight_g.detach().double().cpu().requires_grad_(True)
+    norm = v.norm(dim=1, keepdim=True)
+    weff = torch.where(mask.double() == 0, torch.zeros_like(v), v * (gg / norm))
+    lin2 = masked.masked_weight_norm(masked.MaskedLinear(8, 5, mask=mask)).cuda()
+    lin2.load_state_dict(lin.state_dict())
+    (lin2(xin) ** 2).sum().backward()
+    ((xin.double().cpu() @ weff.t() + lin.bias.detach().double().cpu()) ** 2).sum().backward()
+    live = mask != 0
+    assert rel(lin2.weight_v.grad.cpu()[live], v.grad[live]) < 1e-5
+    rows = [0, 1, 3, 4]
+    assert rel(lin2.weight_g.grad.cpu()[rows], gg.grad[rows]) < 1e-5

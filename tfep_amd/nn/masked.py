@@ -44,19 +44,70 @@ def create_autoregressive_mask(degrees_in, degrees_out, strictly_less=True, tran
 # FUNCTIONAL API
 # =============================================================================
 
+class MaskedLinearFunc(torch.autograd.Function):
+    r"""``y = x (M o A)^T + b`` with the analytic backward of the reference (masked.py:220-302):
+    ``grad_input = g (M o A)``, ``grad_weight = (g^T x) o M``, ``grad_bias = sum_b g`` -- every product on
+    the fp32-MFMA GEMM of ``libtfep_hip.so``.  With ``weight_g`` the weight is the masked weight-norm
+    parametrisation ``M o g v/||v||`` (masked.py:351-404) and the gradients are those of ``g`` and ``v``
+    (masked entries of ``grad_v`` and fully-masked rows of ``grad_g`` are zero, masked.py:401-402, :429).
+    """
+
+    @staticmethod
+    def forward(ctx, input, weight, bias=None, mask=None, weight_g=None):
+        x2 = input.detach().reshape(-1, input.shape[-1])
+        n_out, k = weight.shape
+        tm, tn, tk = ops.tile_sizes()
+        k_pad, n_pad = ops.round_up(k, tk), ops.round_up(n_out, tk)
+        w = ops.masked_weight_prepare(weight.detach(), None if weight_g is None else weight_g.detach(), mask,
+                                      n_rows_padded=n_pad, k_padded=k_pad)
+        xp = ops.pad_columns(x2, k_pad)
+        y = ops.masked_linear_packed(xp, w, None if bias is None else bias.detach(), n_out)
+        ctx.save_for_backward(xp, w, weight, mask, weight_g)
+        ctx.has_bias = bias is not None
+        ctx.in_shape = input.shape
+        return y.reshape(*input.shape[:-1], n_out)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        from .flows._backward import _gemm, _transpose
+        from .. import _lib
+        xp, w, weight, mask, weight_g = ctx.saved_tensors
+        n_out, k = weight.shape
+        n_pad, k_pad = w.shape
+        tm, tn, tk = ops.tile_sizes()
+        f32 = dict(dtype=torch.float32, device=xp.device)
+        g2 = grad_output.reshape(-1, n_out).float()
+        B = g2.shape[0]
+        gp = ops.pad_columns(g2, n_pad)
+        grad_input = grad_weight = grad_bias = grad_g = None
+        if ctx.needs_input_grad[0]:
+            wt = _transpose(w, n_pad, k_pad, torch.zeros(k_pad, n_pad, **f32))
+            gx = _gemm(gp, wt, torch.empty(B, k_pad, **f32), B, k_pad, k_pad)
+            grad_input = gx[:, :k].reshape(ctx.in_shape)
+        if ctx.needs_input_grad[1] or (weight_g is not None and ctx.needs_input_grad[4]):
+            Bp = ops.round_up(B, tk)
+            gT = _transpose(gp, B, n_pad, torch.zeros(n_pad, Bp, **f32))
+            xT = _transpose(xp, B, k_pad, torch.zeros(k_pad, Bp, **f32))
+            gw = _gemm(gT, xT, torch.zeros(n_pad, k_pad, **f32), n_pad, k_pad, k_pad, accumulate=1)
+            grad_weight = torch.empty_like(weight)
+            if weight_g is not None:
+                grad_g = torch.empty_like(weight_g)
+            _lib.call('tfep_weight_norm_backward', _lib.ptr(gw), k_pad, _lib.ptr(weight.detach().contiguous()),
+                      _lib.ptr(None if weight_g is None else weight_g.detach().contiguous()),
+                      _lib.ptr(None if mask is None else mask.contiguous()), n_out, k, None, None,
+                      _lib.ptr(grad_weight), _lib.ptr(grad_g), _lib.stream_of(xp))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            grad_bias = torch.empty(n_out, **f32)
+            _lib.call('tfep_column_sums', _lib.ptr(gp), n_pad, B, n_out, _lib.ptr(grad_bias), 0, _lib.stream_of(xp))
+        return grad_input, grad_weight, grad_bias, None, grad_g
+
+
 def masked_linear(input, weight, bias=None, mask=None):
-    r"""``y = x (M o A)^T + b`` (reference masked.py:265-277), on the HIP GEMM.
+    r"""``y = x (M o A)^T + b`` (reference masked.py:265-277, :305), differentiable.
 
     ``input`` may have extra leading dimensions ``(batch, *, in_features)``.
     """
-    lead = input.shape[:-1]
-    x2 = input.reshape(-1, input.shape[-1])
-    n_out, k = weight.shape
-    tm, tn, tk = ops.tile_sizes()
-    k_padded = ops.round_up(k, tk)
-    w = ops.masked_weight_prepare(weight, None, mask, k_padded=k_padded)
-    y = ops.masked_linear_packed(ops.pad_columns(x2, k_padded), w, bias, n_out)
-    return y.reshape(*lead, n_out)
+    return MaskedLinearFunc.apply(input, weight, bias, mask)
 
 
 # =============================================================================
@@ -111,18 +162,9 @@ class MaskedLinear(torch.nn.Linear):
         return super().__getattr__(name)
 
     def forward(self, input):
-        lead = input.shape[:-1]
-        x2 = input.reshape(-1, input.shape[-1])
-        tm, tn, tk = ops.tile_sizes()
-        k_padded = ops.round_up(self.in_features, tk)
         if self.has_weight_norm:
-            w = ops.masked_weight_prepare(self.weight_v.detach(), self.weight_g.detach(), self.mask,
-                                          k_padded=k_padded)
-        else:
-            w = ops.masked_weight_prepare(self._parameters['weight'].detach(), None, self.mask, k_padded=k_padded)
-        bias = None if self.bias is None else self.bias.detach()
-        y = ops.masked_linear_packed(ops.pad_columns(x2, k_padded), w, bias, self.out_features)
-        return y.reshape(*lead, self.out_features)
+            return MaskedLinearFunc.apply(input, self.weight_v, self.bias, self.mask, self.weight_g)
+        return MaskedLinearFunc.apply(input, self._parameters['weight'], self.bias, self.mask)
 
     def extra_repr(self):
         return 'in_features={}, out_features={}, bias={}, weight_norm={}'.format(
