@@ -462,7 +462,6 @@ static int env_int(const char* name, int dflt) {
 }
 // Tuning switches (A/B experiments; defaults are the measured best).
 static int block_map_mode() { static int m = env_int("TFEP_BLOCK_MAP", 1); return m; }
-static int fused_mrep() { static int m = env_int("TFEP_FUSED_MREP", 2); return m; }
 
 template <int MREP, int NREP, int EPI, int P, int KSPL>
 static int launch_gemm(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStream_t s) {
@@ -653,10 +652,7 @@ int tfep_fused_output_transformer_forward(const float* h, int64_t ldh, const flo
         g.fu.sf.learn_lower = false; g.fu.sf.learn_upper = false;
         g.fu.sf.min_bin = desc->min_bin_size; g.fu.sf.min_slope = desc->min_slope;
         g.fu.sf.slope_offset = (float)log(exp(1.0 - (double)desc->min_slope) - 1.0);
-        if (fused_mrep() == 1)
-            rc = launch_gemm<1, P, EPI_SPLINE, P, KS>(g, n_rows_w, n_groups, s);
-        else
-            rc = launch_gemm<2, P, EPI_SPLINE, P, KS>(g, n_rows_w, n_groups, s);
+        rc = launch_gemm<2, P, EPI_SPLINE, P, KS>(g, n_rows_w, n_groups, s);
     }
     if (rc) return rc;
     ldj_reduce_kernel<<<(unsigned)((B + 255) / 256), 256, 0, s>>>(ldj_partial, n_groups, B, log_det_J, accumulate);
