@@ -56,7 +56,7 @@ def _voidp(t, offset_elems=0):
     return ctypes.c_void_p(t.data_ptr() + 4 * offset_elems)
 
 
-def transformer_vjp(tr, x, theta, th_off, ld_theta, gy, gl, gtheta, gx, stream):
+def transformer_vjp(tr, x, theta, th_off, ld_theta, gy, gl, gtheta, gx, stream, layout=None, order=None):
     """VJP of ``tr.forward(x, theta[:, th_off:th_off + n_par])``: writes the matching block of ``gtheta`` and
     ``gx`` (contiguous (B, D)).  ``theta`` / ``gtheta`` have row stride ``ld_theta``."""
     B, D = x.shape
@@ -73,12 +73,24 @@ def transformer_vjp(tr, x, theta, th_off, ld_theta, gy, gl, gtheta, gx, stream):
             ops.scatter_columns(gxs, ind, gx)
         return
     th, gth = _voidp(theta, th_off), _voidp(gtheta, th_off)
+    # layout: (row stride, stride between parameters, stride between features); default = reference layout.
+    # `order`: the features are given in this permutation (slot order), so per-feature constants follow it.
+    lay = _lib.ParamLayout(*layout) if layout is not None else _lib.ParamLayout(ld_theta, D, 1)
     if type(tr) is NeuralSplineTransformer:
-        lay = _lib.ParamLayout(ld_theta, D, 1)
-        _lib.call('tfep_spline_backward', _lib.ptr(x), D, th, lay, ctypes.byref(tr.config(dev).desc), _lib.ptr(gy), D,
+        cfg = tr.config(dev)
+        if order is not None:
+            key = ('slot_cfg', str(dev))
+            if tr.__dict__.get('_slot_cfg_key') != (key, id(order)):
+                h = tr.host()
+                o = order.long()
+                tr.__dict__['_slot_cfg'] = ops.SplineConfig(cfg.x0[o], cfg.xf[o], cfg.y0[o], cfg.yf[o], h['n_bins'],
+                                                            h['circular'], h['identity'], h['learn_lower'],
+                                                            h['learn_upper'], h['min_bin'], h['min_slope'])
+                tr.__dict__['_slot_cfg_key'] = (key, id(order))
+            cfg = tr.__dict__['_slot_cfg']
+        _lib.call('tfep_spline_backward', _lib.ptr(x), D, th, lay, ctypes.byref(cfg.desc), _lib.ptr(gy), D,
                   _lib.ptr(gl), gth, lay, _lib.ptr(gx), D, B, D, stream)
     elif type(tr) is AffineTransformer:
-        lay = _lib.ParamLayout(ld_theta, D, 1)
         _lib.call('tfep_affine_backward', _lib.ptr(x), D, th, lay, _lib.ptr(gy), D, _lib.ptr(gl), gth, lay,
                   _lib.ptr(gx), D, B, D, stream)
     elif type(tr) is MoebiusTransformer:
@@ -159,6 +171,12 @@ def _transpose(src, rows, cols, out):
 
 
 def _backward_plan(layer, device):
+    """Host-side plan of the backward GEMMs (built once per device).
+
+    Output-layer rows are re-packed FEATURE-MAJOR in degree-sorted feature order (row = slot*P + p) for affine
+    and spline transformers: the rows that feed a tile of hidden units are then one contiguous
+    range, so ``grad_input = g W`` skips the masked half of its contraction like the forward does.
+    """
     key = ('bwd', str(device))
     bp = layer._dev.get(key)
     if bp is not None:
@@ -167,13 +185,32 @@ def _backward_plan(layer, device):
     mplan = made.plan(device)
     tm, tn, tk = ops.tile_sizes()
     lins = made._linears()
+    L = len(lins) - 1
+    tables = layer._tables(device)
+    n_tr = tables['n_tr']
+    n_out = lins[-1].out_features
+    P = n_out // n_tr
+    i32 = dict(device=device, dtype=torch.int32)
+    bp = dict(sorted_out=type(layer._transformer) in (AffineTransformer, NeuralSplineTransformer))
+    k_ranges = list(mplan['k_ranges'])
+    if bp['sorted_out']:
+        deg_tr = made._degrees[-1][:n_tr].cpu()
+        order = torch.argsort(deg_tr, stable=True)                 # slot -> transformed feature
+        slot_of = torch.empty_like(order)
+        slot_of[order] = torch.arange(n_tr, device='cpu')
+        p = torch.arange(P, device='cpu').repeat_interleave(n_tr)
+        row_of_out = (slot_of.repeat(P) * P + p).to(**i32)         # row of reference output o = p*n_tr + t
+        bp.update(order=order.to(**i32), row_of_out=row_of_out)
+        n_out_pad = ops.round_up(n_out, tk)
+        k_ranges[L] = ops.mask_k_ranges(lins[L].mask, tn, (n_out_pad + tn - 1) // tn, mplan['k_pad'][L], row_of_out,
+                                        mplan['col_of_in'][L])
+    bp['k_ranges'] = k_ranges
     dx_ranges, live = [], []
     for li, lin in enumerate(lins):
-        kr = mplan['k_ranges'][li].cpu().long()                   # per 256-row tile of W: [kb, ke)
-        is_out = li == len(lins) - 1
+        kr = k_ranges[li].cpu().long()                            # per 256-row tile of W: [kb, ke)
+        is_out = li == L
         n_pad = ops.round_up(lin.out_features, tk) if is_out else mplan['n_pad'][li]
         k_pad = mplan['k_pad'][li]
-        n_row_tiles = kr.shape[0]
         n_col_tiles = (k_pad + tn - 1) // tn
         lo = torch.arange(n_col_tiles) * tn
         hi = lo + tn
@@ -187,7 +224,7 @@ def _backward_plan(layer, device):
                 rng[j, 0] = int(rows.min()) * tn
                 rng[j, 1] = min((int(rows.max()) + 1) * tn, n_pad)
         dx_ranges.append(rng.to(device))
-    bp = dict(dx_ranges=dx_ranges, live=live)
+    bp.update(dx_ranges=dx_ranges, live=live)
     layer._dev[key] = bp
     return bp
 
@@ -224,8 +261,12 @@ def layer_backward(layer, x, gy, gldj):
     n_pad = [mplan['n_pad'][l] for l in range(L)] + [n_out_pad]
     k_pad = list(mplan['k_pad'])
     W, WT, bias = [], [], []
+    sorted_out = bplan['sorted_out']
     for l, lin in enumerate(lins):
-        w, b = made._pack_layer(mplan, l, lin, n_rows=n_pad[l])
+        if l == L and sorted_out:
+            w, b = made._pack_layer(mplan, l, lin, row_of_out=bplan['row_of_out'], n_rows=n_pad[l])
+        else:
+            w, b = made._pack_layer(mplan, l, lin, n_rows=n_pad[l])
         W.append(w)
         bias.append(b)
         wt = torch.zeros(k_pad[l], n_pad[l], **f32)
@@ -248,7 +289,7 @@ def layer_backward(layer, x, gy, gldj):
         for l in range(L):
             h.append(ops.masked_linear_packed(h[-1], W[l], bias[l], n_pad[l], k_ranges=mplan['k_ranges'][l], act=1))
         theta = torch.empty(Bc, n_out_pad, **f32)
-        _gemm(h[-1], W[L], theta, Bc, n_out_pad, n_pad[L], bias=bias[L], k_ranges=mplan['k_ranges'][L])
+        _gemm(h[-1], W[L], theta, Bc, n_out_pad, n_pad[L], bias=bias[L], k_ranges=bplan['k_ranges'][L])
 
         # ---- transformer VJP: gtheta (reference parameter layout, zero padded columns), direct gx
         if layer.has_fixed_indices:
@@ -258,7 +299,15 @@ def layer_backward(layer, x, gy, gldj):
         gtheta = torch.zeros(Bc, n_out_pad, **f32)
         gx_dir = torch.empty(Bc, n_tr, **f32)
         x_tr, gy_tr = x_tr.contiguous(), gy_tr.contiguous()
-        transformer_vjp(tr, x_tr, theta, 0, n_out_pad, gy_tr, glc, gtheta, gx_dir, stream)
+        if sorted_out:
+            # theta / gtheta are feature-major in slot order: work on slot-ordered copies of x and gy
+            xs, gys = ops.gather_columns(x_tr, bplan['order']), ops.gather_columns(gy_tr, bplan['order'])
+            gxs = torch.empty(Bc, n_tr, **f32)
+            transformer_vjp(tr, xs, theta, 0, n_out_pad, gys, glc, gtheta, gxs, stream, layout=(n_out_pad, 1, P),
+                            order=bplan['order'])
+            ops.scatter_columns(gxs, bplan['order'], gx_dir)
+        else:
+            transformer_vjp(tr, x_tr, theta, 0, n_out_pad, gy_tr, glc, gtheta, gx_dir, stream)
         del theta
 
         # ---- masked linears, last to first.  g = gradient w.r.t. the layer's pre-activation output.
@@ -296,7 +345,7 @@ def layer_backward(layer, x, gy, gldj):
     # ---- packed weight / bias gradients -> parameter gradients
     grads = []
     for l, lin in enumerate(lins):
-        row_of_out = mplan['row_of_out'][l]
+        row_of_out = bplan['row_of_out'] if (l == L and sorted_out) else mplan['row_of_out'][l]
         col_of_in = mplan['col_of_in'][l]
         if lin.has_weight_norm:
             gv = torch.empty_like(lin.weight_v)
