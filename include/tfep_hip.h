@@ -274,7 +274,7 @@ int tfep_add_inplace(const float* in, int64_t ld_in, float* out, int64_t ld_out,
  * g_log_det_J (B,) = dL/d log_det_J (may be NULL) they write gparams (layout glayout, every parameter
  * of every feature) and gx (B, D) = the DIRECT dL/dx (not through the conditioner).
  * Reference: eager autograd through affine.py:321-323 / spline.py:184-241, :319-417, :424-650.
- * The spline version supports plain, circular and identity-boundary-slope splines (fixed bounds). */
+ * The spline version covers every variant: circular, identity boundary slopes, learnable bounds. */
 int tfep_affine_backward(const float* x, int64_t ldx, const float* params, tfep_param_layout layout,
                          const float* gy, int64_t ldgy, const float* g_log_det_J,
                          float* gparams, tfep_param_layout glayout, float* gx, int64_t ldgx,

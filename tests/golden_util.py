@@ -235,6 +235,13 @@ def grad_flow_configs():
         'identslopes': [
             dict(degrees_in=gd(D, 'ascending'), transformer=_spl(D, -2.0, 2.0, 5, identity_boundary_slopes=True),
                  hidden_layers=2, weight_norm=True)],
+        'learnlow': [dict(degrees_in=gd(D, 'ascending'), transformer=_spl(D, -3.0, 3.0, 6, learn_lower_bound=True),
+                          hidden_layers=2, weight_norm=True)],
+        'learnup': [dict(degrees_in=gd(D, 'ascending'), transformer=_spl(D, -3.0, 3.0, 6, learn_upper_bound=True),
+                         hidden_layers=2, weight_norm=True)],
+        'learnboth': [dict(degrees_in=gd(D, 'ascending'),
+                           transformer=_spl(D, -3.0, 3.0, 6, learn_lower_bound=True, learn_upper_bound=True),
+                           hidden_layers=2, weight_norm=True)],
         'moebius': [
             dict(degrees_in=gd(12, 'ascending', repeats=2), transformer=dict(type='moebius', dimension=2, unit_sphere=True),
                  hidden_layers=2, weight_norm=True),

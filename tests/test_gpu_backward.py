@@ -40,7 +40,7 @@ def test_masked_linear_function_gradients():
     assert rel(gw.cpu(), g['ml/gw']) < 1e-6
 
 
-@pytest.mark.parametrize('name', ['affine', 'spline', 'circular', 'identslopes', 'moebius', 'mixed'])
+@pytest.mark.parametrize('name', ['affine', 'spline', 'circular', 'identslopes', 'moebius', 'mixed', 'learnlow', 'learnup', 'learnboth'])
 def test_training_step_gradients_match_reference_autograd(name):
     from tfep_amd.loss import BoltzmannKLDivLoss
     g = gu.load('grads.npz')
@@ -89,13 +89,24 @@ def test_optimizer_step_runs_and_lowers_the_loss():
 
 
 def test_unsupported_backward_fails_loudly():
-    from tfep_amd.nn.conditioners import generate_degrees
-    from tfep_amd.nn.flows import MAF
-    from tfep_amd.nn.transformers import NeuralSplineTransformer
-    maf = MAF(generate_degrees(4), transformer=NeuralSplineTransformer(torch.zeros(4), torch.ones(4), 4,
-                                                                         learn_upper_bound=True),
-              initialize_identity=False).cuda()
-    y, ldj = maf(torch.randn(3, 4, device='cuda'))
+    """A user-supplied conditioner has no HIP backward: the forward works, .backward() raises."""
+    from tfep_amd.nn.conditioners.conditioner import Conditioner
+    from tfep_amd.nn.flows import AutoregressiveFlow
+    from tfep_amd.nn.transformers import AffineTransformer
+
+    class Constant(Conditioner):
+        def __init__(self):
+            super().__init__()
+            self.out = torch.nn.Parameter(torch.zeros(8))
+
+        def forward(self, x):
+            return self.out.detach().expand(x.shape[0], -1).contiguous()
+
+        def set_output(self, output):
+            self.out.data = output
+
+    flow = AutoregressiveFlow(4, [[0, 1], [2, 3]], Constant(), AffineTransformer()).cuda()
+    y, ldj = flow(torch.randn(3, 4, device='cuda'))
     with pytest.raises(NotImplementedError, match='backward is implemented for'):
         (y.sum() + ldj.sum()).backward()
 

@@ -73,16 +73,32 @@ struct SplineArgsB {
 
 __device__ inline double sigmoid_d(double z) { return z > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-z)); }
 
-// Reverse mode through rq_spline_element (spline.h), FORWARD direction only, fixed bounds.
+// Reverse mode through rq_spline_element (spline.h), FORWARD direction, all variants.
 template <int KMAX>
 __device__ inline void rq_spline_backward(const float (&w)[KMAX], const float (&h)[KMAX], const float (&sraw)[KMAX + 1],
-                                          float last, const SplineFlags& f, float x0f, float xff, float y0f, float yff,
-                                          float vin, double gy, double gl, double (&guw)[KMAX], double (&guh)[KMAX],
-                                          double (&gus)[KMAX + 1], double* glast, double* gxin) {
+                                          float last, float last2, const SplineFlags& f, float x0f, float xff,
+                                          float y0f, float yff, float vin, double gy, double gl, double (&guw)[KMAX],
+                                          double (&guh)[KMAX], double (&gus)[KMAX + 1], double* glast, double* glast2,
+                                          double* gxin) {
     const int K = f.K;
     const double mb = (double)f.min_bin;
-    const double x0 = x0f, y0 = y0f;
-    const double W = (double)xff - x0 - K * mb, H = (double)yff - y0 - K * mb;
+    // domain (spline.py:384-410), as in rq_spline_element
+    double x0 = x0f, y0 = y0f;
+    double W = (double)xff - (double)x0f - K * mb, H = (double)yff - (double)y0f - K * mb;
+    const bool learn = f.learn_lower || f.learn_upper;
+    if (learn) {
+        const double scale = exp((double)last);
+        W *= scale;
+        H *= scale;
+        if (f.learn_lower && f.learn_upper) {
+            x0 += (double)last2;
+            y0 += (double)last2;
+        } else if (f.learn_lower) {
+            x0 = (double)xff - W - K * mb;
+            y0 = (double)yff - H - K * mb;
+        }
+    }
+    double gx0 = 0.0, gy0 = 0.0, gWt = 0.0, gHt = 0.0;   // grads w.r.t. x0', y0' and extra direct terms of W, H
     double v = vin;
     if (f.circular) v = py_mod(v - x0 + (double)last, (double)xff - x0) + x0;
 
@@ -155,6 +171,13 @@ __device__ inline void rq_spline_backward(const float (&w)[KMAX], const float (&
         const double d = slope(rs);
         const double bx = lower_tail ? x0 : kx;
         const double gdb = gy * (v - bx) + gl / d;
+        // boundary knot: (x0', y0') below, (x0' + W + K mb, y0' + H + K mb) above
+        gx0 = -gy * d;
+        gy0 = gy;
+        if (!lower_tail) {
+            gWt = -gy * d;
+            gHt = gy;
+        }
 #pragma unroll
         for (int j = 0; j <= KMAX; ++j)
             if (j == jb) gd[j] = gdb;
@@ -185,6 +208,8 @@ __device__ inline void rq_spline_backward(const float (&w)[KMAX], const float (&
         const double gw_bin = -gs * s / bw - geps * eps / bw;
         const double gxk = -geps / bw;
         gv = geps / bw;
+        gx0 = gxk;
+        gy0 = gy;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             if (k < kbin) {
@@ -218,6 +243,18 @@ __device__ inline void rq_spline_backward(const float (&w)[KMAX], const float (&
 #pragma unroll
     for (int j = 0; j <= KMAX; ++j) gus[j] = (j <= K) ? gd[j] * sigmoid_d((double)sraw[j] + (double)f.slope_offset) : 0.0;
     *glast = f.circular ? gv : 0.0;
+    *glast2 = 0.0;
+    if (learn) {
+        // W = W0 e^last, H = H0 e^last; w_k = p_k W + mb
+        double gW = dotw + gWt, gH = doth + gHt;
+        if (f.learn_lower && f.learn_upper) {
+            *glast2 = gx0 + gy0;
+        } else if (f.learn_lower) {      // x0' = xf - W - K mb, y0' = yf - H - K mb
+            gW -= gx0;
+            gH -= gy0;
+        }
+        *glast = gW * W + gH * H;
+    }
     *gxin = gv;
 }
 
@@ -254,10 +291,14 @@ __global__ void __launch_bounds__(256) spline_backward_kernel(const float* __res
                 if (pi >= 0) sraw[j] = pf[pi * L.stride_p];
             }
         }
-        const float last = a.f.circular ? pf[(a.P - 1) * L.stride_p] : 0.f;
-        double guw[KMAX], guh[KMAX], gus[KMAX + 1], glast, gxin;
-        rq_spline_backward<KMAX>(w, h, sraw, last, a.f, a.x0[f], a.xf[f], a.y0[f], a.yf[f], x[(int64_t)b * ldx + f],
-                                 (double)gy[(int64_t)b * ldgy + f], gl, guw, guh, gus, &glast, &gxin);
+        const bool has_last = a.f.circular || a.f.learn_lower || a.f.learn_upper;
+        const bool has_last2 = a.f.learn_lower && a.f.learn_upper;
+        const float last = has_last ? pf[(a.P - 1) * L.stride_p] : 0.f;
+        const float last2 = has_last2 ? pf[(a.P - 2) * L.stride_p] : 0.f;
+        double guw[KMAX], guh[KMAX], gus[KMAX + 1], glast, glast2, gxin;
+        rq_spline_backward<KMAX>(w, h, sraw, last, last2, a.f, a.x0[f], a.xf[f], a.y0[f], a.yf[f],
+                                 x[(int64_t)b * ldx + f], (double)gy[(int64_t)b * ldgy + f], gl, guw, guh, gus, &glast,
+                                 &glast2, &gxin);
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
             if (k < K) {
@@ -277,7 +318,8 @@ __global__ void __launch_bounds__(256) spline_backward_kernel(const float* __res
             const int pi = spline_slope_param(j, K, a.f.circular, a.f.identity);
             if (pi >= 0) gp[pi * GL.stride_p] = (float)(j == 0 ? g0 : gus[j]);
         }
-        if (a.f.circular) gp[(a.P - 1) * GL.stride_p] = (float)glast;
+        if (has_last) gp[(a.P - 1) * GL.stride_p] = (float)glast;
+        if (has_last2) gp[(a.P - 2) * GL.stride_p] = (float)glast2;
         gx[(int64_t)b * ldgx + f] = (float)gxin;
     }
 }
@@ -531,18 +573,16 @@ int tfep_spline_backward(const float* x, int64_t ldx, const float* params, tfep_
                          float* gparams, tfep_param_layout glayout, float* gx, int64_t ldgx, int B, int D, void* stream) {
     TFEP_REQUIRE(d != nullptr, "spline_backward: descriptor is NULL");
     TFEP_REQUIRE(d->n_bins >= 1 && d->n_bins <= 32, "spline_backward: n_bins=%d unsupported (1..32)", d->n_bins);
-    if (d->learn_lower_bound || d->learn_upper_bound)
-        return fail(TFEP_ERR_UNSUPPORTED, "spline_backward: learnable domain bounds are not supported yet");
     TFEP_REQUIRE(B >= 0 && D >= 0, "spline_backward: negative size");
     if (B == 0 || D == 0) return TFEP_OK;
     TFEP_REQUIRE(x && params && gy && gparams && gx && d->x0 && d->xf && d->y0 && d->yf, "spline_backward: NULL pointer");
     SplineArgsB a;
     a.x0 = d->x0; a.xf = d->xf; a.y0 = d->y0; a.yf = d->yf;
     a.f.K = d->n_bins; a.f.circular = d->circular != 0; a.f.identity = d->identity_boundary_slopes != 0;
-    a.f.learn_lower = false; a.f.learn_upper = false;
+    a.f.learn_lower = d->learn_lower_bound != 0; a.f.learn_upper = d->learn_upper_bound != 0;
     a.f.min_bin = d->min_bin_size; a.f.min_slope = d->min_slope;
     a.f.slope_offset = (float)log(exp(1.0 - (double)d->min_slope) - 1.0);
-    a.P = spline_n_params(a.f.K, a.f.circular, a.f.identity, false, false);
+    a.P = spline_n_params(a.f.K, a.f.circular, a.f.identity, a.f.learn_lower, a.f.learn_upper);
     hipStream_t s = (hipStream_t)stream;
     if (a.f.K <= 8)
         spline_backward_kernel<8><<<row_blocks_b(B), 256, 0, s>>>(x, ldx, params, layout, a, gy, ldgy, g_log_det_J, gparams, glayout, gx, ldgx, B, D);

@@ -46,7 +46,7 @@ def _transformer_supported(tr):
     if type(tr) in (AffineTransformer, MoebiusTransformer, VolumePreservingShiftTransformer):
         return True
     if type(tr) is NeuralSplineTransformer:
-        return not tr.host()['learn_lower'] and not tr.host()['learn_upper']
+        return True
     if type(tr) is MixedTransformer:
         return all(_transformer_supported(t) for t in tr._transformers)
     return False

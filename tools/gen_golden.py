@@ -637,6 +637,12 @@ def gen_grads():
                     VolumePreservingShiftTransformer()],
                 indices=[[0, 2, 4, 6], [1, 3, 5], [7, 8, 9]]),
             initialize_identity=False))
+    for tag, (ll, lu) in {'learnlow': (True, False), 'learnup': (False, True), 'learnboth': (True, True)}.items():
+        flows[tag] = (lambda ll, lu: lambda dt: SequentialFlow(
+            MAF(degrees_in=gd(D, 'ascending'),
+                transformer=NeuralSplineTransformer(x0=torch.full((D,), -3.0).to(dt), xf=torch.full((D,), 3.0).to(dt),
+                                                    n_bins=6, learn_lower_bound=ll, learn_upper_bound=lu),
+                initialize_identity=False)))(ll, lu)
     for name, make in flows.items():
         torch.manual_seed(20)
         f32 = make(torch.float32)
