@@ -184,3 +184,42 @@ def test_masked_linear_module_and_functional_autograd():
     assert rel(lin2.weight_v.grad.cpu()[live], v.grad[live]) < 1e-5
     rows = [0, 1, 3, 4]
     assert rel(lin2.weight_g.grad.cpu()[rows], gg.grad[rows]) < 1e-5
+
+
+def test_partial_flow_semantics_and_gradients():
+    """tests/nn/flows/test_partial.py in spirit: fixed DOFs are untouched and invisible to the wrapped flow,
+    the others equal the wrapped flow on the sub-vector; inverse round-trips; return_partial; gradients
+    flow to the mapped inputs through the wrapped flow and to the fixed inputs as the identity."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF, PartialFlow, SequentialFlow
+    torch.manual_seed(0)
+    D, fixed = 9, [1, 4, 8]
+    prop = [i for i in range(D) if i not in fixed]
+    inner = SequentialFlow(MAF(generate_degrees(len(prop)), initialize_identity=False),
+                           MAF(generate_degrees(len(prop), 'descending'), initialize_identity=False))
+    pf = PartialFlow(inner, fixed_indices=fixed).cuda()
+    assert int(pf.n_parameters()) == int(inner.n_parameters())
+    x = torch.randn(13, D, device='cuda')
+    with torch.no_grad():
+        y, l = pf(x)
+        y_in, l_in = inner(x[:, prop].contiguous())
+        assert torch.equal(y[:, fixed], x[:, fixed]) and torch.equal(y[:, prop], y_in) and torch.equal(l, l_in)
+        xi, li = pf.inverse(y)
+        assert torch.allclose(xi, x, atol=1e-5) and torch.allclose(l + li, torch.zeros_like(l), atol=1e-4)
+        pf.return_partial = True
+        yp, lp = pf(x)
+        assert torch.equal(yp, y_in)
+        pf.return_partial = False
+    xg = x.clone().requires_grad_(True)
+    y, l = pf(xg)
+    (y.sum() + l.sum()).backward()
+    xs = x[:, prop].contiguous().requires_grad_(True)
+    ys, ls = inner(xs)
+    (ys.sum() + ls.sum()).backward()
+    assert torch.allclose(xg.grad[:, prop], xs.grad, atol=1e-5)
+    assert torch.equal(xg.grad[:, fixed], torch.ones(13, len(fixed), device='cuda'))
+    # no fixed indices: a transparent wrapper
+    pf0 = PartialFlow(inner, fixed_indices=[]).cuda()
+    with torch.no_grad():
+        x6 = torch.randn(5, len(prop), device='cuda')
+        assert torch.equal(pf0(x6)[0], inner(x6)[0])

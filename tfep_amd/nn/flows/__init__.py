@@ -1,3 +1,4 @@
 from .autoregressive import AutoregressiveFlow  # noqa: F401
 from .maf import MAF  # noqa: F401
 from .sequential import SequentialFlow  # noqa: F401
+from .partial import PartialFlow  # noqa: F401
