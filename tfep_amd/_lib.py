@@ -104,6 +104,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH) and 'TFEP_HIP_LIB' not in os.environ:
+        # Not a fallback: compile the HIP sources in-tree (hipcc, ~10 s) if the library did not travel.
+        try:
+            from . import build as _build
+            _build.build(force=True, verbose=False)
+        except Exception as e:  # noqa: BLE001
+            raise TfepHipError(
+                f'{LIB_PATH} not found and building it failed ({e}); run `python -m tfep_amd.build` '
+                '(tfep_amd has no CPU fallback).') from e
     if not os.path.exists(LIB_PATH):
         raise TfepHipError(
             f'{LIB_PATH} not found: build it with `python -m tfep_amd.build` '
