@@ -254,3 +254,59 @@ def grad_flow_configs():
                                   indices=[[0, 2, 4, 6], [1, 3, 5], [7, 8, 9]], par_lengths=[13 * 4, 2 * 3, 3]),
                  hidden_layers=2, weight_norm=True)],
     }
+
+
+# ---------------------------------------------------------------------------
+# golden wrapped flows (tools/gen_golden.py:gen_wrappers): outermost wrapper first
+# ---------------------------------------------------------------------------
+
+def wrapper_configs():
+    return {
+        # centre of geometry of all points, defaults
+        'cen_default': dict(n_points=5, dim=3, inverse=True,
+                            wrappers=[('centroid', dict(space_dimension=3))]),
+        # weighted centroid of a subset, moved to a non-zero origin and left there
+        'cen_subset_w': dict(n_points=6, dim=3, inverse=False,
+                             wrappers=[('centroid', dict(space_dimension=3, subset_point_indices=[1, 3, 0, 4],
+                                                         weights=[1.0, 12.0, 16.0, 14.0], fixed_point_idx=1,
+                                                         origin=[0.5, -1.0, 2.0], translate_back=False))]),
+        # 2D points, centroid = a single point (which is then simply held fixed)
+        'cen_single_2d': dict(n_points=7, dim=2, inverse=True,
+                              wrappers=[('centroid', dict(space_dimension=2, subset_point_indices=[2]))]),
+        'ori_default': dict(n_points=5, dim=3, inverse=True, wrappers=[('oriented', dict())]),
+        'ori_zyz_partial': dict(n_points=5, dim=3, inverse=False,
+                                wrappers=[('oriented', dict(axis_point_idx=2, plane_point_idx=0, axis='z', plane='yz',
+                                                            rotate_back=False, return_partial=True))]),
+        'ori_yxy_noround': dict(n_points=4, dim=3, inverse=True,
+                                wrappers=[('oriented', dict(axis_point_idx=3, plane_point_idx=1, axis='y', plane='xy',
+                                                            round_off_imprecisions=False))]),
+        # the nesting TFEPMapBase builds (reference app/base.py:601-676): origin atom fixed by the centroid
+        # wrapper, then the frame orientation on the remaining points, then fixed atoms
+        'nested': dict(n_points=6, dim=3, inverse=True, spline=True,
+                       wrappers=[('centroid', dict(space_dimension=3, subset_point_indices=[1])),
+                                 ('oriented', dict(axis_point_idx=0, plane_point_idx=2)),
+                                 ('partial', dict(fixed_indices=[3, 4, 5]))]),
+    }
+
+
+def wrapper_n_inner(cfg):
+    """Number of DOFs that reach the innermost flow."""
+    n = cfg['n_points'] * cfg['dim']
+    for kind, kw in cfg['wrappers']:
+        if kind == 'centroid':
+            n -= cfg['dim']
+        elif kind == 'oriented':
+            n -= 3
+        else:
+            n -= len(kw['fixed_indices'])
+    return n
+
+
+def build_wrapped(cfg, inner, flows_module):
+    """Wrap ``inner`` as ``cfg`` says, with the wrapper classes of ``flows_module`` (tfep_amd or the reference)."""
+    flow = inner
+    for kind, kw in reversed(cfg['wrappers']):
+        cls = {'centroid': flows_module.CenteredCentroidFlow, 'oriented': flows_module.OrientedFlow,
+               'partial': flows_module.PartialFlow}[kind]
+        flow = cls(flow, **kw)
+    return flow

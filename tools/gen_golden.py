@@ -456,10 +456,12 @@ def run_flow(make_flow, x, seed, out, name, inverse=True, store_masks=False):
     torch.manual_seed(seed)
     f32 = make_flow(torch.float32)
     perturb_weight_g(f32, seed + 1)
+    # Taken before the first pass: the reference's PartialFlow registers a new buffer lazily in forward().
+    sd0 = {k: v.clone() for k, v in f32.state_dict().items()}
     y32, l32 = f32(x)
     with f64():
         f64m = make_flow(torch.float64)
-        f64m.load_state_dict(to_double_sd(f32.state_dict()))
+        f64m.load_state_dict(to_double_sd(sd0))
         y64, l64 = f64m(x.double())
         out[f'{name}/y_f64'], out[f'{name}/ldj_f64'] = npy(y64), npy(l64)
         if inverse:
@@ -470,7 +472,7 @@ def run_flow(make_flow, x, seed, out, name, inverse=True, store_masks=False):
             out[f'{name}/xinv_f64'], out[f'{name}/ldjinv_f64'] = npy(xi), npy(li)
     out[f'{name}/x'] = npy(x)
     out[f'{name}/y_f32'], out[f'{name}/ldj_f32'] = npy(y32), npy(l32)
-    for k, v in f32.state_dict().items():
+    for k, v in sd0.items():
         if k.endswith('.mask') and not store_masks:
             continue
         if k.endswith('.mask'):
@@ -744,8 +746,68 @@ def gen_loss():
     np.savez_compressed(os.path.join(OUT, 'loss.npz'), **out)
 
 
+# -----------------------------------------------------------------------------
+# 8. flow wrappers (PartialFlow / CenteredCentroidFlow / OrientedFlow) and the frame rotation
+# -----------------------------------------------------------------------------
+
+def gen_wrappers():
+    import types
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    import golden_util as gu
+    from tfep.nn.flows.centroid import CenteredCentroidFlow
+    from tfep.nn.flows.oriented import OrientedFlow
+    from tfep.nn.flows.partial import PartialFlow
+    from tfep.utils.geometry import reference_frame_rotation_matrix, get_axis_from_name
+    ref_flows = types.SimpleNamespace(CenteredCentroidFlow=CenteredCentroidFlow, OrientedFlow=OrientedFlow,
+                                      PartialFlow=PartialFlow)
+    out = {}
+    for i, (name, cfg) in enumerate(gu.wrapper_configs().items()):
+        n_in = gu.wrapper_n_inner(cfg)
+        x = 1.5 * torch.randn(96, cfg['n_points'] * cfg['dim'], generator=gen(4000 + i))
+
+        def make(dt, cfg=cfg, n_in=n_in):
+            if cfg.get('spline'):
+                tr = NeuralSplineTransformer(x0=torch.full((n_in,), -8.0), xf=torch.full((n_in,), 8.0), n_bins=6)
+            else:
+                tr = AffineTransformer()
+            inner = MAF(degrees_in=generate_degrees(n_in, order='ascending'), transformer=tr,
+                        initialize_identity=False)
+            return gu.build_wrapped(cfg, inner, ref_flows)
+        run_flow(make, x, 500 + i, out, name, inverse=cfg['inverse'])
+        # gradients of  sum(y * c) + sum(ldj)  in float64, c[b, j] = cos(b + 2 j)
+        with f64():
+            m = make(torch.float64)
+            m.load_state_dict(to_double_sd({k[len(name) + 4:]: torch.from_numpy(v) for k, v in out.items()
+                                            if k.startswith(name + '/sd/')}), strict=False)
+            xg = x.double().requires_grad_(True)
+            y, ldj = m(xg)
+            c = torch.cos(torch.arange(y.shape[0]).unsqueeze(1) + 2.0 * torch.arange(y.shape[1]).unsqueeze(0))
+            ((y * c).sum() + ldj.sum()).backward()
+            out[f'{name}/gx_f64'] = npy(xg.grad)
+            for k, prm in m.named_parameters():
+                out[f'{name}/gp/{k}'] = npy(prm.grad)
+
+    # frame rotation matrices on their own (float64), all axis / plane choices
+    pos = torch.randn(64, 2, 3, generator=gen(4100), dtype=torch.float64)
+    out['frame/axis_pos'], out['frame/plane_pos'] = npy(pos[:, 0]), npy(pos[:, 1])
+    with f64():
+        for axis in 'xyz':
+            for plane_axis in 'xyz':
+                if plane_axis == axis:
+                    continue
+                a, p = get_axis_from_name(axis), get_axis_from_name(plane_axis)
+                for positive in (False, True):
+                    r = reference_frame_rotation_matrix(pos[:, 0], pos[:, 1], a, p, project_on_positive_axis=positive)
+                    out[f'frame/{axis}{plane_axis}{int(positive)}'] = npy(r)
+    np.savez_compressed(os.path.join(OUT, 'wrappers.npz'), **out)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
+    if len(sys.argv) > 1:
+        for fn in sys.argv[1:]:
+            globals()['gen_' + fn]()
+        sys.exit(0)
     gen_degrees()
     gen_masked()
     gen_made()
@@ -753,5 +815,6 @@ if __name__ == '__main__':
     gen_flows()
     gen_grads()
     gen_loss()
+    gen_wrappers()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
