@@ -6,8 +6,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one batch: for each of the 4 MAF layers the masked
-weight-norm re-pack (the reference recomputes it on every forward), the two hidden fp32-MFMA
-GEMMs (+ELU) and the fused output-GEMM + spline + log-det kernel, then the TFEP free-energy
+weight-norm re-pack (the reference recomputes it on every forward) and its conversion to split-f16
+rows, the conversion of each layer's activations, the two hidden GEMMs (+ELU) and the fused
+output-GEMM + spline + log-det kernel (split-f16 MFMA by default, exact-fp32 MFMA with
+TFEP_SPLIT_GEMM=0), then the TFEP free-energy
 estimator over the batch's log-weights (sufficient statistics + one RCCL all-gather of 9 scalars
 per rank when N > 1).  Inputs are resident in HBM before the timed region.  Weak scaling: every
 rank processes its own full batch with a full weight replica; there is no collective on the data
@@ -26,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md, chip table (dense fp32 matrix)
+PEAK_F16_MFMA_TFLOPS = 2516.6          # dense fp16 matrix: 256 CUs x 4096 flop/clk x 2.4 GHz ("~2.5 PF")
 
 
 def build_flow(D, n_layers, n_bins, device, seed=0):
@@ -149,8 +152,19 @@ def main():
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
     # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/README.md).
+    split = all(l._use_split_gemm() for l in flow)
+    if split:
+        # three fp16 MFMAs per fp32 product: the matrix-pipe bound for fp32-equivalent flops is a third of the
+        # dense fp16 peak
+        peak = PEAK_F16_MFMA_TFLOPS / 3.0
+        kernel = 'split_gemm_kernel<25,EPI_SPLINE> (fused MADE output layer + RQ spline + log-det; 3 x v_mfma_f32_16x16x32_f16 per fp32 product)'
+        tname = 'r01_split_pmc_traffic.json'
+    else:
+        peak = PEAK_FP32_MFMA_TFLOPS
+        kernel = 'gemm_kernel<2,25,EPI_SPLINE> (fused MADE output layer + RQ spline + log-det; v_mfma_f32_16x16x4_f32)'
+        tname = 'r01_pmc_traffic.json'
     traffic = None
-    tpath = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    tpath = os.path.join(ROOT, 'profiles', tname)
     if D == 3000 and B == 65536 and args.layers == 4 and os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath))['hbm_bytes_per_launch']
@@ -166,15 +180,20 @@ def main():
             'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
+            'gemm_arithmetic': ('fp32 operands as fp16 hi+lo halves, 3 fp16 MFMAs per product, fp32 accumulate '
+                                '(fp32-equivalent; spline / log-det in fp64)' if split else
+                                'fp32 MFMA, fp32 accumulate (spline / log-det in fp64)'),
             'config': {'workload': f'cfg2: {args.layers}-layer MAF + RQ neural-spline ({args.bins} bins), '
                                    f'{D} features (3x{D // 3} atoms), batch {B} per GPU, fp32, '
                                    'forward + log|det J| + TFEP estimator',
                        'global_batch': world * B, 'features': D, 'layers': args.layers,
                        'hidden_width': int(flow[0]._conditioner.dimensions_hidden[0]),
                        'parallelism': f'dp{world} (batch-sharded replicas, 9-scalar RCCL all-gather)'},
-            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
-                         'kernel': 'gemm_kernel<2,25,EPI_SPLINE> (fused MADE output layer + RQ spline + log-det)',
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': traffic, 'kernel': kernel,
+                         'peak_basis': ('fp32-equivalent flops; dense fp16 MFMA peak 2516.6 TFLOP/s / 3 MFMAs per product'
+                                        if split else 'dense fp32 MFMA peak'),
+                         'vs_fp32_mfma_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
                          'flops_per_launch': kern_flops[0], 'avg_launch_ms': float(np.mean(kern_ms)),
                          'whole_step_tflops': 2.0 * sum(nnz_all) * B * args.steps / elapsed / 1e12},
             'delta_f_estimate': float(out[2]),

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFEP_HIP_ABI_VERSION 1
+#define TFEP_HIP_ABI_VERSION 2
 
 typedef enum tfep_status {
     TFEP_OK = 0,
@@ -141,6 +141,9 @@ typedef struct tfep_gemm_desc {
     const uint8_t* tile_live;
     const float* pre_add; int64_t ld_pre_add;   /* optional, layout of y: y = act(x w^T + bias + pre_add) */
     int32_t tile_n;                             /* 0 / wide (default) or tfep_masked_linear_narrow_tile_n() */
+    int32_t split;                              /* 1: x and w are split-f16 rows (tfep_split_rows), wide tile only */
+    const float* x_inv_scale;                   /*    (B) per-row 1/scale of x                                     */
+    const float* w_inv_scale;                   /*    (1) 1/scale of w                                             */
 } tfep_gemm_desc;
 int tfep_masked_linear_gemm(const tfep_gemm_desc* desc, void* stream);
 int tfep_masked_linear_tile_k(void);
@@ -257,6 +260,34 @@ int tfep_fused_output_transformer_forward(const float* h, int64_t ldh, const flo
                                           int n_feature_slots, double* ldj_partial,
                                           float* log_det_J, int accumulate,
                                           int B, int n_rows_w, int k_padded, void* stream);
+
+/*
+ * Split-precision operands for the MADE GEMMs (same results as the fp32 path to fp32 rounding, at the fp16
+ * matrix-core rate).  A "split row" keeps the pitch of the fp32 row (4 bytes per element) and stores, per group of
+ * 8 consecutive columns, 8 fp16 high halves then 8 fp16 low halves of  v * scale = hi + lo,  scale a power of two
+ * with max |v * scale| in [2^14, 2^15):  per row (per_tensor = 0; inv_scale has `rows` entries) or one for the
+ * whole matrix (per_tensor = 1; inv_scale has 2 entries: [0] = 1/scale, [1] = scratch).
+ *   src (rows, >= cols) fp32;  dst (rows, ld_dst elements of 4 bytes), columns [cols, cols_padded) zero filled;
+ *   cols_padded, ld_dst: multiples of tfep_split_tile_k() (32).
+ * Activations use per-row scales, packed weights (tfep_masked_weight_prepare output) one scale.
+ */
+int tfep_split_tile_k(void);
+int tfep_split_rows(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int64_t ld_dst,
+                    int64_t cols_padded, float* inv_scale, int per_tensor, void* stream);
+
+/* tfep_fused_output_transformer_forward on split operands: h_split (B rows, per-row h_inv_scale) and w_split (one
+ * w_inv_scale); every other argument as above.  k_ranges must be multiples of 32. */
+int tfep_fused_output_transformer_forward_split(const void* h_split, int64_t ldh, const float* h_inv_scale,
+                                                const void* w_split, int64_t ldw, const float* w_inv_scale,
+                                                const float* bias_packed, const int32_t* k_ranges,
+                                                const int32_t* tile_order, int kind, const tfep_spline_desc* desc,
+                                                const float* x, int64_t ldx, float* y, int64_t ldy,
+                                                const int32_t* feat_index, const int32_t* feat_tr, int n_feature_slots,
+                                                double* ldj_partial, float* log_det_J, int accumulate, int B,
+                                                int n_rows_w, int k_padded, void* stream);
+
+/* Diagnostic: matrix-pipe ceiling of this device for the split GEMM's instruction mix (cf. tfep_diag_mfma_peak). */
+int tfep_diag_split_mfma_peak(float* scratch, int blocks, int iters, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Backward (training step, app/base.py:780-840 calls loss.backward())         */

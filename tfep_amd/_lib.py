@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TFEP_HIP_LIB') or os.path.join(_HERE, 'lib', 'libtfep_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -29,7 +29,8 @@ class GemmDesc(Structure):
                 ('B', c_int32), ('N', c_int32), ('n_rows_w', c_int32), ('k_padded', c_int32),
                 ('act', c_int32), ('accumulate', c_int32),
                 ('elu_grad_of', c_void_p), ('ld_elu_grad_of', c_int64), ('tile_live', c_void_p),
-                ('pre_add', c_void_p), ('ld_pre_add', c_int64), ('tile_n', c_int32)]
+                ('pre_add', c_void_p), ('ld_pre_add', c_int64), ('tile_n', c_int32),
+                ('split', c_int32), ('x_inv_scale', c_void_p), ('w_inv_scale', c_void_p)]
 
 
 class SplineDesc(Structure):
@@ -73,6 +74,13 @@ _SIGNATURES = {
                                                       POINTER(SplineDesc), _P, c_int64, _P, c_int64,
                                                       _P, _P, c_int, _P, _P, c_int,
                                                       c_int, c_int, c_int, _P]),
+    'tfep_split_tile_k': (c_int, []),
+    'tfep_split_rows': (c_int, [_P, c_int64, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P]),
+    'tfep_fused_output_transformer_forward_split': (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_int,
+                                                            POINTER(SplineDesc), _P, c_int64, _P, c_int64,
+                                                            _P, _P, c_int, _P, _P, c_int,
+                                                            c_int, c_int, c_int, _P]),
+    'tfep_diag_split_mfma_peak': (c_int, [_P, c_int, c_int, _P]),
     'tfep_diag_mfma_peak': (c_int, [_P, c_int, c_int, _P]),
     'tfep_masked_linear_gemm': (c_int, [POINTER(GemmDesc), _P]),
     'tfep_transpose': (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, _P]),

@@ -1,0 +1,199 @@
+// Pieces shared by the two masked-linear GEMM kernels (fp32 MFMA in masked_linear.hip, split-f16 MFMA in
+// split_gemm.hip): launch arguments, workgroup -> tile mapping and the epilogues.
+#pragma once
+
+#include "common.h"
+#include "spline.h"
+
+#include <stdlib.h>
+
+namespace tfep {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum Epilogue { EPI_LINEAR = 0, EPI_ELU = 1, EPI_AFFINE = 2, EPI_SPLINE = 3 };
+
+struct FusedArgs {
+    const float* x;            // transformer input  (B, ldx)
+    int64_t ldx;
+    float* y;                  // transformer output (B, ldy)
+    int64_t ldy;
+    const int32_t* feat_index; // packed feature slot -> column of x / y, -1 = padding slot
+    const int32_t* feat_tr;    // packed feature slot -> index among the transformed features (x0/xf/...)
+    double* ldj_partial;       // (n_col_tiles, B)
+    const float *x0, *xf, *y0, *yf;
+    SplineFlags sf;
+};
+
+struct GemmArgs {
+    const float* a;            // activations (B, lda), zero padded up to k_padded columns
+    int64_t lda;
+    const float* w;            // packed masked weights (n_padded, ldw)
+    int64_t ldw;
+    const float* bias;         // packed bias (n_padded) or NULL
+    const int32_t* k_ranges;   // per column tile [begin, end) or NULL
+    const int32_t* col_map;    // linear epilogues: packed column -> output column, -1 = drop; NULL = identity
+    float* y;
+    int64_t ldy;
+    int B, N, k_padded;
+    const int32_t* tile_order; // optional: launch position -> column tile (heaviest k-range first), or NULL
+    int map_mode;              // 0: row-tile fastest; 1: XCD-aware 8x4 super-tiles
+    int m_tiles, n_tiles;
+    const float* aux;          // linear epilogue: if set, y = acc * elu'(aux) with elu'(h) = h > 0 ? 1 : h + 1
+    int64_t ldaux;             //   (ELU backward from the saved activation h; same indexing as y)
+    int accumulate;            // linear epilogue: y += value instead of y = value
+    const float* pre_add;      // linear epilogue: added BEFORE the activation (partial pre-activations of the
+    int64_t ld_pre_add;        //   two-level blocked inverse); same indexing as y
+    const uint8_t* tile_live;  // optional (m_tiles x n_tiles): 0 = the whole output tile is masked, skip it
+    int diag;                  // diagnostics only (TFEP_DIAG): 1 = skip the epilogue, 4 = skip the LDS-DMA,
+                               // 8 = skip the barriers (garbage results; timing only)
+    const float* a_inv_scale;  // split-f16 operands only: per-row 1/scale of the activations (B)
+    const float* w_inv_scale;  //   and the single 1/scale of the weights
+    FusedArgs fu;
+};
+
+__device__ inline uint32_t clamp_u32(int64_t v) { return v > 0xffffffffLL ? 0xffffffffu : (v < 0 ? 0u : (uint32_t)v); }
+
+__device__ inline float elu_f(float v) { return v > 0.f ? v : expm1f(v); }
+
+// Workgroup -> (row tile, position in the column-tile order); false = nothing to do.
+__device__ inline bool map_block(const GemmArgs& g, int& mt, int& ntp) {
+    // Workgroup -> (row tile, column tile).  Workgroups are dealt round-robin over the 8 XCDs
+    // (id % 8 labels the XCD) and each XCD has its own L2, so in mode 1 the 32 workgroups that are
+    // co-resident on one XCD form an 8 (row tiles) x 4 (column tiles) super-tile: 8 activation
+    // panels + 4 weight panels are fetched once into that L2 instead of 32 + 1.  Pure speed: any
+    // placement gives the same result.
+    if (g.map_mode == 1) {
+        const int id = blockIdx.x;
+        const int xcd = id & 7, seq = id >> 3;
+        const int S = (seq >> 5) * 8 + xcd, w = seq & 31;
+        const int SM = (g.m_tiles + 7) >> 3;
+        mt = (S % SM) * 8 + (w & 7);
+        ntp = (S / SM) * 4 + (w >> 3);
+        if (mt >= g.m_tiles || ntp >= g.n_tiles) return false;
+    } else {
+        mt = blockIdx.x % g.m_tiles;
+        ntp = blockIdx.x / g.m_tiles;
+    }
+    return true;
+}
+
+// Epilogues on the accumulators of one wave: MREP x NREP tiles of 16 x 16, C layout of the 16x16 MFMAs
+// (column = lane & 15, row = (lane >> 4) * 4 + reg).  The wave owns rows [wrow0, wrow0 + 16 * MREP).
+template <int MREP, int NREP, int EPI, int P, int KSPL>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NREP][MREP], int nt, int n0, int wrow0, int lane) {
+    const int cj = lane & 15, rq = (lane >> 4) * 4;
+
+    if constexpr (EPI == EPI_LINEAR || EPI == EPI_ELU) {
+#pragma unroll
+        for (int n = 0; n < NREP; ++n) {
+            const int col = n0 + n * 16 + cj;
+            if (col >= g.N) continue;
+            const float bv = g.bias ? g.bias[col] : 0.f;
+            const int ocol = g.col_map ? g.col_map[col] : col;
+            if (ocol < 0) continue;
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = wrow0 + m * 16 + rq + i;
+                    if (row < g.B) {
+                        float v = acc[n][m][i] + bv;
+                        if (g.pre_add) v += g.pre_add[(int64_t)row * g.ld_pre_add + ocol];
+                        if (EPI == EPI_ELU) v = elu_f(v);
+                        if (g.aux) {
+                            const float h = g.aux[(int64_t)row * g.ldaux + ocol];
+                            v *= h > 0.f ? 1.f : h + 1.f;
+                        }
+                        float* dst = g.y + (int64_t)row * g.ldy + ocol;
+                        *dst = g.accumulate ? *dst + v : v;
+                    }
+                }
+        }
+    } else {
+        // Fused transformer: packed column (ft*P + p)*16 + j of this tile is parameter p of
+        // feature slot (nt*FT + ft)*16 + j; the lane owns that feature for 4*MREP samples.
+        constexpr int FT = NREP / P;
+        const FusedArgs& fu = g.fu;
+#pragma unroll
+        for (int ft = 0; ft < FT; ++ft) {
+            const int slot = (nt * FT + ft) * 16 + cj;
+            const int fcol = fu.feat_index[slot];
+            const bool live = fcol >= 0;
+            float bias_p[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) bias_p[p] = g.bias ? g.bias[n0 + (ft * P + p) * 16 + cj] : 0.f;
+            float x0 = 0.f, xf = 1.f, y0 = 0.f, yf = 1.f;
+            if (EPI == EPI_SPLINE && live) {
+                const int ftr = fu.feat_tr[slot];
+                x0 = fu.x0[ftr];
+                xf = fu.xf[ftr];
+                y0 = fu.y0[ftr];
+                yf = fu.yf[ftr];
+            }
+#pragma unroll
+            for (int m = 0; m < MREP; ++m)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = wrow0 + m * 16 + rq + i;
+                    const bool ok = live && row < g.B;
+                    double ld = 0.0;
+                    if (ok) {
+                        const float xv = fu.x[(int64_t)row * fu.ldx + fcol];
+                        float out;
+                        if constexpr (EPI == EPI_AFFINE) {
+                            const float shift = acc[ft * P + 0][m][i] + bias_p[0];
+                            const float ls = acc[ft * P + 1][m][i] + bias_p[1];
+                            out = xv * expf(ls) + shift;           // affine.py:321-323
+                            ld = (double)ls;
+                        } else {
+                            float w[KSPL], h[KSPL], sraw[KSPL + 1];
+#pragma unroll
+                            for (int k = 0; k < KSPL; ++k) {
+                                w[k] = acc[ft * P + k][m][i] + bias_p[k];
+                                h[k] = acc[ft * P + KSPL + k][m][i] + bias_p[KSPL + k];
+                            }
+                            // plain: K+1 slopes; circular: K slopes, slope_K := slope_0, last = shift
+#pragma unroll
+                            for (int k = 0; k < KSPL; ++k) sraw[k] = acc[ft * P + 2 * KSPL + k][m][i] + bias_p[2 * KSPL + k];
+                            const float lastp = acc[ft * P + 3 * KSPL][m][i] + bias_p[3 * KSPL];
+                            sraw[KSPL] = fu.sf.circular ? sraw[0] : lastp;
+                            out = (float)rq_spline_element<KSPL, false>(w, h, sraw, lastp, 0.f, fu.sf, x0, xf, y0, yf, xv, &ld);
+                        }
+                        fu.y[(int64_t)row * fu.ldy + fcol] = out;
+                    }
+                    // sum over the 16 features held by lanes with the same (lane >> 4)
+#pragma unroll
+                    for (int off = 8; off > 0; off >>= 1) ld += __shfl_xor(ld, off, 64);
+                    if (cj == 0 && row < g.B) {
+                        double* dst = fu.ldj_partial + (int64_t)(nt * FT + ft) * g.B + row;
+                        *dst = ld;
+                    }
+                }
+        }
+    }
+}
+
+inline int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+// Tuning switches (A/B experiments; defaults are the measured best).
+inline int block_map_mode() { static int m = env_int("TFEP_BLOCK_MAP", 1); return m; }
+
+// Grid size for map_block().
+inline long long gemm_grid_blocks(int map_mode, int m_tiles, int n_tiles) {
+    if (map_mode == 1) {
+        const long long SM = (m_tiles + 7) / 8, SN = (n_tiles + 3) / 4;
+        return ((SM * SN + 7) / 8) * 8 * 32;
+    }
+    return (long long)m_tiles * n_tiles;
+}
+
+constexpr int FUSED_TILE_FEATURES = 16;
+
+// split_gemm.hip: the same GEMMs on split-f16 operands (g.a / g.w point to split rows, g.a_inv_scale / g.w_inv_scale set)
+int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s);
+int launch_split_fused(const GemmArgs& g, int n_rows_w, int kind, int n_col_tiles, hipStream_t s);
+
+}  // namespace tfep

@@ -17,20 +17,13 @@
 // tile, a [k_begin, k_end) range bounds the non-zeros.  After sorting hidden units by degree the
 // MADE masks are block triangular (reference conditioners/made.py:286-329), so ~half of the
 // k-tiles are skipped without touching them.
-#include "common.h"
-#include "spline.h"
-
-#include <stdlib.h>
+#include "gemm_common.h"
 
 namespace tfep {
 
 constexpr int BK = 16;
 constexpr int WAVES = 8;
 constexpr int THREADS = WAVES * 64;
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-enum Epilogue { EPI_LINEAR = 0, EPI_ELU = 1, EPI_AFFINE = 2, EPI_SPLINE = 3 };
 
 // ------------------------------------------------------------------------------------------
 // Weight preparation (reference masked.py:369-371, :433-439, :270)
@@ -117,45 +110,8 @@ __global__ void finish_k_ranges_kernel(int32_t* __restrict__ lo_hi, int n_tiles,
 }
 
 // ------------------------------------------------------------------------------------------
-// GEMM
+// GEMM (launch arguments, block mapping and epilogues: gemm_common.h)
 // ------------------------------------------------------------------------------------------
-struct FusedArgs {
-    const float* x;            // transformer input  (B, ldx)
-    int64_t ldx;
-    float* y;                  // transformer output (B, ldy)
-    int64_t ldy;
-    const int32_t* feat_index; // packed feature slot -> column of x / y, -1 = padding slot
-    const int32_t* feat_tr;    // packed feature slot -> index among the transformed features (x0/xf/...)
-    double* ldj_partial;       // (n_col_tiles, B)
-    const float *x0, *xf, *y0, *yf;
-    SplineFlags sf;
-};
-
-struct GemmArgs {
-    const float* a;            // activations (B, lda), zero padded up to k_padded columns
-    int64_t lda;
-    const float* w;            // packed masked weights (n_padded, ldw)
-    int64_t ldw;
-    const float* bias;         // packed bias (n_padded) or NULL
-    const int32_t* k_ranges;   // per column tile [begin, end) or NULL
-    const int32_t* col_map;    // linear epilogues: packed column -> output column, -1 = drop; NULL = identity
-    float* y;
-    int64_t ldy;
-    int B, N, k_padded;
-    const int32_t* tile_order; // optional: launch position -> column tile (heaviest k-range first), or NULL
-    int map_mode;              // 0: row-tile fastest; 1: XCD-aware 8x4 super-tiles
-    int m_tiles, n_tiles;
-    const float* aux;          // linear epilogue: if set, y = acc * elu'(aux) with elu'(h) = h > 0 ? 1 : h + 1
-    int64_t ldaux;             //   (ELU backward from the saved activation h; same indexing as y)
-    int accumulate;            // linear epilogue: y += value instead of y = value
-    const float* pre_add;      // linear epilogue: added BEFORE the activation (partial pre-activations of the
-    int64_t ld_pre_add;        //   two-level blocked inverse); same indexing as y
-    const uint8_t* tile_live;  // optional (m_tiles x n_tiles): 0 = the whole output tile is masked, skip it
-    int diag;                  // diagnostics only (TFEP_DIAG): 1 = skip the epilogue, 4 = skip the LDS-DMA,
-                               // 8 = skip the barriers (garbage results; timing only)
-    FusedArgs fu;
-};
-
 template <int MREP, int NREP>
 struct Tile {
     static constexpr int BM = WAVES * 16 * MREP;
@@ -183,8 +139,6 @@ struct StageCtx {
     uint32_t voff_a, voff_w;      // per-lane byte offset inside a piece
     uint32_t piece_a, piece_w;    // bytes between consecutive 16-row pieces
 };
-
-__device__ inline uint32_t clamp_u32(int64_t v) { return v > 0xffffffffLL ? 0xffffffffu : (v < 0 ? 0u : (uint32_t)v); }
 
 __device__ inline StageCtx make_stage_ctx(const GemmArgs& g, int m0, int n0, int lane, int n_rows_w) {
     StageCtx c;
@@ -218,8 +172,6 @@ __device__ inline void stage_tile(const StageCtx& sc, float* lds_stage, int k0, 
         }
     }
 }
-
-__device__ inline float elu_f(float v) { return v > 0.f ? v : expm1f(v); }
 
 // P parameters x FT feature groups per column tile (NREP = P * FT) for the fused epilogues.
 template <int MREP, int NREP, int EPI, int P, int KSPL>
@@ -314,99 +266,7 @@ __global__ void __launch_bounds__(THREADS, (MREP == 1 ? 4 : 2)) gemm_kernel(Gemm
             for (int m = 0; m < MREP; ++m) asm volatile("" ::"v"(acc[n][m]));
         return;
     }
-    // ---------------------------------------------------------------- epilogues
-    // C layout of 16x16x4: column = lane & 15, row = (lane >> 4) * 4 + reg.
-    const int cj = lane & 15, rq = (lane >> 4) * 4;
-    const int wrow0 = m0 + wave * 16 * MREP;
-
-    if constexpr (EPI == EPI_LINEAR || EPI == EPI_ELU) {
-#pragma unroll
-        for (int n = 0; n < NREP; ++n) {
-            const int col = n0 + n * 16 + cj;
-            if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.f;
-            const int ocol = g.col_map ? g.col_map[col] : col;
-            if (ocol < 0) continue;
-#pragma unroll
-            for (int m = 0; m < MREP; ++m)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = wrow0 + m * 16 + rq + i;
-                    if (row < g.B) {
-                        float v = acc[n][m][i] + bv;
-                        if (g.pre_add) v += g.pre_add[(int64_t)row * g.ld_pre_add + ocol];
-                        if (EPI == EPI_ELU) v = elu_f(v);
-                        if (g.aux) {
-                            const float h = g.aux[(int64_t)row * g.ldaux + ocol];
-                            v *= h > 0.f ? 1.f : h + 1.f;
-                        }
-                        float* dst = g.y + (int64_t)row * g.ldy + ocol;
-                        *dst = g.accumulate ? *dst + v : v;
-                    }
-                }
-        }
-    } else {
-        // Fused transformer: packed column (ft*P + p)*16 + j of this tile is parameter p of
-        // feature slot (nt*FT + ft)*16 + j; the lane owns that feature for 4*MREP samples.
-        constexpr int FT = NREP / P;
-        const FusedArgs& fu = g.fu;
-#pragma unroll
-        for (int ft = 0; ft < FT; ++ft) {
-            const int slot = (nt * FT + ft) * 16 + cj;
-            const int fcol = fu.feat_index[slot];
-            const bool live = fcol >= 0;
-            float bias_p[P];
-#pragma unroll
-            for (int p = 0; p < P; ++p) bias_p[p] = g.bias ? g.bias[n0 + (ft * P + p) * 16 + cj] : 0.f;
-            float x0 = 0.f, xf = 1.f, y0 = 0.f, yf = 1.f;
-            if (EPI == EPI_SPLINE && live) {
-                const int ftr = fu.feat_tr[slot];
-                x0 = fu.x0[ftr];
-                xf = fu.xf[ftr];
-                y0 = fu.y0[ftr];
-                yf = fu.yf[ftr];
-            }
-#pragma unroll
-            for (int m = 0; m < MREP; ++m)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int row = wrow0 + m * 16 + rq + i;
-                    const bool ok = live && row < g.B;
-                    double ld = 0.0;
-                    if (ok) {
-                        const float xv = fu.x[(int64_t)row * fu.ldx + fcol];
-                        float out;
-                        if constexpr (EPI == EPI_AFFINE) {
-                            const float shift = acc[ft * P + 0][m][i] + bias_p[0];
-                            const float ls = acc[ft * P + 1][m][i] + bias_p[1];
-                            out = xv * expf(ls) + shift;           // affine.py:321-323
-                            ld = (double)ls;
-                        } else {
-                            float w[KSPL], h[KSPL], sraw[KSPL + 1];
-#pragma unroll
-                            for (int k = 0; k < KSPL; ++k) {
-                                w[k] = acc[ft * P + k][m][i] + bias_p[k];
-                                h[k] = acc[ft * P + KSPL + k][m][i] + bias_p[KSPL + k];
-                            }
-                            // plain: K+1 slopes; circular: K slopes, slope_K := slope_0, last = shift
-#pragma unroll
-                            for (int k = 0; k < KSPL; ++k) sraw[k] = acc[ft * P + 2 * KSPL + k][m][i] + bias_p[2 * KSPL + k];
-                            const float lastp = acc[ft * P + 3 * KSPL][m][i] + bias_p[3 * KSPL];
-                            sraw[KSPL] = fu.sf.circular ? sraw[0] : lastp;
-                            out = (float)rq_spline_element<KSPL, false>(w, h, sraw, lastp, 0.f, fu.sf, x0, xf, y0, yf, xv, &ld);
-                        }
-                        fu.y[(int64_t)row * fu.ldy + fcol] = out;
-                    }
-                    // sum over the 16 features held by lanes with the same (lane >> 4)
-#pragma unroll
-                    for (int off = 8; off > 0; off >>= 1) ld += __shfl_xor(ld, off, 64);
-                    if (cj == 0 && row < g.B) {
-                        double* dst = fu.ldj_partial + (int64_t)(nt * FT + ft) * g.B + row;
-                        *dst = ld;
-                    }
-                }
-        }
-    }
+    gemm_epilogue<MREP, NREP, EPI, P, KSPL>(g, acc, nt, n0, m0 + wave * 16 * MREP, lane);
 }
 
 // Diagnostic: the matrix-pipe ceiling of THIS device for the GEMM's own instruction mix -- the same
@@ -454,14 +314,7 @@ __global__ void __launch_bounds__(256) ldj_reduce_kernel(const double* __restric
 // ------------------------------------------------------------------------------------------
 constexpr int LIN_MREP = 2, LIN_NREP = 16;          // 256 x 256 tile for the hidden layers
 constexpr int NARROW_NREP = 2;                      // 256 x 32 tile: row slices of the blocked inverse
-constexpr int FUSED_TILE_FEATURES = 16;
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-// Tuning switches (A/B experiments; defaults are the measured best).
-static int block_map_mode() { static int m = env_int("TFEP_BLOCK_MAP", 1); return m; }
 
 template <int MREP, int NREP, int EPI, int P, int KSPL>
 static int launch_gemm(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStream_t s) {
@@ -478,13 +331,7 @@ static int launch_gemm(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStre
     ga.n_tiles = n_col_tiles;
     ga.map_mode = block_map_mode();
     ga.diag = env_int("TFEP_DIAG", 0);
-    long long blocks;
-    if (ga.map_mode == 1) {
-        const long long SM = (ga.m_tiles + 7) / 8, SN = (ga.n_tiles + 3) / 4;
-        blocks = ((SM * SN + 7) / 8) * 8 * 32;
-    } else {
-        blocks = (long long)ga.m_tiles * ga.n_tiles;
-    }
+    const long long blocks = gemm_grid_blocks(ga.map_mode, ga.m_tiles, ga.n_tiles);
     if (blocks > 0x7fffffffLL) return fail(TFEP_ERR_INVALID_ARGUMENT, "gemm: grid too large");
     kern<<<dim3((unsigned)blocks), THREADS, T::LDS_BYTES, s>>>(ga, n_rows_w);
     return check_launch("gemm_kernel");
@@ -508,7 +355,8 @@ extern "C" {
 
 int tfep_masked_linear_tile_m(void) { return Tile<LIN_MREP, LIN_NREP>::BM; }
 int tfep_masked_linear_tile_n(void) { return Tile<LIN_MREP, LIN_NREP>::BN; }
-int tfep_masked_linear_tile_k(void) { return BK; }
+// Alignment of k_padded and of the k-ranges: the larger of the two kernels' k-tiles (fp32: 16, split-f16: 32).
+int tfep_masked_linear_tile_k(void) { return 2 * BK; }
 int tfep_masked_linear_narrow_tile_n(void) { return Tile<LIN_MREP, NARROW_NREP>::BN; }
 int tfep_fused_tile_features(void) { return FUSED_TILE_FEATURES; }
 
@@ -583,6 +431,12 @@ int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
     g.col_map = d->col_map; g.y = d->y; g.ldy = d->ldy; g.B = d->B; g.N = d->N; g.k_padded = d->k_padded;
     g.tile_order = d->tile_order; g.aux = d->elu_grad_of; g.ldaux = d->ld_elu_grad_of; g.accumulate = d->accumulate;
     g.tile_live = d->tile_live; g.pre_add = d->pre_add; g.ld_pre_add = d->ld_pre_add;
+    if (d->split) {
+        constexpr int SPLIT_BN = Tile<LIN_MREP, LIN_NREP>::BN;
+        TFEP_REQUIRE(d->tile_n == 0 || d->tile_n == SPLIT_BN, "masked_linear_gemm: split operands need the wide tile");
+        g.a_inv_scale = d->x_inv_scale; g.w_inv_scale = d->w_inv_scale;
+        return launch_split_linear(g, d->n_rows_w, d->act, (hipStream_t)stream);
+    }
     constexpr int WIDE_BN = Tile<LIN_MREP, LIN_NREP>::BN, NARROW_BN = Tile<LIN_MREP, NARROW_NREP>::BN;
     TFEP_REQUIRE(d->tile_n == 0 || d->tile_n == WIDE_BN || d->tile_n == NARROW_BN,
                  "masked_linear_gemm: tile_n=%d unsupported (0, %d or %d)", d->tile_n, WIDE_BN, NARROW_BN);
@@ -615,13 +469,12 @@ int tfep_fused_tile_columns(int kind, const tfep_spline_desc* d) {
     return fail(TFEP_ERR_UNSUPPORTED, "fused: unsupported transformer configuration");
 }
 
-int tfep_fused_output_transformer_forward(const float* h, int64_t ldh, const float* w, int64_t ldw,
-                                          const float* bias_packed, const int32_t* k_ranges,
-                                          const int32_t* tile_order, int kind,
-                                          const tfep_spline_desc* desc, const float* x, int64_t ldx, float* y,
-                                          int64_t ldy, const int32_t* feat_index, const int32_t* feat_tr,
-                                          int n_feature_slots, double* ldj_partial, float* log_det_J, int accumulate,
-                                          int B, int n_rows_w, int k_padded, void* stream) {
+static int fused_forward(const float* h, int64_t ldh, const float* w, int64_t ldw, const float* bias_packed,
+                         const int32_t* k_ranges, const int32_t* tile_order, int kind, const tfep_spline_desc* desc,
+                         const float* x, int64_t ldx, float* y, int64_t ldy, const int32_t* feat_index,
+                         const int32_t* feat_tr, int n_feature_slots, double* ldj_partial, float* log_det_J,
+                         int accumulate, int B, int n_rows_w, int k_padded, bool split, const float* h_inv_scale,
+                         const float* w_inv_scale, void* stream) {
     int rc = check_gemm_operands(h, ldh, w, ldw, k_padded);
     if (rc) return rc;
     TFEP_REQUIRE(x && y && feat_index && ldj_partial && log_det_J, "fused: NULL pointer");
@@ -635,13 +488,15 @@ int tfep_fused_output_transformer_forward(const float* h, int64_t ldh, const flo
     g.B = B; g.k_padded = k_padded; g.tile_order = tile_order;
     g.fu.x = x; g.fu.ldx = ldx; g.fu.y = y; g.fu.ldy = ldy; g.fu.feat_index = feat_index; g.fu.feat_tr = feat_tr;
     g.fu.ldj_partial = ldj_partial;
+    g.a_inv_scale = h_inv_scale; g.w_inv_scale = w_inv_scale;
     const int n_groups = n_feature_slots / FUSED_TILE_FEATURES;
     if (kind == TFEP_FUSED_AFFINE) {
         constexpr int P = 2, FT = 8;
         TFEP_REQUIRE(n_groups % FT == 0, "fused affine: feature slots must be a multiple of %d", FT * 16);
         TFEP_REQUIRE(n_rows_w >= n_feature_slots * P, "fused: weight has too few rows");
         g.N = n_feature_slots * P;
-        rc = launch_gemm<2, P * FT, EPI_AFFINE, P, 1>(g, n_rows_w, n_groups / FT, s);
+        rc = split ? launch_split_fused(g, n_rows_w, kind, n_groups / FT, s)
+                   : launch_gemm<2, P * FT, EPI_AFFINE, P, 1>(g, n_rows_w, n_groups / FT, s);
     } else {
         constexpr int P = 25, KS = 8;
         TFEP_REQUIRE(feat_tr && desc->x0 && desc->xf && desc->y0 && desc->yf, "fused spline: NULL descriptor arrays");
@@ -652,11 +507,38 @@ int tfep_fused_output_transformer_forward(const float* h, int64_t ldh, const flo
         g.fu.sf.learn_lower = false; g.fu.sf.learn_upper = false;
         g.fu.sf.min_bin = desc->min_bin_size; g.fu.sf.min_slope = desc->min_slope;
         g.fu.sf.slope_offset = (float)log(exp(1.0 - (double)desc->min_slope) - 1.0);
-        rc = launch_gemm<2, P, EPI_SPLINE, P, KS>(g, n_rows_w, n_groups, s);
+        rc = split ? launch_split_fused(g, n_rows_w, kind, n_groups, s)
+                   : launch_gemm<2, P, EPI_SPLINE, P, KS>(g, n_rows_w, n_groups, s);
     }
     if (rc) return rc;
     ldj_reduce_kernel<<<(unsigned)((B + 255) / 256), 256, 0, s>>>(ldj_partial, n_groups, B, log_det_J, accumulate);
     return check_launch("ldj_reduce_kernel");
+}
+
+int tfep_fused_output_transformer_forward(const float* h, int64_t ldh, const float* w, int64_t ldw,
+                                          const float* bias_packed, const int32_t* k_ranges,
+                                          const int32_t* tile_order, int kind,
+                                          const tfep_spline_desc* desc, const float* x, int64_t ldx, float* y,
+                                          int64_t ldy, const int32_t* feat_index, const int32_t* feat_tr,
+                                          int n_feature_slots, double* ldj_partial, float* log_det_J, int accumulate,
+                                          int B, int n_rows_w, int k_padded, void* stream) {
+    return fused_forward(h, ldh, w, ldw, bias_packed, k_ranges, tile_order, kind, desc, x, ldx, y, ldy, feat_index, feat_tr,
+                         n_feature_slots, ldj_partial, log_det_J, accumulate, B, n_rows_w, k_padded, false, nullptr,
+                         nullptr, stream);
+}
+
+int tfep_fused_output_transformer_forward_split(const void* h_split, int64_t ldh, const float* h_inv_scale,
+                                                const void* w_split, int64_t ldw, const float* w_inv_scale,
+                                                const float* bias_packed, const int32_t* k_ranges,
+                                                const int32_t* tile_order, int kind, const tfep_spline_desc* desc,
+                                                const float* x, int64_t ldx, float* y, int64_t ldy,
+                                                const int32_t* feat_index, const int32_t* feat_tr, int n_feature_slots,
+                                                double* ldj_partial, float* log_det_J, int accumulate, int B,
+                                                int n_rows_w, int k_padded, void* stream) {
+    TFEP_REQUIRE(h_inv_scale && w_inv_scale, "fused split: NULL scale pointer");
+    return fused_forward((const float*)h_split, ldh, (const float*)w_split, ldw, bias_packed, k_ranges, tile_order, kind,
+                         desc, x, ldx, y, ldy, feat_index, feat_tr, n_feature_slots, ldj_partial, log_det_J, accumulate, B,
+                         n_rows_w, k_padded, true, h_inv_scale, w_inv_scale, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,403 @@
+// Split-precision masked-linear GEMM for gfx950: fp32 operands carried as two fp16 halves, three
+// v_mfma_f32_16x16x32_f16 per product (hi*hi + lo*hi + hi*lo, fp32 accumulate).
+//
+// Why: the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) peaks at 157 TFLOP/s on MI355X; the fp16 MFMA at 2.5 PFLOP/s.
+// Three fp16 MFMAs per fp32 product leave a 5.3x higher matrix-pipe ceiling, and the result is fp32-equivalent:
+//   v * s = hi + lo + r,  hi = fp16(v * s),  lo = fp16(v * s - hi),  |r| <= 2^-22 |v * s|
+// with s a power of two chosen per activation row / per weight matrix so that max |v * s| lies in [2^14, 2^15)
+// (fp16 never overflows and the low half of every element within 2^-19 of the maximum stays normal).  hi*hi,
+// lo*hi and hi*lo are exact in the fp32 accumulator; only lo*lo (2^-22 relative) is dropped.  Products are
+// un-scaled in the epilogue by the exact powers of two.
+//
+// Operand format ("split rows"): same pitch as the fp32 matrix (4 bytes per element); per row and per group of
+// 8 consecutive k:  [8 x fp16 hi][8 x fp16 lo]  (32 bytes).  Written by tfep_split_rows.
+//
+// Tiling (one workgroup = 4 wavefronts = one per SIMD, 512 registers each, one workgroup per CU):
+//   workgroup tile 256 x (16 * NREP), BK = 32; wave w owns rows [64w, 64w + 64) and all columns as 4 x NREP
+//   tiles of 16x16x32 (accumulators: 16 * NREP registers).  Per k-tile a wave reads its A fragments once
+//   (8 ds_read_b128) and streams the B fragments (2 ds_read_b128 per column group for 12 MFMAs).
+//   LDS: weights double-buffered (2 x 16*NREP x 128 B), activations single-buffered and PRIVATE to the wave
+//   that owns the rows (8 KB each) -- a wave refills its own A region right after reading its fragments, so the
+//   only workgroup barrier per k-tile is the one that publishes the weight tile.
+//   LDS image: row r of a k-tile is 128 B = 8 parts of 16 B (part 2g + h = half h of k-group g); part p sits at
+//   position p ^ swz(r), swz(r) = (e & 1) | (e & 4), e = (r >> 1) & 7, which makes both ds_read_b128 of a fragment
+//   conflict-free for the hardware's 16-lane groups.  The LDS-DMA writes the image directly: lane i of a DMA
+//   instruction fills position i & 7 of row i >> 3 of an 8-row chunk and fetches the part that belongs there.
+#include "gemm_common.h"
+
+#include <type_traits>
+
+namespace tfep {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SBK = 32;
+constexpr int SWAVES = 4, STHREADS = SWAVES * 64, SMREP = 4;
+constexpr int ROW_BYTES = 128;                    // one row of one k-tile: 32 k x (hi, lo)
+constexpr int A_WAVE_BYTES = 16 * SMREP * ROW_BYTES;
+
+template <int NREP>
+struct STile {
+    static constexpr int BM = SWAVES * 16 * SMREP;
+    static constexpr int BN = 16 * NREP;
+    static constexpr int A_BYTES = SWAVES * A_WAVE_BYTES;
+    static constexpr int B_BYTES = BN * ROW_BYTES;
+    static constexpr int LDS_BYTES = A_BYTES + 2 * B_BYTES;
+    static constexpr int A_DMA = A_WAVE_BYTES / 1024;               // DMA instructions per wave per k-tile
+    static constexpr int B_CHUNKS = BN / 8;
+    static constexpr int B_DMA = (B_CHUNKS + SWAVES - 1) / SWAVES;
+    static constexpr int N_DMA = A_DMA + B_DMA;
+};
+
+// ------------------------------------------------------------------------------------------
+// fp32 rows -> split rows
+// ------------------------------------------------------------------------------------------
+__device__ inline float pow2_scale_for(float amax) {
+    // amax * s in [2^14, 2^15); 1 for an all-zero / non-finite row
+    if (!(amax > 0.f) || !(amax < INFINITY)) return 1.0f;
+    int ex;
+    frexpf(amax, &ex);                       // amax = f * 2^ex, f in [0.5, 1)
+    int k = 15 - ex;
+    k = k > 100 ? 100 : k;
+    return ldexpf(1.0f, k);
+}
+
+__global__ void zero_u32_kernel(uint32_t* p) { *p = 0u; }
+
+__global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int64_t cols,
+                                                     uint32_t* __restrict__ out_bits) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* sr = src + row * ld;
+    float m = 0.f;
+    for (int64_t i = lane; i < cols; i += 64) m = fmaxf(m, fabsf(sr[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) atomicMax(out_bits, __float_as_uint(m));     // non-negative floats order like their bits
+}
+
+// One wave per row.  per_tensor: the scale comes from *tensor_max_bits (absmax_kernel) and inv_scale[0] is written
+// once; otherwise each row gets its own scale and inv_scale[row].
+__global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict__ src, int64_t ld_src, int64_t rows,
+                                                         int64_t cols, uint4* __restrict__ dst, int64_t ld_dst,
+                                                         int64_t cols_padded, float* __restrict__ inv_scale,
+                                                         const uint32_t* __restrict__ tensor_max_bits) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* sr = src + row * ld_src;
+    float amax;
+    if (tensor_max_bits) {
+        amax = __uint_as_float(*tensor_max_bits);
+    } else {
+        amax = 0.f;
+        for (int64_t i = lane; i < cols; i += 64) amax = fmaxf(amax, fabsf(sr[i]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+    }
+    const float s = pow2_scale_for(amax);
+    if (lane == 0 && (!tensor_max_bits || row == 0)) inv_scale[tensor_max_bits ? 0 : row] = 1.0f / s;
+    uint4* dr = dst + row * (ld_dst / 4);        // 16 bytes = 4 elements of pitch
+    for (int64_t g8 = lane; g8 * 8 < cols_padded; g8 += 64) {
+        f16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t c = g8 * 8 + j;
+            const float v = c < cols ? sr[c] * s : 0.f;
+            const _Float16 h = (_Float16)v;
+            hi[j] = h;
+            lo[j] = (_Float16)(v - (float)h);
+        }
+        dr[g8 * 2] = *reinterpret_cast<uint4*>(&hi);
+        dr[g8 * 2 + 1] = *reinterpret_cast<uint4*>(&lo);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GEMM
+// ------------------------------------------------------------------------------------------
+// One v_mfma_f32_16x16x32_f16 with the accumulator pinned to a register file.  A wave of this kernel owns 16 * NREP
+// accumulator registers -- 400 for the fused spline tile -- and has 256 AGPRs + 256 VGPRs: the column groups
+// below N_ACC_AGPR accumulate in AGPRs, the rest in VGPRs.  (Left to the register allocator, the builtin form
+// shuffles tiles between the two files inside the k-loop and spills.)
+constexpr int N_ACC_AGPR = 16;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <bool IN_AGPR>
+__device__ __forceinline__ void mfma16(f32x4& acc, const f16x8& a, const f16x8& b) {
+    if constexpr (IN_AGPR)
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+    else
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
+__device__ __forceinline__ void keep_alive(const f32x4& v) { asm volatile("" ::"v"(v)); }
+
+struct SplitCtx {
+    __amdgpu_buffer_rsrc_t ra, rw;
+    uint32_t va_even, va_odd, vw;   // per-lane byte offsets inside an 8-row chunk (A: even / odd chunks)
+    uint32_t piece_a, piece_w;      // bytes between consecutive 8-row chunks
+};
+
+template <int NREP>
+__device__ inline void split_dma(const SplitCtx& sc, char* a_wave, char* b_stage, int k0, int wave, int d) {
+    using T = STile<NREP>;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    if (d < T::A_DMA) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(sc.ra, (lds_ptr)(a_wave + d * 1024), 16,
+                                                 ((d & 1) ? sc.va_odd : sc.va_even) + (uint32_t)d * sc.piece_a, k0 * 4, 0, 0);
+    } else {
+        const int c = wave + SWAVES * (d - T::A_DMA);
+        if (c < T::B_CHUNKS)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(sc.rw, (lds_ptr)(b_stage + c * 1024), 16,
+                                                     sc.vw + (uint32_t)c * sc.piece_w, k0 * 4, 0, 0);
+    }
+}
+
+template <int NREP, int EPI, int P, int KSPL>
+__global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int n_rows_w) {
+    using T = STile<NREP>;
+    extern __shared__ __attribute__((aligned(16))) char slds[];
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int mt, ntp;
+    if (!map_block(g, mt, ntp)) return;
+    const int nt = g.tile_order ? g.tile_order[ntp] : ntp;
+    if (g.tile_live && !g.tile_live[(int64_t)mt * g.n_tiles + nt]) return;
+    const int m0 = mt * T::BM, n0 = nt * T::BN;
+
+    int kb = 0, ke = g.k_padded;
+    if (g.k_ranges) {
+        kb = g.k_ranges[2 * nt];
+        ke = g.k_ranges[2 * nt + 1];
+    }
+
+    f32x4 acc[NREP][SMREP];
+    static_for<0, NREP * SMREP>([&](auto ic) __attribute__((always_inline)) {
+        acc[ic.value / SMREP][ic.value % SMREP] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    });
+
+    SplitCtx sc;
+    {
+        constexpr int FLAGS = 0x00020000;     // gfx9 raw buffer, 32-bit data; rows past the end read as 0
+        const int rows_a = min(g.B - m0, T::BM), rows_w = min(n_rows_w - n0, T::BN);
+        sc.ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.a + (int64_t)m0 * g.lda), 0,
+                                                  (int)clamp_u32((int64_t)rows_a * g.lda * 4), FLAGS);
+        sc.rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.w + (int64_t)n0 * g.ldw), 0,
+                                                  (int)clamp_u32((int64_t)rows_w * g.ldw * 4), FLAGS);
+        const int drow = lane >> 3, p0 = (lane & 7) ^ ((lane >> 4) & 1);
+        const uint32_t arow = (uint32_t)(((int64_t)(wave * 16 * SMREP + drow) * g.lda) * 4);
+        sc.va_even = arow + p0 * 16;
+        sc.va_odd = arow + (p0 ^ 4) * 16;
+        sc.vw = (uint32_t)(((int64_t)drow * g.ldw) * 4) + (((wave & 1) ? (p0 ^ 4) : p0) * 16);
+        sc.piece_a = (uint32_t)(8 * g.lda * 4);
+        sc.piece_w = (uint32_t)(8 * g.ldw * 4);
+    }
+    char* a_wave = slds + wave * A_WAVE_BYTES;
+    char* b_base = slds + T::A_BYTES;
+
+    const int nk = (ke - kb) / SBK;
+    if (nk > 0 && !(g.diag & 4)) {
+#pragma unroll
+        for (int d = 0; d < T::N_DMA; ++d) split_dma<NREP>(sc, a_wave, b_base, kb, wave, d);
+    }
+    // fragment of row (l & 15), k-group (l >> 4): hi at part 2g, lo at part 2g + 1, swizzled
+    const int fr = lane & 15, fg = lane >> 4;
+    const int fe = (fr >> 1) & 7, fsw = (fe & 1) | (fe & 4);
+    const int off_hi = fr * ROW_BYTES + (((2 * fg) ^ fsw) << 4);
+    const int off_lo = fr * ROW_BYTES + (((2 * fg + 1) ^ fsw) << 4);
+
+    for (int t = 0; t < nk; ++t) {
+        if (!(g.diag & 8)) __syncthreads();      // own A DMA + everybody's B DMA of tile t landed; other B stage free
+        const char* Bs = b_base + (t & 1) * T::B_BYTES;
+        char* Bn = b_base + ((t + 1) & 1) * T::B_BYTES;
+        f16x8 ah[SMREP], al[SMREP];
+#pragma unroll
+        for (int m = 0; m < SMREP; ++m) {
+            ah[m] = *(const f16x8*)(a_wave + m * 16 * ROW_BYTES + off_hi);
+            al[m] = *(const f16x8*)(a_wave + m * 16 * ROW_BYTES + off_lo);
+        }
+        f16x8 bh[2], bl[2];
+        bh[0] = *(const f16x8*)(Bs + off_hi);
+        bl[0] = *(const f16x8*)(Bs + off_lo);
+        const bool dma = t + 1 < nk && !(g.diag & 4);
+        const int k_next = kb + (t + 1) * SBK;
+        // Column groups as a compile-time loop: the accumulator indices must be constants in the frontend,
+        // or the 400-register array is not promoted out of scratch memory.
+        static_for<0, NREP>([&](auto nc) __attribute__((always_inline)) {
+            constexpr int n = decltype(nc)::value;
+            if constexpr (n + 1 < NREP) {
+                bh[(n + 1) & 1] = *(const f16x8*)(Bs + (n + 1) * 16 * ROW_BYTES + off_hi);
+                bl[(n + 1) & 1] = *(const f16x8*)(Bs + (n + 1) * 16 * ROW_BYTES + off_lo);
+            }
+            // The next tile's DMA is spread over the column groups 1 .. NREP-2 (the A region is free once the
+            // fragments above are in registers, which the MFMAs of group 0 have waited for).
+            if (dma) {
+                static_for<0, T::N_DMA>([&](auto dc) __attribute__((always_inline)) {
+                    constexpr int d = decltype(dc)::value;
+                    if constexpr (1 + (d * (NREP - 2)) / T::N_DMA == n) split_dma<NREP>(sc, a_wave, Bn, k_next, wave, d);
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const f16x8 h = bh[n & 1], l = bl[n & 1];
+            static_for<0, SMREP>([&](auto mc) __attribute__((always_inline)) { mfma16<(n < N_ACC_AGPR)>(acc[n][mc.value], ah[mc.value], h); });
+            static_for<0, SMREP>([&](auto mc) __attribute__((always_inline)) { mfma16<(n < N_ACC_AGPR)>(acc[n][mc.value], al[mc.value], h); });
+            static_for<0, SMREP>([&](auto mc) __attribute__((always_inline)) { mfma16<(n < N_ACC_AGPR)>(acc[n][mc.value], ah[mc.value], l); });
+        });
+    }
+    // The MFMAs are inline asm: leave the matrix pipe's result latency behind before anything reads acc.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+    if (g.diag & 1) {   // timing-only build of the main loop: keep the accumulators alive, store nothing
+        static_for<0, NREP * SMREP>([&](auto ic) __attribute__((always_inline)) {
+            keep_alive(acc[ic.value / SMREP][ic.value % SMREP]);
+        });
+        return;
+    }
+    // Un-scale by the exact powers of two.  `acc` is only ever indexed by constants (so it lives in registers
+    // through the k-loop); the epilogues get a copy they may index from unrolled loops.
+    const int wrow0 = m0 + wave * 16 * SMREP;
+    f32x4 out[NREP][SMREP];
+    {
+        const float ws = g.w_inv_scale[0];
+        const int rq = (lane >> 4) * 4;
+        f32x4 rs[SMREP];
+        static_for<0, SMREP * 4>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int m = ic.value / 4, i = ic.value % 4;
+            const int row = wrow0 + m * 16 + rq + i;
+            rs[m][i] = row < g.B ? g.a_inv_scale[row] * ws : 0.f;
+        });
+        static_for<0, NREP * SMREP>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int n = ic.value / SMREP, m = ic.value % SMREP;
+            out[n][m] = acc[n][m] * rs[m];
+        });
+    }
+    gemm_epilogue<SMREP, NREP, EPI, P, KSPL>(g, out, nt, n0, wrow0, lane);
+}
+
+// The matrix-pipe ceiling of THIS device for the split GEMM's instruction mix (no memory).
+template <int NREP>
+__global__ void __launch_bounds__(STHREADS, 1) split_peak_kernel(float* out, int iters) {
+    f32x4 acc[NREP][SMREP];
+#pragma unroll
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+        for (int m = 0; m < SMREP; ++m) acc[n][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 a[SMREP], b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        b[j] = (_Float16)(1e-3f * (threadIdx.x + j));
+#pragma unroll
+        for (int m = 0; m < SMREP; ++m) a[m][j] = (_Float16)(0.5f + 0.01f * (threadIdx.x & 31) + m + j);
+    }
+    for (int it = 0; it < iters; ++it) {
+        static_for<0, NREP>([&](auto nc) __attribute__((always_inline)) {
+            constexpr int n = decltype(nc)::value;
+            static_for<0, 3 * SMREP>([&](auto mc) __attribute__((always_inline)) {
+                mfma16<(n < N_ACC_AGPR)>(acc[n][mc.value % SMREP], a[mc.value % SMREP], b);
+            });
+        });
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    float sum = 0.f;
+#pragma unroll
+    for (int n = 0; n < NREP; ++n)
+#pragma unroll
+        for (int m = 0; m < SMREP; ++m) sum += acc[n][m][0] + acc[n][m][1] + acc[n][m][2] + acc[n][m][3];
+    out[blockIdx.x * STHREADS + threadIdx.x] = sum;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+template <int NREP, int EPI, int P, int KSPL>
+static int launch_split(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStream_t s) {
+    using T = STile<NREP>;
+    auto kern = split_gemm_kernel<NREP, EPI, P, KSPL>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
+        if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%d): %s", T::LDS_BYTES, hipGetErrorString(e));
+        attr_set = true;
+    }
+    GemmArgs ga = g;
+    ga.m_tiles = (g.B + T::BM - 1) / T::BM;
+    ga.n_tiles = n_col_tiles;
+    ga.map_mode = block_map_mode();
+    ga.diag = env_int("TFEP_DIAG", 0);
+    const long long blocks = gemm_grid_blocks(ga.map_mode, ga.m_tiles, ga.n_tiles);
+    if (blocks > 0x7fffffffLL) return fail(TFEP_ERR_INVALID_ARGUMENT, "split gemm: grid too large");
+    kern<<<dim3((unsigned)blocks), STHREADS, T::LDS_BYTES, s>>>(ga, n_rows_w);
+    return check_launch("split_gemm_kernel");
+}
+
+int check_split_operands(const GemmArgs& g) {
+    TFEP_REQUIRE(g.a_inv_scale && g.w_inv_scale, "split gemm: NULL scale pointer");
+    TFEP_REQUIRE(g.k_padded > 0 && g.k_padded % SBK == 0, "split gemm: k_padded=%d must be a positive multiple of %d", g.k_padded, SBK);
+    TFEP_REQUIRE(g.lda % SBK == 0 && g.ldw % SBK == 0, "split gemm: row strides must be multiples of %d elements", SBK);
+    TFEP_REQUIRE((int64_t)STile<25>::BM * g.lda * 4 < 0x7fffffffLL && (int64_t)STile<25>::BN * g.ldw * 4 < 0x7fffffffLL,
+                 "split gemm: row stride too large");
+    return TFEP_OK;
+}
+
+int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s) {
+    int rc = check_split_operands(g);
+    if (rc) return rc;
+    constexpr int NREP = 16;
+    const int n_tiles = (g.N + STile<NREP>::BN - 1) / STile<NREP>::BN;
+    if (act == 1) return launch_split<NREP, EPI_ELU, 1, 1>(g, n_rows_w, n_tiles, s);
+    return launch_split<NREP, EPI_LINEAR, 1, 1>(g, n_rows_w, n_tiles, s);
+}
+
+int launch_split_fused(const GemmArgs& g, int n_rows_w, int kind, int n_col_tiles, hipStream_t s) {
+    int rc = check_split_operands(g);
+    if (rc) return rc;
+    if (kind == TFEP_FUSED_AFFINE) return launch_split<16, EPI_AFFINE, 2, 1>(g, n_rows_w, n_col_tiles, s);
+    return launch_split<25, EPI_SPLINE, 25, 8>(g, n_rows_w, n_col_tiles, s);
+}
+
+}  // namespace tfep
+
+using namespace tfep;
+
+extern "C" {
+
+int tfep_split_tile_k(void) { return SBK; }
+
+int tfep_split_rows(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int64_t ld_dst,
+                    int64_t cols_padded, float* inv_scale, int per_tensor, void* stream) {
+    TFEP_REQUIRE(rows >= 0 && cols >= 0, "split_rows: negative size");
+    if (rows == 0) return TFEP_OK;
+    TFEP_REQUIRE(src && dst && inv_scale, "split_rows: NULL pointer");
+    TFEP_REQUIRE(cols_padded >= cols && cols_padded % SBK == 0, "split_rows: cols_padded=%lld must be a multiple of %d >= cols",
+                 (long long)cols_padded, SBK);
+    TFEP_REQUIRE(ld_src >= cols && ld_dst >= cols_padded && ld_dst % 4 == 0, "split_rows: bad row strides");
+    TFEP_REQUIRE((uintptr_t)dst % 16 == 0, "split_rows: dst must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((rows + 3) / 4);
+    uint32_t* max_bits = nullptr;
+    if (per_tensor) {
+        // inv_scale[1] is scratch for the tensor maximum (as bits)
+        max_bits = reinterpret_cast<uint32_t*>(inv_scale + 1);
+        zero_u32_kernel<<<1, 1, 0, s>>>(max_bits);
+        absmax_kernel<<<blocks, 256, 0, s>>>(src, ld_src, rows, cols, max_bits);
+    }
+    split_rows_kernel<<<blocks, 256, 0, s>>>(src, ld_src, rows, cols, (uint4*)dst, ld_dst, cols_padded, inv_scale, max_bits);
+    return check_launch("split_rows_kernel");
+}
+
+int tfep_diag_split_mfma_peak(float* scratch, int blocks, int iters, void* stream) {
+    TFEP_REQUIRE(scratch && blocks > 0 && iters > 0, "diag_split_mfma_peak: bad arguments");
+    split_peak_kernel<25><<<blocks, STHREADS, 0, (hipStream_t)stream>>>(scratch, iters);
+    return check_launch("split_peak_kernel");
+}
+
+}  // extern "C"

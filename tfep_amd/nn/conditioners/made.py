@@ -279,6 +279,24 @@ class MADE(Conditioner):
             plan[('packed', li, n_rows)] = (buf, bias[0])
         return buf, bias[0]
 
+    def _pack_layer_split(self, plan, li, lin, row_of_out=None, n_rows=None):
+        """``_pack_layer`` followed by the conversion to split-f16 rows (one scale for the matrix).
+        Returns ``(w_split, w_inv_scale, bias)``."""
+        n_rows_key = plan['n_pad'][li] if n_rows is None else n_rows
+        if self._frozen and ('packed_split', li, n_rows_key) in plan:
+            return plan[('packed_split', li, n_rows_key)]
+        w, b = self._pack_layer(plan, li, lin, row_of_out, n_rows)
+        key = ('ws', li, n_rows_key)
+        buf = plan.get(key)
+        if buf is None or buf[0].shape != w.shape:
+            buf = (torch.empty_like(w), torch.empty(2, dtype=torch.float32, device=w.device))
+            plan[key] = buf
+        ops.split_rows(w, w.shape[1], per_tensor=True, out=buf[0], inv_scale=buf[1])
+        res = (buf[0], buf[1], b)
+        if self._frozen:
+            plan[('packed_split', li, n_rows_key)] = res
+        return res
+
     def _embed(self, x):
         return x
 
@@ -287,9 +305,10 @@ class MADE(Conditioner):
         block (the D sequential passes of the autoregressive inverse share one set of weights)."""
         return _FrozenWeights(self)
 
-    def forward_hidden(self, x):
+    def forward_hidden(self, x, split=False):
         """Run every layer but the last; returns the last hidden activations (zero padded,
-        units sorted by degree) and the plan."""
+        units sorted by degree) and the plan.  ``split``: the GEMMs take split-f16 operands
+        (``csrc/split_gemm.hip``); the activations returned are fp32 either way."""
         ops.check_device_tensor(x, 'x')
         x = self._embed(x)
         if x.shape[1] != self.dimension_in:
@@ -298,9 +317,15 @@ class MADE(Conditioner):
         lins = self._linears()
         h = ops.pad_columns(x, plan['k_pad'][0])
         for li, lin in enumerate(lins[:-1]):
-            w, b = self._pack_layer(plan, li, lin)
-            h = ops.masked_linear_packed(h, w, b, plan['n_pad'][li], k_ranges=plan['k_ranges'][li], act=1,
-                                         tile_order=plan['tile_order'][li])
+            if split:
+                ws, w_inv, b = self._pack_layer_split(plan, li, lin)
+                hs, h_inv = ops.split_rows(h, plan['k_pad'][li])
+                h = ops.masked_linear_split(hs, h_inv, ws, w_inv, b, plan['n_pad'][li], k_ranges=plan['k_ranges'][li],
+                                            act=1, tile_order=plan['tile_order'][li])
+            else:
+                w, b = self._pack_layer(plan, li, lin)
+                h = ops.masked_linear_packed(h, w, b, plan['n_pad'][li], k_ranges=plan['k_ranges'][li], act=1,
+                                             tile_order=plan['tile_order'][li])
         return h, plan
 
     def forward(self, x):
@@ -321,7 +346,7 @@ class _FrozenWeights:
 
     def _drop(self):
         for plan in self.made._plans.values():
-            for k in [k for k in plan if isinstance(k, tuple) and k[0] == 'packed']:
+            for k in [k for k in plan if isinstance(k, tuple) and k[0] in ('packed', 'packed_split')]:
                 del plan[k]
 
     def __enter__(self):

@@ -69,6 +69,7 @@ class AutoregressiveFlow(torch.nn.Module):
         self._dev = {}
         self.fused = True             # set False to force the generic (unfused) forward path
         self.blocked_inverse = True   # set False to force the reference's one-full-pass-per-degree inverse
+        self.split_gemm = None        # None: TFEP_SPLIT_GEMM (default on); False: exact-fp32 MFMA GEMMs in forward
 
         if initialize_identity:
             identity_parameters = self._transformer.get_identity_parameters(n_transformer_indices)
@@ -130,6 +131,10 @@ class AutoregressiveFlow(torch.nn.Module):
                 return _FUSED_SPLINE
         return None
 
+    def _use_split_gemm(self):
+        """Split-f16 GEMMs for the forward pass: ``self.split_gemm`` if set, else ``TFEP_SPLIT_GEMM`` (default on)."""
+        return ops.split_gemm_enabled() if self.split_gemm is None else bool(self.split_gemm)
+
     def _fused_plan(self, device, kind, tables):
         key = ('fused', str(device), kind)
         fp = self._dev.get(key)
@@ -178,8 +183,14 @@ class AutoregressiveFlow(torch.nn.Module):
         tables = self._tables(x.device)
         fp = self._fused_plan(x.device, kind, tables)
         made = self._conditioner
-        h, mplan = made.forward_hidden(x)
-        w, b = made._pack_layer(mplan, fp['li'], made.layers[-1], row_of_out=fp['row_of_out'], n_rows=fp['n_rows'])
+        split = self._use_split_gemm()
+        h, mplan = made.forward_hidden(x, split=split)
+        if split:
+            w, w_inv, b = made._pack_layer_split(mplan, fp['li'], made.layers[-1], row_of_out=fp['row_of_out'],
+                                                 n_rows=fp['n_rows'])
+            h, h_inv = ops.split_rows(h, w.shape[1])
+        else:
+            w, b = made._pack_layer(mplan, fp['li'], made.layers[-1], row_of_out=fp['row_of_out'], n_rows=fp['n_rows'])
         y = x.clone() if self.has_fixed_indices else torch.empty(B, D, dtype=x.dtype, device=x.device)
         ldj = torch.empty(B, dtype=torch.float32, device=x.device)
         ws = torch.empty(fp['n_slots'] // 16, B, dtype=torch.float64, device=x.device)
@@ -188,11 +199,15 @@ class AutoregressiveFlow(torch.nn.Module):
         if prof is not None:                     # bench.py: HIP events around the fused launch
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record(torch.cuda.current_stream(x.device))
-        _lib.call('tfep_fused_output_transformer_forward', _lib.ptr(h), h.shape[1], _lib.ptr(w), w.shape[1],
-                  _lib.ptr(b), _lib.ptr(fp['k_ranges']), _lib.ptr(fp['tile_order']), kind,
-                  ctypes.byref(desc) if desc is not None else None,
-                  _lib.ptr(x), ldx, _lib.ptr(y), D, _lib.ptr(fp['feat_index']), _lib.ptr(fp['feat_tr']),
-                  fp['n_slots'], _lib.ptr(ws), _lib.ptr(ldj), 0, B, fp['n_rows'], w.shape[1], _lib.stream_of(x))
+        tail = (_lib.ptr(b), _lib.ptr(fp['k_ranges']), _lib.ptr(fp['tile_order']), kind,
+                ctypes.byref(desc) if desc is not None else None,
+                _lib.ptr(x), ldx, _lib.ptr(y), D, _lib.ptr(fp['feat_index']), _lib.ptr(fp['feat_tr']),
+                fp['n_slots'], _lib.ptr(ws), _lib.ptr(ldj), 0, B, fp['n_rows'], w.shape[1], _lib.stream_of(x))
+        if split:
+            _lib.call('tfep_fused_output_transformer_forward_split', _lib.ptr(h), h.shape[1], _lib.ptr(h_inv),
+                      _lib.ptr(w), w.shape[1], _lib.ptr(w_inv), *tail)
+        else:
+            _lib.call('tfep_fused_output_transformer_forward', _lib.ptr(h), h.shape[1], _lib.ptr(w), w.shape[1], *tail)
         if prof is not None:
             ev1.record(torch.cuda.current_stream(x.device))
             prof.append((ev0, ev1))

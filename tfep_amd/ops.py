@@ -5,6 +5,7 @@ tensor's device and returns fresh output tensors (inputs are never modified, lik
 reference: flows/autoregressive.py:165-166).  No autograd, no CPU path.
 """
 import ctypes
+import os
 
 import torch
 
@@ -223,6 +224,50 @@ def gemm_slice(x_padded, w_packed, row0, n_rows, bias, k_ranges, kr_offset, out,
          ctypes.c_void_p(k_ranges.data_ptr() + kr_offset * 2 * 4), None, None,
          ctypes.c_void_p(out.data_ptr() + col0 * esz), out.shape[1], B, n_rows, n_rows, k_padded, int(act),
          _lib.load().tfep_masked_linear_narrow_tile_n(), stream_of(x_padded))
+
+
+# ----------------------------------------------------------------------------- split-precision operands
+
+def split_gemm_enabled():
+    """The MADE GEMMs of the forward pass run on split-f16 operands (3 fp16 MFMAs per fp32 product, fp32-equivalent
+    results) unless ``TFEP_SPLIT_GEMM=0`` selects the exact-fp32 MFMA kernel."""
+    return os.environ.get('TFEP_SPLIT_GEMM', '1') != '0'
+
+
+def split_rows(x, cols_padded, per_tensor=False, out=None, inv_scale=None):
+    """fp32 rows -> split-f16 rows (``tfep_split_rows``).  Returns ``(split, inv_scale)``: ``split`` is a
+    (rows, cols_padded) float32-TYPED container of the bit pattern, ``inv_scale`` has one entry per row, or
+    [1/scale, scratch] with ``per_tensor``."""
+    x, ldx = rows(x, 'x')
+    R, C = x.shape
+    if out is None:
+        out = torch.empty(R, cols_padded, dtype=torch.float32, device=x.device)
+    if inv_scale is None:
+        inv_scale = torch.empty(2 if per_tensor else max(R, 1), dtype=torch.float32, device=x.device)
+    call('tfep_split_rows', ptr(x), ldx, R, C, ptr(out), out.shape[1], cols_padded, ptr(inv_scale), int(per_tensor),
+         stream_of(x))
+    return out, inv_scale
+
+
+def masked_linear_split(x_split, x_inv_scale, w_split, w_inv_scale, bias, n_out, k_ranges=None, act=0, out=None,
+                        tile_order=None):
+    """``masked_linear_packed`` on split-f16 operands; the output is ordinary fp32."""
+    B = x_split.shape[0]
+    n_rows_w, k_padded = w_split.shape
+    if out is None:
+        out = torch.empty(B, n_out, dtype=torch.float32, device=x_split.device)
+    d = _lib.GemmDesc()
+    d.x, d.ldx = x_split.data_ptr(), x_split.shape[1]
+    d.w, d.ldw = w_split.data_ptr(), k_padded
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.k_ranges = k_ranges.data_ptr() if k_ranges is not None else None
+    d.tile_order = tile_order.data_ptr() if tile_order is not None else None
+    d.col_map = None
+    d.y, d.ldy = out.data_ptr(), out.shape[1]
+    d.B, d.N, d.n_rows_w, d.k_padded, d.act, d.accumulate = B, n_out, n_rows_w, k_padded, int(act), 0
+    d.split, d.x_inv_scale, d.w_inv_scale = 1, x_inv_scale.data_ptr(), w_inv_scale.data_ptr()
+    call('tfep_masked_linear_gemm', ctypes.byref(d), stream_of(x_split))
+    return out
 
 
 # ----------------------------------------------------------------------------- reductions
