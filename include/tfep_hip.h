@@ -288,6 +288,10 @@ int tfep_fused_output_transformer_forward_split(const void* h_split, int64_t ldh
 
 /* Diagnostic: matrix-pipe ceiling of this device for the split GEMM's instruction mix (cf. tfep_diag_mfma_peak). */
 int tfep_diag_split_mfma_peak(float* scratch, int blocks, int iters, void* stream);
+/* With TFEP_DIAG=16 the split kernels accumulate shader-cycle totals per phase; this reads and resets them
+ * (synchronous): out[0] = k-loop, out[1] = epilogue, out[2] = workgroups counted, out[3] = sum of workgroup
+ * lifetimes in 100 MHz real-time ticks. */
+int tfep_diag_split_cycles(unsigned long long* out);
 
 /* ------------------------------------------------------------------------- */
 /* Backward (training step, app/base.py:780-840 calls loss.backward())         */

@@ -347,6 +347,16 @@ def test_cfg2_size_properties():
     flow[0].fused = True
     assert float((y2 - y[:256]).detach().norm() / y[:256].detach().norm()) < 1e-6
     assert torch.allclose(l2, l[:256], rtol=1e-5, atol=1e-3)
+    # split-f16 GEMMs (default) vs exact-fp32 MFMA GEMMs: fp32-equivalent, and deterministic run to run
+    assert flow[0]._use_split_gemm()
+    ya, la = flow(x)
+    assert torch.equal(ya, y) and torch.equal(la, l)
+    flow[0].split_gemm = False
+    yb, lb = flow(x)
+    flow[0].split_gemm = None
+    assert float((yb - y).detach().norm() / yb.detach().norm()) < 1e-6
+    assert float((yb - y).detach().abs().max()) < 2e-5
+    assert torch.allclose(lb, l, rtol=1e-5, atol=1e-3)
     # row independence, bitwise
     y3, l3 = flow(x[100:300])
     assert torch.equal(y3, y[100:300]) and torch.equal(l3, l[100:300])
@@ -376,7 +386,7 @@ def test_cfg4_size_properties():
     yp, lp = flow(x[:4096] + 1.0)                      # one period later
     dp = (yp - y[:4096]).abs()
     dp = torch.minimum(dp, 1.0 - dp)                   # on the circle: y = 0 and y = 1 are the same point
-    assert float(dp.max()) < 2e-5 and torch.allclose(lp, l[:4096], atol=2e-3)
+    assert float(dp.detach().max()) < 2e-5 and torch.allclose(lp, l[:4096], atol=2e-3)
     xi, li = flow.inverse(y[:512])
     d = (xi - x[:512]).abs()
     d = torch.minimum(d, 1.0 - d)                      # distance on the circle

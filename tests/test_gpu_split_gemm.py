@@ -1,0 +1,126 @@
+"""GPU tests of the split-precision operands (csrc/split_gemm.hip): conversion, GEMM accuracy against float64
+(the exact-fp32 MFMA kernel beside it), masks / k-ranges, ragged shapes and the HIP-graph-safe weight scale."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def unsplit(s, inv, cols):
+    """Rebuild fp32 values from split rows (host-side check only)."""
+    R = s.shape[0]
+    raw = s.view(torch.float16).reshape(R, -1, 2, 8).float()          # (rows, k-groups, hi/lo, 8)
+    v = (raw[:, :, 0] + raw[:, :, 1]).reshape(R, -1)[:, :cols]
+    return v * (inv.reshape(-1, 1) if inv.numel() == R else inv[0])
+
+
+def test_split_rows_round_trip_and_scales():
+    from tfep_amd import ops
+    tk = ops.tile_sizes()[2]
+    assert tk == 32
+    torch.manual_seed(0)
+    x = torch.randn(300, 1000, device='cuda') * torch.logspace(-6, 6, 300, device='cuda')[:, None]
+    x[7] = 0.0                                             # all-zero row: scale 1
+    xs, inv = ops.split_rows(x, ops.round_up(1000, tk))
+    assert xs.shape == (300, 1024) and inv.shape == (300,)
+    raw = xs.view(torch.float16).reshape(300, -1, 2, 8)
+    assert torch.isfinite(raw.float()).all()
+    amax = (raw[:, :, 0].float().abs()).amax(dim=(1, 2))
+    live = x.abs().amax(1) > 0
+    assert bool(((amax[live] >= 2.0 ** 14 - 8) & (amax[live] <= 2.0 ** 15)).all())      # max |v * s| in [2^14, 2^15)
+    assert float(inv[7]) == 1.0 and bool((raw[7] == 0).all())
+    lg = torch.log2(inv)
+    assert torch.equal(lg, lg.round())                                                  # powers of two
+    err = (unsplit(xs, inv, 1000).double() - x.double()).abs() / x.abs().amax(1, keepdim=True).clamp_min(1e-30).double()
+    assert float(err.max()) < 2.0 ** -22
+    assert bool((xs[:, 1000:] == 0).all())                                              # zero padding
+    ws, winv = ops.split_rows(x, 1024, per_tensor=True)
+    assert winv.shape == (2,)
+    err = (unsplit(ws, winv, 1000).double() - x.double()).abs().max() / x.abs().max()
+    assert float(err) < 2.0 ** -22
+
+
+@pytest.mark.parametrize('B,K,N', [(1000, 1000, 700), (513, 4097, 300), (1, 33, 17), (255, 64, 256), (257, 31, 1)])
+@pytest.mark.parametrize('act', [0, 1])
+def test_split_gemm_matches_float64(B, K, N, act):
+    from tfep_amd import ops
+    tm, tn, tk = ops.tile_sizes()
+    torch.manual_seed(B + K + N)
+    kp, npad = ops.round_up(K, tk), ops.round_up(N, tk)
+    a = torch.randn(B, K, device='cuda')
+    a = torch.where(a > 0, a, torch.expm1(a))
+    w = torch.randn(N, K, device='cuda') / K ** 0.5
+    bias = torch.zeros(npad, device='cuda')
+    bias[:N] = torch.randn(N, device='cuda')
+    ap = ops.pad_columns(a, kp)
+    wp = ops.masked_weight_prepare(w, None, None, n_rows_padded=npad, k_padded=kp)
+    ref = a.double() @ w.double().T + bias[:N].double()
+    if act:
+        ref = torch.where(ref > 0, ref, torch.expm1(ref))
+    as_, ainv = ops.split_rows(ap, kp)
+    ws_, winv = ops.split_rows(wp, kp, per_tensor=True)
+    y = ops.masked_linear_split(as_, ainv, ws_, winv, bias, N, act=act)
+    y32 = ops.masked_linear_packed(ap, wp, bias, N, act=act)
+    scale = a.double().abs() @ w.double().abs().T + bias[:N].double().abs()
+    e_split = float(((y.double() - ref).abs() / scale).max())
+    e_fp32 = float(((y32.double() - ref).abs() / scale).max())
+    assert e_split < 1e-6, (e_split, e_fp32)
+    assert e_split < 4 * e_fp32 + 2e-7, (e_split, e_fp32)             # fp32-equivalent
+    y2 = ops.masked_linear_split(as_, ainv, ws_, winv, bias, N, act=act)
+    assert torch.equal(y, y2)
+
+
+def test_split_gemm_with_mask_k_ranges_and_tile_order():
+    """Block-triangular mask (sorted MADE degrees): k-ranges in units of 32 skip tiles; results as the dense product."""
+    from tfep_amd import ops
+    tm, tn, tk = ops.tile_sizes()
+    torch.manual_seed(3)
+    B, K, N = 300, 640, 700
+    deg_in = torch.sort(torch.randint(1, 20, (K,), device='cuda')).values
+    deg_out = torch.sort(torch.randint(1, 20, (N,), device='cuda')).values
+    mask = (deg_out[:, None] >= deg_in[None, :]).float()
+    a = torch.randn(B, K, device='cuda')
+    w = torch.randn(N, K, device='cuda')
+    npad = ops.round_up(N, tk)
+    wp = ops.masked_weight_prepare(w, None, mask, n_rows_padded=npad, k_padded=K)
+    n_tiles = (npad + tn - 1) // tn
+    kr = ops.mask_k_ranges(mask, tn, n_tiles, K)
+    assert bool((kr % tk == 0).all()) and int(kr[0, 1]) < K            # first tile really skips k-tiles
+    order = ops.heavy_first_order(kr)
+    bias = torch.zeros(npad, device='cuda')
+    as_, ainv = ops.split_rows(a, K)
+    ws_, winv = ops.split_rows(wp, K, per_tensor=True)
+    y = ops.masked_linear_split(as_, ainv, ws_, winv, bias, N, k_ranges=kr, tile_order=order)
+    ref = a.double() @ (w * mask).double().T
+    scale = a.double().abs() @ (w * mask).double().abs().T + 1e-30
+    assert float(((y.double() - ref).abs() / scale).max()) < 1e-6
+
+
+def test_split_operand_validation():
+    from tfep_amd import ops
+    a = torch.randn(4, 48, device='cuda')
+    with pytest.raises(ValueError, match='cols_padded'):
+        ops.split_rows(a, 48)                                          # not a multiple of 32
+    as_, ainv = ops.split_rows(a, 64)
+    assert as_.shape == (4, 64)
+    e, einv = ops.split_rows(torch.empty(0, 64, device='cuda'), 64)
+    assert e.shape == (0, 64)
+
+
+def test_forward_paths_agree_on_golden_flows():
+    """Every golden flow through the split-f16 and the exact-fp32 GEMM paths: same outputs to fp32 rounding."""
+    import golden_util as gu
+    g = gu.load('flows.npz')
+    for name in ['cfg1', 'rq4', 'cond', 'circ', 'mixflow']:
+        flow = gu.build_flow(name, g)
+        x = torch.from_numpy(g[f'{name}/x']).cuda()
+        with torch.no_grad():
+            for layer in flow:
+                layer.split_gemm = True
+            ys, ls = flow(x)
+            for layer in flow:
+                layer.split_gemm = False
+            yf, lf = flow(x)
+        assert float((ys - yf).norm() / yf.norm()) < 1e-6, name
+        assert torch.allclose(ls, lf, rtol=1e-5, atol=2e-5), name

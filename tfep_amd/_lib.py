@@ -81,6 +81,7 @@ _SIGNATURES = {
                                                             _P, _P, c_int, _P, _P, c_int,
                                                             c_int, c_int, c_int, _P]),
     'tfep_diag_split_mfma_peak': (c_int, [_P, c_int, c_int, _P]),
+    'tfep_diag_split_cycles': (c_int, [_P]),
     'tfep_diag_mfma_peak': (c_int, [_P, c_int, c_int, _P]),
     'tfep_masked_linear_gemm': (c_int, [POINTER(GemmDesc), _P]),
     'tfep_transpose': (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, _P]),

@@ -203,4 +203,80 @@ __device__ inline double rq_spline_element(const float (&w)[KMAX], const float (
     return out;
 }
 
+// Branch-free forward evaluation for the fused epilogue of the split-f16 GEMM: exactly K bins, K + 1 slopes,
+// no learnable bounds, no identity slopes.  The same arithmetic in the same order as
+// rq_spline_element<K, false> (bit-identical results), written as straight-line code with selects: a lone wave
+// on a SIMD has no partner to hide the latency of a dependent fp64 chain behind, so the caller evaluates
+// several elements in one basic block and lets the scheduler interleave their chains.
+template <int K>
+__device__ __forceinline__ double rq_spline_forward_full(const float (&w)[K], const float (&h)[K],
+                                                        const float (&sraw)[K + 1], float last,
+                                                        const SplineFlags& f, float x0f, float xff, float y0f,
+                                                        float yff, float vin, double* logd) {
+    const double mb = (double)f.min_bin;
+    const double x0 = x0f, y0 = y0f;
+    const double W = (double)xff - (double)x0f - K * mb;
+    const double H = (double)yff - (double)y0f - K * mb;
+    double v = vin;
+    if (f.circular) v = py_mod(v - x0 + (double)last, (double)xff - x0) + x0;     // wave-uniform branch
+
+    float mw = w[0], mh = h[0];
+#pragma unroll
+    for (int k = 1; k < K; ++k) {
+        mw = fmaxf(mw, w[k]);
+        mh = fmaxf(mh, h[k]);
+    }
+    double ew[K], eh[K];
+    double sw = 0.0, sh = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        ew[k] = exp_nonpos((double)w[k] - (double)mw);
+        eh[k] = exp_nonpos((double)h[k] - (double)mh);
+        sw += ew[k];
+        sh += eh[k];
+    }
+    const double iw = W / sw, ih = H / sh;
+
+    double kx = x0, ky = y0, bw = 0.0, bh = 0.0;
+    float rs0 = sraw[K], rs1 = sraw[K];          // never found -> upper tail: boundary slope of the last knot
+    bool found = false;
+    const bool lower_tail = !(v > x0);
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const double wk = ew[k] * iw + mb;
+        const double hk = eh[k] * ih + mb;
+        const double upper = kx + wk;
+        const bool above = v > upper;
+        const bool here = !found && !above;
+        const bool adv = !found && above;
+        bw = here ? wk : bw;
+        bh = here ? hk : bh;
+        rs0 = here ? sraw[k] : rs0;
+        rs1 = here ? sraw[k + 1] : rs1;
+        kx = adv ? upper : kx;
+        ky = adv ? ky + hk : ky;
+        found = found || here;
+    }
+    rs0 = lower_tail ? sraw[0] : rs0;
+    const bool tail = lower_tail || !found;
+
+    const double dk = (double)(softplus_f(rs0 + f.slope_offset) + f.min_slope);
+    const double dk1 = (double)(softplus_f(rs1 + f.slope_offset) + f.min_slope);
+    // tail: linear continuation with the boundary slope
+    const double bx = lower_tail ? x0 : kx, by = lower_tail ? y0 : ky;
+    const double out_t = by + dk * (v - bx);
+    // interior
+    const double s = bh / bw;
+    const double t = dk1 + dk - 2.0 * s;
+    const double eps = (v - kx) / bw;
+    const double e1 = eps * (1.0 - eps);
+    const double out_i = ky + bh * (s * eps * eps + dk * e1) / (s + t * e1);
+    const double om = 1.0 - eps;
+    const double num = s * s * (dk1 * eps * eps + 2.0 * s * e1 + dk * om * om);
+    const double den = s + t * e1;
+    const double arg = tail ? dk : num / (den * den);
+    *logd = (double)logf((float)arg);
+    return tail ? out_t : out_i;
+}
+
 }  // namespace tfep

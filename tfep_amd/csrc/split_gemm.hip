@@ -122,6 +122,7 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
 // below N_ACC_AGPR accumulate in AGPRs, the rest in VGPRs.  (Left to the register allocator, the builtin form
 // shuffles tiles between the two files inside the k-loop and spills.)
 constexpr int N_ACC_AGPR = 16;
+constexpr int DMA_PER_GROUP = 4;   // LDS-DMA instructions issued per column group at the head of a k-tile
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -140,6 +141,9 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const f16x8& a, const f16x8& 
 }
 
 __device__ __forceinline__ void keep_alive(const f32x4& v) { asm volatile("" ::"v"(v)); }
+
+// TFEP_DIAG & 16: per-phase cycle totals of the fused kernel (wave 0 of every workgroup): [k-loop, epilogue, workgroups]
+__device__ unsigned long long g_split_cycles[4];   // [3]: workgroup lifetimes in 100 MHz real-time ticks
 
 struct SplitCtx {
     __amdgpu_buffer_rsrc_t ra, rw;
@@ -162,6 +166,95 @@ __device__ inline void split_dma(const SplitCtx& sc, char* a_wave, char* b_stage
     }
 }
 
+// Fused RQ-spline epilogue of the split kernel (P = 25 parameters per feature, one feature per lane column,
+// 16 samples per lane).  With one wave per SIMD there is no partner wave to hide latency behind, and 400
+// accumulator registers cannot be indexed by a run-time (m, i): so the wave stages its tile through its own LDS
+// region, one 16-row block at a time -- element (row, feature) becomes a 28-float record [25 parameters (bias and
+// un-scaling applied), x, pad] -- and a 4-iteration run-time loop evaluates one record per lane per iteration.
+// Same arithmetic as gemm_epilogue<EPI_SPLINE> (spline.h), same outputs.
+// the records are written float by float and read back 16 bytes at a time: the vector type must be allowed to alias
+typedef float f32x4_alias __attribute__((ext_vector_type(4), may_alias));
+constexpr int SPL_REC = 28;                                   // floats per record: 16-byte aligned, conflict-free
+constexpr int SPL_WAVE_BYTES = 16 * 16 * SPL_REC * 4;         // one 16-row block of one wave
+
+template <int KSPL>
+__device__ __forceinline__ void split_spline_epilogue(const GemmArgs& g, f32x4 (&acc)[3 * KSPL + 1][SMREP],
+                                                      const f32x4 (&rs)[SMREP], int nt, int n0, int wrow0, int lane,
+                                                      float* rec_base) {
+    constexpr int P = 3 * KSPL + 1;
+    static_assert(P + 1 <= SPL_REC, "record too small");
+    const FusedArgs& fu = g.fu;
+    const int cj = lane & 15, gq = lane >> 4;
+    const int slot = nt * 16 + cj;
+    const int fcol = fu.feat_index[slot];
+    const bool live = fcol >= 0;
+    float bias_p[P];
+    static_for<0, P>([&](auto pc) __attribute__((always_inline)) {
+        bias_p[pc.value] = g.bias ? g.bias[n0 + pc.value * 16 + cj] : 0.f;
+    });
+    float x0 = 0.f, xf = 1.f, y0 = 0.f, yf = 1.f;
+    if (live) {
+        const int ftr = fu.feat_tr[slot];
+        x0 = fu.x0[ftr];
+        xf = fu.xf[ftr];
+        y0 = fu.y0[ftr];
+        yf = fu.yf[ftr];
+    }
+    // all 16 inputs of this lane in flight at once
+    f32x4 xin[SMREP];
+    static_for<0, SMREP * 4>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int m = ic.value / 4, i = ic.value % 4;
+        const int row = wrow0 + m * 16 + gq * 4 + i;
+        xin[m][i] = (live && row < g.B) ? fu.x[(int64_t)row * fu.ldx + fcol] : 0.f;
+    });
+    float* rec0 = rec_base + ((gq * 4) * 16 + cj) * SPL_REC;      // record of (row gq*4, feature cj)
+    static_for<0, SMREP>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int m = mc.value;
+        static_for<0, P * 4>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int n = ic.value / 4, i = ic.value % 4;
+            rec0[i * 16 * SPL_REC + n] = acc[n][m][i] * rs[m][i] + bias_p[n];
+        });
+        static_for<0, 4>([&](auto ic) __attribute__((always_inline)) { rec0[ic.value * 16 * SPL_REC + P] = xin[m][ic.value]; });
+        // two records per iteration, in one basic block: their fp64 chains are independent and interleave
+#pragma nounroll
+        for (int i0 = 0; i0 < 4; i0 += 2) {
+            float prm[2][SPL_REC];
+            static_for<0, 2 * (SPL_REC / 4)>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int e = qc.value / (SPL_REC / 4), q4 = qc.value % (SPL_REC / 4);
+                const f32x4_alias q = ((const f32x4_alias*)(rec0 + (i0 + e) * 16 * SPL_REC))[q4];
+                prm[e][4 * q4] = q[0];
+                prm[e][4 * q4 + 1] = q[1];
+                prm[e][4 * q4 + 2] = q[2];
+                prm[e][4 * q4 + 3] = q[3];
+            });
+            double ld[2];
+            float outv[2];
+            static_for<0, 2>([&](auto ec) __attribute__((always_inline)) {
+                constexpr int e = ec.value;
+                float w[KSPL], h[KSPL], sraw[KSPL + 1];
+                static_for<0, KSPL>([&](auto kc) __attribute__((always_inline)) {
+                    w[kc.value] = prm[e][kc.value];
+                    h[kc.value] = prm[e][KSPL + kc.value];
+                    sraw[kc.value] = prm[e][2 * KSPL + kc.value];
+                });
+                const float lastp = prm[e][3 * KSPL];
+                sraw[KSPL] = fu.sf.circular ? sraw[0] : lastp;      // plain: K+1 slopes; circular: slope_K := slope_0
+                outv[e] = (float)rq_spline_forward_full<KSPL>(w, h, sraw, lastp, fu.sf, x0, xf, y0, yf, prm[e][P], &ld[e]);
+            });
+            static_for<0, 2>([&](auto ec) __attribute__((always_inline)) {
+                constexpr int e = ec.value;
+                const int row = wrow0 + m * 16 + gq * 4 + i0 + e;
+                const bool ok = live && row < g.B;
+                if (ok) fu.y[(int64_t)row * fu.ldy + fcol] = outv[e];
+                double l = ok ? ld[e] : 0.0;
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
+                if (cj == 0 && row < g.B) fu.ldj_partial[(int64_t)nt * g.B + row] = l;
+            });
+        }
+    });
+}
+
 template <int NREP, int EPI, int P, int KSPL>
 __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int n_rows_w) {
     using T = STile<NREP>;
@@ -173,6 +266,8 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
     const int nt = g.tile_order ? g.tile_order[ntp] : ntp;
     if (g.tile_live && !g.tile_live[(int64_t)mt * g.n_tiles + nt]) return;
     const int m0 = mt * T::BM, n0 = nt * T::BN;
+    const unsigned long long t_start = (g.diag & 16) ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long r_start = (g.diag & 16) ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     int kb = 0, ke = g.k_padded;
     if (g.k_ranges) {
@@ -204,7 +299,7 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
     char* a_wave = slds + wave * A_WAVE_BYTES;
     char* b_base = slds + T::A_BYTES;
 
-    const int nk = (ke - kb) / SBK;
+    const int nk = (g.diag & 2) ? 0 : (ke - kb) / SBK;      // diag 2: epilogue only (timing)
     if (nk > 0 && !(g.diag & 4)) {
 #pragma unroll
         for (int d = 0; d < T::N_DMA; ++d) split_dma<NREP>(sc, a_wave, b_base, kb, wave, d);
@@ -216,7 +311,10 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
     const int off_lo = fr * ROW_BYTES + (((2 * fg + 1) ^ fsw) << 4);
 
     for (int t = 0; t < nk; ++t) {
-        if (!(g.diag & 8)) __syncthreads();      // own A DMA + everybody's B DMA of tile t landed; other B stage free
+        // Own A DMA + everybody's B DMA of tile t landed; other B stage free.  The wait is explicit: the compiler's
+        // own LDS-DMA tracking was seen to emit vmcnt(1) here, leaving the last-issued chunk in flight.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(g.diag & 8)) __syncthreads();
         const char* Bs = b_base + (t & 1) * T::B_BYTES;
         char* Bn = b_base + ((t + 1) & 1) * T::B_BYTES;
         f16x8 ah[SMREP], al[SMREP];
@@ -238,12 +336,16 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
                 bh[(n + 1) & 1] = *(const f16x8*)(Bs + (n + 1) * 16 * ROW_BYTES + off_hi);
                 bl[(n + 1) & 1] = *(const f16x8*)(Bs + (n + 1) * 16 * ROW_BYTES + off_lo);
             }
-            // The next tile's DMA is spread over the column groups 1 .. NREP-2 (the A region is free once the
-            // fragments above are in registers, which the MFMAs of group 0 have waited for).
+            // The next tile's DMA goes out EARLY in this tile (a DMA issued late meets the barrier before it has
+            // landed): DMA_PER_GROUP instructions per column group from group 0 on, weights first -- their stage
+            // is free since the barrier -- then the wave's own A rows, whose region is free once the fragments
+            // above are in registers (the MFMAs of group 0 have waited for them).
             if (dma) {
                 static_for<0, T::N_DMA>([&](auto dc) __attribute__((always_inline)) {
-                    constexpr int d = decltype(dc)::value;
-                    if constexpr (1 + (d * (NREP - 2)) / T::N_DMA == n) split_dma<NREP>(sc, a_wave, Bn, k_next, wave, d);
+                    constexpr int d = decltype(dc)::value;                  // issue order
+                    constexpr int dd = d < T::B_DMA ? T::A_DMA + d : d - T::B_DMA;   // split_dma index: B first
+                    constexpr int slot = d < T::B_DMA ? d / DMA_PER_GROUP : 1 + d / DMA_PER_GROUP;
+                    if constexpr ((slot < NREP - 1 ? slot : NREP - 2) == n) split_dma<NREP>(sc, a_wave, Bn, k_next, wave, dd);
                 });
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -260,27 +362,47 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
         static_for<0, NREP * SMREP>([&](auto ic) __attribute__((always_inline)) {
             keep_alive(acc[ic.value / SMREP][ic.value % SMREP]);
         });
+        if (EPI == EPI_SPLINE && (g.diag & 16) && threadIdx.x == 0) {
+            atomicAdd(&g_split_cycles[0], __builtin_readcyclecounter() - t_start);
+            atomicAdd(&g_split_cycles[2], 1ull);
+            atomicAdd(&g_split_cycles[3], __builtin_amdgcn_s_memrealtime() - r_start);
+        }
         return;
     }
-    // Un-scale by the exact powers of two.  `acc` is only ever indexed by constants (so it lives in registers
-    // through the k-loop); the epilogues get a copy they may index from unrolled loops.
+    const unsigned long long t_loop = (g.diag & 16) ? __builtin_readcyclecounter() : 0ull;
+    // Un-scale by the exact powers of two (rs: per-row 1/scale of the activations times the weights' 1/scale).
+    // `acc` is only ever indexed by constants, so it lives in registers through the k-loop.
     const int wrow0 = m0 + wave * 16 * SMREP;
-    f32x4 out[NREP][SMREP];
+    f32x4 rs[SMREP];
     {
         const float ws = g.w_inv_scale[0];
         const int rq = (lane >> 4) * 4;
-        f32x4 rs[SMREP];
         static_for<0, SMREP * 4>([&](auto ic) __attribute__((always_inline)) {
             constexpr int m = ic.value / 4, i = ic.value % 4;
             const int row = wrow0 + m * 16 + rq + i;
             rs[m][i] = row < g.B ? g.a_inv_scale[row] * ws : 0.f;
         });
+    }
+    if constexpr (EPI == EPI_SPLINE) {
+        static_assert(SWAVES * SPL_WAVE_BYTES <= T::LDS_BYTES, "epilogue records do not fit in LDS");
+        __syncthreads();                        // every wave is done with the operand stages: LDS is reused below
+        split_spline_epilogue<KSPL>(g, acc, rs, nt, n0, wrow0, lane, (float*)(slds + wave * SPL_WAVE_BYTES));
+    } else {
+        // the other epilogues get a copy they may index from unrolled loops
+        f32x4 out[NREP][SMREP];
         static_for<0, NREP * SMREP>([&](auto ic) __attribute__((always_inline)) {
             constexpr int n = ic.value / SMREP, m = ic.value % SMREP;
             out[n][m] = acc[n][m] * rs[m];
         });
+        gemm_epilogue<SMREP, NREP, EPI, P, KSPL>(g, out, nt, n0, wrow0, lane);
     }
-    gemm_epilogue<SMREP, NREP, EPI, P, KSPL>(g, out, nt, n0, wrow0, lane);
+    if (EPI == EPI_SPLINE && (g.diag & 16) && threadIdx.x == 0) {
+        const unsigned long long t_end = __builtin_readcyclecounter();
+        atomicAdd(&g_split_cycles[0], t_loop - t_start);
+        atomicAdd(&g_split_cycles[1], t_end - t_loop);
+        atomicAdd(&g_split_cycles[2], 1ull);
+        atomicAdd(&g_split_cycles[3], __builtin_amdgcn_s_memrealtime() - r_start);
+    }
 }
 
 // The matrix-pipe ceiling of THIS device for the split GEMM's instruction mix (no memory).
@@ -392,6 +514,16 @@ int tfep_split_rows(const float* src, int64_t ld_src, int64_t rows, int64_t cols
     }
     split_rows_kernel<<<blocks, 256, 0, s>>>(src, ld_src, rows, cols, (uint4*)dst, ld_dst, cols_padded, inv_scale, max_bits);
     return check_launch("split_rows_kernel");
+}
+
+// Read and reset the TFEP_DIAG=16 cycle counters: out[0] k-loop, out[1] epilogue (shader cycles summed over workgroups), out[2] workgroups, out[3] lifetimes (100 MHz ticks).
+int tfep_diag_split_cycles(unsigned long long* out) {
+    TFEP_REQUIRE(out, "diag_split_cycles: NULL");
+    unsigned long long zero[4] = {0, 0, 0, 0};
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_split_cycles), sizeof(zero));
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_split_cycles), zero, sizeof(zero));
+    if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "diag_split_cycles: %s", hipGetErrorString(e));
+    return TFEP_OK;
 }
 
 int tfep_diag_split_mfma_peak(float* scratch, int blocks, int iters, void* stream) {
