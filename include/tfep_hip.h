@@ -275,6 +275,15 @@ int tfep_split_tile_k(void);
 int tfep_split_rows(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int64_t ld_dst,
                     int64_t cols_padded, float* inv_scale, int per_tensor, void* stream);
 
+/* tfep_masked_weight_prepare writing split rows directly (one scale for the matrix, an upper bound of max |w|:
+ * max |weight_g| with weight norm, max |weight_v| without).  in_of_col: PACKED column -> input column (the inverse
+ * of tfep_masked_weight_prepare's col_of_in), or NULL for the identity.  Only the out_features real rows are
+ * written (all k_padded columns of each): padding rows of w_split_out must already be zero.
+ * inv_scale: 2 floats as for tfep_split_rows(per_tensor = 1). */
+int tfep_masked_weight_prepare_split(const float* weight_v, const float* weight_g, const float* mask, int out_features,
+                                     int in_features, const int32_t* row_of_out, const int32_t* in_of_col,
+                                     void* w_split_out, int64_t ldw, int k_padded, float* inv_scale, void* stream);
+
 /* tfep_fused_output_transformer_forward on split operands: h_split (B rows, per-row h_inv_scale) and w_split (one
  * w_inv_scale); every other argument as above.  k_ranges must be multiples of 32. */
 int tfep_fused_output_transformer_forward_split(const void* h_split, int64_t ldh, const float* h_inv_scale,

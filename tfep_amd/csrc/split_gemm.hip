@@ -114,6 +114,54 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
     }
 }
 
+// Masked weight preparation straight into split rows (masked_linear.hip's weight_prepare_kernel + split_rows in one
+// pass over the weights).  One wave per output row: the row of v is read once coalesced for the weight-norm, then
+// gathered in PACKED column order (in_of_col: packed column -> input column; the row sits in L2 by then) so that
+// the split row is written with coalesced 32-byte pieces.  The matrix scale comes from *max_bits, an upper bound of
+// max |w|: max |g| with weight norm (|w_ij| = |g_i| |v_ij| / ||v_i|| <= |g_i|), max |v| without.
+__global__ void __launch_bounds__(256) weight_prepare_split_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                                   const float* __restrict__ mask, int N, int K,
+                                                                   const int32_t* __restrict__ row_of_out,
+                                                                   const int32_t* __restrict__ in_of_col,
+                                                                   uint4* __restrict__ w_out, int64_t ldw, int k_padded,
+                                                                   const uint32_t* __restrict__ max_bits,
+                                                                   float* __restrict__ inv_scale) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= N) return;
+    const int lane = threadIdx.x & 63;
+    const float* vr = v + (int64_t)o * K;
+    const float* mr = mask ? mask + (int64_t)o * K : nullptr;
+    float wn = 1.0f;
+    if (g) {
+        float ss = 0.f;
+        for (int i = lane; i < K; i += 64) ss += vr[i] * vr[i];
+        ss = wave_sum(ss);
+        wn = g[o] / sqrtf(ss);             // may be inf/NaN for a fully-masked row: never used below
+    }
+    const float s = pow2_scale_for(__uint_as_float(*max_bits));
+    if (o == 0 && lane == 0) inv_scale[0] = 1.0f / s;
+    const int64_t orow = row_of_out ? row_of_out[o] : o;
+    uint4* dr = w_out + orow * (ldw / 4);
+    for (int g8 = lane; g8 * 8 < k_padded; g8 += 64) {
+        f16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = g8 * 8 + j;
+            float val = 0.f;
+            if (c < K) {
+                const int i = in_of_col ? in_of_col[c] : c;
+                if (!(mr && mr[i] == 0.0f)) val = g ? vr[i] * wn : (mr ? vr[i] * mr[i] : vr[i]);
+            }
+            val *= s;
+            const _Float16 h = (_Float16)val;
+            hi[j] = h;
+            lo[j] = (_Float16)(val - (float)h);
+        }
+        dr[g8 * 2] = *reinterpret_cast<uint4*>(&hi);
+        dr[g8 * 2 + 1] = *reinterpret_cast<uint4*>(&lo);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // GEMM
 // ------------------------------------------------------------------------------------------
@@ -524,6 +572,28 @@ int tfep_diag_split_cycles(unsigned long long* out) {
     if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_split_cycles), zero, sizeof(zero));
     if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "diag_split_cycles: %s", hipGetErrorString(e));
     return TFEP_OK;
+}
+
+int tfep_masked_weight_prepare_split(const float* weight_v, const float* weight_g, const float* mask, int out_features,
+                                     int in_features, const int32_t* row_of_out, const int32_t* in_of_col,
+                                     void* w_split_out, int64_t ldw, int k_padded, float* inv_scale, void* stream) {
+    TFEP_REQUIRE(weight_v && w_split_out && inv_scale, "masked_weight_prepare_split: NULL pointer");
+    TFEP_REQUIRE(out_features >= 0 && in_features >= 0, "masked_weight_prepare_split: negative size");
+    TFEP_REQUIRE(k_padded >= in_features && k_padded % SBK == 0 && ldw >= k_padded && ldw % 4 == 0,
+                 "masked_weight_prepare_split: k_padded=%d must be a multiple of %d >= in_features, ldw >= k_padded", k_padded, SBK);
+    TFEP_REQUIRE((uintptr_t)w_split_out % 16 == 0, "masked_weight_prepare_split: output must be 16-byte aligned");
+    if (out_features == 0) return TFEP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* max_bits = reinterpret_cast<uint32_t*>(inv_scale + 1);
+    zero_u32_kernel<<<1, 1, 0, s>>>(max_bits);
+    if (weight_g)
+        absmax_kernel<<<1, 256, 0, s>>>(weight_g, 0, 1, out_features, max_bits);          // one wave over the N gains
+    else if (in_features > 0)
+        absmax_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, s>>>(weight_v, in_features, out_features, in_features, max_bits);
+    weight_prepare_split_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, s>>>(
+        weight_v, weight_g, mask, out_features, in_features, row_of_out, in_of_col, (uint4*)w_split_out, ldw, k_padded,
+        max_bits, inv_scale);
+    return check_launch("weight_prepare_split_kernel");
 }
 
 int tfep_diag_split_mfma_peak(float* scratch, int blocks, int iters, void* stream) {

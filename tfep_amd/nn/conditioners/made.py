@@ -227,7 +227,7 @@ class MADE(Conditioner):
         tm, tn, tk = ops.tile_sizes()
         lins = self._linears()
         n_lin = len(lins)
-        plan = {'row_of_out': [], 'col_of_in': [], 'n_pad': [], 'k_pad': [], 'k_ranges': [], 'tile_order': [],
+        plan = {'row_of_out': [], 'col_of_in': [], 'in_of_col': [], 'n_pad': [], 'k_pad': [], 'k_ranges': [], 'tile_order': [],
                 'w': [None] * n_lin, 'bias': [None] * n_lin}
         col_of_in = None
         for li, lin in enumerate(lins):
@@ -245,6 +245,12 @@ class MADE(Conditioner):
                 n_pad = ops.round_up(lin.out_features, tk)
             plan['row_of_out'].append(row_of_out)
             plan['col_of_in'].append(col_of_in)
+            if col_of_in is None:
+                plan['in_of_col'].append(None)
+            else:                                                     # packed column -> input unit
+                inv = torch.empty_like(col_of_in)
+                inv[col_of_in.long()] = torch.arange(len(col_of_in), device=device, dtype=torch.int32)
+                plan['in_of_col'].append(inv)
             plan['n_pad'].append(n_pad)
             plan['k_pad'].append(k_pad)
             n_tiles = (n_pad + tn - 1) // tn
@@ -279,22 +285,37 @@ class MADE(Conditioner):
             plan[('packed', li, n_rows)] = (buf, bias[0])
         return buf, bias[0]
 
+    def _pack_bias(self, lin, row_of_out, n_rows):
+        bias = torch.zeros(1, n_rows, dtype=torch.float32, device=lin.bias.device)
+        if row_of_out is None:
+            bias[0, :lin.out_features] = lin.bias.detach()
+        else:
+            ops.scatter_columns(lin.bias.detach()[None, :], row_of_out, bias)
+        return bias[0]
+
     def _pack_layer_split(self, plan, li, lin, row_of_out=None, n_rows=None):
-        """``_pack_layer`` followed by the conversion to split-f16 rows (one scale for the matrix).
-        Returns ``(w_split, w_inv_scale, bias)``."""
-        n_rows_key = plan['n_pad'][li] if n_rows is None else n_rows
-        if self._frozen and ('packed_split', li, n_rows_key) in plan:
-            return plan[('packed_split', li, n_rows_key)]
-        w, b = self._pack_layer(plan, li, lin, row_of_out, n_rows)
-        key = ('ws', li, n_rows_key)
+        """Weight norm + mask + permutation + padding of layer ``li`` written directly as split-f16 rows (one scale
+        for the matrix).  Returns ``(w_split, w_inv_scale, bias)``."""
+        row_of_out = plan['row_of_out'][li] if row_of_out is None else row_of_out
+        n_rows = plan['n_pad'][li] if n_rows is None else n_rows
+        if self._frozen and ('packed_split', li, n_rows) in plan:
+            return plan[('packed_split', li, n_rows)]
+        if lin.has_weight_norm:
+            v, g = lin.weight_v.detach(), lin.weight_g.detach()
+        else:
+            v, g = lin._parameters['weight'].detach(), None
+        key = ('ws', li, n_rows, None if row_of_out is None else row_of_out.data_ptr())
         buf = plan.get(key)
-        if buf is None or buf[0].shape != w.shape:
-            buf = (torch.empty_like(w), torch.empty(2, dtype=torch.float32, device=w.device))
+        if buf is None:
+            # zero once: the kernel writes the real rows only, padding rows / columns stay zero for good
+            buf = (torch.zeros(n_rows, plan['k_pad'][li], dtype=torch.float32, device=v.device),
+                   torch.empty(2, dtype=torch.float32, device=v.device))
             plan[key] = buf
-        ops.split_rows(w, w.shape[1], per_tensor=True, out=buf[0], inv_scale=buf[1])
-        res = (buf[0], buf[1], b)
+        in_of_col = plan['in_of_col'][li]
+        ops.masked_weight_prepare_split(v, g, lin.mask, row_of_out, in_of_col, buf[0], buf[1])
+        res = (buf[0], buf[1], self._pack_bias(lin, row_of_out, n_rows))
         if self._frozen:
-            plan[('packed_split', li, n_rows_key)] = res
+            plan[('packed_split', li, n_rows)] = res
         return res
 
     def _embed(self, x):

@@ -249,6 +249,18 @@ def split_rows(x, cols_padded, per_tensor=False, out=None, inv_scale=None):
     return out, inv_scale
 
 
+def masked_weight_prepare_split(weight_v, weight_g, mask, row_of_out, in_of_col, out, inv_scale):
+    """Effective masked weight written directly as split-f16 rows into ``out`` (n_rows_padded, k_padded), whose
+    padding rows must already be zero (``tfep_masked_weight_prepare_split``)."""
+    check_device_tensor(weight_v, 'weight')
+    N, K = weight_v.shape
+    call('tfep_masked_weight_prepare_split', ptr(weight_v.contiguous()),
+         ptr(None if weight_g is None else weight_g.contiguous()),
+         ptr(None if mask is None else mask.contiguous()), N, K, ptr(row_of_out), ptr(in_of_col),
+         ptr(out), out.shape[1], out.shape[1], ptr(inv_scale), stream_of(weight_v))
+    return out, inv_scale
+
+
 def masked_linear_split(x_split, x_inv_scale, w_split, w_inv_scale, bias, n_out, k_ranges=None, act=0, out=None,
                         tile_order=None):
     """``masked_linear_packed`` on split-f16 operands; the output is ordinary fp32."""
