@@ -148,8 +148,16 @@ class UnsupportedBackward(torch.autograd.Function):
             'transformers.')
 
 
-def _gemm(x, w, y, B, N, n_rows_w, bias=None, k_ranges=None, act=0, accumulate=0, elu_grad_of=None, tile_live=None):
+def _gemm(x, w, y, B, N, n_rows_w, bias=None, k_ranges=None, act=0, accumulate=0, elu_grad_of=None, tile_live=None,
+          split=False, w_split=None):
+    """``split``: run on split-f16 operands (x converted here with one scale per row; ``w_split`` = already converted
+    ``(rows, inv_scale)`` of w, else w is converted here with one scale for the matrix)."""
     d = _lib.GemmDesc()
+    if split:
+        xs, x_inv = ops.split_rows(x, x.shape[1])
+        ws, w_inv = w_split if w_split is not None else ops.split_rows(w, w.shape[1], per_tensor=True)
+        d.split, d.x_inv_scale, d.w_inv_scale = 1, x_inv.data_ptr(), w_inv.data_ptr()
+        x, w = xs, ws
     d.x, d.ldx = x.data_ptr(), x.shape[1]
     d.w, d.ldw = w.data_ptr(), w.shape[1]
     d.bias = bias.data_ptr() if bias is not None else None
@@ -271,6 +279,11 @@ def layer_backward(layer, x, gy, gldj):
         bias.append(b)
         wt = torch.zeros(k_pad[l], n_pad[l], **f32)
         WT.append(_transpose(w, n_pad[l], k_pad[l], wt))
+    # Split-f16 operands for every GEMM of the step (the same fp32-equivalent kernel as the forward pass): the packed
+    # weights and their transposes are converted once per backward, activations / gradients per use.
+    split = layer._use_split_gemm()
+    Ws = [ops.split_rows(w, w.shape[1], per_tensor=True) for w in W] if split else [None] * (L + 1)
+    WTs = [ops.split_rows(w, w.shape[1], per_tensor=True) for w in WT] if split else [None] * (L + 1)
     gW = [torch.zeros(n_pad[l], k_pad[l], **f32) for l in range(L + 1)]
     gb = [torch.zeros(n_pad[l], **f32) for l in range(L + 1)]
     gx = torch.empty(B, D, **f32)
@@ -287,9 +300,11 @@ def layer_backward(layer, x, gy, gldj):
         cin = emb(xc) if emb is not None else xc
         h = [ops.pad_columns(cin, k_pad[0])]
         for l in range(L):
-            h.append(ops.masked_linear_packed(h[-1], W[l], bias[l], n_pad[l], k_ranges=mplan['k_ranges'][l], act=1))
+            h.append(_gemm(h[-1], W[l], torch.empty(Bc, n_pad[l], **f32), Bc, n_pad[l], n_pad[l], bias=bias[l],
+                           k_ranges=mplan['k_ranges'][l], act=1, split=split, w_split=Ws[l]))
         theta = torch.empty(Bc, n_out_pad, **f32)
-        _gemm(h[-1], W[L], theta, Bc, n_out_pad, n_pad[L], bias=bias[L], k_ranges=bplan['k_ranges'][L])
+        _gemm(h[-1], W[L], theta, Bc, n_out_pad, n_pad[L], bias=bias[L], k_ranges=bplan['k_ranges'][L],
+              split=split, w_split=Ws[L])
 
         # ---- transformer VJP: gtheta (reference parameter layout, zero padded columns), direct gx
         if layer.has_fixed_indices:
@@ -317,12 +332,12 @@ def layer_backward(layer, x, gy, gldj):
             gT = _transpose(g, Bc, n_pad[l], torch.zeros(n_pad[l], Bc_pad, **f32))
             hT = _transpose(h[l], Bc, k_pad[l], torch.zeros(k_pad[l], Bc_pad, **f32))
             # grad_weight (packed) += g^T h   [rows n, cols k], masked tiles skipped
-            _gemm(gT, hT, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=1, tile_live=bplan['live'][l])
+            _gemm(gT, hT, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=1, tile_live=bplan['live'][l], split=split)
             del gT, hT
             # grad_input = g W  (x ELU'(h) for hidden inputs)
             gin = torch.empty(Bc, k_pad[l], **f32)
             _gemm(g, WT[l], gin, Bc, k_pad[l], k_pad[l], k_ranges=bplan['dx_ranges'][l],
-                  elu_grad_of=h[l] if l > 0 else None)
+                  elu_grad_of=h[l] if l > 0 else None, split=split, w_split=WTs[l])
             g = gin
 
         # ---- gradient w.r.t. the layer input: through the conditioner + direct
