@@ -349,15 +349,24 @@ class MADE(Conditioner):
                                              tile_order=plan['tile_order'][li])
         return h, plan
 
-    def forward(self, x):
+    def forward(self, x, split=None):
+        """Transformer parameters ``(..., n_out)`` (reference made.py:355).  ``split``: run the GEMMs on split-f16
+        operands (fp32-equivalent, ``csrc/split_gemm.hip``); None = the ``TFEP_SPLIT_GEMM`` default."""
+        split = ops.split_gemm_enabled() if split is None else bool(split)
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
-        h, plan = self.forward_hidden(x2)
+        h, plan = self.forward_hidden(x2, split=split)
         li = len(plan['n_pad']) - 1
         lin = self.layers[-1]
-        w, b = self._pack_layer(plan, li, lin)
-        out = ops.masked_linear_packed(h, w, b, lin.out_features, k_ranges=plan['k_ranges'][li], act=0,
-                                       tile_order=plan['tile_order'][li])
+        if split:
+            ws, w_inv, b = self._pack_layer_split(plan, li, lin)
+            hs, h_inv = ops.split_rows(h, plan['k_pad'][li])
+            out = ops.masked_linear_split(hs, h_inv, ws, w_inv, b, lin.out_features, k_ranges=plan['k_ranges'][li],
+                                          act=0, tile_order=plan['tile_order'][li])
+        else:
+            w, b = self._pack_layer(plan, li, lin)
+            out = ops.masked_linear_packed(h, w, b, lin.out_features, k_ranges=plan['k_ranges'][li], act=0,
+                                           tile_order=plan['tile_order'][li])
         return out.reshape(*lead, lin.out_features)
 
 

@@ -494,6 +494,8 @@ class AutoregressiveFlow(torch.nn.Module):
         """Run the conditioner (reference autoregressive.py:231-247)."""
         if len(self._conditioner_indices) > 0:
             x = ops.gather_columns(x, self._tables(x.device)['cond'])
+        if isinstance(self._conditioner, MADE):
+            return self._conditioner(x, split=self._use_split_gemm())
         return self._conditioner(x)
 
 
