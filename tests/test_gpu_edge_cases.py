@@ -133,3 +133,15 @@ def test_hip_graph_replay_matches_eager_and_tracks_parameter_updates():
         assert torch.equal(y2, ye) and torch.equal(l2, le2) and not torch.equal(y2, y1)
     with pytest.raises(ValueError, match='captured for shape'):
         gf(x[:10])
+
+
+def test_graft_entry_smoke_runs():
+    """The driver's round-end smoke test: forward vs oracle + one backward."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    entry = importlib.import_module('__graft_entry__')
+    entry.smoke()
