@@ -170,7 +170,7 @@ __global__ void __launch_bounds__(256) weight_prepare_split_kernel(const float* 
 // below N_ACC_AGPR accumulate in AGPRs, the rest in VGPRs.  (Left to the register allocator, the builtin form
 // shuffles tiles between the two files inside the k-loop and spills.)
 constexpr int N_ACC_AGPR = 16;
-constexpr int DMA_PER_GROUP = 4;   // LDS-DMA instructions issued per column group at the head of a k-tile
+constexpr int B_AHEAD = 2;         // column groups of B fragments in flight ahead of the MFMAs
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -308,7 +308,8 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
     using T = STile<NREP>;
     extern __shared__ __attribute__((aligned(16))) char slds[];
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave index in an SGPR: LDS addresses of the DMA (M0) are then scalar arithmetic, no v_readfirstlane per instruction
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int mt, ntp;
     if (!map_block(g, mt, ntp)) return;
     const int nt = g.tile_order ? g.tile_order[ntp] : ntp;
@@ -348,7 +349,7 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
     char* b_base = slds + T::A_BYTES;
 
     const int nk = (g.diag & 2) ? 0 : (ke - kb) / SBK;      // diag 2: epilogue only (timing)
-    if (nk > 0 && !(g.diag & 4)) {
+    if (nk > 0) {
 #pragma unroll
         for (int d = 0; d < T::N_DMA; ++d) split_dma<NREP>(sc, a_wave, b_base, kb, wave, d);
     }
@@ -358,7 +359,10 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
     const int off_hi = fr * ROW_BYTES + (((2 * fg) ^ fsw) << 4);
     const int off_lo = fr * ROW_BYTES + (((2 * fg + 1) ^ fsw) << 4);
 
-    for (int t = 0; t < nk; ++t) {
+    // One k-tile.  DMA = true: also issue the LDS-DMA of tile t + 1 (every tile but the last; a separate
+    // instantiation, so the k-loop has no branch around the DMA instructions and they sit BETWEEN the MFMAs).
+    auto tile = [&](auto dma_c, int t) __attribute__((always_inline)) {
+        constexpr bool DMA = decltype(dma_c)::value;
         // Own A DMA + everybody's B DMA of tile t landed; other B stage free.  The wait is explicit: the compiler's
         // own LDS-DMA tracking was seen to emit vmcnt(1) here, leaving the last-issued chunk in flight.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -371,38 +375,51 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
             ah[m] = *(const f16x8*)(a_wave + m * 16 * ROW_BYTES + off_hi);
             al[m] = *(const f16x8*)(a_wave + m * 16 * ROW_BYTES + off_lo);
         }
-        f16x8 bh[2], bl[2];
-        bh[0] = *(const f16x8*)(Bs + off_hi);
-        bl[0] = *(const f16x8*)(Bs + off_lo);
-        const bool dma = t + 1 < nk && !(g.diag & 4);
+        // B fragments run B_AHEAD column groups ahead of the MFMAs that use them (ring of B_AHEAD + 1 register sets):
+        // a lone wave per SIMD has to cover the LDS latency itself.
+        f16x8 bh[B_AHEAD + 1], bl[B_AHEAD + 1];
+        static_for<0, B_AHEAD>([&](auto pc) __attribute__((always_inline)) {
+            if constexpr (pc.value < NREP) {
+                bh[pc.value] = *(const f16x8*)(Bs + pc.value * 16 * ROW_BYTES + off_hi);
+                bl[pc.value] = *(const f16x8*)(Bs + pc.value * 16 * ROW_BYTES + off_lo);
+            }
+        });
         const int k_next = kb + (t + 1) * SBK;
+        // The next tile's DMA goes out EARLY in this tile (a DMA issued late meets the barrier before it has landed),
+        // one instruction after each group of four MFMAs -- a lone wave that issues a clump of DMA instructions
+        // starves its matrix pipe meanwhile.  Weights first: their stage is free since the barrier; then the wave's
+        // own A rows, whose region is free once the fragments above are in registers (group 0 has waited for them).
+        auto dma_slot = [&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;                                   // issue order
+            if constexpr (DMA && q < T::N_DMA) {
+                constexpr int dd = q < T::B_DMA ? T::A_DMA + q : q - T::B_DMA;       // split_dma index: B first
+                static_assert(q < T::B_DMA || q / 3 >= 1, "A DMA before the A fragments are read");
+                __builtin_amdgcn_sched_barrier(0);
+                split_dma<NREP>(sc, a_wave, Bn, k_next, wave, dd);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         // Column groups as a compile-time loop: the accumulator indices must be constants in the frontend,
         // or the 400-register array is not promoted out of scratch memory.
         static_for<0, NREP>([&](auto nc) __attribute__((always_inline)) {
             constexpr int n = decltype(nc)::value;
-            if constexpr (n + 1 < NREP) {
-                bh[(n + 1) & 1] = *(const f16x8*)(Bs + (n + 1) * 16 * ROW_BYTES + off_hi);
-                bl[(n + 1) & 1] = *(const f16x8*)(Bs + (n + 1) * 16 * ROW_BYTES + off_lo);
-            }
-            // The next tile's DMA goes out EARLY in this tile (a DMA issued late meets the barrier before it has
-            // landed): DMA_PER_GROUP instructions per column group from group 0 on, weights first -- their stage
-            // is free since the barrier -- then the wave's own A rows, whose region is free once the fragments
-            // above are in registers (the MFMAs of group 0 have waited for them).
-            if (dma) {
-                static_for<0, T::N_DMA>([&](auto dc) __attribute__((always_inline)) {
-                    constexpr int d = decltype(dc)::value;                  // issue order
-                    constexpr int dd = d < T::B_DMA ? T::A_DMA + d : d - T::B_DMA;   // split_dma index: B first
-                    constexpr int slot = d < T::B_DMA ? d / DMA_PER_GROUP : 1 + d / DMA_PER_GROUP;
-                    if constexpr ((slot < NREP - 1 ? slot : NREP - 2) == n) split_dma<NREP>(sc, a_wave, Bn, k_next, wave, dd);
-                });
+            if constexpr (n + B_AHEAD < NREP) {
+                bh[(n + B_AHEAD) % (B_AHEAD + 1)] = *(const f16x8*)(Bs + (n + B_AHEAD) * 16 * ROW_BYTES + off_hi);
+                bl[(n + B_AHEAD) % (B_AHEAD + 1)] = *(const f16x8*)(Bs + (n + B_AHEAD) * 16 * ROW_BYTES + off_lo);
             }
             __builtin_amdgcn_sched_barrier(0);
-            const f16x8 h = bh[n & 1], l = bl[n & 1];
+            const f16x8 h = bh[n % (B_AHEAD + 1)], l = bl[n % (B_AHEAD + 1)];
             static_for<0, SMREP>([&](auto mc) __attribute__((always_inline)) { mfma16<(n < N_ACC_AGPR)>(acc[n][mc.value], ah[mc.value], h); });
+            dma_slot(std::integral_constant<int, 3 * n>{});
             static_for<0, SMREP>([&](auto mc) __attribute__((always_inline)) { mfma16<(n < N_ACC_AGPR)>(acc[n][mc.value], al[mc.value], h); });
+            dma_slot(std::integral_constant<int, 3 * n + 1>{});
             static_for<0, SMREP>([&](auto mc) __attribute__((always_inline)) { mfma16<(n < N_ACC_AGPR)>(acc[n][mc.value], ah[mc.value], l); });
+            dma_slot(std::integral_constant<int, 3 * n + 2>{});
         });
-    }
+    };
+    static_assert(T::N_DMA <= 3 * NREP, "not enough DMA slots in a k-tile");
+    for (int t = 0; t + 1 < nk; ++t) tile(std::true_type{}, t);
+    if (nk > 0) tile(std::false_type{}, nk - 1);
     // The MFMAs are inline asm: leave the matrix pipe's result latency behind before anything reads acc.
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
