@@ -124,3 +124,34 @@ def test_forward_paths_agree_on_golden_flows():
             yf, lf = flow(x)
         assert float((ys - yf).norm() / yf.norm()) < 1e-6, name
         assert torch.allclose(ls, lf, rtol=1e-5, atol=2e-5), name
+
+
+def test_split_gemm_non_finite_and_extreme_rows_stay_local():
+    """A NaN / inf / huge / tiny activation row must not disturb the other rows (per-row scales)."""
+    from tfep_amd import ops
+    torch.manual_seed(5)
+    B, K, N = 64, 256, 96
+    a = torch.randn(B, K, device='cuda')
+    w = torch.randn(N, K, device='cuda') / 16
+    bias = torch.zeros(N, device='cuda')
+    wp = ops.masked_weight_prepare(w, None, None, n_rows_padded=N, k_padded=K)
+    ws_, winv = ops.split_rows(wp, K, per_tensor=True)
+
+    def run(a_):
+        as_, ainv = ops.split_rows(a_, K)
+        return ops.masked_linear_split(as_, ainv, ws_, winv, bias, N)
+    clean = run(a)
+    a2 = a.clone()
+    a2[3, 5] = float('nan')
+    a2[7, 9] = float('inf')
+    a2[11] *= 1e30
+    a2[13] *= 1e-30
+    y = run(a2)
+    keep = torch.ones(B, dtype=torch.bool, device='cuda')
+    keep[[3, 7, 11, 13]] = False
+    assert torch.equal(y[keep], clean[keep])
+    assert not torch.isfinite(y[3]).any() and not torch.isfinite(y[7]).all()
+    ref11 = (a2[11].double() @ w.double().T)
+    assert float(((y[11].double() - ref11).abs() / (a2[11].double().abs() @ w.double().abs().T)).max()) < 1e-6
+    ref13 = (a2[13].double() @ w.double().T)
+    assert float(((y[13].double() - ref13).abs() / (a2[13].double().abs() @ w.double().abs().T)).max()) < 1e-6
