@@ -338,3 +338,45 @@ def periodic_embedding_degrees_out(degrees_in, periodic_indices, nonperiodic_ind
     degrees_in = np.asarray(degrees_in)
     return np.concatenate([degrees_in[nonperiodic_indices],
                            np.repeat(degrees_in[periodic_indices], 2)])
+
+
+# -----------------------------------------------------------------------------
+# Flip-invariant and mixed embeddings (mafembed.py:174-446)
+# -----------------------------------------------------------------------------
+
+def _elu(v):
+    return np.where(v > 0, v, np.expm1(np.minimum(v, 0)))
+
+
+def _mlp2(v, w0, b0, w1, b1):
+    """Linear -> ELU -> Linear with torch.nn.Linear weights (out, in).  Ref: mafembed.py:219-228."""
+    return _elu(v @ w0.T + b0) @ w1.T + b1
+
+
+def flip_invariant_embedding(x, embedded_indices, nonembedded_indices, vector_dimension, emb_net, weight_net):
+    """[x_nonembedded..., per vector: softmax-weighted sum of emb_net(v) and emb_net(-v)].
+    ``emb_net`` / ``weight_net``: (w0, b0, w1, b1).  Ref: mafembed.py:257-306."""
+    b = x.shape[0]
+    v = x[:, embedded_indices].reshape(-1, vector_dimension)
+    e = np.stack([_mlp2(v, *emb_net), _mlp2(-v, *emb_net)], axis=1)           # (b * n_vec, 2, E)
+    a = np.stack([_mlp2(v, *weight_net), _mlp2(-v, *weight_net)], axis=1)     # (b * n_vec, 2, 1)
+    a = a - a.max(axis=1, keepdims=True)
+    wgt = np.exp(a)
+    wgt = wgt / wgt.sum(axis=1, keepdims=True)
+    emb = (wgt * e).sum(axis=1).reshape(b, -1)
+    return np.concatenate([x[:, nonembedded_indices], emb], axis=1).astype(x.dtype)
+
+
+def flip_invariant_embedding_degrees_out(degrees_in, embedded_indices, nonembedded_indices, vector_dimension,
+                                         embedding_dimension):
+    """Ref: mafembed.py:308-348."""
+    degrees_in = np.asarray(degrees_in)
+    vec = degrees_in[embedded_indices].reshape(-1, vector_dimension)
+    if not np.all(vec == vec[:, [0]]):
+        raise ValueError('The same degree must be assigned to all components of each embedded vectors.')
+    return np.concatenate([degrees_in[nonembedded_indices], np.repeat(vec[:, 0], embedding_dimension)])
+
+
+def mixed_embedding(x, parts, nonembedded_indices):
+    """``parts``: list of (indices, callable) -- each callable embeds ``x[:, indices]``.  Ref: mafembed.py:411-427."""
+    return np.concatenate([x[:, nonembedded_indices]] + [f(x[:, idx]) for idx, f in parts], axis=1).astype(x.dtype)

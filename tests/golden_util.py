@@ -310,3 +310,54 @@ def build_wrapped(cfg, inner, flows_module):
                'partial': flows_module.PartialFlow}[kind]
         flow = cls(flow, **kw)
     return flow
+
+
+# ---------------------------------------------------------------------------
+# golden embeddings (tools/gen_golden.py:gen_embeddings)
+# ---------------------------------------------------------------------------
+
+def embedding_configs():
+    """name -> config; ``degrees_in`` is only used for get_degrees_out."""
+    return {
+        'flip_all': dict(kind='flip', n_features_in=8, embedding_dimension=3, degrees_in=[0, 0, 0, 0, 1, 1, 1, 1]),
+        'flip_some': dict(kind='flip', n_features_in=9, embedding_dimension=5, embedded_indices=[2, 3, 4, 6, 7, 8],
+                          vector_dimension=3, hidden_layer_width=16, degrees_in=[2, 0, 1, 1, 1, 4, 3, 3, 3]),
+        'mixed': dict(kind='mixed', n_features_in=13, degrees_in=[0, 5, 1, 2, 2, 2, 6, 3, 3, 3, 4, 7, 8],
+                      layers=[dict(kind='periodic', n_features_in=2, limits=[-1.0, 1.0]),
+                              dict(kind='flip', n_features_in=6, embedding_dimension=2, vector_dimension=3)],
+                      embedded_indices=[[1, 11], [3, 4, 5, 7, 8, 9]]),
+    }
+
+
+def embedded_flow_configs():
+    """MAF layers whose conditioner sees an embedding (reference tests/nn/flows/test_maf.py:60-110)."""
+    return {
+        # two quaternions after two plain features; fused spline path
+        'flipflow': dict(degrees_in=[0, 1, 2, 2, 2, 2, 3, 3, 3, 3], transformer='spline',
+                         embedding=dict(kind='flip', n_features_in=10, embedding_dimension=3,
+                                        embedded_indices=[2, 3, 4, 5, 6, 7, 8, 9])),
+        # periodic + flip-invariant embeddings side by side, one conditioning feature, affine transformer
+        'mixembflow': dict(degrees_in=[0, -1, 1, 2, 2, 2, 3, 4, 4, 4], transformer='affine',
+                           embedding=dict(kind='mixed', n_features_in=10,
+                                          layers=[dict(kind='periodic', n_features_in=2, limits=[-3.0, 3.0]),
+                                                  dict(kind='flip', n_features_in=6, embedding_dimension=2,
+                                                       vector_dimension=3, hidden_layer_width=8)],
+                                          embedded_indices=[[0, 6], [3, 4, 5, 7, 8, 9]])),
+    }
+
+
+def build_embedding(cfg, module):
+    """Embedding described by ``cfg`` from the classes of ``module`` (tfep_amd.nn.embeddings or the reference)."""
+    kind = cfg['kind']
+    if kind == 'periodic':
+        return module.PeriodicEmbedding(n_features_in=cfg['n_features_in'], limits=list(cfg['limits']),
+                                        periodic_indices=cfg.get('periodic_indices'))
+    if kind == 'flip':
+        kw = {k: cfg[k] for k in ('embedded_indices', 'vector_dimension', 'hidden_layer_width') if k in cfg}
+        return module.FlipInvariantEmbedding(n_features_in=cfg['n_features_in'],
+                                             embedding_dimension=cfg['embedding_dimension'], **kw)
+    if kind == 'mixed':
+        return module.MixedEmbedding(n_features_in=cfg['n_features_in'],
+                                     embedding_layers=[build_embedding(c, module) for c in cfg['layers']],
+                                     embedded_indices=cfg['embedded_indices'])
+    raise ValueError(kind)

@@ -1,1 +1,1 @@
-from .mafembed import MAFEmbedding, PeriodicEmbedding  # noqa: F401
+from .mafembed import FlipInvariantEmbedding, MAFEmbedding, MixedEmbedding, PeriodicEmbedding  # noqa: F401

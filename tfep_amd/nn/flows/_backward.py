@@ -22,7 +22,7 @@ import torch
 
 from ... import _lib, ops
 from ..conditioners.made import MADE
-from ..embeddings.mafembed import PeriodicEmbedding
+from ..embeddings.mafembed import MAFEmbedding, PeriodicEmbedding
 from ..transformers.affine import AffineTransformer, VolumePreservingShiftTransformer
 from ..transformers.mixed import MixedTransformer
 from ..transformers.moebius import MoebiusTransformer
@@ -37,9 +37,15 @@ def supported(layer):
     if not isinstance(made, MADE) or len(layer._conditioner_indices) > 0:
         return False
     emb = getattr(made, 'embedding', None)
-    if emb is not None and type(emb) is not PeriodicEmbedding:
+    if emb is not None and not isinstance(emb, MAFEmbedding):
         return False
     return _transformer_supported(layer._transformer)
+
+
+def _embedding_params(layer):
+    """Trainable parameters of the conditioner's embedding (FlipInvariantEmbedding networks), if any."""
+    emb = getattr(layer._conditioner, 'embedding', None)
+    return [] if emb is None else list(emb.parameters())
 
 
 def _transformer_supported(tr):
@@ -111,7 +117,7 @@ def trainable_tensors(layer):
         else:
             out += [lin._parameters['weight']]
         out.append(lin.bias)
-    return out
+    return out + _embedding_params(layer)
 
 
 class MAFLayerFunction(torch.autograd.Function):
@@ -144,7 +150,7 @@ class UnsupportedBackward(torch.autograd.Function):
     def backward(ctx, gy, gldj):
         raise NotImplementedError(
             'tfep_amd: backward is implemented for MAF layers with a MADE conditioner (optionally with a '
-            'PeriodicEmbedding) and affine / fixed-bound neural-spline / Moebius / volume-preserving / mixed '
+            'MAFEmbedding) and affine / fixed-bound neural-spline / Moebius / volume-preserving / mixed '
             'transformers.')
 
 
@@ -242,7 +248,7 @@ def layer_backward(layer, x, gy, gldj):
     if not supported(layer):
         raise NotImplementedError(
             'tfep_amd: backward is implemented for MAF layers with a MADE conditioner (optionally with a '
-            'PeriodicEmbedding) and affine / fixed-bound neural-spline / Moebius / volume-preserving / mixed '
+            'MAFEmbedding) and affine / fixed-bound neural-spline / Moebius / volume-preserving / mixed '
             'transformers.')
     x, _ = _lib.rows(x, 'x')
     gy = gy.contiguous().float()
@@ -287,6 +293,9 @@ def layer_backward(layer, x, gy, gldj):
     gW = [torch.zeros(n_pad[l], k_pad[l], **f32) for l in range(L + 1)]
     gb = [torch.zeros(n_pad[l], **f32) for l in range(L + 1)]
     gx = torch.empty(B, D, **f32)
+    emb_generic = emb is not None and type(emb) is not PeriodicEmbedding
+    emb_params = _embedding_params(layer)
+    g_emb = [torch.zeros_like(p) for p in emb_params]
 
     chunk = max(tm, min(B, (_CHUNK_BYTES // (4 * n_out_pad)) // tm * tm))
     for b0 in range(0, B, chunk):
@@ -297,7 +306,14 @@ def layer_backward(layer, x, gy, gldj):
         glc = gldj[b0:b1] if gldj is not None else None
 
         # ---- recompute the conditioner forward for the chunk
-        cin = emb(xc) if emb is not None else xc
+        if emb_generic:
+            # any other MAFEmbedding (flip-invariant / mixed): differentiated by autograd, chunk by chunk
+            with torch.enable_grad():
+                x_emb = xc.detach().requires_grad_(True)
+                cin_graph = emb(x_emb)
+            cin = cin_graph.detach()
+        else:
+            cin = emb(xc) if emb is not None else xc
         h = [ops.pad_columns(cin, k_pad[0])]
         for l in range(L):
             h.append(_gemm(h[-1], W[l], torch.empty(Bc, n_pad[l], **f32), Bc, n_pad[l], n_pad[l], bias=bias[l],
@@ -341,8 +357,15 @@ def layer_backward(layer, x, gy, gldj):
             g = gin
 
         # ---- gradient w.r.t. the layer input: through the conditioner + direct
-        if emb is not None:
-            per, non = emb._i32[str(dev)]
+        if emb_generic:
+            g_in = torch.autograd.grad(cin_graph, [x_emb] + emb_params, g[:, :cin.shape[1]].contiguous(), allow_unused=True)
+            gxc = g_in[0].contiguous() if g_in[0] is not None else torch.zeros(Bc, D, **f32)
+            for acc_g, new_g in zip(g_emb, g_in[1:]):
+                if new_g is not None:
+                    acc_g += new_g
+            del cin_graph, x_emb
+        elif emb is not None:
+            per, non = emb.device_indices(dev)
             gxc = torch.zeros(Bc, D, **f32)
             _lib.call('tfep_periodic_embedding_backward', _lib.ptr(xc), xc.shape[1] if Bc > 1 else D, _lib.ptr(per),
                       per.numel(), _lib.ptr(non), non.numel(), *emb.host_limits(),
@@ -379,4 +402,4 @@ def layer_backward(layer, x, gy, gldj):
             grads.append(gb[l][:lin.out_features].clone())
         else:
             grads.append(ops.gather_columns(gb[l][None, :], row_of_out)[0])
-    return gx, grads
+    return gx, grads + g_emb

@@ -23,7 +23,7 @@ import ref_shim  # noqa: F401,E402
 
 from tfep.nn import masked as rmasked  # noqa: E402
 from tfep.nn.conditioners.made import MADE, generate_degrees  # noqa: E402
-from tfep.nn.embeddings.mafembed import PeriodicEmbedding  # noqa: E402
+from tfep.nn.embeddings.mafembed import FlipInvariantEmbedding, MixedEmbedding, PeriodicEmbedding  # noqa: E402
 from tfep.nn.flows.maf import MAF  # noqa: E402
 from tfep.nn.flows.sequential import SequentialFlow  # noqa: E402
 from tfep.nn.transformers.affine import AffineTransformer, VolumePreservingShiftTransformer  # noqa: E402
@@ -802,6 +802,56 @@ def gen_wrappers():
     np.savez_compressed(os.path.join(OUT, 'wrappers.npz'), **out)
 
 
+# -----------------------------------------------------------------------------
+# 9. flip-invariant / mixed embeddings: standalone and in front of a MAF (forward, inverse, gradients)
+# -----------------------------------------------------------------------------
+
+def gen_embeddings():
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    import golden_util as gu
+    out = {}
+    for i, (name, cfg) in enumerate(gu.embedding_configs().items()):
+        torch.manual_seed(900 + i)
+        emb = gu.build_embedding(cfg, sys.modules[__name__])
+        x = torch.randn(24, cfg['n_features_in'], generator=gen(5000 + i))
+        with f64():
+            e64 = gu.build_embedding(cfg, sys.modules[__name__])
+            e64.load_state_dict(to_double_sd(emb.state_dict()))
+            out[f'emb/{name}/out_f64'] = npy(e64(x.double()))
+        out[f'emb/{name}/x'] = npy(x)
+        out[f'emb/{name}/out_f32'] = npy(emb(x))
+        for k, v in emb.state_dict().items():
+            out[f'emb/{name}/sd/{k}'] = npy(v)
+        deg = torch.as_tensor(cfg['degrees_in'])
+        out[f'emb/{name}/degrees_out'] = npy(emb.get_degrees_out(deg))
+
+    for i, (name, cfg) in enumerate(gu.embedded_flow_configs().items()):
+        x = torch.randn(40, len(cfg['degrees_in']), generator=gen(5100 + i)) * 0.8
+
+        def make(dt, cfg=cfg):
+            n_tr = sum(1 for d in cfg['degrees_in'] if d >= 0)
+            if cfg['transformer'] == 'spline':
+                tr = NeuralSplineTransformer(x0=torch.full((n_tr,), -4.0), xf=torch.full((n_tr,), 4.0), n_bins=8)
+            else:
+                tr = AffineTransformer()
+            return SequentialFlow(MAF(degrees_in=torch.as_tensor(cfg['degrees_in']), transformer=tr,
+                                      embedding=gu.build_embedding(cfg['embedding'], sys.modules[__name__]),
+                                      initialize_identity=False))
+        run_flow(make, x, 700 + i, out, name, inverse=True)
+        with f64():
+            m = make(torch.float64)
+            m.load_state_dict(to_double_sd({k[len(name) + 4:]: torch.from_numpy(v) for k, v in out.items()
+                                            if k.startswith(name + '/sd/')}), strict=False)
+            xg = x.double().requires_grad_(True)
+            y, ldj = m(xg)
+            c = torch.cos(torch.arange(y.shape[0]).unsqueeze(1) + 2.0 * torch.arange(y.shape[1]).unsqueeze(0))
+            ((y * c).sum() + ldj.sum()).backward()
+            out[f'{name}/gx_f64'] = npy(xg.grad)
+            for k, prm in m.named_parameters():
+                out[f'{name}/gp/{k}'] = npy(prm.grad)
+    np.savez_compressed(os.path.join(OUT, 'embeddings.npz'), **out)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
     if len(sys.argv) > 1:
@@ -816,5 +866,6 @@ if __name__ == '__main__':
     gen_grads()
     gen_loss()
     gen_wrappers()
+    gen_embeddings()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
