@@ -382,6 +382,18 @@ int tfep_tfep_reduce(const float* target_potentials, const float* log_det_J,
 /* Size (in doubles) of the device workspace tfep_tfep_reduce needs for N samples. */
 int tfep_tfep_reduce_workspace_doubles(int N);
 
+/*
+ * Bootstrap distribution of fep_estimator (analysis/bootstrap.py:185-262 with statistic = fep_estimator,
+ * estimator.py:73-86), one workgroup per resample, the resampled data never materialised:
+ *   out[r] = -kT (logsumexp_j(-work[i]/kT [+ bias[i]/kT]) - log sample_size [or - logsumexp_j bias[i]/kT]),
+ *   i = indices[r][j]  (indices: (n_resamples, sample_size) int64 in [0, n_data), as drawn by torch.randint), or
+ *   Bayesian bootstrap (indices == NULL, i = j, sample_size <= n_data): weights (n_resamples, sample_size) summing to
+ *   one per row, out[r] = -kT logsumexp_j(-work[j]/kT + log weights[r][j])   (bias must be NULL).
+ * work / bias: (n_data) fp32; out: (n_resamples) float64.
+ */
+int tfep_bootstrap_fep(const float* work, const float* bias, const int64_t* indices, const float* weights,
+                       int64_t n_data, int64_t n_resamples, int64_t sample_size, float kT, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

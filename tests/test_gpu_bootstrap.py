@@ -1,0 +1,99 @@
+"""GPU tests of the bootstrap analysis (tfep_amd.analysis.bootstrap, kernel tfep_bootstrap_fep) against the reference's
+bootstrap(fep_estimator) run with the same CPU generator (tests/golden/bootstrap.npz), plus the reference's own
+statistical checks (tests/analysis/test_bootstrap.py)."""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    'plain': dict(data='work', kw=dict(n_resamples=300)),
+    'batched_cl80': dict(data='work', kw=dict(n_resamples=250, batch=64, confidence_level=0.8)),
+    'sizes': dict(data='work', kw=dict(n_resamples=200, bootstrap_sample_size=[50, 600])),
+    'sizes_first': dict(data='work', kw=dict(n_resamples=200, bootstrap_sample_size=[50, 300], take_first_only=True)),
+    'biased': dict(data='biased', kw=dict(n_resamples=200, batch=50)),
+}
+
+
+def _data(g, kind):
+    work, bias = torch.from_numpy(g['work']).cuda(), torch.from_numpy(g['bias']).cuda()
+    return work if kind == 'work' else torch.stack([work, bias], dim=1)
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_bootstrap_matches_reference_with_the_same_generator(name):
+    from tfep_amd.analysis import bootstrap, fep_estimator
+    g = gu.load('bootstrap.npz')
+    c = CASES[name]
+    res = bootstrap(_data(g, c['data']), fep_estimator, generator=torch.Generator().manual_seed(7100), **c['kw'])
+    res = res if isinstance(res, list) else [res]
+    assert len(res) == int(g[f'{name}/n'])
+    for i, r in enumerate(res):
+        got = np.array([float(r['confidence_interval']['low']), float(r['confidence_interval']['high']),
+                        float(r['standard_deviation']), float(r['mean']), float(r['median'])])
+        np.testing.assert_allclose(got, g[f'{name}/{i}'], rtol=2e-5, atol=2e-5)
+
+
+def test_bootstrap_kernel_on_explicit_resamples_and_bayesian_weights():
+    from tfep_amd.analysis import bootstrap_fep
+    g = gu.load('bootstrap.npz')
+    idx = torch.from_numpy(g['explicit/idx']).cuda()
+    np.testing.assert_allclose(bootstrap_fep(_data(g, 'work'), indices=idx).cpu().numpy(), g['explicit/df_work'], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(bootstrap_fep(_data(g, 'biased'), indices=idx).cpu().numpy(), g['explicit/df_biased'], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(bootstrap_fep(_data(g, 'work'), indices=idx, kT=0.7).cpu().numpy(), g['explicit/df_work_kT'],
+                               rtol=2e-6, atol=2e-6)
+    w = torch.from_numpy(g['bayes/weights']).cuda()
+    np.testing.assert_allclose(bootstrap_fep(_data(g, 'work'), weights=w).cpu().numpy(), g['bayes/df'], rtol=2e-6, atol=2e-6)
+    with pytest.raises(NotImplementedError):
+        bootstrap_fep(_data(g, 'biased'), weights=w)
+    with pytest.raises(ValueError):
+        bootstrap_fep(_data(g, 'work'))
+
+
+@pytest.mark.parametrize('bayesian', [False, True])
+def test_fep_estimator_bootstrap_statistics(bayesian):
+    """Work values ~ N(0, 1) give dF ~ -0.5 (reference test_bootstrap.py:178-190); device generator, partial(kT)."""
+    from tfep_amd.analysis import bootstrap, fep_estimator
+    work = torch.randn(10000, device='cuda', generator=torch.Generator('cuda').manual_seed(1))
+    res = bootstrap(work, fep_estimator, n_resamples=2000, batch=500, bayesian=bayesian, method='basic',
+                    generator=None if bayesian else 3)
+    assert abs(float(res['mean']) + 0.5) < 0.1
+    assert float(res['confidence_interval']['low']) < float(res['median']) < float(res['confidence_interval']['high'])
+    res2 = bootstrap(2.0 * work, functools.partial(fep_estimator, kT=2.0), n_resamples=500, bayesian=bayesian)
+    assert abs(float(res2['mean']) + 1.0) < 0.2
+
+
+@pytest.mark.parametrize('bayesian', [False, True])
+def test_generic_statistics_and_errors(bayesian):
+    """A user statistic goes through the gather-and-call path (reference test_bootstrap.py:112-176, 193-206)."""
+    from tfep_amd.analysis import bootstrap
+
+    def mean(data, weights=None, vectorized=True):
+        if weights is not None:
+            return torch.sum(data * weights, dim=-1)
+        return torch.mean(data, dim=-1)
+
+    def triple_sum(_data, weights=None, vectorized=True):
+        s = torch.sum(_data, dim=-1)
+        if weights is not None:
+            return torch.sum(s * weights, dim=-1)
+        return torch.mean(s, dim=-1)
+
+    data = torch.randn(1000, device='cuda')
+    results = bootstrap(data, mean, n_resamples=500, bootstrap_sample_size=[10, 100, 1000], take_first_only=bayesian,
+                        bayesian=bayesian)
+    width = [float(r['confidence_interval']['high'] - r['confidence_interval']['low']) for r in results]
+    assert len(results) == 3 and width[0] > width[1] > width[2]
+    triplets = torch.tensor([[0, 3, 2], [1, 4, 0], [3, 1, 1], [5, 0, 0]], dtype=torch.float64, device='cuda')
+    r = bootstrap(triplets, triple_sum, n_resamples=100, bayesian=bayesian, method='basic')
+    assert np.isclose(float(r['mean']), 5) and np.isclose(float(r['standard_deviation']), 0, atol=2e-6)
+    if bayesian:
+        with pytest.raises(ValueError, match='generator'):
+            bootstrap(data, mean, bayesian=True, generator=torch.Generator())
+        with pytest.raises(ValueError, match='take_first_only'):
+            bootstrap(data, mean, bayesian=True, bootstrap_sample_size=[10])

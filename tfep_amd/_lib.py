@@ -100,6 +100,7 @@ _SIGNATURES = {
                                                  _P, c_int64, c_int, _P]),
     'tfep_tfep_reduce': (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P]),
     'tfep_tfep_reduce_workspace_doubles': (c_int, [c_int]),
+    'tfep_bootstrap_fep': (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int64, c_float, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

@@ -189,6 +189,84 @@ __global__ void __launch_bounds__(256) tfep_reduce_final_kernel(const double* __
     block_reduce_and_store(st, out);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Bootstrap of the FEP estimator (reference analysis/bootstrap.py:185-262 with statistic = fep_estimator):
+// one workgroup per resample; the resampled data are never materialised.
+//   standard:  a_j = -work[idx[r][j]] / kT (+ bias[idx[r][j]] / kT),
+//              dF_r = -kT (logsumexp_j a_j - log S)                     (no bias)
+//              dF_r = -kT (logsumexp_j a_j - logsumexp_j bias_j / kT)   (bias: log_softmax of the resampled biases)
+//   Bayesian:  idx == NULL, weights (R, S) >= 0 summing to 1:  dF_r = -kT logsumexp_j (-work[j]/kT + log weights[r][j])
+// Online (max, rescaled sum) in fp64 per thread, merged across the workgroup.
+// ------------------------------------------------------------------------------------------
+struct MaxSum {
+    double m, s;
+};
+__device__ inline void ms_add(MaxSum& a, double v) {
+    if (v == -INFINITY) return;
+    if (v <= a.m) {
+        a.s += exp(v - a.m);
+    } else {
+        a.s = a.s * exp(a.m - v) + 1.0;
+        a.m = v;
+    }
+}
+__device__ inline MaxSum ms_merge(MaxSum a, MaxSum b) {
+    if (b.s == 0.0) return a;
+    if (a.s == 0.0) return b;
+    MaxSum r;
+    r.m = fmax(a.m, b.m);
+    r.s = a.s * exp(a.m - r.m) + b.s * exp(b.m - r.m);
+    return r;
+}
+__device__ inline MaxSum ms_block_reduce(MaxSum v, MaxSum* sh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        MaxSum o;
+        o.m = __shfl_xor(v.m, off, 64);
+        o.s = __shfl_xor(v.s, off, 64);
+        v = ms_merge(v, o);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    MaxSum r = sh[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = ms_merge(r, sh[w]);
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(256) bootstrap_fep_kernel(const float* __restrict__ work, const float* __restrict__ bias,
+                                                            const int64_t* __restrict__ idx, const float* __restrict__ weights,
+                                                            int64_t n_data, int64_t S, double inv_kT, double kT,
+                                                            double* __restrict__ out) {
+    __shared__ MaxSum sh[4];
+    const int64_t r = blockIdx.x;
+    MaxSum a = {-INFINITY, 0.0}, b = {-INFINITY, 0.0};
+    for (int64_t j = threadIdx.x; j < S; j += blockDim.x) {
+        const int64_t i = idx ? idx[r * S + j] : j;
+        if (i < 0 || i >= n_data) continue;                       // never for torch.randint(0, n_data) indices
+        double v = -(double)work[i] * inv_kT;
+        if (weights) v += log((double)weights[r * S + j]);
+        if (bias) {
+            const double bb = (double)bias[i] * inv_kT;
+            v += bb;
+            ms_add(b, bb);
+        }
+        ms_add(a, v);
+    }
+    a = ms_block_reduce(a, sh);
+    if (bias) b = ms_block_reduce(b, sh);
+    if (threadIdx.x == 0) {
+        double lse = a.m + log(a.s);
+        if (bias)
+            lse -= b.m + log(b.s);
+        else if (!weights)
+            lse -= log((double)S);
+        out[r] = -kT * lse;
+    }
+}
+
 }  // namespace tfep
 
 using namespace tfep;
@@ -216,6 +294,20 @@ int tfep_tfep_reduce(const float* target_potentials, const float* log_det_J, con
                                                       1.0 / (double)kT, ignore_nan, N, workspace);
     tfep_reduce_final_kernel<<<1, 256, 0, s>>>(workspace, blocks, out);
     return check_launch("tfep_reduce");
+}
+
+int tfep_bootstrap_fep(const float* work, const float* bias, const int64_t* indices, const float* weights,
+                       int64_t n_data, int64_t n_resamples, int64_t sample_size, float kT, double* out, void* stream) {
+    TFEP_REQUIRE(n_resamples >= 0 && sample_size >= 0 && n_data >= 0, "bootstrap_fep: negative size");
+    if (n_resamples == 0) return TFEP_OK;
+    TFEP_REQUIRE(work && out, "bootstrap_fep: NULL pointer");
+    TFEP_REQUIRE(kT > 0.f, "bootstrap_fep: kT must be positive");
+    TFEP_REQUIRE(indices || sample_size <= n_data, "bootstrap_fep: without indices sample_size must be <= n_data");
+    TFEP_REQUIRE(!(bias && weights), "bootstrap_fep: Bayesian weights are not supported with biased data");
+    TFEP_REQUIRE(n_resamples <= 0x7fffffffLL, "bootstrap_fep: too many resamples");
+    bootstrap_fep_kernel<<<(unsigned)n_resamples, 256, 0, (hipStream_t)stream>>>(work, bias, indices, weights, n_data, sample_size,
+                                                                              1.0 / (double)kT, (double)kT, out);
+    return check_launch("bootstrap_fep_kernel");
 }
 
 }  // extern "C"

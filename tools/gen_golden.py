@@ -852,6 +852,46 @@ def gen_embeddings():
     np.savez_compressed(os.path.join(OUT, 'embeddings.npz'), **out)
 
 
+# -----------------------------------------------------------------------------
+# 10. bootstrap of fep_estimator (analysis/bootstrap.py)
+# -----------------------------------------------------------------------------
+
+def gen_bootstrap():
+    from tfep.analysis.bootstrap import bootstrap
+    out = {}
+    g0 = gen(7000)
+    work = torch.randn(600, generator=g0) * 1.5 + 0.3
+    bias = torch.randn(600, generator=g0) * 0.5
+    out['work'], out['bias'] = npy(work), npy(bias)
+    cases = {
+        'plain': dict(data='work', kw=dict(n_resamples=300)),
+        'batched_cl80': dict(data='work', kw=dict(n_resamples=250, batch=64, confidence_level=0.8)),
+        'sizes': dict(data='work', kw=dict(n_resamples=200, bootstrap_sample_size=[50, 600])),
+        'sizes_first': dict(data='work', kw=dict(n_resamples=200, bootstrap_sample_size=[50, 300], take_first_only=True)),
+        'biased': dict(data='biased', kw=dict(n_resamples=200, batch=50)),
+    }
+    for name, c in cases.items():
+        data = work if c['data'] == 'work' else torch.stack([work, bias], dim=1)
+        res = bootstrap(data, fep_estimator, generator=gen(7100), **c['kw'])
+        res = res if isinstance(res, list) else [res]
+        out[f'{name}/n'] = np.array(len(res))
+        for i, r in enumerate(res):
+            out[f'{name}/{i}'] = np.array([float(r['confidence_interval']['low']), float(r['confidence_interval']['high']),
+                                           float(r['standard_deviation']), float(r['mean']), float(r['median'])])
+    # Bayesian bootstrap: the Dirichlet weights are stored (drawn from the global RNG in the reference)
+    torch.manual_seed(7200)
+    weights = torch.distributions.Dirichlet(torch.ones(600)).sample((40,))
+    out['bayes/weights'] = npy(weights)
+    out['bayes/df'] = npy(fep_estimator(work.expand(40, 600), weights=weights, vectorized=True))
+    # explicit resamples: indices and the per-resample estimates
+    idx = torch.randint(0, 600, (30, 450), generator=gen(7300))
+    out['explicit/idx'] = npy(idx)
+    out['explicit/df_work'] = npy(fep_estimator(work[idx], vectorized=True))
+    out['explicit/df_biased'] = npy(fep_estimator(torch.stack([work, bias], dim=1)[idx], vectorized=True))
+    out['explicit/df_work_kT'] = npy(fep_estimator(work[idx], kT=0.7, vectorized=True))
+    np.savez_compressed(os.path.join(OUT, 'bootstrap.npz'), **out)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
     if len(sys.argv) > 1:
@@ -867,5 +907,6 @@ if __name__ == '__main__':
     gen_loss()
     gen_wrappers()
     gen_embeddings()
+    gen_bootstrap()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
