@@ -144,6 +144,9 @@ typedef struct tfep_gemm_desc {
     int32_t split;                              /* 1: x and w are split-f16 rows (tfep_split_rows), wide tile only */
     const float* x_inv_scale;                   /*    (B) per-row 1/scale of x                                     */
     const float* w_inv_scale;                   /*    (1) 1/scale of w                                             */
+    int32_t k_split;                            /* > 1: split-K for products with few output tiles: slice s of the  */
+    int64_t slab_stride;                        /*   k-range writes its partial sums to y + s * slab_stride (bias and */
+                                                /*   pre_add in slice 0); the caller adds the k_split slabs           */
 } tfep_gemm_desc;
 int tfep_masked_linear_gemm(const tfep_gemm_desc* desc, void* stream);
 int tfep_masked_linear_tile_k(void);
@@ -301,6 +304,47 @@ int tfep_diag_split_mfma_peak(float* scratch, int blocks, int iters, void* strea
  * (synchronous): out[0] = k-loop, out[1] = epilogue, out[2] = workgroups counted, out[3] = sum of workgroup
  * lifetimes in 100 MHz real-time ticks. */
 int tfep_diag_split_cycles(unsigned long long* out);
+
+/*
+ * Fused inner loop of the blocked autoregressive inverse (flows/autoregressive.py:179-229): one launch runs, for a
+ * block of consecutive degrees, the whole per-degree chain -- hidden units of the degree in every layer (ELU),
+ * the P parameters of the degree's features, the transformer inverse (affine.py:361-363 / spline.py:504-543) and
+ * the update of x -- one thread per sample row.  The contribution of all EARLIER blocks to the block's rows must
+ * already be in z[l] / zout (one tfep_masked_linear_gemm per layer, bias included).
+ *   x (B, ldx), xpad (B, ldxpad): inverse output / zero-padded conditioner input, filled feature by feature;
+ *   y (B, ldy): the transformed features; h[l] (B, ldh): hidden activations, units sorted by degree;
+ *   w[l], wout: packed masked weights (tfep_masked_weight_prepare; wout rows grouped by degree: p * n_d + f);
+ *   steps: n_steps records of tfep_inverse_block_step_ints() int32:
+ *     per layer l < 4: [row0, n, kb, ke] -- units [row0, row0 + n) of layer l from the first ke features of the
+ *     block (l = 0) or the packed columns [kb, ke) of layer l - 1 (l >= 1); then [out_row0, n_d, kb, ke, feat_off, 0];
+ *   feat_cols / feat_sel: column in x / index in y and in the spline tables of every feature of the block, in step order;
+ *   cache_col0[l], cache_n_old[l]: first packed column of layer l held in LDS and how many of them earlier blocks
+ *     computed; cache_len / max_feats: LDS entries per layer / for the block's features
+ *     ((n_layers * cache_len + max_feats) * 256 bytes <= 160 KiB).
+ *   kind: 0 affine, 1 spline (desc, n_bins <= 8).  log_det_J (B) is accumulated.
+ */
+typedef struct tfep_inverse_block_desc {
+    int32_t B, n_layers, n_steps, kind;
+    float* x; int64_t ldx;
+    float* xpad; int64_t ldxpad;
+    const float* y; int64_t ldy;
+    float* h[4]; int64_t ldh[4];
+    const float* z[4]; int64_t ldz[4];
+    const float* zout; int64_t ldzout;
+    int32_t z_slabs[4]; int64_t z_slab_stride[4];   /* z[l] / zout given as split-K slabs (tfep_gemm_desc.k_split): */
+    int32_t zout_slabs; int64_t zout_slab_stride;   /*   the kernel adds slabs s = 0 .. n-1 at z + s * stride; 0/1 = plain */
+    float* log_det_J;
+    const float* w[4]; int64_t ldw[4];
+    const float* wout; int64_t ldwout;
+    const int32_t* steps;
+    const int32_t* feat_cols;
+    const int32_t* feat_sel;
+    int32_t cache_col0[4], cache_n_old[4];
+    int32_t cache_len, max_feats;
+    const tfep_spline_desc* spline;
+} tfep_inverse_block_desc;
+int tfep_inverse_block_step_ints(void);
+int tfep_inverse_block(const tfep_inverse_block_desc* desc, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Backward (training step, app/base.py:780-840 calls loss.backward())         */

@@ -30,7 +30,22 @@ class GemmDesc(Structure):
                 ('act', c_int32), ('accumulate', c_int32),
                 ('elu_grad_of', c_void_p), ('ld_elu_grad_of', c_int64), ('tile_live', c_void_p),
                 ('pre_add', c_void_p), ('ld_pre_add', c_int64), ('tile_n', c_int32),
-                ('split', c_int32), ('x_inv_scale', c_void_p), ('w_inv_scale', c_void_p)]
+                ('split', c_int32), ('x_inv_scale', c_void_p), ('w_inv_scale', c_void_p),
+                ('k_split', c_int32), ('slab_stride', c_int64)]
+
+
+class InverseBlockDesc(Structure):
+    _fields_ = [('B', c_int32), ('n_layers', c_int32), ('n_steps', c_int32), ('kind', c_int32),
+                ('x', c_void_p), ('ldx', c_int64), ('xpad', c_void_p), ('ldxpad', c_int64),
+                ('y', c_void_p), ('ldy', c_int64),
+                ('h', c_void_p * 4), ('ldh', c_int64 * 4), ('z', c_void_p * 4), ('ldz', c_int64 * 4),
+                ('zout', c_void_p), ('ldzout', c_int64),
+                ('z_slabs', c_int32 * 4), ('z_slab_stride', c_int64 * 4),
+                ('zout_slabs', c_int32), ('zout_slab_stride', c_int64), ('log_det_J', c_void_p),
+                ('w', c_void_p * 4), ('ldw', c_int64 * 4), ('wout', c_void_p), ('ldwout', c_int64),
+                ('steps', c_void_p), ('feat_cols', c_void_p), ('feat_sel', c_void_p),
+                ('cache_col0', c_int32 * 4), ('cache_n_old', c_int32 * 4),
+                ('cache_len', c_int32), ('max_feats', c_int32), ('spline', c_void_p)]
 
 
 class SplineDesc(Structure):
@@ -83,6 +98,8 @@ _SIGNATURES = {
                                                             c_int, c_int, c_int, _P]),
     'tfep_diag_split_mfma_peak': (c_int, [_P, c_int, c_int, _P]),
     'tfep_diag_split_cycles': (c_int, [_P]),
+    'tfep_inverse_block_step_ints': (c_int, []),
+    'tfep_inverse_block': (c_int, [POINTER(InverseBlockDesc), _P]),
     'tfep_diag_mfma_peak': (c_int, [_P, c_int, c_int, _P]),
     'tfep_masked_linear_gemm': (c_int, [POINTER(GemmDesc), _P]),
     'tfep_transpose': (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, _P]),

@@ -47,6 +47,9 @@ struct GemmArgs {
     const uint8_t* tile_live;  // optional (m_tiles x n_tiles): 0 = the whole output tile is masked, skip it
     int diag;                  // diagnostics only (TFEP_DIAG): 1 = skip the epilogue, 4 = skip the LDS-DMA,
                                // 8 = skip the barriers (garbage results; timing only)
+    int ksplit;                // linear epilogues: > 1 = split-K: launch position (column tile, k slice); slice s writes
+    int64_t slab_stride;       //   its partial sums to y + s * slab_stride (bias / pre_add in slice 0 only); the
+                               //   consumer adds the slabs (deterministic, no atomics)
     const float* a_inv_scale;  // split-f16 operands only: per-row 1/scale of the activations (B)
     const float* w_inv_scale;  //   and the single 1/scale of the weights
     FusedArgs fu;
@@ -81,7 +84,8 @@ __device__ inline bool map_block(const GemmArgs& g, int& mt, int& ntp) {
 // Epilogues on the accumulators of one wave: MREP x NREP tiles of 16 x 16, C layout of the 16x16 MFMAs
 // (column = lane & 15, row = (lane >> 4) * 4 + reg).  The wave owns rows [wrow0, wrow0 + 16 * MREP).
 template <int MREP, int NREP, int EPI, int P, int KSPL>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NREP][MREP], int nt, int n0, int wrow0, int lane) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NREP][MREP], int nt, int n0, int wrow0, int lane,
+                                              int k_slice = 0) {
     const int cj = lane & 15, rq = (lane >> 4) * 4;
 
     if constexpr (EPI == EPI_LINEAR || EPI == EPI_ELU) {
@@ -89,7 +93,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
         for (int n = 0; n < NREP; ++n) {
             const int col = n0 + n * 16 + cj;
             if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.f;
+            const float bv = (g.bias && k_slice == 0) ? g.bias[col] : 0.f;
             const int ocol = g.col_map ? g.col_map[col] : col;
             if (ocol < 0) continue;
 #pragma unroll
@@ -99,13 +103,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
                     const int row = wrow0 + m * 16 + rq + i;
                     if (row < g.B) {
                         float v = acc[n][m][i] + bv;
-                        if (g.pre_add) v += g.pre_add[(int64_t)row * g.ld_pre_add + ocol];
+                        if (g.pre_add && k_slice == 0) v += g.pre_add[(int64_t)row * g.ld_pre_add + ocol];
                         if (EPI == EPI_ELU) v = elu_f(v);
                         if (g.aux) {
                             const float h = g.aux[(int64_t)row * g.ldaux + ocol];
                             v *= h > 0.f ? 1.f : h + 1.f;
                         }
-                        float* dst = g.y + (int64_t)row * g.ldy + ocol;
+                        float* dst = g.y + (int64_t)k_slice * g.slab_stride + (int64_t)row * g.ldy + ocol;
                         *dst = g.accumulate ? *dst + v : v;
                     }
                 }

@@ -198,7 +198,15 @@ __global__ void __launch_bounds__(THREADS, (MREP == 1 ? 4 : 2)) gemm_kernel(Gemm
         mt = blockIdx.x % g.m_tiles;
         ntp = blockIdx.x / g.m_tiles;
     }
-    const int nt = g.tile_order ? g.tile_order[ntp] : ntp;
+    int nt = g.tile_order ? g.tile_order[ntp] : ntp;
+    // split-K (short-and-wide products, e.g. the block GEMMs of the inverse: too few output tiles to fill 256 CUs):
+    // the launch has ksplit x as many column positions; position -> (column tile, k slice)
+    int k_slice = 0;
+    if (g.ksplit > 1) {
+        const int n_real = g.n_tiles / g.ksplit;
+        k_slice = nt / n_real;
+        nt -= k_slice * n_real;
+    }
     if (g.tile_live && !g.tile_live[(int64_t)mt * g.n_tiles + nt]) return;
     const int m0 = mt * T::BM, n0 = nt * T::BN;
 
@@ -206,6 +214,11 @@ __global__ void __launch_bounds__(THREADS, (MREP == 1 ? 4 : 2)) gemm_kernel(Gemm
     if (g.k_ranges) {
         kb = g.k_ranges[2 * nt];
         ke = g.k_ranges[2 * nt + 1];
+    }
+    if (g.ksplit > 1) {
+        const int per = (((ke - kb) / BK + g.ksplit - 1) / g.ksplit) * BK;     // k per slice, whole tiles
+        kb = min(ke, kb + k_slice * per);
+        ke = min(ke, kb + per);
     }
 
     f32x4 acc[NREP][MREP];
@@ -266,7 +279,7 @@ __global__ void __launch_bounds__(THREADS, (MREP == 1 ? 4 : 2)) gemm_kernel(Gemm
             for (int m = 0; m < MREP; ++m) asm volatile("" ::"v"(acc[n][m]));
         return;
     }
-    gemm_epilogue<MREP, NREP, EPI, P, KSPL>(g, acc, nt, n0, m0 + wave * 16 * MREP, lane);
+    gemm_epilogue<MREP, NREP, EPI, P, KSPL>(g, acc, nt, n0, m0 + wave * 16 * MREP, lane, k_slice);
 }
 
 // Diagnostic: the matrix-pipe ceiling of THIS device for the GEMM's own instruction mix -- the same
@@ -328,7 +341,7 @@ static int launch_gemm(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStre
     }
     GemmArgs ga = g;
     ga.m_tiles = (g.B + T::BM - 1) / T::BM;
-    ga.n_tiles = n_col_tiles;
+    ga.n_tiles = n_col_tiles * (g.ksplit > 1 ? g.ksplit : 1);
     ga.map_mode = block_map_mode();
     ga.diag = env_int("TFEP_DIAG", 0);
     const long long blocks = gemm_grid_blocks(ga.map_mode, ga.m_tiles, ga.n_tiles);
@@ -431,6 +444,12 @@ int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
     g.col_map = d->col_map; g.y = d->y; g.ldy = d->ldy; g.B = d->B; g.N = d->N; g.k_padded = d->k_padded;
     g.tile_order = d->tile_order; g.aux = d->elu_grad_of; g.ldaux = d->ld_elu_grad_of; g.accumulate = d->accumulate;
     g.tile_live = d->tile_live; g.pre_add = d->pre_add; g.ld_pre_add = d->ld_pre_add;
+    if (d->k_split > 1) {
+        TFEP_REQUIRE(!d->split && !d->accumulate && !d->tile_order && !d->tile_live && !d->elu_grad_of && d->act == 0,
+                     "masked_linear_gemm: k_split needs a plain linear product (no activation / accumulate / tile_order / tile_live)");
+        TFEP_REQUIRE(d->k_split <= 64 && d->slab_stride > 0, "masked_linear_gemm: bad k_split / slab_stride");
+        g.ksplit = d->k_split; g.slab_stride = d->slab_stride;
+    }
     if (d->split) {
         constexpr int SPLIT_BN = Tile<LIN_MREP, LIN_NREP>::BN;
         TFEP_REQUIRE(d->tile_n == 0 || d->tile_n == SPLIT_BN, "masked_linear_gemm: split operands need the wide tile");

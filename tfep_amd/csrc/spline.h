@@ -279,4 +279,38 @@ __device__ __forceinline__ double rq_spline_forward_full(const float (&w)[K], co
     return tail ? out_t : out_i;
 }
 
+// Kernel-side view of a tfep_spline_desc and its (host) validation, shared by the transformer kernels and the
+// fused inverse-block kernel.
+struct SplineArgs {
+    const float *x0, *xf, *y0, *yf;
+    SplineFlags f;
+    int P;
+};
+
+
+inline int make_spline_args(const tfep_spline_desc* d, SplineArgs* a) {
+    TFEP_REQUIRE(d != nullptr, "spline descriptor is NULL");
+    TFEP_REQUIRE(d->x0 && d->xf && d->y0 && d->yf, "spline descriptor: x0/xf/y0/yf must be non-NULL");
+    TFEP_REQUIRE(d->n_bins >= 1 && d->n_bins <= 32, "spline: n_bins=%d unsupported (1..32)", d->n_bins);
+    TFEP_REQUIRE(!(d->circular && (d->learn_lower_bound || d->learn_upper_bound)),
+                 "Cannot instantiate a circular spline with learnable limits.");
+    TFEP_REQUIRE(d->min_bin_size > 0.f, "The minimum bin size should be positive.");
+    TFEP_REQUIRE(d->min_slope > 0.f && d->min_slope < 1.f, "The minimum slope should be between 0 and 1.");
+    a->x0 = d->x0;
+    a->xf = d->xf;
+    a->y0 = d->y0;
+    a->yf = d->yf;
+    a->f.K = d->n_bins;
+    a->f.circular = d->circular != 0;
+    a->f.identity = d->identity_boundary_slopes != 0;
+    a->f.learn_lower = d->learn_lower_bound != 0;
+    a->f.learn_upper = d->learn_upper_bound != 0;
+    a->f.min_bin = d->min_bin_size;
+    a->f.min_slope = d->min_slope;
+    a->f.slope_offset = (float)log(exp(1.0 - (double)d->min_slope) - 1.0);
+    a->P = spline_n_params(a->f.K, a->f.circular, a->f.identity, a->f.learn_lower, a->f.learn_upper);
+    return TFEP_OK;
+}
+
+
 }  // namespace tfep

@@ -394,16 +394,75 @@ class AutoregressiveFlow(torch.nn.Module):
                 blk['steps'].append(dict(hidden=hidden, out=dict(row0=base[d], n_rows=P * len(sel), kr=rng(kA[L], ke)),
                                          n_d=len(sel), sel=sel.to(**i32), cols=tr_idx[sel].to(**i32),
                                          sub=self._sub_transformer(sel.to(device), device)))
+            blk['fused'] = self._fused_block_tables(d0, d1, blk, kA, r_lo, r_hi, base, sels, tr_idx, deg_in, mplan, L, P,
+                                                    rng, up, i32)
             blocks.append(blk)
         narrow = lib.tfep_masked_linear_narrow_tile_n()
         max_rows = max([w['n_rows'] for b_ in blocks for w in b_['wide']] + [b_['out_wide']['n_rows'] for b_ in blocks] +
                        [h_['n_rows'] for b_ in blocks for st in b_['steps'] for h_ in st['hidden']] +
                        [st['out']['n_rows'] for b_ in blocks for st in b_['steps']])
+        fused_ok = self._fused_inverse_supported(L) and all(b_['fused'] is not None for b_ in blocks)
+        if fused_ok:
+            cache_len = max(b_['fused']['cache_need'] for b_ in blocks)
+            max_feats = max(b_['fused']['n_feats'] for b_ in blocks)
+            fused_ok = (L * cache_len + max_feats) * 256 <= 160 * 1024
         bp = dict(blocks=blocks, P=P, L=L, row_inv=row_inv.to(**i32), n_rows_out=P * n_tr,
+                  fused=dict(cache_len=cache_len, max_feats=max_feats) if fused_ok else None,
                   max_tiles=(max_rows + narrow - 1) // narrow,
                   k_ranges=torch.tensor(kr, dtype=torch.int32).reshape(-1, 2).to(device))
         self._dev[key] = bp
         return bp
+
+    #: Run the per-degree chain of each block in ONE kernel (``tfep_inverse_block``) when the layer qualifies.
+    fused_inverse = True
+
+    def _fused_inverse_supported(self, L):
+        if not self.fused_inverse or L > 4:
+            return False
+        tr = self._transformer
+        if type(tr) is AffineTransformer:
+            return True
+        return type(tr) is NeuralSplineTransformer and tr.host()['n_bins'] <= 8
+
+    def _fused_block_tables(self, d0, d1, blk, kA, r_lo, r_hi, base, sels, tr_idx, deg_in, mplan, L, P, rng, up, i32):
+        """Device tables of ``tfep_inverse_block`` for the block of degrees [d0, d1) (see include/tfep_hip.h)."""
+        if not self._fused_inverse_supported(L):
+            return None
+        lib = _lib.load()
+        tk = lib.tfep_masked_linear_tile_k()
+        n_ints = lib.tfep_inverse_block_step_ints()
+        # layer 0 gets a wide GEMM too: every feature of an earlier block (bounding column range; the block's own
+        # features are still zero in the padded input when it runs)
+        known = torch.nonzero(deg_in <= d0 - 1).flatten()
+        if len(known):
+            kb0, ke0 = (int(known.min()) // tk) * tk, min(up(int(known.max()) + 1), mplan['k_pad'][0])
+        else:
+            kb0, ke0 = 0, 0
+        r0, r1 = r_lo(0, d0 - 1), r_hi(0, d1 - 2)
+        wide0 = dict(layer=0, row0=r0, n_rows=r1 - r0, kr=rng(kb0, ke0)) if r1 > r0 else None
+        c0 = [kA[l + 1] for l in range(L)]
+        n_old = [max(0, r_hi(l, d0 - 2) - c0[l]) for l in range(L)]
+        cache_need = max([r_hi(l, d1 - 2) - c0[l] for l in range(L)] + [1])
+        steps, cols, selv = [], [], []
+        for d in range(d0, d1):
+            e = d - 1
+            rec = [0] * n_ints
+            for l in range(L):
+                a, b = r_lo(l, e), r_hi(l, e)
+                rec[4 * l], rec[4 * l + 1] = a, max(0, b - a)
+                if l == 0:
+                    rec[2], rec[3] = 0, len(cols)
+                else:
+                    rec[4 * l + 2], rec[4 * l + 3] = c0[l - 1], max(c0[l - 1], r_hi(l - 1, e))
+            sel = sels[d]
+            rec[16:21] = [base[d], len(sel), c0[L - 1], max(c0[L - 1], r_hi(L - 1, e)), len(cols)]
+            steps.append(rec)
+            cols += tr_idx[sel].tolist()
+            selv += sel.tolist()
+        return dict(wide0=wide0, c0=c0, n_old=n_old, cache_need=cache_need, n_feats=max(len(cols), 1), n_steps=len(steps),
+                    steps=torch.tensor(steps, dtype=torch.int32).reshape(-1, n_ints).to(i32['device']),
+                    cols=torch.tensor(cols + [0], dtype=torch.int32).to(i32['device']),
+                    sel=torch.tensor(selv + [0], dtype=torch.int32).to(i32['device']))
 
     def _inverse_blocked(self, y):
         from ._backward import _gemm
@@ -420,16 +479,19 @@ class AutoregressiveFlow(torch.nn.Module):
         f32 = dict(dtype=torch.float32, device=dev)
         kr_all = bp['k_ranges']
 
-        def launch(x_in, w, bias, desc, out, out_col0, act, pre=None, pre_col0=0, wide=False):
-            """out[:, out_col0 : +n] = act(x_in W[row0 : row0+n]^T + bias[row0:] (+ pre[:, pre_col0 : +n]))"""
+        def launch(x_in, w, bias, desc, out, out_col0, act, pre=None, pre_col0=0, wide=False, k_split=1):
+            """out[:, out_col0 : +n] = act(x_in W[row0 : row0+n]^T + bias[row0:] (+ pre[:, pre_col0 : +n]));
+            ``k_split`` > 1: ``out`` is (k_split, B, cols) and receives the partial sums of the k slices."""
             n, row0 = desc['n_rows'], desc['row0']
             d = _lib.GemmDesc()
             d.x, d.ldx = x_in.data_ptr(), x_in.shape[1]
             d.w, d.ldw = w.data_ptr() + 4 * row0 * w.shape[1], w.shape[1]
             d.bias = (bias.data_ptr() + 4 * row0) if bias is not None else None
             d.k_ranges = krs[desc['kr']].data_ptr()
-            d.y, d.ldy = out.data_ptr() + 4 * out_col0, out.shape[1]
+            d.y, d.ldy = out.data_ptr() + 4 * out_col0, out.shape[-1]
             d.B, d.N, d.n_rows_w, d.k_padded, d.act, d.accumulate = B, n, n, w.shape[1], act, 0
+            if k_split > 1:
+                d.k_split, d.slab_stride = k_split, out.shape[-2] * out.shape[-1]
             if pre is not None:
                 d.pre_add, d.ld_pre_add = pre.data_ptr() + 4 * pre_col0, pre.shape[1]
             d.tile_n = 0 if wide else narrow
@@ -457,13 +519,63 @@ class AutoregressiveFlow(torch.nn.Module):
             z = [None] + [torch.empty(B, mplan['n_pad'][l], **f32) for l in range(1, L)]   # partial pre-activations
             zout = torch.empty(B, bp['n_rows_out'], **f32)
             ldj = torch.zeros(B, **f32)
+            fused = bp['fused']
+            if fused is not None:
+                # The block GEMMs are short and wide (B x ~100 rows of W over up to 15 000 k): too few output tiles for
+                # 256 CUs, so they run split-K into S slabs that the block kernel adds up.
+                tm = ops.tile_sizes()[0]
+                m_tiles = (B + tm - 1) // tm
+                S = int(min(8, max(1, 256 // max(1, 2 * m_tiles)), max(1, max(mplan['k_pad']) // 512)))   # >= 512 k per slice
+                # slabs hold only the block's own rows: column c of a slab is packed row (first row of the block + c)
+                wz = [1] * L
+                wzout = 1
+                for b_ in bp['blocks']:
+                    for wd in b_['wide'] + ([b_['fused']['wide0']] if b_['fused']['wide0'] is not None else []):
+                        wz[wd['layer']] = max(wz[wd['layer']], wd['n_rows'])
+                    wzout = max(wzout, b_['out_wide']['n_rows'])
+                z = [torch.empty(S, B, ops.round_up(wz[l], 4), **f32) for l in range(L)]
+                zout = torch.empty(S, B, ops.round_up(wzout, 4), **f32)
+                kind = 1 if type(self._transformer) is NeuralSplineTransformer else 0
+                spl = self._transformer.config(dev).desc if kind == 1 else None
+                d = _lib.InverseBlockDesc()
+                d.B, d.n_layers, d.kind = B, L, kind
+                d.x, d.ldx, d.xpad, d.ldxpad = x.data_ptr(), D, xpad.data_ptr(), xpad.shape[1]
+                d.y, d.ldy = y_tr.data_ptr(), y_tr.shape[1]
+                for l in range(L):
+                    d.h[l], d.ldh[l] = h[l].data_ptr(), h[l].shape[1]
+                    d.z[l], d.ldz[l] = z[l].data_ptr(), z[l].shape[-1]
+                    d.z_slabs[l], d.z_slab_stride[l] = S, B * z[l].shape[-1]
+                    d.w[l], d.ldw[l] = packs[l][0].data_ptr(), packs[l][0].shape[1]
+                d.zout, d.ldzout, d.log_det_J = zout.data_ptr(), zout.shape[-1], ldj.data_ptr()
+                d.zout_slabs, d.zout_slab_stride = S, B * zout.shape[-1]
+                d.wout, d.ldwout = w_out.data_ptr(), w_out.shape[1]
+                d.cache_len, d.max_feats = fused['cache_len'], fused['max_feats']
+                d.spline = ctypes.cast(ctypes.pointer(spl), ctypes.c_void_p) if spl is not None else None
+                stream = _lib.stream_of(y)
             for blk in bp['blocks']:
                 # ---- contribution of all earlier degrees to the whole block, once
-                for wd in blk['wide']:
-                    l = wd['layer']
-                    launch(h[l - 1], packs[l][0], packs[l][1], wd, z[l], wd['row0'], act=0)
                 ow = blk['out_wide']
-                launch(h[L - 1], w_out, b_out, ow, zout, ow['row0'], act=0, wide=ow['n_rows'] > 4 * narrow)
+                if fused is not None:
+                    # ---- the block's own degrees: wide GEMMs into compact slabs, then one kernel, one thread per sample
+                    fb = blk['fused']
+                    for wd in blk['wide'] + ([fb['wide0']] if fb['wide0'] is not None else []):
+                        l = wd['layer']
+                        launch(h[l - 1] if l > 0 else xpad, packs[l][0], packs[l][1], wd, z[l], 0, act=0, k_split=S)
+                        d.z[l] = z[l].data_ptr() - 4 * wd['row0']       # the kernel indexes by packed row
+                    launch(h[L - 1], w_out, b_out, ow, zout, 0, act=0, wide=ow['n_rows'] > 4 * narrow, k_split=S)
+                    d.zout = zout.data_ptr() - 4 * ow['row0']
+                else:
+                    for wd in blk['wide']:
+                        l = wd['layer']
+                        launch(h[l - 1], packs[l][0], packs[l][1], wd, z[l], wd['row0'], act=0)
+                    launch(h[L - 1], w_out, b_out, ow, zout, ow['row0'], act=0, wide=ow['n_rows'] > 4 * narrow)
+                if fused is not None:
+                    d.n_steps = fb['n_steps']
+                    d.steps, d.feat_cols, d.feat_sel = fb['steps'].data_ptr(), fb['cols'].data_ptr(), fb['sel'].data_ptr()
+                    for l in range(L):
+                        d.cache_col0[l], d.cache_n_old[l] = fb['c0'][l], fb['n_old'][l]
+                    _lib.call('tfep_inverse_block', ctypes.byref(d), stream)
+                    continue
                 # ---- the block's own degrees, one after the other
                 for st in blk['steps']:
                     for hd in st['hidden']:
