@@ -424,3 +424,33 @@ def test_circular_spline_fixed_points_and_periodicity():
     _, la = t1(x0[:1][None].cuda() + 1e-6, p1)
     _, lb = t1(xf[:1][None].cuda() - 1e-6, p1)
     assert abs(float(la - lb)) < 1e-4
+
+
+@pytest.mark.parametrize('name', ['cfg1', 'rq4', 'moeb'])
+def test_fused_inverse_block_kernel_matches_per_step_launches(name):
+    """tfep_inverse_block (one kernel per block of degrees, split-K block GEMMs) against the same blocked algorithm
+    launched step by step; ragged batch (dead lanes in the last wave)."""
+    g = gu.load('flows.npz')
+    flow = gu.build_flow(name, g)
+    yin = dev(g[f'{name}/y_f32'][:77])
+    with torch.no_grad():
+        expect_fused = name != 'moeb'                  # Moebius keeps the per-step launches
+        for layer in flow:
+            assert layer._blocked_ok()
+            assert (layer._blocked_plan(yin.device)['fused'] is not None) == expect_fused
+        xf, lf = flow.inverse(yin)
+        for layer in flow:
+            layer.fused_inverse = False
+            layer._dev.clear()
+        xs, ls = flow.inverse(yin)
+        for layer in flow:
+            assert layer._blocked_plan(yin.device)['fused'] is None
+    assert torch.allclose(xf, xs, rtol=1e-5, atol=2e-5)
+    assert torch.allclose(lf, ls, rtol=1e-5, atol=1e-4)
+    # deterministic
+    with torch.no_grad():
+        for layer in flow:
+            layer.fused_inverse = True
+            layer._dev.clear()
+        xf2, lf2 = flow.inverse(yin)
+    assert torch.equal(xf, xf2) and torch.equal(lf, lf2)
