@@ -47,18 +47,22 @@ def shard_rows(n_rows, rank, world_size):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def allreduce_gradients(module, group=None, bucket_bytes=1 << 30, average=True):
+def allreduce_gradients(module, group=None, bucket_bytes=1 << 30, average=True, reduce_scatter=None):
     """Data-parallel training: sum (average) the ``.grad`` of every parameter across ranks.
 
     Gradients are copied into a few large flat buckets (default 1 GiB: the 22 GB of cfg2 gradients
     go out as ~22 collectives, each long enough to run at link bandwidth on the point-to-point
-    xGMI fabric) and all-reduced with RCCL (``backend='nccl'``); ``gloo`` works for CPU tests.
+    xGMI fabric).  On RCCL (``backend='nccl'``) each bucket goes out as an explicit reduce-scatter followed by an
+    all-gather (``reduce_scatter=None``: chosen when the backend supports it) -- the two halves of a ring all-reduce,
+    with the averaging applied to the 1/world shard between them; ``gloo`` (CPU tests) uses ``all_reduce``.
     Call between ``loss.backward()`` and ``optimizer.step()``.
     """
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
     world = dist.get_world_size(group)
     grads = [p.grad for p in module.parameters() if p.grad is not None]
+    if reduce_scatter is None:
+        reduce_scatter = dist.get_backend(group) == 'nccl'
     bucket, size = [], 0
 
     def flush():
@@ -66,9 +70,20 @@ def allreduce_gradients(module, group=None, bucket_bytes=1 << 30, average=True):
         if not bucket:
             return
         flat = torch.cat([g.reshape(-1) for g in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        if average:
-            flat /= world
+        if reduce_scatter:
+            n = flat.numel()
+            padded = (n + world - 1) // world * world
+            if padded != n:
+                flat = torch.cat([flat, flat.new_zeros(padded - n)])
+            shard = torch.empty(padded // world, dtype=flat.dtype, device=flat.device)
+            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                shard /= world
+            dist.all_gather_into_tensor(flat, shard, group=group)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            if average:
+                flat /= world
         off = 0
         for g in bucket:
             n = g.numel()
