@@ -14,6 +14,19 @@ from ... import ops
 from ...utils.misc import ensure_tensor_sequence, remove_and_shift_sorted_indices
 
 
+def _selected_and_rest(n_features_in, selected, what):
+    """``(selected, rest)`` index tensors: ``selected`` defaults to every feature and must not repeat an index;
+    ``rest`` are the features left alone, in order."""
+    if selected is None:
+        selected = torch.arange(n_features_in)
+    else:
+        selected = ensure_tensor_sequence(selected)
+        if len(selected.unique()) < len(selected):
+            raise ValueError(f'Found duplicated indices in {what}.')
+    rest = remove_and_shift_sorted_indices(indices=torch.arange(n_features_in), removed_indices=selected, shift=False)
+    return selected, rest
+
+
 class MAFEmbedding(abc.ABC, torch.nn.Module):
     """Embedding applied to the conditioner input of a MAF (reference mafembed.py:31-60)."""
 
@@ -32,16 +45,10 @@ class PeriodicEmbedding(MAFEmbedding):
     def __init__(self, n_features_in: int, limits: Sequence[float],
                  periodic_indices: Optional[Sequence[int]] = None):
         super().__init__()
+        periodic, rest = _selected_and_rest(n_features_in, periodic_indices, 'periodic_indices')
         self.register_buffer('limits', ensure_tensor_sequence(limits))
-        if periodic_indices is None:
-            periodic_indices = torch.arange(n_features_in)
-        else:
-            periodic_indices = ensure_tensor_sequence(periodic_indices)
-            if len(periodic_indices.unique()) < len(periodic_indices):
-                raise ValueError('Found duplicated indices in periodic_indices.')
-        self.register_buffer('_periodic_indices', periodic_indices)
-        self.register_buffer('_nonperiodic_indices', remove_and_shift_sorted_indices(
-            indices=torch.arange(n_features_in), removed_indices=periodic_indices, shift=False))
+        self.register_buffer('_periodic_indices', periodic)
+        self.register_buffer('_nonperiodic_indices', rest)
         self._i32 = {}
 
     def _apply(self, fn, *args, **kwargs):
@@ -116,21 +123,15 @@ class FlipInvariantEmbedding(MAFEmbedding):
                  embedded_indices: Optional[Sequence[int]] = None, vector_dimension: int = 4,
                  hidden_layer_width: int = 32):
         super().__init__()
-        self.embedding_layer = torch.nn.Sequential(
-            torch.nn.Linear(vector_dimension, hidden_layer_width), torch.nn.ELU(),
-            torch.nn.Linear(hidden_layer_width, embedding_dimension))
-        self.weight_layer = torch.nn.Sequential(
-            torch.nn.Linear(vector_dimension, hidden_layer_width), torch.nn.ELU(),
-            torch.nn.Linear(hidden_layer_width, 1))
-        if embedded_indices is None:
-            embedded_indices = torch.arange(n_features_in)
-        else:
-            embedded_indices = ensure_tensor_sequence(embedded_indices)
-            if len(embedded_indices.unique()) < len(embedded_indices):
-                raise ValueError('Found duplicated indices in embedded_indices.')
-        self.register_buffer('_embedded_indices', embedded_indices)
-        self.register_buffer('_nonembedded_indices', remove_and_shift_sorted_indices(
-            indices=torch.arange(n_features_in), removed_indices=embedded_indices, shift=False))
+        embedded, rest = _selected_and_rest(n_features_in, embedded_indices, 'embedded_indices')
+
+        def perceptron(n_out):          # vector_dimension -> hidden_layer_width -> n_out
+            return torch.nn.Sequential(torch.nn.Linear(vector_dimension, hidden_layer_width), torch.nn.ELU(),
+                                       torch.nn.Linear(hidden_layer_width, n_out))
+        self.embedding_layer = perceptron(embedding_dimension)      # the candidate embeddings of v and -v
+        self.weight_layer = perceptron(1)                           # their (pre-softmax) weights
+        self.register_buffer('_embedded_indices', embedded)
+        self.register_buffer('_nonembedded_indices', rest)
 
     @property
     def vector_dimension(self) -> int:

@@ -12,6 +12,10 @@ from ...utils.misc import atom_to_flattened, atom_to_flattened_indices, ensure_t
 from .partial import PartialFlow
 
 
+def _optional_tensor(values):
+    return None if values is None else ensure_tensor_sequence(values)
+
+
 class CenteredCentroidFlow(PartialFlow):
     """Translate the centroid to ``origin``, map all points but one with the wrapped flow, then place the
     remaining point so that the centroid is unchanged.  Arguments and attributes as reference
@@ -28,41 +32,30 @@ class CenteredCentroidFlow(PartialFlow):
             translate_back: bool = True,
             return_partial: bool = False,
     ):
-        if return_partial and translate_back:
+        if translate_back and return_partial:
             raise ValueError("'return_partial=True' is supported only if 'translate_back=False'")
-        if origin is None:
-            origin = torch.zeros(space_dimension)
-        else:
-            if len(origin) != space_dimension:
-                raise ValueError("'origin' must have length equal to 'space_dimension'.")
-            origin = ensure_tensor_sequence(origin)
-        if subset_point_indices is not None:
-            subset_point_indices = ensure_tensor_sequence(subset_point_indices)
-        if weights is not None:
-            weights = ensure_tensor_sequence(weights)
+        if origin is not None and len(origin) != space_dimension:
+            raise ValueError("'origin' must have length equal to 'space_dimension'.")
+        subset, weights = _optional_tensor(subset_point_indices), _optional_tensor(weights)
+        if subset is not None and weights is not None and len(weights) != len(subset):
+            raise ValueError("'weights' must have the same length as 'subset_point_indices'.")
 
-        # fixed_point_idx counts within the subset when there is one.
-        if subset_point_indices is None:
-            fixed_point = fixed_point_idx
-        else:
-            fixed_point = int(subset_point_indices[fixed_point_idx])
-            if (weights is not None) and (len(weights) != len(subset_point_indices)):
-                raise ValueError("'weights' must have the same length as 'subset_point_indices'.")
-        fixed_indices = atom_to_flattened_indices(torch.tensor([fixed_point]), space_dimension)
-        super().__init__(flow, fixed_indices=fixed_indices, return_partial=return_partial)
+        # `fixed_point_idx` counts within the subset when there is one: the point itself is subset[fixed_point_idx].
+        fixed_point = int(fixed_point_idx if subset is None else subset[fixed_point_idx])
+        super().__init__(flow, fixed_indices=atom_to_flattened_indices(torch.tensor([fixed_point]), space_dimension),
+                         return_partial=return_partial)
 
-        if weights is not None:
-            weights = (weights / torch.sum(weights)).unsqueeze(1)
         self._space_dimension = space_dimension
-        self.register_buffer('_fixed_point_idx', torch.as_tensor(fixed_point_idx))
-        self.register_buffer('_subset_point_indices', subset_point_indices)
-        self.register_buffer('_weights', weights)
-        self.register_buffer('origin', origin)
         self.translate_back = translate_back
+        self.register_buffer('_fixed_point_idx', torch.as_tensor(fixed_point_idx))
+        self.register_buffer('_subset_point_indices', subset)
+        # normalised, as a column: multiplies (batch, n_points, dim) directly
+        self.register_buffer('_weights', None if weights is None else (weights / weights.sum()).unsqueeze(1))
+        self.register_buffer('origin', torch.zeros(space_dimension) if origin is None else ensure_tensor_sequence(origin))
         # Host copies so that no pass reads a device scalar back.
         self._host_fixed_point_idx = int(fixed_point_idx)
-        self._host_fixed_point = int(fixed_point)
-        self._single_point_centroid = subset_point_indices is not None and len(subset_point_indices) <= 1
+        self._host_fixed_point = fixed_point
+        self._single_point_centroid = subset is not None and len(subset) <= 1
 
     @property
     def space_dimension(self):
@@ -70,7 +63,7 @@ class CenteredCentroidFlow(PartialFlow):
         return self._space_dimension
 
     def forward(self, x: torch.Tensor) -> Tuple[torch.Tensor]:
-        return self._transform(x)
+        return self._transform(x, inverse=False)
 
     def inverse(self, y: torch.Tensor) -> Tuple[torch.Tensor]:
         if not self.translate_back:
@@ -79,7 +72,7 @@ class CenteredCentroidFlow(PartialFlow):
                              " the forward and inverse transformations.")
         return self._transform(y, inverse=True)
 
-    def _transform(self, x, inverse=False):
+    def _transform(self, x, inverse):
         dim = self._space_dimension
         pts = flattened_to_atom(x, dim)
         shift = (self.origin - self._centroid(pts)).unsqueeze(1)

@@ -29,39 +29,35 @@ class MAF(AutoregressiveFlow):
             weight_norm: bool = True,
             initialize_identity: bool = True,
     ):
-        if transformer is None:
-            transformer = AffineTransformer()
         degrees_in = ensure_tensor_sequence(degrees_in)
-
-        min_degree_in = degrees_in.min().tolist()
-        max_degree_in = degrees_in.max().tolist()
-        if ((set(degrees_in.tolist()) != set(range(min_degree_in, max_degree_in + 1))) or
-                (min_degree_in not in {-1, 0})):
-            raise ValueError('degrees_in must assume consecutive values starting '
-                             'from 0 (or -1 for conditioning input features).')
-
-        degrees_in_embedded = degrees_in if embedding is None else embedding.get_degrees_out(degrees_in)
-        transformer_indices = [(degrees_in == degree).nonzero().flatten() for degree in range(max_degree_in + 1)]
-        degrees_out = transformer.get_degrees_out(degrees_in[degrees_in != -1])
-
-        super().__init__(
-            n_features_in=len(degrees_in),
-            transformer_indices=transformer_indices,
-            conditioner=_EmbeddedMADE(
-                embedding=embedding,
-                degrees_in=degrees_in_embedded,
-                degrees_out=degrees_out,
-                hidden_layers=hidden_layers,
-                weight_norm=weight_norm,
-            ),
-            transformer=transformer,
-            initialize_identity=initialize_identity,
+        highest = _check_degrees(degrees_in)
+        transformer = AffineTransformer() if transformer is None else transformer
+        # degree d >= 0: the features transformed at step d of the inverse; -1: conditioning features
+        groups = [torch.nonzero(degrees_in == d).flatten() for d in range(highest + 1)]
+        conditioner = _EmbeddedMADE(
+            embedding=embedding,
+            degrees_in=degrees_in if embedding is None else embedding.get_degrees_out(degrees_in),
+            degrees_out=transformer.get_degrees_out(degrees_in[degrees_in != -1]),
+            hidden_layers=hidden_layers,
+            weight_norm=weight_norm,
         )
+        super().__init__(n_features_in=len(degrees_in), transformer_indices=groups, conditioner=conditioner,
+                         transformer=transformer, initialize_identity=initialize_identity)
         self._embedding = embedding
 
     def n_parameters(self) -> int:
         """The total number of (unmasked) parameters."""
         return self._conditioner.n_parameters()
+
+
+def _check_degrees(degrees_in):
+    """Degrees must be -1 (conditioning) or 0, 1, 2, ... without gaps; returns the largest one."""
+    present = sorted(set(degrees_in.tolist()))
+    lowest, highest = present[0], present[-1]
+    if lowest not in (-1, 0) or present != list(range(lowest, highest + 1)):
+        raise ValueError('degrees_in must assume consecutive values starting '
+                         'from 0 (or -1 for conditioning input features).')
+    return highest
 
 
 class _EmbeddedMADE(MADE):
