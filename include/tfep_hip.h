@@ -144,6 +144,10 @@ typedef struct tfep_gemm_desc {
     int32_t split;                              /* 1: x and w are split-f16 rows (tfep_split_rows), wide tile only */
     const float* x_inv_scale;                   /*    (B) per-row 1/scale of x                                     */
     const float* w_inv_scale;                   /*    (1) 1/scale of w                                             */
+    int32_t split_out;                          /* with split = 1, act = 1: y receives ELU(...) as SPLIT rows for the */
+    float* y_inv_scale;                         /*   next layer (ldy = pitch in 4-byte elements); per-row 1/scale (B)  */
+    const float* w_l1max;                       /*   scale from the bound max|x_row| * w_l1max + bias_absmax:          */
+    const float* bias_absmax;                   /*   inv_scale[2] of tfep_masked_weight_prepare_split, max |bias|      */
     int32_t k_split;                            /* > 1: split-K for products with few output tiles: slice s of the  */
     int64_t slab_stride;                        /*   k-range writes its partial sums to y + s * slab_stride (bias and */
                                                 /*   pre_add in slice 0); the caller adds the k_split slabs           */
@@ -282,7 +286,8 @@ int tfep_split_rows(const float* src, int64_t ld_src, int64_t rows, int64_t cols
  * max |weight_g| with weight norm, max |weight_v| without).  in_of_col: PACKED column -> input column (the inverse
  * of tfep_masked_weight_prepare's col_of_in), or NULL for the identity.  Only the out_features real rows are
  * written (all k_padded columns of each): padding rows of w_split_out must already be zero.
- * inv_scale: 2 floats as for tfep_split_rows(per_tensor = 1). */
+ * inv_scale: 4 floats: [0] = 1/scale, [1] = scratch, [2] = max_j sum_k |w_jk| (row-L1 maximum of the effective
+ * weights, used to bound the next layer's activations: tfep_gemm_desc.split_out), [3] unused. */
 int tfep_masked_weight_prepare_split(const float* weight_v, const float* weight_g, const float* mask, int out_features,
                                      int in_features, const int32_t* row_of_out, const int32_t* in_of_col,
                                      void* w_split_out, int64_t ldw, int k_padded, float* inv_scale, void* stream);

@@ -155,3 +155,33 @@ def test_split_gemm_non_finite_and_extreme_rows_stay_local():
     assert float(((y[11].double() - ref11).abs() / (a2[11].double().abs() @ w.double().abs().T)).max()) < 1e-6
     ref13 = (a2[13].double() @ w.double().T)
     assert float(((y[13].double() - ref13).abs() / (a2[13].double().abs() @ w.double().abs().T)).max()) < 1e-6
+
+
+@pytest.mark.parametrize('B,K,N', [(300, 640, 704), (1, 64, 32), (257, 96, 288)])
+def test_elu_layer_writing_split_rows_directly(B, K, N):
+    """Hidden layer with the split-row epilogue (scale from the bound max|x| * max_j sum_k |w_jk| + max|b|): the rows
+    it writes decode to ELU(x W^T + b) as accurately as the fp32 output converted afterwards."""
+    from tfep_amd import ops
+    torch.manual_seed(B + N)
+    x = torch.randn(B, K, device='cuda') * torch.logspace(-2, 2, B, device='cuda')[:, None]
+    w = torch.randn(N, K, device='cuda') / K ** 0.5
+    g = torch.rand(N, 1, device='cuda') + 0.5
+    bias = torch.randn(N, device='cuda')
+    ws = torch.zeros(N, K, device='cuda')
+    w_buf = torch.zeros(4, device='cuda')
+    ops.masked_weight_prepare_split(w, g, None, None, None, ws, w_buf)
+    w_eff = (g * w / w.norm(dim=1, keepdim=True)).double()
+    l1 = float(w_eff.abs().sum(1).max())
+    assert abs(float(w_buf[2]) - l1) < 1e-4 * l1                      # row-L1 maximum of the effective weights
+    xs, x_inv = ops.split_rows(x, K)
+    hs, h_inv = ops.masked_linear_split(xs, x_inv, ws, w_buf, bias, N, act=1, split_out=True)
+    assert hs.shape == (B, N) and h_inv.shape == (B,)
+    ref = x.double() @ w_eff.T + bias.double()
+    ref = torch.where(ref > 0, ref, torch.expm1(ref))
+    got = unsplit(hs, h_inv, N).double()
+    scale = x.double().abs() @ w_eff.abs().T + bias.double().abs() + 1.0
+    assert float(((got - ref).abs() / scale).max()) < 1e-6
+    raw = hs.view(torch.float16).reshape(B, -1, 2, 8).float()
+    assert torch.isfinite(raw).all() and float(raw.abs().max()) < 2.0 ** 15   # the bound keeps fp16 in range
+    fp32 = ops.masked_linear_split(xs, x_inv, ws, w_buf, bias, N, act=1)
+    assert float(((got - fp32.double()).abs() / scale).max()) < 5e-7

@@ -31,6 +31,7 @@ class GemmDesc(Structure):
                 ('elu_grad_of', c_void_p), ('ld_elu_grad_of', c_int64), ('tile_live', c_void_p),
                 ('pre_add', c_void_p), ('ld_pre_add', c_int64), ('tile_n', c_int32),
                 ('split', c_int32), ('x_inv_scale', c_void_p), ('w_inv_scale', c_void_p),
+                ('split_out', c_int32), ('y_inv_scale', c_void_p), ('w_l1max', c_void_p), ('bias_absmax', c_void_p),
                 ('k_split', c_int32), ('slab_stride', c_int64)]
 
 

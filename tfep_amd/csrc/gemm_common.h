@@ -11,7 +11,7 @@ namespace tfep {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum Epilogue { EPI_LINEAR = 0, EPI_ELU = 1, EPI_AFFINE = 2, EPI_SPLINE = 3 };
+enum Epilogue { EPI_LINEAR = 0, EPI_ELU = 1, EPI_AFFINE = 2, EPI_SPLINE = 3, EPI_ELU_SPLIT = 4 };
 
 struct FusedArgs {
     const float* x;            // transformer input  (B, ldx)
@@ -50,6 +50,9 @@ struct GemmArgs {
     int ksplit;                // linear epilogues: > 1 = split-K: launch position (column tile, k slice); slice s writes
     int64_t slab_stride;       //   its partial sums to y + s * slab_stride (bias / pre_add in slice 0 only); the
                                //   consumer adds the slabs (deterministic, no atomics)
+    float* y_inv_scale;        // EPI_ELU_SPLIT (split kernel): y receives split rows; per-row 1/scale written here (B)
+    const float* w_l1max;      //   max_j sum_k |w_jk| of the weights and max |bias|: bound the outputs, hence the scale
+    const float* bias_absmax;
     const float* a_inv_scale;  // split-f16 operands only: per-row 1/scale of the activations (B)
     const float* w_inv_scale;  //   and the single 1/scale of the weights
     FusedArgs fu;

@@ -454,6 +454,10 @@ int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
         constexpr int SPLIT_BN = Tile<LIN_MREP, LIN_NREP>::BN;
         TFEP_REQUIRE(d->tile_n == 0 || d->tile_n == SPLIT_BN, "masked_linear_gemm: split operands need the wide tile");
         g.a_inv_scale = d->x_inv_scale; g.w_inv_scale = d->w_inv_scale;
+        if (d->split_out) {
+            TFEP_REQUIRE(d->act == 1 && d->y_inv_scale, "masked_linear_gemm: split_out needs act = 1 (ELU) and y_inv_scale");
+            g.y_inv_scale = d->y_inv_scale; g.w_l1max = d->w_l1max; g.bias_absmax = d->bias_absmax;
+        }
         return launch_split_linear(g, d->n_rows_w, d->act, (hipStream_t)stream);
     }
     constexpr int WIDE_BN = Tile<LIN_MREP, LIN_NREP>::BN, NARROW_BN = Tile<LIN_MREP, NARROW_NREP>::BN;

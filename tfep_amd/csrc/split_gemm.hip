@@ -62,7 +62,9 @@ __device__ inline float pow2_scale_for(float amax) {
     return ldexpf(1.0f, k);
 }
 
-__global__ void zero_u32_kernel(uint32_t* p) { *p = 0u; }
+__global__ void zero_u32_kernel(uint32_t* p, int n = 1) {
+    for (int i = 0; i < n; ++i) p[i] = 0u;
+}
 
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int64_t cols,
                                                      uint32_t* __restrict__ out_bits) {
@@ -142,6 +144,7 @@ __global__ void __launch_bounds__(256) weight_prepare_split_kernel(const float* 
     if (o == 0 && lane == 0) inv_scale[0] = 1.0f / s;
     const int64_t orow = row_of_out ? row_of_out[o] : o;
     uint4* dr = w_out + orow * (ldw / 4);
+    float l1 = 0.f;                              // sum_k |w_ok|: bounds this unit's pre-activation (see EPI_ELU_SPLIT)
     for (int g8 = lane; g8 * 8 < k_padded; g8 += 64) {
         f16x8 hi, lo;
 #pragma unroll
@@ -152,6 +155,7 @@ __global__ void __launch_bounds__(256) weight_prepare_split_kernel(const float* 
                 const int i = in_of_col ? in_of_col[c] : c;
                 if (!(mr && mr[i] == 0.0f)) val = g ? vr[i] * wn : (mr ? vr[i] * mr[i] : vr[i]);
             }
+            l1 += fabsf(val);
             val *= s;
             const _Float16 h = (_Float16)val;
             hi[j] = h;
@@ -160,6 +164,8 @@ __global__ void __launch_bounds__(256) weight_prepare_split_kernel(const float* 
         dr[g8 * 2] = *reinterpret_cast<uint4*>(&hi);
         dr[g8 * 2 + 1] = *reinterpret_cast<uint4*>(&lo);
     }
+    l1 = wave_sum(l1);
+    if (lane == 0 && l1 < INFINITY) atomicMax(reinterpret_cast<uint32_t*>(inv_scale + 2), __float_as_uint(l1));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -452,6 +458,46 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
         static_assert(SWAVES * SPL_WAVE_BYTES <= T::LDS_BYTES, "epilogue records do not fit in LDS");
         __syncthreads();                        // every wave is done with the operand stages: LDS is reused below
         split_spline_epilogue<KSPL>(g, acc, rs, nt, n0, wrow0, lane, (float*)(slds + wave * SPL_WAVE_BYTES));
+    } else if constexpr (EPI == EPI_ELU_SPLIT) {
+        // y = ELU(x W^T + b) written straight as split rows for the next GEMM.  The row scale cannot wait for the row
+        // maximum (other workgroups hold the other columns), so it comes from a bound every workgroup can compute:
+        //   |y| <= max(1, max|x_row| * max_j sum_k |w_jk| + max|b|),   max|x_row| < 2^15 * x_inv_scale[row].
+        // A bound even 100x above the true maximum costs nothing: the split format keeps an absolute error of
+        // 2^-40 of the scaled maximum, far below fp32 rounding of the sums that consume it.
+        const float wl1 = g.w_l1max[0], bmax = g.bias_absmax[0];
+        const int cj = lane & 15, rq = (lane >> 4) * 4;
+        uint16_t* yb = reinterpret_cast<uint16_t*>(g.y);
+        f32x4 so[SMREP];
+        static_for<0, SMREP * 4>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int m = ic.value / 4, i = ic.value % 4;
+            const int row = wrow0 + m * 16 + rq + i;
+            float s_out = 1.f;
+            if (row < g.B) {
+                s_out = pow2_scale_for(fmaxf(1.f, 32768.f * g.a_inv_scale[row] * wl1 + bmax));
+                if (nt == 0 && cj == 0) g.y_inv_scale[row] = 1.0f / s_out;
+            }
+            so[m][i] = s_out;
+        });
+        static_for<0, NREP>([&](auto nc) __attribute__((always_inline)) {
+            constexpr int n = nc.value;
+            const int col = n0 + n * 16 + cj;
+            if (col < g.N) {
+                const float bv = g.bias ? g.bias[col] : 0.f;
+                const int64_t cbyte = (int64_t)(col >> 3) * 32 + (col & 7) * 2;        // hi half; lo half 16 bytes on
+                static_for<0, SMREP * 4>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int m = ic.value / 4, i = ic.value % 4;
+                    const int row = wrow0 + m * 16 + rq + i;
+                    if (row < g.B) {
+                        const float v = elu_f(acc[n][m][i] * rs[m][i] + bv) * so[m][i];
+                        const _Float16 h = (_Float16)v;
+                        const _Float16 l = (_Float16)(v - (float)h);
+                        uint16_t* dst = yb + ((int64_t)row * g.ldy * 4 + cbyte) / 2;
+                        dst[0] = __builtin_bit_cast(uint16_t, h);
+                        dst[8] = __builtin_bit_cast(uint16_t, l);
+                    }
+                });
+            }
+        });
     } else {
         // the other epilogues get a copy they may index from unrolled loops
         f32x4 out[NREP][SMREP];
@@ -540,6 +586,12 @@ int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s)
     if (rc) return rc;
     constexpr int NREP = 16;
     const int n_tiles = (g.N + STile<NREP>::BN - 1) / STile<NREP>::BN;
+    if (act == 1 && g.y_inv_scale) {
+        TFEP_REQUIRE(g.w_l1max && g.bias_absmax, "split gemm: split output needs w_l1max and bias_absmax");
+        TFEP_REQUIRE(!g.col_map && !g.aux && !g.pre_add && !g.accumulate && g.ldy % 8 == 0 && g.N <= g.ldy,
+                     "split gemm: split output supports the plain ELU layer only");
+        return launch_split<NREP, EPI_ELU_SPLIT, 1, 1>(g, n_rows_w, n_tiles, s);
+    }
     if (act == 1) return launch_split<NREP, EPI_ELU, 1, 1>(g, n_rows_w, n_tiles, s);
     return launch_split<NREP, EPI_LINEAR, 1, 1>(g, n_rows_w, n_tiles, s);
 }
@@ -602,7 +654,7 @@ int tfep_masked_weight_prepare_split(const float* weight_v, const float* weight_
     if (out_features == 0) return TFEP_OK;
     hipStream_t s = (hipStream_t)stream;
     uint32_t* max_bits = reinterpret_cast<uint32_t*>(inv_scale + 1);
-    zero_u32_kernel<<<1, 1, 0, s>>>(max_bits);
+    zero_u32_kernel<<<1, 1, 0, s>>>(max_bits, 2);          // the maximum and the row-L1 maximum (inv_scale[1], [2])
     if (weight_g)
         absmax_kernel<<<1, 256, 0, s>>>(weight_g, 0, 1, out_features, max_bits);          // one wave over the N gains
     else if (in_features > 0)

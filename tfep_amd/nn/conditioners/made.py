@@ -309,11 +309,12 @@ class MADE(Conditioner):
         if buf is None:
             # zero once: the kernel writes the real rows only, padding rows / columns stay zero for good
             buf = (torch.zeros(n_rows, plan['k_pad'][li], dtype=torch.float32, device=v.device),
-                   torch.empty(2, dtype=torch.float32, device=v.device))
+                   torch.zeros(4, dtype=torch.float32, device=v.device))
             plan[key] = buf
         in_of_col = plan['in_of_col'][li]
         ops.masked_weight_prepare_split(v, g, lin.mask, row_of_out, in_of_col, buf[0], buf[1])
-        res = (buf[0], buf[1], self._pack_bias(lin, row_of_out, n_rows))
+        bias = self._pack_bias(lin, row_of_out, n_rows)
+        res = (buf[0], buf[1], bias, bias.abs().max().reshape(1))
         if self._frozen:
             plan[('packed_split', li, n_rows)] = res
         return res
@@ -339,7 +340,7 @@ class MADE(Conditioner):
         h = ops.pad_columns(x, plan['k_pad'][0])
         for li, lin in enumerate(lins[:-1]):
             if split:
-                ws, w_inv, b = self._pack_layer_split(plan, li, lin)
+                ws, w_inv, b, _ = self._pack_layer_split(plan, li, lin)
                 hs, h_inv = ops.split_rows(h, plan['k_pad'][li])
                 h = ops.masked_linear_split(hs, h_inv, ws, w_inv, b, plan['n_pad'][li], k_ranges=plan['k_ranges'][li],
                                             act=1, tile_order=plan['tile_order'][li])
@@ -349,18 +350,39 @@ class MADE(Conditioner):
                                              tile_order=plan['tile_order'][li])
         return h, plan
 
+    def forward_hidden_split(self, x):
+        """``forward_hidden`` for the split-f16 GEMMs without fp32 intermediates: every hidden layer writes its
+        ELU activations directly as split rows (scale from a bound on the row, see ``EPI_ELU_SPLIT``).
+        Returns ``(h_split, h_inv_scale, plan)`` of the last hidden layer."""
+        ops.check_device_tensor(x, 'x')
+        x = self._embed(x)
+        if x.shape[1] != self.dimension_in:
+            raise ValueError(f'expected {self.dimension_in} input features, got {x.shape[1]}')
+        plan = self.plan(x.device)
+        lins = self._linears()
+        hs, h_inv = ops.split_rows(x, plan['k_pad'][0])
+        for li, lin in enumerate(lins[:-1]):
+            ws, w_inv, b, bmax = self._pack_layer_split(plan, li, lin)
+            if plan['n_pad'][li] != plan['k_pad'][li + 1]:
+                raise RuntimeError('hidden layer width and next layer input padding differ')
+            hs, h_inv = ops.masked_linear_split(hs, h_inv, ws, w_inv, b, plan['n_pad'][li], k_ranges=plan['k_ranges'][li],
+                                                act=1, tile_order=plan['tile_order'][li], split_out=True, bias_absmax=bmax)
+        return hs, h_inv, plan
+
     def forward(self, x, split=None):
         """Transformer parameters ``(..., n_out)`` (reference made.py:355).  ``split``: run the GEMMs on split-f16
         operands (fp32-equivalent, ``csrc/split_gemm.hip``); None = the ``TFEP_SPLIT_GEMM`` default."""
         split = ops.split_gemm_enabled() if split is None else bool(split)
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
-        h, plan = self.forward_hidden(x2, split=split)
+        if split:
+            hs, h_inv, plan = self.forward_hidden_split(x2)
+        else:
+            h, plan = self.forward_hidden(x2)
         li = len(plan['n_pad']) - 1
         lin = self.layers[-1]
         if split:
-            ws, w_inv, b = self._pack_layer_split(plan, li, lin)
-            hs, h_inv = ops.split_rows(h, plan['k_pad'][li])
+            ws, w_inv, b, _ = self._pack_layer_split(plan, li, lin)
             out = ops.masked_linear_split(hs, h_inv, ws, w_inv, b, lin.out_features, k_ranges=plan['k_ranges'][li],
                                           act=0, tile_order=plan['tile_order'][li])
         else:

@@ -184,12 +184,12 @@ class AutoregressiveFlow(torch.nn.Module):
         fp = self._fused_plan(x.device, kind, tables)
         made = self._conditioner
         split = self._use_split_gemm()
-        h, mplan = made.forward_hidden(x, split=split)
         if split:
-            w, w_inv, b = made._pack_layer_split(mplan, fp['li'], made.layers[-1], row_of_out=fp['row_of_out'],
-                                                 n_rows=fp['n_rows'])
-            h, h_inv = ops.split_rows(h, w.shape[1])
+            h, h_inv, mplan = made.forward_hidden_split(x)
+            w, w_inv, b, _ = made._pack_layer_split(mplan, fp['li'], made.layers[-1], row_of_out=fp['row_of_out'],
+                                                    n_rows=fp['n_rows'])
         else:
+            h, mplan = made.forward_hidden(x)
             w, b = made._pack_layer(mplan, fp['li'], made.layers[-1], row_of_out=fp['row_of_out'], n_rows=fp['n_rows'])
         y = x.clone() if self.has_fixed_indices else torch.empty(B, D, dtype=x.dtype, device=x.device)
         ldj = torch.empty(B, dtype=torch.float32, device=x.device)

@@ -262,13 +262,21 @@ def masked_weight_prepare_split(weight_v, weight_g, mask, row_of_out, in_of_col,
 
 
 def masked_linear_split(x_split, x_inv_scale, w_split, w_inv_scale, bias, n_out, k_ranges=None, act=0, out=None,
-                        tile_order=None):
-    """``masked_linear_packed`` on split-f16 operands; the output is ordinary fp32."""
+                        tile_order=None, split_out=False, bias_absmax=None):
+    """``masked_linear_packed`` on split-f16 operands; the output is ordinary fp32, or -- ``split_out`` with
+    ``act=1`` -- the ELU activations as split rows for the next layer: returns ``(rows, inv_scale)`` then.
+    ``w_inv_scale`` is the 4-float buffer of ``masked_weight_prepare_split`` (its entry 2 bounds the outputs)."""
     B = x_split.shape[0]
     n_rows_w, k_padded = w_split.shape
     if out is None:
         out = torch.empty(B, n_out, dtype=torch.float32, device=x_split.device)
     d = _lib.GemmDesc()
+    if split_out:
+        if bias_absmax is None:
+            bias_absmax = bias.abs().max().reshape(1) if bias is not None else torch.zeros(1, device=out.device)
+        y_inv = torch.empty(max(B, 1), dtype=torch.float32, device=out.device)
+        d.split_out, d.y_inv_scale = 1, y_inv.data_ptr()
+        d.w_l1max, d.bias_absmax = w_inv_scale.data_ptr() + 8, bias_absmax.data_ptr()
     d.x, d.ldx = x_split.data_ptr(), x_split.shape[1]
     d.w, d.ldw = w_split.data_ptr(), k_padded
     d.bias = bias.data_ptr() if bias is not None else None
@@ -279,7 +287,7 @@ def masked_linear_split(x_split, x_inv_scale, w_split, w_inv_scale, bias, n_out,
     d.B, d.N, d.n_rows_w, d.k_padded, d.act, d.accumulate = B, n_out, n_rows_w, k_padded, int(act), 0
     d.split, d.x_inv_scale, d.w_inv_scale = 1, x_inv_scale.data_ptr(), w_inv_scale.data_ptr()
     call('tfep_masked_linear_gemm', ctypes.byref(d), stream_of(x_split))
-    return out
+    return (out, y_inv) if split_out else out
 
 
 # ----------------------------------------------------------------------------- reductions
