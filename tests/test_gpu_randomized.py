@@ -2,6 +2,8 @@
 permutations, repeats, conditioning features, hidden depth/width, weight norm) and random transformers,
 each checked three ways -- fused vs generic HIP path, HIP vs the float64 oracle, blocked vs pass-per-degree
 inverse -- plus finite-difference gradients from the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -61,7 +63,9 @@ def oracle_layer(maf, spec):
                 made=omade.made_layers_from_state(sd, prefix='_conditioner.'))
 
 
-@pytest.mark.parametrize('seed', list(range(40)))
+# TFEP_RANDOM_SEEDS=N widens the sweep (soak runs: 1500 seeds pass); the default includes seed 128, which caught a
+# k-range table one tile short for the layer-0 block GEMM of the fused inverse (affine + conditioning features)
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('TFEP_RANDOM_SEEDS', 160)))))
 def test_random_structure(seed):
     case = random_case(seed)
     if case is None:

@@ -10,6 +10,7 @@ Same constructor, buffers (``_transformer_indices``, ``_inverse_masks``, ``_fixe
   ``(batch, P*D)`` parameter tensor lives only in MFMA accumulators.
 """
 import ctypes
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -399,6 +400,7 @@ class AutoregressiveFlow(torch.nn.Module):
             blocks.append(blk)
         narrow = lib.tfep_masked_linear_narrow_tile_n()
         max_rows = max([w['n_rows'] for b_ in blocks for w in b_['wide']] + [b_['out_wide']['n_rows'] for b_ in blocks] +
+                       [b_['fused']['wide0']['n_rows'] for b_ in blocks if b_['fused'] and b_['fused']['wide0']] +
                        [h_['n_rows'] for b_ in blocks for st in b_['steps'] for h_ in st['hidden']] +
                        [st['out']['n_rows'] for b_ in blocks for st in b_['steps']])
         fused_ok = self._fused_inverse_supported(L) and all(b_['fused'] is not None for b_ in blocks)
