@@ -122,3 +122,49 @@ def test_random_structure(seed):
         fd = (loss_np(xp) - loss_np(xm)) / (2 * eps)
         got = float(xq.grad[i, j])
         assert abs(got - fd) <= 2e-4 * max(1.0, abs(fd)) + 1e-6, (kind, i, j, got, fd)
+
+
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('TFEP_RANDOM_MEDIUM_SEEDS', 12)))))
+def test_random_medium_size_cross_path_consistency(seed):
+    """Medium sizes (several row / column / k tiles per kernel, ragged everywhere): the independent implementations of
+    the same maths must agree -- split-f16 vs exact-fp32 GEMMs, fused vs generic forward, fused block kernel vs
+    per-step launches vs one pass per degree in the inverse -- and the inverse must undo the forward."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import AffineTransformer, NeuralSplineTransformer
+    rng = np.random.default_rng(10_000 + seed)
+    D = int(rng.integers(40, 420))
+    B = int(rng.integers(1, 700))
+    repeats = int(rng.choice([1, 1, 2, 3]))
+    order = str(rng.choice(['ascending', 'descending', 'random']))
+    n_hidden = int(rng.integers(1, 4))
+    hidden = [int(rng.integers(D, 4 * D)) for _ in range(n_hidden)] if rng.random() < 0.7 else n_hidden
+    spline = bool(rng.random() < 0.6)
+    torch.manual_seed(seed)
+    deg = generate_degrees(D, order, repeats=repeats)
+    tr = NeuralSplineTransformer(torch.full((D,), -4.0), torch.full((D,), 4.0), 8) if spline else AffineTransformer()
+    maf = MAF(deg, transformer=tr, hidden_layers=hidden, weight_norm=bool(rng.random() < 0.7), initialize_identity=False).cuda()
+    x = (torch.randn(B, D, generator=torch.Generator().manual_seed(seed)) * 1.2).cuda()
+    with torch.no_grad():
+        maf.split_gemm = True
+        y, l = maf(x)
+        maf.split_gemm = False
+        y32, l32 = maf(x)
+        maf.fused = False
+        yg, lg = maf(x)
+        maf.fused, maf.split_gemm = True, None
+        scale = float(y32.abs().max()) + 1.0
+        assert float((y - y32).abs().max()) < 2e-5 * scale and torch.allclose(l, l32, rtol=1e-5, atol=1e-3 + 2e-6 * D)
+        assert float((yg - y32).abs().max()) < 2e-5 * scale and torch.allclose(lg, l32, rtol=1e-5, atol=1e-3 + 2e-6 * D)
+        xf, lf = maf.inverse(y)
+        fused_taken = maf._blocked_plan(x.device)['fused'] is not None     # not when a 2-degree block exceeds the LDS
+        maf.fused_inverse = False
+        maf._dev.clear()
+        xs, ls = maf.inverse(y)
+        assert torch.allclose(xf, xs, rtol=1e-4, atol=2e-4) and torch.allclose(lf, ls, rtol=1e-4, atol=2e-3)
+        if B <= 64:                                   # the reference algorithm: one full pass per degree
+            maf.blocked_inverse = False
+            xr, lr = maf.inverse(y)
+            assert torch.allclose(xf, xr, rtol=1e-4, atol=2e-4) and torch.allclose(lf, lr, rtol=1e-4, atol=2e-3)
+        assert torch.allclose(xf, x, rtol=1e-3, atol=5e-3)
+        assert torch.allclose(lf + l, torch.zeros_like(l), atol=5e-3 + 1e-5 * D)

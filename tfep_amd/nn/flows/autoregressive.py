@@ -309,6 +309,26 @@ class AutoregressiveFlow(torch.nn.Module):
     inverse_block = 16
 
     def _blocked_plan(self, device):
+        """The plan of ``_blocked_plan_for`` with ``inverse_block`` degrees per block, or fewer (halved down to 2) when
+        that is what lets the block's state fit the LDS of the fused block kernel."""
+        key = ('blocked', str(device), self.inverse_block)
+        bp = self._dev.get(key)
+        if bp is not None:
+            return bp
+        G = max(1, int(self.inverse_block))
+        bp = self._blocked_plan_for(device, G)
+        if bp['fused'] is None and self._fused_inverse_supported(bp['L']):
+            g = G
+            while g > 2:
+                g //= 2
+                cand = self._blocked_plan_for(device, g)
+                if cand['fused'] is not None:
+                    bp = cand
+                    break
+        self._dev[key] = bp
+        return bp
+
+    def _blocked_plan_for(self, device, G):
         """Host-side plan of the two-level blocked forward substitution.
 
         Degrees are processed in blocks of ``inverse_block``.  For a block, the contribution of every
@@ -317,10 +337,6 @@ class AutoregressiveFlow(torch.nn.Module):
         the block each degree adds the (short) range of units that the block itself has produced.
         Hidden units are stored sorted by degree, so all of these are contiguous row / column ranges.
         """
-        key = ('blocked', str(device), self.inverse_block)
-        bp = self._dev.get(key)
-        if bp is not None:
-            return bp
         lib = _lib.load()
         made = self._conditioner
         mplan = made.plan(device)
@@ -335,7 +351,6 @@ class AutoregressiveFlow(torch.nn.Module):
         P = lins[-1].out_features // n_tr
         max_deg = int(deg_tr.max())
         hid = [torch.sort(made._degrees[l + 1].cpu()).values for l in range(L)]
-        G = int(self.inverse_block)
 
         def up(v):
             return (v + tk - 1) // tk * tk
@@ -412,7 +427,6 @@ class AutoregressiveFlow(torch.nn.Module):
                   fused=dict(cache_len=cache_len, max_feats=max_feats) if fused_ok else None,
                   max_tiles=(max_rows + narrow - 1) // narrow,
                   k_ranges=torch.tensor(kr, dtype=torch.int32).reshape(-1, 2).to(device))
-        self._dev[key] = bp
         return bp
 
     #: Run the per-degree chain of each block in ONE kernel (``tfep_inverse_block``) when the layer qualifies.
