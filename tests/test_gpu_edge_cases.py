@@ -145,3 +145,53 @@ def test_graft_entry_smoke_runs():
         sys.path.insert(0, root)
     entry = importlib.import_module('__graft_entry__')
     entry.smoke()
+
+
+def test_new_entry_points_reject_bad_arguments():
+    """Argument validation of the split-GEMM / inverse-block / bootstrap entry points: an error code and a message,
+    never a launch with inconsistent shapes."""
+    import ctypes
+    from tfep_amd import _lib, ops
+    a = torch.randn(8, 64, device='cuda')
+    out = torch.empty(8, 64, device='cuda')
+    inv = torch.empty(8, device='cuda')
+    with pytest.raises(ValueError, match='cols_padded'):
+        _lib.call('tfep_split_rows', _lib.ptr(a), 64, 8, 64, _lib.ptr(out), 64, 48, _lib.ptr(inv), 0, _lib.stream_of(a))
+    with pytest.raises(ValueError, match='NULL'):
+        _lib.call('tfep_split_rows', None, 64, 8, 64, _lib.ptr(out), 64, 64, _lib.ptr(inv), 0, _lib.stream_of(a))
+    # split GEMM: k_padded must be a multiple of 32, scales must be given
+    d = _lib.GemmDesc()
+    w = torch.randn(32, 48, device='cuda')
+    d.x, d.ldx, d.w, d.ldw, d.y, d.ldy = a.data_ptr(), 48, w.data_ptr(), 48, out.data_ptr(), 64
+    d.B, d.N, d.n_rows_w, d.k_padded, d.split = 8, 32, 32, 48, 1
+    d.x_inv_scale, d.w_inv_scale = inv.data_ptr(), inv.data_ptr()
+    with pytest.raises(ValueError, match='multiple of 32'):
+        _lib.call('tfep_masked_linear_gemm', ctypes.byref(d), _lib.stream_of(a))
+    d.k_padded, d.ldx, d.ldw, d.x_inv_scale = 64, 64, 64, None
+    with pytest.raises(ValueError, match='scale'):
+        _lib.call('tfep_masked_linear_gemm', ctypes.byref(d), _lib.stream_of(a))
+    # split-K needs a plain linear product
+    d2 = _lib.GemmDesc()
+    d2.x, d2.ldx, d2.w, d2.ldw, d2.y, d2.ldy = a.data_ptr(), 64, a.data_ptr(), 64, out.data_ptr(), 64
+    d2.B, d2.N, d2.n_rows_w, d2.k_padded, d2.act, d2.k_split, d2.slab_stride = 8, 8, 8, 64, 1, 2, 512
+    with pytest.raises(ValueError, match='k_split'):
+        _lib.call('tfep_masked_linear_gemm', ctypes.byref(d2), _lib.stream_of(a))
+    # inverse block: descriptor checks
+    ib = _lib.InverseBlockDesc()
+    ib.B, ib.n_layers, ib.n_steps, ib.kind = 8, 5, 1, 0
+    with pytest.raises(ValueError, match='hidden layers'):
+        _lib.call('tfep_inverse_block', ctypes.byref(ib), _lib.stream_of(a))
+    ib.n_layers = 1
+    with pytest.raises(ValueError, match='NULL'):
+        _lib.call('tfep_inverse_block', ctypes.byref(ib), _lib.stream_of(a))
+    # bootstrap: weights with biased data, non-positive kT
+    work = torch.randn(16, device='cuda')
+    res = torch.empty(2, dtype=torch.float64, device='cuda')
+    wts = torch.full((2, 16), 1 / 16, device='cuda')
+    with pytest.raises(ValueError, match='not supported with biased'):
+        _lib.call('tfep_bootstrap_fep', _lib.ptr(work), _lib.ptr(work), None, _lib.ptr(wts), 16, 2, 16, 1.0, _lib.ptr(res),
+                  _lib.stream_of(work))
+    with pytest.raises(ValueError, match='kT'):
+        _lib.call('tfep_bootstrap_fep', _lib.ptr(work), None, None, _lib.ptr(wts), 16, 2, 16, 0.0, _lib.ptr(res),
+                  _lib.stream_of(work))
+    assert ops.tile_sizes()[2] == _lib.load().tfep_split_tile_k() == 32
