@@ -45,7 +45,19 @@ __device__ inline double wave_max(double v) {
 }
 
 // Python / torch `%` for floats: result has the sign of the divisor.
+// For a positive divisor (a period) the remainder is formed with one floor and one fma: a - floor(a/b) * b is exactly
+// representable whenever |a| >= b (it is a multiple of ulp(b) below 2b), so the fma returns it exactly, and for
+// |a| < b it is a or a + b rounded once -- the same values fmod() + the sign fix-up produce, without fmod's
+// data-dependent reduction loop (which serialised the lanes of the circular-spline epilogues).  A quotient that rounds
+// across an integer leaves r just outside [0, b): one exact-sum correction brings it back.
 __device__ inline double py_mod(double a, double b) {
+    if (b > 0.0 && fabs(a) < 1e300) {
+        const double q = floor(a / b);
+        double r = fma(-q, b, a);
+        if (r < 0.0) r += b;
+        if (r >= b) r -= b;
+        return r;
+    }
     double r = fmod(a, b);
     if (r != 0.0 && ((r < 0.0) != (b < 0.0))) r += b;
     return r;
