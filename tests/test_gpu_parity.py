@@ -454,3 +454,30 @@ def test_fused_inverse_block_kernel_matches_per_step_launches(name):
             layer._dev.clear()
         xf2, lf2 = flow.inverse(yin)
     assert torch.equal(xf, xf2) and torch.equal(lf, lf2)
+
+
+def test_cfg2_full_batch_properties():
+    """BASELINE cfg2 at its full batch (65 536 x 3000, one of the four layers): size-independent properties -- every row
+    of the big batch equals, bit for bit, the same row pushed through in a small batch; run-to-run determinism; the
+    blocked inverse undoes the forward on a slice; finite outputs."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF, SequentialFlow
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    D, B = 3000, 65536
+    torch.manual_seed(0)
+    with torch.device('cuda'):
+        flow = SequentialFlow(MAF(generate_degrees(D, 'ascending'),
+                                  transformer=NeuralSplineTransformer(torch.full((D,), -5.0), torch.full((D,), 5.0), 8),
+                                  initialize_identity=False))
+    x = torch.randn(B, D, device='cuda', generator=torch.Generator('cuda').manual_seed(7)).clamp_(-4.9, 4.9)
+    with torch.no_grad():
+        y, l = flow(x)
+        assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(l).all())
+        y2, l2 = flow(x)
+        assert torch.equal(y, y2) and torch.equal(l, l2)
+        for lo, hi in ((0, 256), (12345, 12345 + 77), (B - 300, B)):
+            ys, ls = flow(x[lo:hi].clone())
+            assert torch.equal(ys, y[lo:hi]) and torch.equal(ls, l[lo:hi]), (lo, hi)
+        xi, li = flow.inverse(y[40000:40000 + 192])
+        assert float((xi - x[40000:40000 + 192]).norm() / x[40000:40000 + 192].norm()) < 1e-5
+        assert torch.allclose(li + l[40000:40000 + 192], torch.zeros(192, device='cuda'), atol=2e-3)
