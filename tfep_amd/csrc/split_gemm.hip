@@ -466,7 +466,6 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
         // 2^-40 of the scaled maximum, far below fp32 rounding of the sums that consume it.
         const float wl1 = g.w_l1max[0], bmax = g.bias_absmax[0];
         const int cj = lane & 15, rq = (lane >> 4) * 4;
-        uint16_t* yb = reinterpret_cast<uint16_t*>(g.y);
         f32x4 so[SMREP];
         static_for<0, SMREP * 4>([&](auto ic) __attribute__((always_inline)) {
             constexpr int m = ic.value / 4, i = ic.value % 4;
@@ -478,25 +477,28 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
             }
             so[m][i] = s_out;
         });
+        // Lanes 2j and 2j+1 hold adjacent columns: the even lane stores both halves' pairs as 32-bit words (half as
+        // many, aligned stores; g.N is even and a pair never straddles a group of 8 columns).
         static_for<0, NREP>([&](auto nc) __attribute__((always_inline)) {
             constexpr int n = nc.value;
             const int col = n0 + n * 16 + cj;
-            if (col < g.N) {
-                const float bv = g.bias ? g.bias[col] : 0.f;
-                const int64_t cbyte = (int64_t)(col >> 3) * 32 + (col & 7) * 2;        // hi half; lo half 16 bytes on
-                static_for<0, SMREP * 4>([&](auto ic) __attribute__((always_inline)) {
-                    constexpr int m = ic.value / 4, i = ic.value % 4;
-                    const int row = wrow0 + m * 16 + rq + i;
-                    if (row < g.B) {
-                        const float v = elu_f(acc[n][m][i] * rs[m][i] + bv) * so[m][i];
-                        const _Float16 h = (_Float16)v;
-                        const _Float16 l = (_Float16)(v - (float)h);
-                        uint16_t* dst = yb + ((int64_t)row * g.ldy * 4 + cbyte) / 2;
-                        dst[0] = __builtin_bit_cast(uint16_t, h);
-                        dst[8] = __builtin_bit_cast(uint16_t, l);
-                    }
-                });
-            }
+            const bool in_range = col < g.N;
+            const float bv = (in_range && g.bias) ? g.bias[col] : 0.f;
+            const int64_t cbyte = (int64_t)(col >> 3) * 32 + (col & 7) * 2;            // hi half; lo half 16 bytes on
+            static_for<0, SMREP * 4>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int m = ic.value / 4, i = ic.value % 4;
+                const int row = wrow0 + m * 16 + rq + i;
+                const float v = elu_f(acc[n][m][i] * rs[m][i] + bv) * so[m][i];
+                const _Float16 h = (_Float16)v;
+                const _Float16 l = (_Float16)(v - (float)h);
+                const uint32_t mine = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
+                const uint32_t next = (uint32_t)__shfl_xor((int)mine, 1, 64);           // the odd neighbour's (hi, lo)
+                if (!(cj & 1) && in_range && row < g.B) {
+                    uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(g.y) + (int64_t)row * g.ldy * 4 + cbyte);
+                    dst[0] = (mine & 0xffffu) | (next << 16);                            // hi of col, hi of col + 1
+                    dst[4] = (mine >> 16) | (next & 0xffff0000u);                        // lo of col, lo of col + 1
+                }
+            });
         });
     } else {
         // the other epilogues get a copy they may index from unrolled loops
@@ -588,7 +590,7 @@ int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s)
     const int n_tiles = (g.N + STile<NREP>::BN - 1) / STile<NREP>::BN;
     if (act == 1 && g.y_inv_scale) {
         TFEP_REQUIRE(g.w_l1max && g.bias_absmax, "split gemm: split output needs w_l1max and bias_absmax");
-        TFEP_REQUIRE(!g.col_map && !g.aux && !g.pre_add && !g.accumulate && g.ldy % 8 == 0 && g.N <= g.ldy,
+        TFEP_REQUIRE(!g.col_map && !g.aux && !g.pre_add && !g.accumulate && g.ldy % 8 == 0 && g.N <= g.ldy && g.N % 2 == 0,
                      "split gemm: split output supports the plain ELU layer only");
         return launch_split<NREP, EPI_ELU_SPLIT, 1, 1>(g, n_rows_w, n_tiles, s);
     }
