@@ -142,6 +142,7 @@ class MADE(Conditioner):
         self._degrees = [d.detach().cpu().clone() for d in (degrees_in, *degrees_hidden, degrees_out)]
         self._plans = {}
         self._frozen = False
+        self._packed_ahead = None      # split weights packed on a side stream for the next forward (prepack_split_async)
 
     # ------------------------------------------------------------------ reference API
     @property
@@ -217,6 +218,7 @@ class MADE(Conditioner):
 
     def _apply(self, fn, *args, **kwargs):
         self._plans = {}
+        self._packed_ahead = None
         return super()._apply(fn, *args, **kwargs)
 
     def plan(self, device):
@@ -300,6 +302,18 @@ class MADE(Conditioner):
         n_rows = plan['n_pad'][li] if n_rows is None else n_rows
         if self._frozen and ('packed_split', li, n_rows) in plan:
             return plan[('packed_split', li, n_rows)]
+        ahead = self._packed_ahead
+        if ahead is not None and ahead['versions'] != self._param_versions():
+            ahead = self._packed_ahead = None                     # parameters changed since: pack again
+        if ahead is not None and (li, n_rows) in ahead['items']:
+            # packed on the side stream while the previous layer of the flow was computing (prepack_split_async)
+            if not ahead['joined']:
+                torch.cuda.current_stream(ahead['device']).wait_event(ahead['event'])
+                ahead['joined'] = True
+            res = ahead['items'].pop((li, n_rows))
+            for t in res[2:]:
+                t.record_stream(torch.cuda.current_stream(ahead['device']))     # small tensors allocated on the side stream
+            return res
         if lin.has_weight_norm:
             v, g = lin.weight_v.detach(), lin.weight_g.detach()
         else:
@@ -318,6 +332,32 @@ class MADE(Conditioner):
         if self._frozen:
             plan[('packed_split', li, n_rows)] = res
         return res
+
+    def prepack_split_async(self, device, stream, last=None):
+        """Pack every layer's split weights on ``stream`` (ordered after everything already queued on the current
+        stream), for the NEXT forward pass of this conditioner: the HBM-bound weight preparation of one flow layer
+        then overlaps the (power-bound) GEMMs of the layer before it.  ``last``: ``(row_of_out, n_rows)`` of the output
+        layer when the fused path packs it its own way."""
+        plan = self.plan(device)
+        lins = self._linears()
+        self._packed_ahead = None
+        stream.wait_stream(torch.cuda.current_stream(device))
+        items = {}
+        with torch.cuda.stream(stream):
+            for li, lin in enumerate(lins):
+                if li == len(lins) - 1 and last is not None:
+                    items[(li, last[1])] = self._pack_layer_split(plan, li, lin, row_of_out=last[0], n_rows=last[1])
+                else:
+                    items[(li, plan['n_pad'][li])] = self._pack_layer_split(plan, li, lin)
+            event = stream.record_event()
+        self._packed_ahead = dict(items=items, event=event, joined=False, device=device, versions=self._param_versions())
+
+    def _param_versions(self):
+        """In-place update counters of every tensor the packed weights depend on."""
+        return tuple(t._version for lin in self._linears() for t in (*lin.parameters(), lin.mask))
+
+    def drop_packed_ahead(self):
+        self._packed_ahead = None
 
     def _embed(self, x):
         return x

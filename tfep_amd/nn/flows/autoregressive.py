@@ -132,6 +132,15 @@ class AutoregressiveFlow(torch.nn.Module):
                 return _FUSED_SPLINE
         return None
 
+    def prepack_async(self, device, stream):
+        """Start packing this layer's weights on ``stream`` for its next forward pass (called by SequentialFlow while
+        the previous layer computes).  Only for the fused split-f16 path; a no-op otherwise."""
+        kind = self._fused_kind()
+        if kind is None or not self._use_split_gemm() or not isinstance(self._conditioner, MADE):
+            return
+        fp = self._fused_plan(device, kind, self._tables(device))
+        self._conditioner.prepack_split_async(device, stream, last=(fp['row_of_out'], fp['n_rows']))
+
     def _use_split_gemm(self):
         """Split-f16 GEMMs for the forward pass: ``self.split_gemm`` if set, else ``TFEP_SPLIT_GEMM`` (default on)."""
         return ops.split_gemm_enabled() if self.split_gemm is None else bool(self.split_gemm)
@@ -212,6 +221,8 @@ class AutoregressiveFlow(torch.nn.Module):
         if prof is not None:
             ev1.record(torch.cuda.current_stream(x.device))
             prof.append((ev0, ev1))
+        if split:
+            made.drop_packed_ahead()
         return y, ldj
 
     # ------------------------------------------------------------------ reference API

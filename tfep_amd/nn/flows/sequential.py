@@ -1,11 +1,32 @@
 """Sequence of flows (reference ``tfep/nn/flows/sequential.py:24-68``)."""
+import os
+
 import torch
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    """One extra HIP stream per device for work that overlaps the main stream (weight packing of the next layer)."""
+    key = str(device)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device)
+    return _side_streams[key]
+
+
 def _run_chain(layers, method, x):
-    """Apply ``layer.<method>`` along ``layers``; the per-layer log|det J| are summed on the device."""
+    """Apply ``layer.<method>`` along ``layers``; the per-layer log|det J| are summed on the device.
+
+    Forward pass on a HIP device: while layer i computes (matrix-core bound), the masked weight-norm re-pack of layer
+    i + 1 (HBM bound, independent of x) runs on a side stream.
+    """
     total = None
-    for layer in layers:
+    overlap = (method == 'forward' and x.is_cuda and len(layers) > 1
+               and os.environ.get('TFEP_OVERLAP_PACK', '1') != '0')
+    for i, layer in enumerate(layers):
+        if overlap and i + 1 < len(layers) and hasattr(layers[i + 1], 'prepack_async'):
+            layers[i + 1].prepack_async(x.device, _side_stream(x.device))
         x, log_det_J = getattr(layer, method)(x)
         total = log_det_J if total is None else total + log_det_J
     if total is None:                                   # no layers: the identity map
