@@ -195,3 +195,37 @@ def test_new_entry_points_reject_bad_arguments():
         _lib.call('tfep_bootstrap_fep', _lib.ptr(work), None, None, _lib.ptr(wts), 16, 2, 16, 0.0, _lib.ptr(res),
                   _lib.stream_of(work))
     assert ops.tile_sizes()[2] == _lib.load().tfep_split_tile_k() == 32
+
+
+def test_weight_prepack_on_side_stream_is_transparent_and_never_stale():
+    """SequentialFlow packs layer i+1's weights on a side stream while layer i computes: same results as without the
+    overlap, and weights packed ahead are discarded when a parameter changed in the meantime."""
+    import os
+    from tfep_amd.nn.flows.sequential import _side_stream
+    g = gu.load('flows.npz')
+    flow = gu.build_flow('rq4', g)
+    x = torch.from_numpy(g['rq4/x']).cuda()
+    with torch.no_grad():
+        y1, l1 = flow(x)
+        os.environ['TFEP_OVERLAP_PACK'] = '0'
+        try:
+            y0, l0 = flow(x)
+        finally:
+            del os.environ['TFEP_OVERLAP_PACK']
+        assert torch.equal(y0, y1) and torch.equal(l0, l1)
+        assert all(layer._conditioner._packed_ahead is None for layer in flow)        # consumed and dropped
+        # pack layer 1 ahead, then change its parameters: the stale pack must not be used
+        layer = flow[1]
+        h = flow[0](x)[0]
+        layer.prepack_async(x.device, _side_stream(x.device))
+        assert layer._conditioner._packed_ahead is not None
+        for p in layer.parameters():
+            p.mul_(1.25)
+        got = layer(h)
+        assert layer._conditioner._packed_ahead is None
+        ref = layer(h)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+        # and an up-to-date pack IS used, with the same result
+        layer.prepack_async(x.device, _side_stream(x.device))
+        got2 = layer(h)
+        assert torch.equal(got2[0], ref[0]) and torch.equal(got2[1], ref[1])
