@@ -27,6 +27,14 @@ inline int check_launch(const char* what) {
 
 constexpr int WAVE = 64;
 
+// Slot of the current HIP device for per-device one-time state (kernel attributes).
+constexpr int TFEP_MAX_DEVICES = 64;
+inline int current_device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev % TFEP_MAX_DEVICES;
+}
+
 // Sum over the 64 lanes of a wavefront (butterfly; every lane gets the total).
 __device__ inline double wave_sum(double v) {
 #pragma unroll

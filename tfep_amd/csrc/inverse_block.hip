@@ -239,7 +239,8 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
     TFEP_REQUIRE(a.P <= IB_MAX_P, "inverse_block: too many parameters per feature");
     const size_t lds = ((size_t)a.L * a.cache_len + a.max_feats) * 64 * sizeof(float);
     TFEP_REQUIRE(lds <= 160 * 1024, "inverse_block: block needs %zu bytes of LDS (> 160 KiB)", lds);
-    static size_t lds_attr = 0;
+    static size_t lds_attr_on[TFEP_MAX_DEVICES] = {};          // per device: a process may drive several GPUs
+    size_t& lds_attr = lds_attr_on[current_device_slot()];
     if (lds > lds_attr) {
         hipError_t e = hipFuncSetAttribute((const void*)inverse_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));

@@ -333,7 +333,9 @@ template <int MREP, int NREP, int EPI, int P, int KSPL>
 static int launch_gemm(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStream_t s) {
     using T = Tile<MREP, NREP>;
     auto kern = gemm_kernel<MREP, NREP, EPI, P, KSPL>;
-    static bool attr_set = false;
+    // per device: a process may drive several GPUs
+    static bool attr_set_on[TFEP_MAX_DEVICES] = {};
+    bool& attr_set = attr_set_on[current_device_slot()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
         if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%d): %s", T::LDS_BYTES, hipGetErrorString(e));

@@ -557,7 +557,9 @@ template <int NREP, int EPI, int P, int KSPL>
 static int launch_split(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStream_t s) {
     using T = STile<NREP>;
     auto kern = split_gemm_kernel<NREP, EPI, P, KSPL>;
-    static bool attr_set = false;
+    // per device: a process may drive several GPUs
+    static bool attr_set_on[TFEP_MAX_DEVICES] = {};
+    bool& attr_set = attr_set_on[current_device_slot()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::LDS_BYTES);
         if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%d): %s", T::LDS_BYTES, hipGetErrorString(e));
