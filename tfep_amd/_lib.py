@@ -177,6 +177,12 @@ def ptr(t):
 
 
 def stream_of(t):
+    """The current HIP stream of the tensor's device.  Kernels launch on the CURRENT device: a tensor that lives on
+    another GPU is an error here (wrap the call in ``torch.cuda.device(tensor.device)``), never a silent cross-device
+    launch."""
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise TfepHipError(f'tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: '
+                           'run under torch.cuda.device(tensor.device)')
     return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
