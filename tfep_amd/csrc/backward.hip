@@ -37,8 +37,15 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ i
                                                      float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    double s = 0.0;
-    for (int r = 0; r < R; ++r) s += (double)in[(int64_t)r * ld + c];
+    // 8 independent partial sums: 8 row loads in flight per thread instead of a load-add dependency chain
+    double p[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int r = 0;
+    for (; r + 8 <= R; r += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p[j] += (double)in[(int64_t)(r + j) * ld + c];
+    }
+    for (; r < R; ++r) p[0] += (double)in[(int64_t)r * ld + c];
+    const double s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     out[c] = accumulate ? (float)((double)out[c] + s) : (float)s;
 }
 
