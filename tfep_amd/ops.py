@@ -251,8 +251,11 @@ def split_rows(x, cols_padded, per_tensor=False, out=None, inv_scale=None):
 
 def masked_weight_prepare_split(weight_v, weight_g, mask, row_of_out, in_of_col, out, inv_scale):
     """Effective masked weight written directly as split-f16 rows into ``out`` (n_rows_padded, k_padded), whose
-    padding rows must already be zero (``tfep_masked_weight_prepare_split``)."""
+    padding rows must already be zero (``tfep_masked_weight_prepare_split``).  ``inv_scale``: 4 floats --
+    [1/scale, scratch, max_j sum_k |w_jk|, unused]."""
     check_device_tensor(weight_v, 'weight')
+    if inv_scale.numel() < 4:
+        raise ValueError('inv_scale must have 4 entries')
     N, K = weight_v.shape
     call('tfep_masked_weight_prepare_split', ptr(weight_v.contiguous()),
          ptr(None if weight_g is None else weight_g.contiguous()),
