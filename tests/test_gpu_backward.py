@@ -40,11 +40,14 @@ def test_masked_linear_function_gradients():
     assert rel(gw.cpu(), g['ml/gw']) < 1e-6
 
 
+@pytest.mark.parametrize('split', [False, True])          # exact-fp32 MFMA GEMMs / split-f16 GEMMs (forced: these are small)
 @pytest.mark.parametrize('name', ['affine', 'spline', 'circular', 'identslopes', 'moebius', 'mixed', 'learnlow', 'learnup', 'learnboth'])
-def test_training_step_gradients_match_reference_autograd(name):
+def test_training_step_gradients_match_reference_autograd(name, split):
     from tfep_amd.loss import BoltzmannKLDivLoss
     g = gu.load('grads.npz')
     flow = gu.build_flow(name, g, configs=gu.grad_flow_configs())
+    for layer in flow:
+        layer.split_gemm = split
     x = torch.from_numpy(g[f'{name}/x']).cuda().requires_grad_(True)
     c, d = torch.from_numpy(g[f'{name}/c']).cuda(), torch.from_numpy(g[f'{name}/d']).cuda()
     y, ldj = flow(x)

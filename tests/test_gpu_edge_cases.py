@@ -202,9 +202,15 @@ def test_weight_prepack_on_side_stream_is_transparent_and_never_stale():
     overlap, and weights packed ahead are discarded when a parameter changed in the meantime."""
     import os
     from tfep_amd.nn.flows.sequential import _side_stream
-    g = gu.load('flows.npz')
-    flow = gu.build_flow('rq4', g)
-    x = torch.from_numpy(g['rq4/x']).cuda()
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF, SequentialFlow
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    D = 300                                             # large enough for the overlap to switch on (>= 4 M weights)
+    torch.manual_seed(0)
+    flow = SequentialFlow(*[MAF(generate_degrees(D, o), transformer=NeuralSplineTransformer(torch.full((D,), -5.), torch.full((D,), 5.), 8),
+                                initialize_identity=False) for o in ('ascending', 'descending')]).cuda()
+    assert sum(lin.mask.numel() for lin in flow[1]._conditioner._linears()) >= 1 << 22
+    x = torch.randn(500, D, device='cuda')
     with torch.no_grad():
         y1, l1 = flow(x)
         os.environ['TFEP_OVERLAP_PACK'] = '0'

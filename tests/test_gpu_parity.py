@@ -171,11 +171,12 @@ def test_made_forward(name):
 
 # ------------------------------------------------------------------ flows end to end
 
-def _flow_check(name, fused):
+def _flow_check(name, fused, split=None):
     g = gu.load('flows.npz')
     flow = gu.build_flow(name, g)
     for layer in flow:
         layer.fused = fused
+        layer.split_gemm = split
     x = dev(g[f'{name}/x'])
     x_before = x.clone()
     y, l = flow(x)
@@ -187,10 +188,11 @@ def _flow_check(name, fused):
     return flow, g
 
 
+@pytest.mark.parametrize('split', [None, True])             # None: size heuristic (exact fp32 here); True: split-f16 GEMMs
 @pytest.mark.parametrize('fused', [True, False])
 @pytest.mark.parametrize('name', ['cfg1', 'rq4', 'cond', 'circ', 'moeb', 'mixflow'])
-def test_flow_forward(name, fused):
-    _flow_check(name, fused)
+def test_flow_forward(name, fused, split):
+    _flow_check(name, fused, split)
 
 
 def test_fused_path_is_taken_where_expected():

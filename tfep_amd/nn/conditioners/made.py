@@ -390,6 +390,14 @@ class MADE(Conditioner):
                                              tile_order=plan['tile_order'][li])
         return h, plan
 
+    def split_worthwhile(self):
+        """True when the layers are large enough (>= 4 M weights) for the split-f16 GEMMs to pay for their operand
+        conversions; tiny conditioners are launch bound either way."""
+        n = self.__dict__.get('_n_weights')
+        if n is None:
+            n = self.__dict__['_n_weights'] = sum(lin.mask.numel() for lin in self._linears())
+        return n >= (1 << 22)
+
     def forward_hidden_split(self, x):
         """``forward_hidden`` for the split-f16 GEMMs without fp32 intermediates: every hidden layer writes its
         ELU activations directly as split rows (scale from a bound on the row, see ``EPI_ELU_SPLIT``).
@@ -412,7 +420,7 @@ class MADE(Conditioner):
     def forward(self, x, split=None):
         """Transformer parameters ``(..., n_out)`` (reference made.py:355).  ``split``: run the GEMMs on split-f16
         operands (fp32-equivalent, ``csrc/split_gemm.hip``); None = the ``TFEP_SPLIT_GEMM`` default."""
-        split = ops.split_gemm_enabled() if split is None else bool(split)
+        split = (ops.split_gemm_enabled() and self.split_worthwhile()) if split is None else bool(split)
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
         if split:

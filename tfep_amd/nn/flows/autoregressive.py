@@ -138,12 +138,20 @@ class AutoregressiveFlow(torch.nn.Module):
         kind = self._fused_kind()
         if kind is None or not self._use_split_gemm() or not isinstance(self._conditioner, MADE):
             return
+        # only worth the stream fork / join when the re-pack moves real data (cfg1-sized layers are launch bound)
+        if not self._conditioner.split_worthwhile():
+            return
         fp = self._fused_plan(device, kind, self._tables(device))
         self._conditioner.prepack_split_async(device, stream, last=(fp['row_of_out'], fp['n_rows']))
 
     def _use_split_gemm(self):
-        """Split-f16 GEMMs for the forward pass: ``self.split_gemm`` if set, else ``TFEP_SPLIT_GEMM`` (default on)."""
-        return ops.split_gemm_enabled() if self.split_gemm is None else bool(self.split_gemm)
+        """Split-f16 GEMMs for the forward pass: ``self.split_gemm`` if set; else ``TFEP_SPLIT_GEMM`` (default on) for
+        conditioners with at least 4 M weights -- smaller layers are launch bound and the exact-fp32 kernel needs no
+        operand conversions."""
+        if self.split_gemm is not None:
+            return bool(self.split_gemm)
+        made = self._conditioner
+        return ops.split_gemm_enabled() and isinstance(made, MADE) and made.split_worthwhile()
 
     def _fused_plan(self, device, kind, tables):
         key = ('fused', str(device), kind)
