@@ -323,6 +323,10 @@ int tfep_diag_split_cycles(unsigned long long* out);
  *     per layer l < 4: [row0, n, kb, ke] -- units [row0, row0 + n) of layer l from the first ke features of the
  *     block (l = 0) or the packed columns [kb, ke) of layer l - 1 (l >= 1); then [out_row0, n_d, kb, ke, feat_off, 0];
  *   feat_cols / feat_sel: column in x / index in y and in the spline tables of every feature of the block, in step order;
+ *   conditioner inputs: a new feature enters xpad as itself, or as (cos, sin) of (x - emb_lower) * 2 pi / (emb_upper -
+ *     emb_lower) under a PeriodicEmbedding (mafembed.py:112-145).  in_cols: xpad column of every input ENTRY of the
+ *     block in step order (a periodic feature has two consecutive entries / columns); feat_in: first entry of each
+ *     feature; feat_periodic: 1 / 0.  Layer-0 step records count entries, max_feats sizes the LDS for entries;
  *   cache_col0[l], cache_n_old[l]: first packed column of layer l held in LDS and how many of them earlier blocks
  *     computed; cache_len / max_feats: LDS entries per layer / for the block's features
  *     ((n_layers * cache_len + max_feats) * 256 bytes <= 160 KiB).
@@ -344,6 +348,10 @@ typedef struct tfep_inverse_block_desc {
     const int32_t* steps;
     const int32_t* feat_cols;
     const int32_t* feat_sel;
+    const int32_t* feat_in;
+    const int32_t* feat_periodic;
+    const int32_t* in_cols;
+    float emb_lower, emb_upper;
     int32_t cache_col0[4], cache_n_old[4];
     int32_t cache_len, max_feats;
     const tfep_spline_desc* spline;

@@ -221,7 +221,7 @@ def test_flow_inverse(name):
     assert torch.allclose(l + l2, torch.zeros_like(l), atol=1e-3)
 
 
-@pytest.mark.parametrize('name', ['cond', 'moeb', 'rq4', 'cfg1'])
+@pytest.mark.parametrize('name', ['cond', 'moeb', 'rq4', 'cfg1', 'circ'])
 def test_blocked_inverse_matches_pass_per_degree_inverse(name):
     """The blocked forward-substitution inverse (row slices per degree) against the reference
     algorithm (one full conditioner pass per degree, autoregressive.py:216-227) on the same kernels."""
@@ -428,7 +428,7 @@ def test_circular_spline_fixed_points_and_periodicity():
     assert abs(float(la - lb)) < 1e-4
 
 
-@pytest.mark.parametrize('name', ['cfg1', 'rq4', 'moeb'])
+@pytest.mark.parametrize('name', ['cfg1', 'rq4', 'moeb', 'circ'])
 def test_fused_inverse_block_kernel_matches_per_step_launches(name):
     """tfep_inverse_block (one kernel per block of degrees, split-K block GEMMs) against the same blocked algorithm
     launched step by step; ragged batch (dead lanes in the last wave)."""

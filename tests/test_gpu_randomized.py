@@ -46,20 +46,33 @@ def random_case(seed):
         hi = np.full(n_free, 3.0) if kind == 'spline' else np.full(n_free, 2.0)
         spec['transformer'] = dict(type='spline', x0=lo, xf=hi, n_bins=K, circular=(kind == 'circular'),
                                    identity_boundary_slopes=bool(kind == 'spline' and rng.random() < 0.3))
+    if kind == 'circular' and rng.random() < 0.6:
+        # periodic embedding of a random subset of the features (cfg4 recipe); limits = the spline domain
+        n_per = int(rng.integers(1, D + 1))
+        per = sorted(rng.choice(D, size=n_per, replace=False).tolist())
+        spec['embedding'] = dict(type='periodic', limits=(0.0, 2.0), periodic_indices=per,
+                                 nonperiodic_indices=[i for i in range(D) if i not in per])
+        if isinstance(spec['hidden_layers'], list):          # explicit widths must cover the widened input
+            spec['hidden_layers'] = [max(h, D + n_per + 1) for h in spec['hidden_layers']]
     B = int(rng.integers(1, 70))
     return spec, B, kind
 
 
 def build(spec):
+    from tfep_amd.nn.embeddings import PeriodicEmbedding
     from tfep_amd.nn.flows import MAF
+    emb = spec.get('embedding')
+    if emb is not None:
+        emb = PeriodicEmbedding(n_features_in=len(spec['degrees_in']), limits=list(emb['limits']),
+                                periodic_indices=emb['periodic_indices'])
     return MAF(degrees_in=torch.as_tensor(np.asarray(spec['degrees_in'])), transformer=gu.build_transformer(spec['transformer']),
-               hidden_layers=spec['hidden_layers'], weight_norm=spec['weight_norm'], initialize_identity=False)
+               hidden_layers=spec['hidden_layers'], weight_norm=spec['weight_norm'], embedding=emb, initialize_identity=False)
 
 
 def oracle_layer(maf, spec):
     sd = {k: (v.cpu().numpy().astype(np.float64) if v.dtype == torch.float32 else v.cpu().numpy())
           for k, v in maf.state_dict().items()}
-    return dict(degrees_in=spec['degrees_in'], transformer=spec['transformer'], embedding=None,
+    return dict(degrees_in=spec['degrees_in'], transformer=spec['transformer'], embedding=spec.get('embedding'),
                 made=omade.made_layers_from_state(sd, prefix='_conditioner.'))
 
 

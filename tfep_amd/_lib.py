@@ -45,6 +45,8 @@ class InverseBlockDesc(Structure):
                 ('zout_slabs', c_int32), ('zout_slab_stride', c_int64), ('log_det_J', c_void_p),
                 ('w', c_void_p * 4), ('ldw', c_int64 * 4), ('wout', c_void_p), ('ldwout', c_int64),
                 ('steps', c_void_p), ('feat_cols', c_void_p), ('feat_sel', c_void_p),
+                ('feat_in', c_void_p), ('feat_periodic', c_void_p), ('in_cols', c_void_p),
+                ('emb_lower', c_float), ('emb_upper', c_float),
                 ('cache_col0', c_int32 * 4), ('cache_n_old', c_int32 * 4),
                 ('cache_len', c_int32), ('max_feats', c_int32), ('spline', c_void_p)]
 

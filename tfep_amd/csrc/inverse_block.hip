@@ -37,6 +37,10 @@ struct InverseBlockArgs {
     const int32_t* steps;
     const int32_t* feat_cols;
     const int32_t* feat_sel;
+    const int32_t* feat_in;       // per feature: first conditioner-input entry of the block it feeds (index into in_cols / LDS)
+    const int32_t* feat_per;      // per feature: 1 = periodic (two entries: cos, sin), 0 = plain (one entry)
+    const int32_t* in_cols;       // per entry: column of the (embedded) conditioner input
+    float emb_lower, emb_scale;   // periodic embedding: t = (x - lower) * scale
     int c0[IB_MAX_LAYERS];        // first packed column of layer l held in the LDS cache
     int n_old[IB_MAX_LAYERS];     // units [c0, c0 + n_old) were computed by earlier blocks: preloaded from h
     int cache_len;                // LDS entries per layer
@@ -82,7 +86,7 @@ __device__ __forceinline__ void dot_rows(float (&acc)[G], const float* __restric
 }
 
 // Step record: per layer l  [row0, n, kb, ke]: units [row0, row0 + n) of layer l are computed from the inputs
-//   l == 0: the first `ke` features of the block (feat_cols order);  l >= 1: packed columns [kb, ke) of layer l - 1
+//   l == 0: the first `ke` conditioner-input entries of the block (in_cols order);  l >= 1: packed columns [kb, ke) of layer l - 1
 // then [out_row0, n_d, out_kb, out_ke, feat_off, 0].
 __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
     extern __shared__ float cache[];              // [L][cache_len][64] hidden activations, then [max_feats][64] x values
@@ -116,7 +120,7 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
                 if (l == 0) {
                     for (int j = 0; j < ke; ++j) {
                         const float xv = xc[j * 64 + lane];
-                        const int col = a.feat_cols[j];
+                        const int col = a.in_cols[j];
 #pragma unroll
                         for (int g = 0; g < 8; ++g)
                             acc[g] = fmaf(a.w[0][(int64_t)(u0 + (g < nu ? g : 0)) * a.ldw[0] + col], xv, acc[g]);
@@ -188,10 +192,18 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
                                                        a.sp.y0[sel], a.sp.yf[sel], yv, &ld);
                 ldj_acc -= ld;
             }
-            xc[(foff + f) * 64 + lane] = xv;
+            // the new feature becomes conditioner input: itself, or (cos, sin) under a periodic embedding
+            // (same arithmetic as periodic_embedding_kernel, mafembed.py:112-145)
+            const int e0 = a.feat_in[foff + f], icol = a.in_cols[e0];
+            float in0 = xv, in1 = 0.f;
+            const bool per = a.feat_per[foff + f] != 0;
+            if (per) sincosf((xv - a.emb_lower) * a.emb_scale, &in1, &in0);
+            xc[e0 * 64 + lane] = in0;
+            if (per) xc[(e0 + 1) * 64 + lane] = in1;
             if (live) {
                 a.x[r * a.ldx + col] = xv;
-                a.xpad[r * a.ldxpad + col] = xv;
+                a.xpad[r * a.ldxpad + icol] = in0;
+                if (per) a.xpad[r * a.ldxpad + icol + 1] = in1;
             }
         }
     }
@@ -226,7 +238,11 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
     }
     a.zout = d->zout; a.ldzout = d->ldzout; a.ldj = d->log_det_J;
     a.zout_slabs = d->zout_slabs > 1 ? d->zout_slabs : 1; a.zout_slab_stride = d->zout_slab_stride; a.wout = d->wout; a.ldwout = d->ldwout;
+    TFEP_REQUIRE(d->feat_in && d->feat_periodic && d->in_cols, "inverse_block: NULL pointer");
     a.steps = d->steps; a.feat_cols = d->feat_cols; a.feat_sel = d->feat_sel;
+    a.feat_in = d->feat_in; a.feat_per = d->feat_periodic; a.in_cols = d->in_cols;
+    a.emb_lower = d->emb_lower;
+    a.emb_scale = (float)(2.0 * 3.14159265358979323846 / ((double)d->emb_upper - (double)d->emb_lower));
     a.cache_len = d->cache_len; a.max_feats = d->max_feats;
     if (d->kind == 1) {
         int rc = make_spline_args(d->spline, &a.sp);

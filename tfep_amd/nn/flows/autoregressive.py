@@ -10,6 +10,7 @@ Same constructor, buffers (``_transformer_indices``, ``_inverse_masks``, ``_fixe
   ``(batch, P*D)`` parameter tensor lives only in MFMA accumulators.
 """
 import ctypes
+import math
 import os
 from typing import Optional, Sequence
 
@@ -18,6 +19,7 @@ import torch
 from ... import _lib, ops
 from ...utils.misc import ensure_tensor_sequence
 from ..conditioners.made import MADE
+from ..embeddings.mafembed import PeriodicEmbedding
 from ..transformers.affine import AffineTransformer
 from ..transformers.moebius import MoebiusTransformer
 from ..transformers.spline import NeuralSplineTransformer
@@ -299,7 +301,8 @@ class AutoregressiveFlow(torch.nn.Module):
         made = self._conditioner
         if not self.blocked_inverse or not isinstance(made, MADE) or len(self._conditioner_indices) > 0:
             return False
-        if getattr(made, 'embedding', None) is not None or len(made._linears()) < 2:
+        emb = getattr(made, 'embedding', None)
+        if (emb is not None and type(emb) is not PeriodicEmbedding) or len(made._linears()) < 2:
             return False
         tr = self._transformer
         if type(tr) in (AffineTransformer, NeuralSplineTransformer):
@@ -326,6 +329,43 @@ class AutoregressiveFlow(torch.nn.Module):
 
     #: Degrees per block of the two-level blocked inverse.
     inverse_block = 16
+
+    def _input_columns(self):
+        """Where feature column c of x enters the conditioner input: ``(first_col[c], periodic[c], limits)``.  Without an
+        embedding the input IS x; a PeriodicEmbedding puts the non-periodic features first and then a (cos, sin) pair
+        per periodic feature (mafembed.py:137-145)."""
+        emb = getattr(self._conditioner, 'embedding', None)
+        D = self._inverse_masks.shape[1]
+        if emb is None:
+            return list(range(D)), [False] * D, (0.0, 1.0)
+        non, per = emb._nonperiodic_indices.tolist(), emb._periodic_indices.tolist()
+        first, periodic = [0] * D, [False] * D
+        for pos, c in enumerate(non):
+            first[c] = pos
+        for pos, c in enumerate(per):
+            first[c], periodic[c] = len(non) + 2 * pos, True
+        return first, periodic, emb.host_limits()
+
+    def _input_info(self, x_cols, device):
+        """Index tensors to write the features ``x_cols`` (a list, in the order of the value columns) into the
+        conditioner-input buffer: plain features are copied, periodic ones become cos / sin."""
+        first, periodic, _ = self._input_columns()
+        i32 = dict(device=device, dtype=torch.int32)
+        plain = [j for j, c in enumerate(x_cols) if not periodic[c]]
+        per = [j for j, c in enumerate(x_cols) if periodic[c]]
+        return dict(plain_sel=torch.tensor(plain, **i32), plain_cols=torch.tensor([first[x_cols[j]] for j in plain], **i32),
+                    per_sel=torch.tensor(per, **i32), cos_cols=torch.tensor([first[x_cols[j]] for j in per], **i32),
+                    sin_cols=torch.tensor([first[x_cols[j]] + 1 for j in per], **i32))
+
+    def _scatter_inputs(self, xpad, values, info):
+        """Write ``values`` (B, n) into the conditioner-input buffer as ``info`` (``_input_info``) says."""
+        if info['plain_sel'].numel():
+            ops.scatter_columns(ops.gather_columns(values, info['plain_sel']), info['plain_cols'], xpad)
+        if info['per_sel'].numel():
+            lo, hi = self._input_columns()[2]
+            t = (ops.gather_columns(values, info['per_sel']) - lo) * float(2.0 * math.pi / (hi - lo))
+            ops.scatter_columns(torch.cos(t), info['cos_cols'], xpad)
+            ops.scatter_columns(torch.sin(t), info['sin_cols'], xpad)
 
     def _blocked_plan(self, device):
         """The plan of ``_blocked_plan_for`` with ``inverse_block`` degrees per block, or fewer (halved down to 2) when
@@ -365,7 +405,12 @@ class AutoregressiveFlow(torch.nn.Module):
         tables = self._tables(device)
         deg_in = made._degrees[0].cpu()
         tr_idx = tables['tr'].cpu().long()
-        deg_tr = deg_in[tr_idx]
+        # degrees in x space (deg_in lives in the conditioner-input space, which an embedding widens): feature c is
+        # transformed at step d of the inverse iff _inverse_masks[d, c]
+        deg_x = torch.full((self._inverse_masks.shape[1],), -1, dtype=torch.long)
+        for d_, m_ in enumerate(self._inverse_masks.cpu()):
+            deg_x[m_] = d_
+        deg_tr = deg_x[tr_idx]
         n_tr = len(tr_idx)
         P = lins[-1].out_features // n_tr
         max_deg = int(deg_tr.max())
@@ -428,6 +473,7 @@ class AutoregressiveFlow(torch.nn.Module):
                 ke = min(up(r_hi(L - 1, e)), mplan['k_pad'][L])
                 blk['steps'].append(dict(hidden=hidden, out=dict(row0=base[d], n_rows=P * len(sel), kr=rng(kA[L], ke)),
                                          n_d=len(sel), sel=sel.to(**i32), cols=tr_idx[sel].to(**i32),
+                                         inputs=self._input_info(tr_idx[sel].tolist(), device),
                                          sub=self._sub_transformer(sel.to(device), device)))
             blk['fused'] = self._fused_block_tables(d0, d1, blk, kA, r_lo, r_hi, base, sels, tr_idx, deg_in, mplan, L, P,
                                                     rng, up, i32)
@@ -478,7 +524,8 @@ class AutoregressiveFlow(torch.nn.Module):
         c0 = [kA[l + 1] for l in range(L)]
         n_old = [max(0, r_hi(l, d0 - 2) - c0[l]) for l in range(L)]
         cache_need = max([r_hi(l, d1 - 2) - c0[l] for l in range(L)] + [1])
-        steps, cols, selv = [], [], []
+        first, periodic, _ = self._input_columns()
+        steps, cols, selv, feat_in, feat_per, in_cols = [], [], [], [], [], []
         for d in range(d0, d1):
             e = d - 1
             rec = [0] * n_ints
@@ -486,18 +533,25 @@ class AutoregressiveFlow(torch.nn.Module):
                 a, b = r_lo(l, e), r_hi(l, e)
                 rec[4 * l], rec[4 * l + 1] = a, max(0, b - a)
                 if l == 0:
-                    rec[2], rec[3] = 0, len(cols)
+                    rec[2], rec[3] = 0, len(in_cols)          # conditioner-input entries of the block known so far
                 else:
                     rec[4 * l + 2], rec[4 * l + 3] = c0[l - 1], max(c0[l - 1], r_hi(l - 1, e))
             sel = sels[d]
             rec[16:21] = [base[d], len(sel), c0[L - 1], max(c0[L - 1], r_hi(L - 1, e)), len(cols)]
             steps.append(rec)
+            for c in tr_idx[sel].tolist():
+                feat_in.append(len(in_cols))
+                feat_per.append(int(periodic[c]))
+                in_cols += [first[c], first[c] + 1] if periodic[c] else [first[c]]
             cols += tr_idx[sel].tolist()
             selv += sel.tolist()
-        return dict(wide0=wide0, c0=c0, n_old=n_old, cache_need=cache_need, n_feats=max(len(cols), 1), n_steps=len(steps),
+
+        def dev_i32(v):
+            return torch.tensor(v + [0], dtype=torch.int32).to(i32['device'])
+        return dict(wide0=wide0, c0=c0, n_old=n_old, cache_need=cache_need, n_feats=max(len(in_cols), 1), n_steps=len(steps),
                     steps=torch.tensor(steps, dtype=torch.int32).reshape(-1, n_ints).to(i32['device']),
-                    cols=torch.tensor(cols + [0], dtype=torch.int32).to(i32['device']),
-                    sel=torch.tensor(selv + [0], dtype=torch.int32).to(i32['device']))
+                    cols=dev_i32(cols), sel=dev_i32(selv), feat_in=dev_i32(feat_in), feat_per=dev_i32(feat_per),
+                    in_cols=dev_i32(in_cols))
 
     def _inverse_blocked(self, y):
         from ._backward import _gemm
@@ -546,7 +600,9 @@ class AutoregressiveFlow(torch.nn.Module):
             if self.has_fixed_indices:
                 fixed = ops.gather_columns(y, tables['fixed'])
                 ops.scatter_columns(fixed, tables['fixed'], x)
-                ops.scatter_columns(fixed, tables['fixed'], xpad)
+                if 'fixed_inputs' not in bp:
+                    bp['fixed_inputs'] = self._input_info(tables['fixed'].tolist(), dev)
+                self._scatter_inputs(xpad, fixed, bp['fixed_inputs'])
                 y_tr = ops.gather_columns(y, tables['tr'])
             else:
                 y_tr = y
@@ -586,6 +642,7 @@ class AutoregressiveFlow(torch.nn.Module):
                 d.wout, d.ldwout = w_out.data_ptr(), w_out.shape[1]
                 d.cache_len, d.max_feats = fused['cache_len'], fused['max_feats']
                 d.spline = ctypes.cast(ctypes.pointer(spl), ctypes.c_void_p) if spl is not None else None
+                d.emb_lower, d.emb_upper = self._input_columns()[2]
                 stream = _lib.stream_of(y)
             for blk in bp['blocks']:
                 # ---- contribution of all earlier degrees to the whole block, once
@@ -607,6 +664,7 @@ class AutoregressiveFlow(torch.nn.Module):
                 if fused is not None:
                     d.n_steps = fb['n_steps']
                     d.steps, d.feat_cols, d.feat_sel = fb['steps'].data_ptr(), fb['cols'].data_ptr(), fb['sel'].data_ptr()
+                    d.feat_in, d.feat_periodic, d.in_cols = fb['feat_in'].data_ptr(), fb['feat_per'].data_ptr(), fb['in_cols'].data_ptr()
                     for l in range(L):
                         d.cache_col0[l], d.cache_n_old[l] = fb['c0'][l], fb['n_old'][l]
                     _lib.call('tfep_inverse_block', ctypes.byref(d), stream)
@@ -634,7 +692,7 @@ class AutoregressiveFlow(torch.nn.Module):
                     else:
                         x_d, _ = ops.affine(y_d, par, inverse=True, log_det_J=ldj)
                     ops.scatter_columns(x_d, st['cols'], x)
-                    ops.scatter_columns(x_d, st['cols'], xpad)
+                    self._scatter_inputs(xpad, x_d, st['inputs'])
         return x, ldj
 
     def get_transformer_parameters(self, x: torch.Tensor) -> torch.Tensor:

@@ -118,6 +118,12 @@ if 'cfg4' in which:
     dt, (y, _) = timeit(lambda: flow(x), 1, 3)
     report('cfg4-i forward: 4-layer MAF + circular RQ-8 + periodic embedding, 512 torsions', B, dt,
            y_in_domain=bool(((y >= 0) & (y <= 1)).all()))
+    Bi = 16384
+    with torch.no_grad():
+        dti, (xi, _) = timeit(lambda: flow.inverse(y[:Bi]), 1, 2)
+    dcirc = (xi - x[:Bi]).abs()
+    report('cfg4-i inverse (blocked, fused block kernel; 4 layers x 512 degrees)', Bi, dti,
+           roundtrip_circle_max=float(torch.minimum(dcirc, 1 - dcirc).max()))
     with torch.device(dev):
         flow = SequentialFlow(*[MAF(generate_degrees(2 * D, order(i), repeats=2),
                                     transformer=MoebiusTransformer(dimension=2, unit_sphere=True),
