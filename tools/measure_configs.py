@@ -133,6 +133,10 @@ if 'cfg4' in which:
     dt, (y, _) = timeit(lambda: flow(x), 1, 3)
     report('cfg4-ii forward: 4-layer MAF + Moebius(d=2, unit sphere), 512 torsions as 1024 features', B, dt,
            max_norm_error=float((y.reshape(B, D, 2).norm(dim=2) - 1).abs().max()))
+    with torch.no_grad():
+        dti, (xi, _) = timeit(lambda: flow.inverse(y[:Bi]), 1, 2)
+    report('cfg4-ii inverse (blocked; 4 layers x 512 degrees)', Bi, dti,
+           roundtrip_max_abs=float((xi - x[:Bi]).abs().max()))
 
 if 'hbm' in which:
     # HBM-bound kernels in isolation: algorithmic bytes / time vs the 8 TB/s HBM3E peak.
