@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFEP_HIP_ABI_VERSION 2
+#define TFEP_HIP_ABI_VERSION 3
 
 typedef enum tfep_status {
     TFEP_OK = 0,
@@ -328,9 +328,11 @@ int tfep_diag_split_cycles(unsigned long long* out);
  *     block in step order (a periodic feature has two consecutive entries / columns); feat_in: first entry of each
  *     feature; feat_periodic: 1 / 0.  Layer-0 step records count entries, max_feats sizes the LDS for entries;
  *   cache_col0[l], cache_n_old[l]: first packed column of layer l held in LDS and how many of them earlier blocks
- *     computed; cache_len / max_feats: LDS entries per layer / for the block's features
- *     ((n_layers * cache_len + max_feats) * 256 bytes <= 160 KiB).
- *   kind: 0 affine, 1 spline (desc, n_bins <= 8).  log_det_J (B) is accumulated.
+ *     computed (a multiple of 4; w[l], wout 16-byte aligned with ldw % 4 == 0: the kernel stages weight rows in LDS
+ *     with 16-byte loads); cache_len / max_feats: LDS entries per layer / for the block's features
+ *     (tfep_inverse_block_lds_bytes(n_layers, cache_len, max_feats) <= 160 KiB).
+ *   kind: 0 affine, 1 spline (desc, n_bins <= 8), 2 Moebius (moebius.py:142-147: moebius_dim consecutive features of
+ *     a degree form one vector, so every step's n_d must be a multiple of it).  log_det_J (B) is accumulated.
  */
 typedef struct tfep_inverse_block_desc {
     int32_t B, n_layers, n_steps, kind;
@@ -355,8 +357,13 @@ typedef struct tfep_inverse_block_desc {
     int32_t cache_col0[4], cache_n_old[4];
     int32_t cache_len, max_feats;
     const tfep_spline_desc* spline;
+    int32_t moebius_dim, moebius_unit_sphere;
+    float moebius_max_radius;
 } tfep_inverse_block_desc;
 int tfep_inverse_block_step_ints(void);
+/* LDS bytes a launch with these sizes needs (activation cache + input entries + the weight stage); a block fits iff
+ * this is <= 160 KiB.  -1 for invalid arguments. */
+int64_t tfep_inverse_block_lds_bytes(int n_layers, int cache_len, int max_feats);
 int tfep_inverse_block(const tfep_inverse_block_desc* desc, void* stream);
 
 /* ------------------------------------------------------------------------- */

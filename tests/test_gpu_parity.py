@@ -436,10 +436,9 @@ def test_fused_inverse_block_kernel_matches_per_step_launches(name):
     flow = gu.build_flow(name, g)
     yin = dev(g[f'{name}/y_f32'][:77])
     with torch.no_grad():
-        expect_fused = name != 'moeb'                  # Moebius keeps the per-step launches
         for layer in flow:
             assert layer._blocked_ok()
-            assert (layer._blocked_plan(yin.device)['fused'] is not None) == expect_fused
+            assert layer._blocked_plan(yin.device)['fused'] is not None
         xf, lf = flow.inverse(yin)
         for layer in flow:
             layer.fused_inverse = False

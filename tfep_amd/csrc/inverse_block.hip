@@ -9,11 +9,16 @@
 //   one thread per sample row, one wave per workgroup;
 //   the row's in-block hidden activations (and the block's new x values) live in LDS as [unit][lane] (conflict free),
 //     the old units of the bottom partial k-tile are preloaded from HBM;
-//   the masked packed weights are read with wave-uniform addresses (scalar loads, broadcast);
+//   the masked packed weights of a step are the same for all 64 rows: the wave fetches them COOPERATIVELY (one
+//     global_load_dwordx4 per lane = 8 weight rows x 32 columns per instruction, up to 16 instructions in flight) into
+//     an LDS stage and reads them back as same-address (broadcast) ds_read_b128.  Wave-uniform loads straight from
+//     HBM/L2 cost one ~600-cycle round trip per 4 columns on this latency-bound chain; the stage pays one per dot;
 //   fp32 FMA -- the arithmetic is ~20 kFLOP per row per block, nothing for the matrix cores to do;
-//   the transformer inverse is spline.h's rq_spline_element (same code as the stand-alone kernel) or the affine map.
+//   the transformer inverse is spline.h's rq_spline_element / moebius.h's moebius_vector (same code as the stand-alone
+//     kernels) or the affine map.
 #include "common.h"
 #include "spline.h"
+#include "moebius.h"
 
 namespace tfep {
 
@@ -45,6 +50,10 @@ struct InverseBlockArgs {
     int n_old[IB_MAX_LAYERS];     // units [c0, c0 + n_old) were computed by earlier blocks: preloaded from h
     int cache_len;                // LDS entries per layer
     int max_feats;                // LDS entries for the block's new x values
+    int stage_gstride;            // floats per 8-row group of the LDS weight stage
+    int lds_floats;               // whole dynamic LDS allocation (a multiple of 4)
+    int mb_dim, mb_unit_sphere;   // kind 2: Moebius
+    float mb_max_radius;
     SplineArgs sp;
 };
 
@@ -57,45 +66,205 @@ __device__ __forceinline__ float slab_sum(const float* p, int slabs, int64_t str
     return v;
 }
 
-// acc[g] += sum_{j in [kb, ke)} w[(row0 + g * row_stride) * ldw + j] * cache[(j - c0) * 64 + lane],  g < G.
-// G independent accumulators share every LDS read: a single wave has no other source of instruction-level
-// parallelism, and a one-accumulator loop runs at the LDS + scalar-load latency per FMA.
-template <int G>
-__device__ __forceinline__ void dot_rows(float (&acc)[G], const float* __restrict__ w, int64_t ldw, int row0, int row_stride,
-                                         int n_valid, const float* __restrict__ cp, int c0, int kb, int ke, int lane) {
-    const float* wr[G];
+constexpr int IB_STAGE_ROWS = 32;      // weight rows staged at once (>= the 25 spline parameters of a feature)
+
+__host__ __device__ inline int ib_round4(int n) { return (n + 3) & ~3; }
+// The weight stage holds 4 groups of 8 rows, each group TRANSPOSED: [column j][8 rows].  One same-address (broadcast)
+// ds_read_b128 then yields 4 rows of one column in adjacent registers, which is what v_pk_fma_f32 wants (row-major
+// staging cost ~2 v_mov per packed FMA to pair the operands).  Columns per group: the longest dot of the launch.
+__host__ __device__ inline int ib_round8(int n) { return (n + 7) & ~7; }
+__host__ __device__ inline int ib_stage_cols(int cache_len, int max_feats) {
+    return ib_round8(cache_len > max_feats ? cache_len : max_feats);
+}
+constexpr int IB_LDS_SLACK = 12 * 64;    // floats after the weight stage: the one-slice-ahead reads of dot_staged stay in bounds
+constexpr int IB_Z_PITCH = 72;           // floats per value of the pre-activation stage [IB_STAGE_ROWS values][64 sample rows + 8]
+__host__ __device__ inline size_t ib_lds_floats(int L, int cache_len, int max_feats) {
+    return ((size_t)L * ib_round4(cache_len) + ib_round4(max_feats)) * 64 + (size_t)IB_STAGE_ROWS * ib_stage_cols(cache_len, max_feats) +
+           IB_LDS_SLACK + (size_t)IB_STAGE_ROWS * IB_Z_PITCH;
+}
+
+typedef float ib_f4 __attribute__((ext_vector_type(4)));
+typedef ib_f4 __attribute__((may_alias)) ib_f4_alias;
+
+// Stage element (row r, column j):  st[(r >> 3) * gstride + j * 8 + (r & 7)],  gstride = 8 * ib_stage_cols.
+//
+// stage_rows: w[(row0 + r * row_stride) * ldw + kb + j]  for r < nrows (<= 32), j < ke - kb; columns up to the next
+// multiple of 8 are zero-filled.  Lane t fetches row (t >> 3) (+8, +16, +24), columns 4 (t & 7) .. +3 (+32, +64, +96)
+// with one 16-byte load: all loads of a 128-column batch are issued before the first LDS write.  kb, ldw and w must be
+// multiples of 4 floats.
+__device__ __forceinline__ void stage_rows(float* __restrict__ st, int gstride, const float* __restrict__ w, int64_t ldw,
+                                           int row0, int row_stride, int nrows, int kb, int ke, int lane) {
+    const int g = lane >> 3, c = (lane & 7) * 4;
+    const int len = ke - kb, len8 = ib_round8(len);
+    for (int s0 = 0; s0 < len; s0 += 128) {
+        ib_f4 v[4][4];
 #pragma unroll
-    for (int g = 0; g < G; ++g) wr[g] = w + (int64_t)(row0 + (g < n_valid ? g : 0) * row_stride) * ldw;
-    int j = kb;
-    for (; j + 4 <= ke; j += 4) {
-        const float h0 = cp[(j - c0) * 64 + lane], h1 = cp[(j + 1 - c0) * 64 + lane];
-        const float h2 = cp[(j + 2 - c0) * 64 + lane], h3 = cp[(j + 3 - c0) * 64 + lane];
+        for (int rg = 0; rg < 4; ++rg)
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            acc[g] = fmaf(wr[g][j], h0, acc[g]);
-            acc[g] = fmaf(wr[g][j + 1], h1, acc[g]);
-            acc[g] = fmaf(wr[g][j + 2], h2, acc[g]);
-            acc[g] = fmaf(wr[g][j + 3], h3, acc[g]);
+            for (int u = 0; u < 4; ++u) {
+                const int r = rg * 8 + g, j = s0 + u * 32 + c;
+                v[rg][u] = ib_f4{0.f, 0.f, 0.f, 0.f};
+                if (r < nrows && j < len)
+                    v[rg][u] = *(const ib_f4_alias*)(w + (int64_t)(row0 + r * row_stride) * ldw + kb + j);
+            }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = rg * 8 + g, j = s0 + u * 32 + c;
+                if (r < nrows && j < len8) {
+                    float* d = st + rg * gstride + j * 8 + g;
+                    d[0] = j < len ? v[rg][u].x : 0.f;
+                    d[8] = j + 1 < len ? v[rg][u].y : 0.f;
+                    d[16] = j + 2 < len ? v[rg][u].z : 0.f;
+                    d[24] = j + 3 < len ? v[rg][u].w : 0.f;
+                }
+            }
+    }
+    __builtin_amdgcn_wave_barrier();      // one wave: LDS is in order, this only pins the compiler's schedule
+}
+
+// Layer 0: element (r, e) = w[(row0 + r) * ldw + in_cols[e]]  for r < nrows, e < ke (the block's input entries so far)
+__device__ __forceinline__ void stage_gather(float* __restrict__ st, int gstride, const float* __restrict__ w, int64_t ldw,
+                                             int row0, int nrows, const int32_t* __restrict__ in_cols, int ke, int lane) {
+    const int g = lane & 7, c = lane >> 3;            // 8 rows x 8 entries per instruction; LDS writes are contiguous
+    const int ke8 = ib_round8(ke);
+    for (int s0 = 0; s0 < ke8; s0 += 32) {
+        int col[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = s0 + u * 8 + c;
+            col[u] = e < ke ? in_cols[e] : -1;
+        }
+        float v[4][4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = rg * 8 + g;
+                v[rg][u] = 0.f;
+                if (r < nrows && col[u] >= 0) v[rg][u] = w[(int64_t)(row0 + r) * ldw + col[u]];
+            }
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = rg * 8 + g, e = s0 + u * 8 + c;
+                if (r < nrows && e < ke8) st[rg * gstride + e * 8 + g] = v[rg][u];
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Pre-activations of a step (the wide GEMMs' contribution of all earlier degrees): value v < nv (<= 32) of sample row i
+// of this wave is  sum_s z[s * slab_stride + (wave_row0 + i) * ldz + base + v * vstride].  One lane per sample row would
+// touch 64 cache lines per load instruction, on the critical path; here the wave loads 8 rows x 8 values per instruction
+// (8 lines when vstride = 1), everything in flight at once, and transposes through LDS: zs[v * IB_Z_PITCH + i].
+__device__ __forceinline__ void stage_z(float* __restrict__ zs, const float* __restrict__ z, int64_t ldz, int wave_row0, int n_rows_total,
+                                        int base, int vstride, int nv, int slabs, int64_t slab_stride, int lane) {
+    const int vq = lane & 7, rq = lane >> 3;
+    float val[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) val[q][i] = 0.f;
+    // slabs outermost: the (up to) 32 loads of one slab are independent and all in flight; the sum runs in slab order.
+    // No per-lane predicate on the loads (a predicated `val += load` makes the compiler wait for each load inside its
+    // own exec region): lanes past nv re-read value nv - 1 and are dropped at the LDS write; the q blocks are skipped
+    // wave-uniformly.
+    for (int sl = 0; sl < slabs; ++sl) {
+        float t[4][8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q * 8 < nv) {
+                const int v = min(q * 8 + vq, nv - 1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = min(wave_row0 + rq + 8 * i, n_rows_total - 1);      // dead rows shadow the last one
+                    t[q][i] = z[sl * slab_stride + (int64_t)row * ldz + base + v * vstride];
+                }
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q * 8 < nv) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) val[q][i] += t[q][i];
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int v = q * 8 + vq;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (v < nv) zs[v * IB_Z_PITCH + rq + 8 * i] = val[q][i];              // bank = 8 vq + rq (+8i): conflict free
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One 4-column slice of a staged dot: the activations of this lane's sample row and 8 weight rows x 4 columns.
+struct IbSlice {
+    float h[4];
+    ib_f4 wa[4], wb[4];
+    __device__ __forceinline__ void load(const float* __restrict__ st, const float* __restrict__ act, int j, int lane) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            h[i] = act[(j + i) * 64 + lane];
+            wa[i] = *(const ib_f4_alias*)(st + (j + i) * 8);
+            wb[i] = *(const ib_f4_alias*)(st + (j + i) * 8 + 4);
         }
     }
-    for (; j < ke; ++j) {
-        const float h0 = cp[(j - c0) * 64 + lane];
+    __device__ __forceinline__ void fma_into(float (&acc)[8]) const {
 #pragma unroll
-        for (int g = 0; g < G; ++g) acc[g] = fmaf(wr[g][j], h0, acc[g]);
+        for (int i = 0; i < 4; ++i) {
+            acc[0] = fmaf(wa[i].x, h[i], acc[0]);
+            acc[1] = fmaf(wa[i].y, h[i], acc[1]);
+            acc[2] = fmaf(wa[i].z, h[i], acc[2]);
+            acc[3] = fmaf(wa[i].w, h[i], acc[3]);
+            acc[4] = fmaf(wb[i].x, h[i], acc[4]);
+            acc[5] = fmaf(wb[i].y, h[i], acc[5]);
+            acc[6] = fmaf(wb[i].z, h[i], acc[6]);
+            acc[7] = fmaf(wb[i].w, h[i], acc[7]);
+        }
+    }
+};
+
+// acc[g] += sum_{j < len} stage(g, j) * act[j * 64 + lane],  g < 8, in the order of j.  `st` points at the row group; len is
+// a multiple of 8 (the stage holds zeros in the round-up, and everything in LDS is finite: zero-initialised).  The LDS
+// reads run one 4-column slice ahead of the multiplies, unconditionally (a lone wave has nobody else to hide that latency;
+// conditional loads or multiplies make the compiler sink or copy the slice registers): they touch up to 4 columns past
+// the dot, inside the LDS allocation (IB_LDS_SLACK).
+__device__ __forceinline__ void dot_staged(float (&acc)[8], const float* __restrict__ st, const float* __restrict__ act,
+                                           int len, int lane) {
+    IbSlice A, B;
+    A.load(st, act, 0, lane);
+    for (int j = 0; j < len; j += 8) {
+        B.load(st, act, j + 4, lane);
+        A.fma_into(acc);
+        A.load(st, act, j + 8, lane);
+        B.fma_into(acc);
     }
 }
 
 // Step record: per layer l  [row0, n, kb, ke]: units [row0, row0 + n) of layer l are computed from the inputs
 //   l == 0: the first `ke` conditioner-input entries of the block (in_cols order);  l >= 1: packed columns [kb, ke) of layer l - 1
 // then [out_row0, n_d, out_kb, out_ke, feat_off, 0].
+// KIND: 0 affine, 1 spline, 2 Moebius (one instantiation each: the spline code needs most of the register file).
+template <int KIND>
 __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
     extern __shared__ float cache[];              // [L][cache_len][64] hidden activations, then [max_feats][64] x values
     const int lane = threadIdx.x;
     const int row = blockIdx.x * 64 + lane;
     const bool live = row < a.B;
     const int64_t r = live ? row : 0;             // dead lanes shadow row 0 and store nothing
-    float* xc = cache + (size_t)a.L * a.cache_len * 64;
+    float* xc = cache + (size_t)a.L * a.cache_len * 64;            // a.cache_len, a.max_feats: multiples of 4
+    float* stg = xc + (size_t)a.max_feats * 64;                    // weight stage [4 row groups][column][8 rows]
+    const int gstride = a.stage_gstride;
+    float* zs = stg + (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK;   // pre-activation stage
+    const int wave_row0 = blockIdx.x * 64;
 
+    // dots run over column counts rounded up to 8 (against staged zeros) and read one slice ahead: everything in LDS
+    // must be a finite number
+    for (int j = lane * 4; j < a.lds_floats; j += 256) *(ib_f4_alias*)(cache + j) = ib_f4{0.f, 0.f, 0.f, 0.f};
     for (int l = 0; l < a.L; ++l) {
         const float* hr = a.h[l] + r * a.ldh[l] + a.c0[l];
         float* cl = cache + (size_t)l * a.cache_len * 64;
@@ -109,45 +278,83 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
         for (int l = 0; l < a.L; ++l) {
             const int row0 = st[4 * l], n = st[4 * l + 1], kb = st[4 * l + 2], ke = st[4 * l + 3];
             float* cl = cache + (size_t)l * a.cache_len * 64;
-            const float* zr = a.z[l] + r * a.ldz[l];
             float* hr = a.h[l] + r * a.ldh[l];
-            for (int u0 = row0; u0 < row0 + n; u0 += 8) {
-                const int nu = min(8, row0 + n - u0);
-                float acc[8];
+            const float* act = l == 0 ? xc : cache + ((size_t)(l - 1) * a.cache_len + (kb - a.c0[l - 1])) * 64;
+            const int len = ib_round8(l == 0 ? ke : ke - kb);
+            for (int ub = row0; ub < row0 + n; ub += IB_STAGE_ROWS) {
+                const int nb = min(IB_STAGE_ROWS, row0 + n - ub);
+                if (l == 0) stage_gather(stg, gstride, a.w[0], a.ldw[0], ub, nb, a.in_cols, ke, lane);
+                else stage_rows(stg, gstride, a.w[l], a.ldw[l], ub, 1, nb, kb, ke, lane);
+                stage_z(zs, a.z[l], a.ldz[l], wave_row0, a.B, ub, 1, nb, a.z_slabs[l], a.z_slab_stride[l], lane);
+                for (int u0 = ub; u0 < ub + nb; u0 += 8) {
+                    const int nu = min(8, ub + nb - u0);
+                    float acc[8];
 #pragma unroll
-                for (int g = 0; g < 8; ++g)                                     // earlier blocks + bias
-                    acc[g] = g < nu ? slab_sum(zr + u0 + g, a.z_slabs[l], a.z_slab_stride[l]) : 0.f;
-                if (l == 0) {
-                    for (int j = 0; j < ke; ++j) {
-                        const float xv = xc[j * 64 + lane];
-                        const int col = a.in_cols[j];
+                    for (int g = 0; g < 8; ++g)                                 // earlier blocks + bias
+                        acc[g] = g < nu ? zs[(u0 - ub + g) * IB_Z_PITCH + lane] : 0.f;
+                    dot_staged(acc, stg + ((u0 - ub) >> 3) * gstride, act, len, lane);
 #pragma unroll
-                        for (int g = 0; g < 8; ++g)
-                            acc[g] = fmaf(a.w[0][(int64_t)(u0 + (g < nu ? g : 0)) * a.ldw[0] + col], xv, acc[g]);
-                    }
-                } else {
-                    dot_rows<8>(acc, a.w[l], a.ldw[l], u0, 1, nu, cache + (size_t)(l - 1) * a.cache_len * 64, a.c0[l - 1],
-                                kb, ke, lane);
+                    for (int g = 0; g < 8; ++g)
+                        if (g < nu) {
+                            const float hv = elu_ib(acc[g]);
+                            cl[(u0 + g - a.c0[l]) * 64 + lane] = hv;
+                            if (live) hr[u0 + g] = hv;
+                        }
                 }
-#pragma unroll
-                for (int g = 0; g < 8; ++g)
-                    if (g < nu) {
-                        const float hv = elu_ib(acc[g]);
-                        cl[(u0 + g - a.c0[l]) * 64 + lane] = hv;
-                        if (live) hr[u0 + g] = hv;
-                    }
+                __builtin_amdgcn_wave_barrier();
             }
         }
         // ---- parameters and transformer inverse of this degree's features
         const int out_row0 = st[4 * IB_MAX_LAYERS], n_d = st[4 * IB_MAX_LAYERS + 1];
         const int okb = st[4 * IB_MAX_LAYERS + 2], oke = st[4 * IB_MAX_LAYERS + 3], foff = st[4 * IB_MAX_LAYERS + 4];
-        const float* cp = cache + (size_t)(a.L - 1) * a.cache_len * 64;
-        const int c0p = a.c0[a.L - 1];
-        const float* zo = a.zout + r * a.ldzout;
-        for (int f = 0; f < n_d; ++f) {
-            float prm[IB_MAX_P];
+        const float* cp = cache + ((size_t)(a.L - 1) * a.cache_len + (okb - a.c0[a.L - 1])) * 64;
+        const int olen = ib_round8(oke - okb);
+        // the new feature becomes conditioner input: itself, or (cos, sin) under a periodic embedding
+        // (same arithmetic as periodic_embedding_kernel, mafembed.py:112-145)
+        auto emit = [&](int fi, float xv) {
+            const int col = a.feat_cols[fi], e0 = a.feat_in[fi], icol = a.in_cols[e0];
+            float in0 = xv, in1 = 0.f;
+            const bool per = a.feat_per[fi] != 0;
+            if (per) sincosf((xv - a.emb_lower) * a.emb_scale, &in1, &in0);
+            xc[e0 * 64 + lane] = in0;
+            if (per) xc[(e0 + 1) * 64 + lane] = in1;
+            if (live) {
+                a.x[r * a.ldx + col] = xv;
+                a.xpad[r * a.ldxpad + icol] = in0;
+                if (per) a.xpad[r * a.ldxpad + icol + 1] = in1;
+            }
+        };
+        if constexpr (KIND == 2) {
+            // Moebius (moebius.py:142-147, :374-478): one parameter per feature, `dim` consecutive features of the
+            // degree form a vector; the dim parameter rows are adjacent, so one staged dot computes the vector's w.
+            const int dim = a.mb_dim;
+            for (int f = 0; f < n_d; f += dim) {
+                stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, 1, dim, okb, oke, lane);
+                stage_z(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, 1, dim, a.zout_slabs, a.zout_slab_stride, lane);
+                float acc[8];
 #pragma unroll
-            for (int p0 = 0; p0 < IB_MAX_P; p0 += 8) {
+                for (int g = 0; g < 8; ++g) acc[g] = g < dim ? zs[g * IB_Z_PITCH + lane] : 0.f;
+                dot_staged(acc, stg, cp, olen, lane);
+                double yv[MOEBIUS_MAX_DIM], wv[MOEBIUS_MAX_DIM], xv[MOEBIUS_MAX_DIM];
+#pragma unroll
+                for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+                    if (i < dim) {
+                        yv[i] = (double)a.y[r * a.ldy + a.feat_sel[foff + f + i]];
+                        wv[i] = (double)(-acc[i]);
+                    }
+                ldj_acc += moebius_vector(yv, wv, dim, a.mb_max_radius, a.mb_unit_sphere, xv);
+#pragma unroll
+                for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+                    if (i < dim) emit(foff + f + i, (float)xv[i]);
+            }
+        } else {
+        constexpr int MAXP = KIND == 0 ? 8 : IB_MAX_P;
+        for (int f = 0; f < n_d; ++f) {
+            float prm[MAXP];
+            stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, n_d, a.P, okb, oke, lane);   // the feature's P rows at once
+            stage_z(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, n_d, a.P, a.zout_slabs, a.zout_slab_stride, lane);
+#pragma unroll
+            for (int p0 = 0; p0 < MAXP; p0 += 8) {
                 float acc[8];
 #pragma unroll
                 for (int g = 0; g < 8; ++g) acc[g] = 0.f;
@@ -155,16 +362,16 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
                     const int np = min(8, a.P - p0);
 #pragma unroll
                     for (int g = 0; g < 8; ++g)
-                        if (g < np) acc[g] = slab_sum(zo + out_row0 + (p0 + g) * n_d + f, a.zout_slabs, a.zout_slab_stride);
-                    dot_rows<8>(acc, a.wout, a.ldwout, out_row0 + p0 * n_d + f, n_d, np, cp, c0p, okb, oke, lane);
+                        if (g < np) acc[g] = zs[(p0 + g) * IB_Z_PITCH + lane];
+                    dot_staged(acc, stg + (p0 >> 3) * gstride, cp, olen, lane);
                 }
 #pragma unroll
                 for (int g = 0; g < 8; ++g) prm[p0 + g] = acc[g];
             }
-            const int sel = a.feat_sel[foff + f], col = a.feat_cols[foff + f];
+            const int sel = a.feat_sel[foff + f];
             const float yv = a.y[r * a.ldy + sel];
             float xv;
-            if (a.kind == 0) {                                          // affine.py:361-363
+            if constexpr (KIND == 0) {                                  // affine.py:361-363
                 xv = (yv - prm[0]) * expf(-prm[1]);
                 ldj_acc -= (double)prm[1];
             } else {
@@ -192,8 +399,8 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
                                                        a.sp.y0[sel], a.sp.yf[sel], yv, &ld);
                 ldj_acc -= ld;
             }
-            // the new feature becomes conditioner input: itself, or (cos, sin) under a periodic embedding
-            // (same arithmetic as periodic_embedding_kernel, mafembed.py:112-145)
+            // (emit, written out: the lambda call here costs the spline kernel ~50% -- different SGPR spill placement)
+            const int col = a.feat_cols[foff + f];
             const int e0 = a.feat_in[foff + f], icol = a.in_cols[e0];
             float in0 = xv, in1 = 0.f;
             const bool per = a.feat_per[foff + f] != 0;
@@ -205,6 +412,7 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
                 a.xpad[r * a.ldxpad + icol] = in0;
                 if (per) a.xpad[r * a.ldxpad + icol + 1] = in1;
             }
+        }
         }
     }
     if (live) a.ldj[row] = (float)((double)a.ldj[row] + ldj_acc);
@@ -218,12 +426,17 @@ extern "C" {
 
 int tfep_inverse_block_step_ints(void) { return IB_STEP_INTS; }
 
+int64_t tfep_inverse_block_lds_bytes(int n_layers, int cache_len, int max_feats) {
+    if (n_layers < 1 || cache_len < 0 || max_feats < 0) return -1;
+    return (int64_t)(ib_lds_floats(n_layers, cache_len, max_feats) * sizeof(float));
+}
+
 int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
     TFEP_REQUIRE(d != nullptr, "inverse_block: NULL descriptor");
     TFEP_REQUIRE(d->B >= 0 && d->n_steps >= 0, "inverse_block: negative size");
     if (d->B == 0 || d->n_steps == 0) return TFEP_OK;
     TFEP_REQUIRE(d->n_layers >= 1 && d->n_layers <= IB_MAX_LAYERS, "inverse_block: 1..%d hidden layers", IB_MAX_LAYERS);
-    TFEP_REQUIRE(d->kind == 0 || d->kind == 1, "inverse_block: kind must be 0 (affine) or 1 (spline)");
+    TFEP_REQUIRE(d->kind >= 0 && d->kind <= 2, "inverse_block: kind must be 0 (affine), 1 (spline) or 2 (Moebius)");
     TFEP_REQUIRE(d->x && d->xpad && d->y && d->zout && d->wout && d->log_det_J && d->steps && d->feat_cols && d->feat_sel,
                  "inverse_block: NULL pointer");
     InverseBlockArgs a = {};
@@ -243,26 +456,40 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
     a.feat_in = d->feat_in; a.feat_per = d->feat_periodic; a.in_cols = d->in_cols;
     a.emb_lower = d->emb_lower;
     a.emb_scale = (float)(2.0 * 3.14159265358979323846 / ((double)d->emb_upper - (double)d->emb_lower));
-    a.cache_len = d->cache_len; a.max_feats = d->max_feats;
+    TFEP_REQUIRE(d->cache_len >= 0 && d->max_feats >= 0, "inverse_block: negative LDS size");
+    a.cache_len = ib_round4(d->cache_len); a.max_feats = ib_round4(d->max_feats);
+    a.stage_gstride = 8 * ib_stage_cols(d->cache_len, d->max_feats);
+    for (int l = 0; l < d->n_layers; ++l)            // the weight stage is filled with 16-byte loads
+        TFEP_REQUIRE(((uintptr_t)d->w[l] & 15) == 0 && d->ldw[l] % 4 == 0 && d->cache_col0[l] % 4 == 0,
+                     "inverse_block: packed weights / cache_col0 of layer %d not aligned to 4 floats", l);
+    TFEP_REQUIRE(((uintptr_t)d->wout & 15) == 0 && d->ldwout % 4 == 0, "inverse_block: packed output weights not aligned to 4 floats");
     if (d->kind == 1) {
         int rc = make_spline_args(d->spline, &a.sp);
         if (rc) return rc;
         TFEP_REQUIRE(a.sp.f.K <= 8, "inverse_block: at most 8 spline bins");
         a.P = a.sp.P;
+    } else if (d->kind == 2) {
+        TFEP_REQUIRE(d->moebius_dim >= 1 && d->moebius_dim <= MOEBIUS_MAX_DIM, "inverse_block: Moebius dimension=%d unsupported (1..%d)",
+                     d->moebius_dim, MOEBIUS_MAX_DIM);
+        a.mb_dim = d->moebius_dim; a.mb_unit_sphere = d->moebius_unit_sphere; a.mb_max_radius = d->moebius_max_radius;
+        a.P = 1;
     } else {
         a.P = 2;
     }
     TFEP_REQUIRE(a.P <= IB_MAX_P, "inverse_block: too many parameters per feature");
-    const size_t lds = ((size_t)a.L * a.cache_len + a.max_feats) * 64 * sizeof(float);
+    const size_t lds = ib_lds_floats(d->n_layers, d->cache_len, d->max_feats) * sizeof(float);
+    a.lds_floats = (int)(lds / sizeof(float));
     TFEP_REQUIRE(lds <= 160 * 1024, "inverse_block: block needs %zu bytes of LDS (> 160 KiB)", lds);
-    static size_t lds_attr_on[TFEP_MAX_DEVICES] = {};          // per device: a process may drive several GPUs
-    size_t& lds_attr = lds_attr_on[current_device_slot()];
+    static size_t lds_attr_on[3][TFEP_MAX_DEVICES] = {};       // per kernel and device: a process may drive several GPUs
+    size_t& lds_attr = lds_attr_on[d->kind][current_device_slot()];
+    void (*kernel)(InverseBlockArgs) = d->kind == 0 ? inverse_block_kernel<0> : d->kind == 1 ? inverse_block_kernel<1>
+                                                                                             : inverse_block_kernel<2>;
     if (lds > lds_attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)inverse_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));
         lds_attr = lds;
     }
-    inverse_block_kernel<<<(unsigned)((d->B + 63) / 64), 64, lds, (hipStream_t)stream>>>(a);
+    kernel<<<(unsigned)((d->B + 63) / 64), 64, lds, (hipStream_t)stream>>>(a);
     return check_launch("inverse_block_kernel");
 }
 

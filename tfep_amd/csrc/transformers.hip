@@ -5,6 +5,7 @@
 // is summed in fp64 with a wave butterfly -- no atomics, bit-reproducible.
 #include "common.h"
 #include "spline.h"
+#include "moebius.h"
 
 #include <stdarg.h>
 
@@ -131,12 +132,7 @@ __global__ void __launch_bounds__(256) spline_kernel(const float* __restrict__ x
 }
 
 // ---------------------------------------------------------------- Moebius (moebius.py:374-478)
-// One lane per d-vector.  log|det J| in closed form: with c = N/|x-w|^2 and the reflection
-// R = I - 2 dd^T/|d|^2 (d = x - w) the unit-sphere Jacobian is c R, so log|det| = dim*log|c|;
-// the general Jacobian is c R (I - xx^T/|x|^2) + y x^T/|x|^2 whose determinant is
-// -(c^(dim-1)/|x|) * xhat . (R y)   (matrix-determinant lemma for a rank-(dim-1) + rank-1 sum).
-constexpr int MOEBIUS_MAX_DIM = 8;
-
+// One lane per d-vector; the map and its closed-form log|det J| are in moebius.h.
 __global__ void __launch_bounds__(256) moebius_kernel(const float* __restrict__ x, int64_t ldx,
                                                       const float* __restrict__ params, int64_t ldp, int dim,
                                                       float max_radius, int unit_sphere, float sign,
@@ -151,52 +147,17 @@ __global__ void __launch_bounds__(256) moebius_kernel(const float* __restrict__ 
     float* yr = y + (int64_t)b * ldy;
     double acc = 0.0;
     for (int v = lane; v < nvec; v += 64) {
-        double xv[MOEBIUS_MAX_DIM], wv[MOEBIUS_MAX_DIM], dv[MOEBIUS_MAX_DIM], yv[MOEBIUS_MAX_DIM];
-        double wn2 = 0.0, xn2 = 0.0;
+        double xv[MOEBIUS_MAX_DIM], wv[MOEBIUS_MAX_DIM], yv[MOEBIUS_MAX_DIM];
 #pragma unroll
         for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
             if (i < dim) {
                 xv[i] = (double)xr[v * dim + i];
                 wv[i] = (double)(sign * pr[v * dim + i]);
-                wn2 += wv[i] * wv[i];
-                xn2 += xv[i] * xv[i];
             }
-        const double wn = sqrt(wn2), xn = sqrt(xn2);
-        double resc = (double)max_radius / (1.0 + wn);             // moebius.py:437-441
-        if (!unit_sphere) resc *= xn;
-        const double wns = resc * wn;
-        const double numer = (unit_sphere ? 1.0 : xn2) - wns * wns;   // moebius.py:446-449
-        double dn2 = 0.0;
+        acc += moebius_vector(xv, wv, dim, max_radius, unit_sphere, yv);
 #pragma unroll
         for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
-            if (i < dim) {
-                wv[i] *= resc;
-                dv[i] = xv[i] - wv[i];
-                dn2 += dv[i] * dv[i];
-            }
-        const double c = numer / dn2;
-        double dy = 0.0;   // d . y
-        double xy = 0.0;   // x . y
-#pragma unroll
-        for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
-            if (i < dim) {
-                yv[i] = c * dv[i] - wv[i];                         // moebius.py:452
-                yr[v * dim + i] = (float)yv[i];
-                dy += dv[i] * yv[i];
-                xy += xv[i] * yv[i];
-            }
-        double ld;
-        if (unit_sphere) {
-            ld = dim * log(fabs(c));
-        } else {
-            double xd = 0.0;
-#pragma unroll
-            for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
-                if (i < dim) xd += xv[i] * dv[i];
-            const double xRy = xy - 2.0 * xd * dy / dn2;           // x . (R y)
-            ld = (dim - 1) * log(fabs(c)) - 2.0 * log(xn) + log(fabs(xRy));
-        }
-        acc += ld;
+            if (i < dim) yr[v * dim + i] = (float)yv[i];
     }
     acc = wave_sum(acc);
     if (ldj) store_ldj(ldj, b, acc, accumulate);

@@ -487,7 +487,7 @@ class AutoregressiveFlow(torch.nn.Module):
         if fused_ok:
             cache_len = max(b_['fused']['cache_need'] for b_ in blocks)
             max_feats = max(b_['fused']['n_feats'] for b_ in blocks)
-            fused_ok = (L * cache_len + max_feats) * 256 <= 160 * 1024
+            fused_ok = 0 <= lib.tfep_inverse_block_lds_bytes(L, cache_len, max_feats) <= 160 * 1024
         bp = dict(blocks=blocks, P=P, L=L, row_inv=row_inv.to(**i32), n_rows_out=P * n_tr,
                   fused=dict(cache_len=cache_len, max_feats=max_feats) if fused_ok else None,
                   max_tiles=(max_rows + narrow - 1) // narrow,
@@ -503,6 +503,8 @@ class AutoregressiveFlow(torch.nn.Module):
         tr = self._transformer
         if type(tr) is AffineTransformer:
             return True
+        if type(tr) is MoebiusTransformer:
+            return 1 <= tr.dimension <= 8
         return type(tr) is NeuralSplineTransformer and tr.host()['n_bins'] <= 8
 
     def _fused_block_tables(self, d0, d1, blk, kA, r_lo, r_hi, base, sels, tr_idx, deg_in, mplan, L, P, rng, up, i32):
@@ -537,6 +539,8 @@ class AutoregressiveFlow(torch.nn.Module):
                 else:
                     rec[4 * l + 2], rec[4 * l + 3] = c0[l - 1], max(c0[l - 1], r_hi(l - 1, e))
             sel = sels[d]
+            if type(self._transformer) is MoebiusTransformer and len(sel) % self._transformer.dimension:
+                return None                                   # a degree must hold whole vectors
             rec[16:21] = [base[d], len(sel), c0[L - 1], max(c0[L - 1], r_hi(L - 1, e)), len(cols)]
             steps.append(rec)
             for c in tr_idx[sel].tolist():
@@ -626,10 +630,14 @@ class AutoregressiveFlow(torch.nn.Module):
                     wzout = max(wzout, b_['out_wide']['n_rows'])
                 z = [torch.empty(S, B, ops.round_up(wz[l], 4), **f32) for l in range(L)]
                 zout = torch.empty(S, B, ops.round_up(wzout, 4), **f32)
-                kind = 1 if type(self._transformer) is NeuralSplineTransformer else 0
-                spl = self._transformer.config(dev).desc if kind == 1 else None
+                tr = self._transformer
+                kind = {NeuralSplineTransformer: 1, MoebiusTransformer: 2}.get(type(tr), 0)
+                spl = tr.config(dev).desc if kind == 1 else None
                 d = _lib.InverseBlockDesc()
                 d.B, d.n_layers, d.kind = B, L, kind
+                if kind == 2:
+                    d.moebius_dim, d.moebius_unit_sphere = tr.dimension, int(tr.unit_sphere)
+                    d.moebius_max_radius = tr.max_radius
                 d.x, d.ldx, d.xpad, d.ldxpad = x.data_ptr(), D, xpad.data_ptr(), xpad.shape[1]
                 d.y, d.ldy = y_tr.data_ptr(), y_tr.shape[1]
                 for l in range(L):
