@@ -471,10 +471,10 @@ class AutoregressiveFlow(torch.nn.Module):
                     hidden.append(dict(layer=l, row0=r0, n_rows=r1 - r0, kr=rng(kb, ke)))
                 sel = sels[d]
                 ke = min(up(r_hi(L - 1, e)), mplan['k_pad'][L])
+                # the device-side tables of a step (index tensors, sliced transformer) are only needed by the per-step
+                # launches: built on first use (_step_tables), not for every degree of a layer the block kernel handles
                 blk['steps'].append(dict(hidden=hidden, out=dict(row0=base[d], n_rows=P * len(sel), kr=rng(kA[L], ke)),
-                                         n_d=len(sel), sel=sel.to(**i32), cols=tr_idx[sel].to(**i32),
-                                         inputs=self._input_info(tr_idx[sel].tolist(), device),
-                                         sub=self._sub_transformer(sel.to(device), device)))
+                                         n_d=len(sel), sel_host=sel, cols_host=tr_idx[sel]))
             blk['fused'] = self._fused_block_tables(d0, d1, blk, kA, r_lo, r_hi, base, sels, tr_idx, deg_in, mplan, L, P,
                                                     rng, up, i32)
             blocks.append(blk)
@@ -493,6 +493,17 @@ class AutoregressiveFlow(torch.nn.Module):
                   max_tiles=(max_rows + narrow - 1) // narrow,
                   k_ranges=torch.tensor(kr, dtype=torch.int32).reshape(-1, 2).to(device))
         return bp
+
+    def _step_tables(self, st, device):
+        """Device tensors of one degree for the per-step launches (cached in the step record)."""
+        if 'sel' not in st:
+            i32 = dict(device=device, dtype=torch.int32)
+            sel, cols = st['sel_host'], st['cols_host']
+            st['cols'] = cols.to(**i32)
+            st['inputs'] = self._input_info(cols.tolist(), device)
+            st['sub'] = self._sub_transformer(sel.to(device), device)
+            st['sel'] = sel.to(**i32)
+        return st
 
     #: Run the per-degree chain of each block in ONE kernel (``tfep_inverse_block``) when the layer qualifies.
     fused_inverse = True
@@ -687,6 +698,7 @@ class AutoregressiveFlow(torch.nn.Module):
                             launch(h[l - 1], packs[l][0], None, hd, h[l], hd['row0'], act=1, pre=z[l], pre_col0=hd['row0'])
                     if st['n_d'] == 0:
                         continue
+                    self._step_tables(st, dev)
                     od = st['out']
                     launch(h[L - 1], w_out, None, od, zout, od['row0'], act=0, pre=zout, pre_col0=od['row0'])
                     y_d = ops.gather_columns(y_tr, st['sel'])
