@@ -120,3 +120,44 @@ def test_two_rank_gloo_allreduce_of_tfep_statistics():
         np.testing.assert_allclose(df, oloss.fep_estimator(uB - ldj - uA), rtol=1e-6)
         assert gavg == [1.5, 2.5]                           # mean over ranks of (rank + 1 + i)
     assert res[0][1:] == res[1][1:]
+
+
+def _log_worker(rank, world, port, q, log_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import warnings
+        from tfep_amd.io import TFEPLogger, gather_to_rank0
+        n, batch = 7, 7                                        # 7 rows over 2 ranks: ragged shards (4 + 3)
+        b, e = shard_rows(n, rank, world)
+        shard = {'dataset_sample_index': torch.arange(b, e), 'potential': torch.arange(b, e, dtype=torch.float32) * 0.5 - 1.0}
+        full = gather_to_rank0(shard)
+        if rank == 0:
+            loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(torch.arange(n)), batch_size=batch)
+            with warnings.catch_warnings():
+                warnings.simplefilter('error')
+                TFEPLogger(save_dir_path=log_dir, data_loader=loader).save_eval_tensors(full, step_idx=0)
+        q.put((rank, None if full is None else {k: v.tolist() for k, v in full.items()}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather_of_per_sample_logs(tmp_path):
+    """Per-sample potentials of a sharded batch reach rank 0 in row order and land in one TFEPLogger file."""
+    from tfep_amd.io import TFEPLogger
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_log_worker, args=(r, world, port, q, str(tmp_path / 'log'))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[1] is None
+    assert res[0]['dataset_sample_index'] == list(range(7))
+    assert res[0]['potential'] == [i * 0.5 - 1.0 for i in range(7)]
+    back = TFEPLogger(save_dir_path=str(tmp_path / 'log')).read_eval_tensors(step_idx=0)
+    assert back['dataset_sample_index'].tolist() == list(range(7)) and back['potential'].tolist() == res[0]['potential']

@@ -892,6 +892,66 @@ def gen_bootstrap():
     np.savez_compressed(os.path.join(OUT, 'bootstrap.npz'), **out)
 
 
+def gen_logger():
+    """A small log directory written by the reference TFEPLogger (data files only): tests/golden/logger_ref/, plus the
+    inputs of every call and the reference's answers to a few reads in logger.npz."""
+    import shutil
+    import warnings
+    from tfep.io.log import TFEPLogger
+    root = os.path.join(OUT, 'logger_ref')
+    shutil.rmtree(root, ignore_errors=True)
+    n, bs = 9, 2
+    loader = torch.utils.data.DataLoader(torch.utils.data.TensorDataset(torch.arange(n)), batch_size=bs, drop_last=False)
+    log = TFEPLogger(save_dir_path=root, data_loader=loader)
+    g0 = gen(8000)
+    out = {'n': np.array(n), 'batch_size': np.array(bs)}
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        # training: epoch 0 batches 0, 1, 3, 4 (batch 2 never saved; the last batch has one sample), epoch 1 whole epoch
+        for b in (0, 1, 3, 4):
+            m = min(bs, n - b * bs)
+            t = {'dataset_sample_index': torch.arange(b * bs, b * bs + m), 'potential': torch.randn(m, generator=g0),
+                 'log_det_J': torch.randn(m, generator=g0)}
+            if b == 3:
+                t['potential'][0] = float('nan')
+            for k, v in t.items():
+                out[f'train/e0b{b}/{k}'] = npy(v)
+            log.save_train_tensors(t, epoch_idx=0, batch_idx=b)
+        t = {'dataset_sample_index': torch.randperm(n, generator=g0), 'potential': torch.randn(n, generator=g0)}
+        for k, v in t.items():
+            out[f'train/e1/{k}'] = npy(v)
+        log.save_train_tensors(t, epoch_idx=1)
+        # evaluation at step 7: three batches out of order, then an update of two stored samples
+        for j, idx in enumerate(([4, 5, 6], [0, 1], [7, 8, 2, 3])):
+            t = {'trajectory_sample_index': torch.tensor(idx), 'work': torch.randn(len(idx), generator=g0)}
+            if j == 1:
+                t['work'][1] = float('nan')
+            for k, v in t.items():
+                out[f'eval/s7c{j}/{k}'] = npy(v)
+            log.save_eval_tensors(t, step_idx=7)
+        t = {'trajectory_sample_index': torch.tensor([5, 0, 11]), 'work': torch.tensor([10.0, 20.0, 30.0])}
+        for k, v in t.items():
+            out[f'eval/s7upd/{k}'] = npy(v)
+        log.save_eval_tensors(t, step_idx=7, update=True)
+    reads = {
+        'r_train_e0': log.read_train_tensors(epoch_idx=0, as_numpy=True),
+        'r_train_e0_nonan': log.read_train_tensors(epoch_idx=0, remove_nans=True, as_numpy=True),
+        'r_train_e0b3': log.read_train_tensors(epoch_idx=0, batch_idx=3, remove_nans='potential', as_numpy=True),
+        'r_train_step6': log.read_train_tensors(step_idx=6, names=['potential'], as_numpy=True),
+        'r_eval': log.read_eval_tensors(step_idx=7, as_numpy=True),
+        'r_eval_nonan': log.read_eval_tensors(epoch_idx=1, batch_idx=2, remove_nans=True, as_numpy=True),
+    }
+    for rname, d in reads.items():
+        for k, v in d.items():
+            out[f'{rname}/{k}'] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, 'logger.npz'), **out)
+    # (sorting rewrites the file: do it on a copy, the unsorted directory above stays the read fixture)
+    sorted_root = os.path.join(OUT, 'logger_ref_sorted')
+    shutil.rmtree(sorted_root, ignore_errors=True)
+    shutil.copytree(root, sorted_root)
+    TFEPLogger(save_dir_path=sorted_root).read_eval_tensors(step_idx=7, sort_by='trajectory_sample_index')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
     if len(sys.argv) > 1:
@@ -908,5 +968,6 @@ if __name__ == '__main__':
     gen_wrappers()
     gen_embeddings()
     gen_bootstrap()
+    gen_logger()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
