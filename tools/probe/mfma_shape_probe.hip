@@ -33,8 +33,11 @@ __global__ void __launch_bounds__(256, 1) probe16(float* out, int iters) {
     }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
-        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[i & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+        for (int i = 0; i < NACC; ++i)      // inline asm pins the accumulators in place (the builtin made the compiler
+                                            // rename half of them and pad with s_nop: 1702 instead of ~2400 TFLOP/s on zeros)
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[i & 3]), "v"(b[(i >> 2) & 3]));
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
@@ -60,8 +63,9 @@ __global__ void __launch_bounds__(256, 1) probe32(float* out, int iters) {
         for (int rep = 0; rep < 2; ++rep)                                // same flops per iteration as probe16
 #pragma unroll
             for (int i = 0; i < NACC; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(i + rep) & 3], b[(i >> 2) & 3], acc[i], 0, 0, 0);
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc[i]) : "v"(a[(i + rep) & 3]), "v"(b[(i >> 2) & 3]));
     }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NACC; ++i)
