@@ -217,3 +217,61 @@ def test_random_medium_size_gradient_cross_path(seed):
         assert torch.isfinite(a).all(), n
         err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-8)
         assert err < 2e-4, (n, err)
+
+
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('TFEP_RANDOM_BLOCK_KINDS_SEEDS', 8)))))
+def test_random_medium_size_block_kernel_kinds(seed):
+    """The fused inverse block kernel at medium size for the layers the other medium test does not draw: Moebius vectors
+    (dimension 2 / 3, unit sphere or not, conditioning features) and circular splines behind a periodic embedding, wide
+    enough for split-K slabs (S > 1) and several blocks: block kernel vs per-step launches vs the forward map."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.embeddings import PeriodicEmbedding
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import MoebiusTransformer, NeuralSplineTransformer
+    rng = np.random.default_rng(30_000 + seed)
+    B = int(rng.integers(1, 400))
+    hidden = [int(rng.integers(1100, 1700)) for _ in range(int(rng.integers(1, 3)))]      # k_pad >= 1024: two slabs and more
+    torch.manual_seed(seed)
+    if seed % 2 == 0:
+        dim = int(rng.choice([2, 3]))
+        n_vec = int(rng.integers(20, 70))
+        n_cond = int(rng.integers(0, 3))
+        D = dim * n_vec + n_cond
+        cond = sorted(rng.choice(D, size=n_cond, replace=False).tolist()) if n_cond else None
+        unit = bool(rng.random() < 0.5)
+        deg = generate_degrees(D, str(rng.choice(['ascending', 'descending'])), conditioning_indices=cond, repeats=dim)
+        maf = MAF(deg, transformer=MoebiusTransformer(dimension=dim, unit_sphere=unit), hidden_layers=hidden,
+                  initialize_identity=False).cuda()
+        v = torch.randn(B, n_vec, dim, generator=torch.Generator().manual_seed(seed))
+        if unit:
+            v = v / v.norm(dim=2, keepdim=True)
+        x = torch.randn(B, D, generator=torch.Generator().manual_seed(seed + 1))
+        free = [i for i in range(D) if cond is None or i not in cond]
+        x[:, free] = v.reshape(B, -1)
+        x = x.cuda()
+        circle = None
+    else:
+        D = int(rng.integers(60, 200))
+        n_per = int(rng.integers(1, D + 1))
+        per = sorted(rng.choice(D, size=n_per, replace=False).tolist())
+        maf = MAF(generate_degrees(D, str(rng.choice(['ascending', 'descending', 'random']))),
+                  transformer=NeuralSplineTransformer(torch.zeros(D), torch.full((D,), 2.0), 8, circular=True),
+                  embedding=PeriodicEmbedding(D, limits=[0.0, 2.0], periodic_indices=per), hidden_layers=hidden,
+                  initialize_identity=False).cuda()
+        x = (torch.rand(B, D, generator=torch.Generator().manual_seed(seed)) * 2.0).cuda()
+        circle = 2.0
+    with torch.no_grad():
+        y, l = maf(x)
+        xf, lf = maf.inverse(y)
+        plan = maf._blocked_plan(x.device)
+        assert plan['fused'] is not None and len(plan['blocks']) > 1
+        maf.fused_inverse = False
+        maf._dev.clear()
+        xs, ls = maf.inverse(y)
+    d = (xf - xs).abs()
+    dx = (xf - x).abs()
+    if circle is not None:
+        d, dx = torch.minimum(d, circle - d), torch.minimum(dx, circle - dx)
+    assert float(d.max()) < 2e-4 and torch.allclose(lf, ls, rtol=1e-4, atol=2e-3)
+    assert float(dx.max()) < 5e-3
+    assert torch.allclose(lf + l, torch.zeros_like(l), atol=5e-3 + 1e-5 * D)
