@@ -282,6 +282,13 @@ int tfep_split_tile_k(void);
 int tfep_split_rows(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int64_t ld_dst,
                     int64_t cols_padded, float* inv_scale, int per_tensor, void* stream);
 
+/* Columns [col0, col0 + cols) (col0 % 8 == 0; whole groups of 8 are converted) of fp32 rows into the same columns of split
+ * rows, with the per-row scale given by the caller (inv_scale[row], a power of two, e.g. from a bound on the row): for
+ * operands that are filled incrementally -- the hidden-activation panels of the blocked inverse
+ * (reference flows/autoregressive.py:179-229 recomputes every panel per degree instead). */
+int tfep_split_columns_scaled(const float* src, int64_t ld_src, int64_t rows, int64_t col0, int64_t cols, void* dst,
+                              int64_t ld_dst, const float* inv_scale, void* stream);
+
 /* tfep_masked_weight_prepare writing split rows directly (one scale for the matrix, an upper bound of max |w|:
  * max |weight_g| with weight norm, max |weight_v| without).  in_of_col: PACKED column -> input column (the inverse
  * of tfep_masked_weight_prepare's col_of_in), or NULL for the identity.  Only the out_features real rows are

@@ -185,3 +185,66 @@ def test_elu_layer_writing_split_rows_directly(B, K, N):
     assert torch.isfinite(raw).all() and float(raw.abs().max()) < 2.0 ** 15   # the bound keeps fp16 in range
     fp32 = ops.masked_linear_split(xs, x_inv, ws, w_buf, bias, N, act=1)
     assert float(((got - fp32.double()).abs() / scale).max()) < 5e-7
+
+
+@pytest.mark.parametrize('B,K,N,S', [(700, 4096, 300, 3), (257, 1000, 90, 2), (64, 2048, 513, 8), (5, 64, 7, 4)])
+def test_split_gemm_split_k_slabs_add_up(B, K, N, S):
+    """k_split: S slabs of partial sums (bias in slab 0) whose sum is the un-split product -- bit for bit the same
+    fp32 partial products, summed in another order -- with a k-range per column tile; deterministic."""
+    from tfep_amd import ops
+    tm, tn, tk = ops.tile_sizes()
+    torch.manual_seed(B + K + N + S)
+    kp, npad = ops.round_up(K, tk), ops.round_up(N, tk)
+    a = ops.pad_columns(torch.randn(B, K, device='cuda'), kp)
+    w = ops.masked_weight_prepare(torch.randn(N, K, device='cuda') / K ** 0.5, None, None, n_rows_padded=npad, k_padded=kp)
+    bias = torch.randn(npad, device='cuda')
+    n_tiles = (N + tn - 1) // tn
+    kr = torch.tensor([[0, kp - tk * min(t, kp // tk - 1)] for t in range(n_tiles)], dtype=torch.int32, device='cuda')
+    as_, ainv = ops.split_rows(a, kp)
+    ws_, winv = ops.split_rows(w, kp, per_tensor=True)
+    full = ops.masked_linear_split(as_, ainv, ws_, winv, bias, N, k_ranges=kr)
+    slabs = ops.masked_linear_split(as_, ainv, ws_, winv, bias, N, k_ranges=kr, k_split=S)
+    assert slabs.shape == (S, B, N)
+    scale = float(full.abs().max()) + 1.0
+    assert float((slabs.sum(0) - full).abs().max()) < 2e-6 * scale
+    cols = torch.arange(N, device='cuda')
+    ref = torch.zeros(B, N, dtype=torch.float64, device='cuda')
+    for t in range(n_tiles):                                   # float64 reference honouring the k-ranges
+        c = cols[t * tn:(t + 1) * tn]
+        ke = int(kr[t, 1])
+        ref[:, c] = a[:, :ke].double() @ w[c, :ke].double().T + bias[c].double()
+    assert float((slabs.double().sum(0) - ref).abs().max()) < 2e-6 * scale
+    again = ops.masked_linear_split(as_, ainv, ws_, winv, bias, N, k_ranges=kr, k_split=S)
+    assert torch.equal(slabs, again)
+
+
+def test_split_columns_with_a_caller_fixed_scale():
+    """tfep_split_columns_scaled: a panel filled a few columns at a time ends up as the same split rows as converting it
+    whole with the same (bound-based) scale; untouched columns stay untouched; loose bounds keep fp32-level accuracy."""
+    from tfep_amd import ops
+    torch.manual_seed(3)
+    R, C = 300, 200
+    x = torch.randn(R, C, device='cuda') * torch.logspace(-3, 3, R, device='cuda')[:, None]
+    bound = x.abs().amax(1) * torch.logspace(0, 3, R, device='cuda')          # up to 1000x above the true maximum
+    inv = ops.pow2_inv_scale(bound)
+    assert torch.equal(torch.log2(inv), torch.log2(inv).round())
+    assert bool((bound / inv < 2.0 ** 15).all()) and bool((bound / inv >= 2.0 ** 14 * 0.999).all())
+    whole = torch.zeros(R, 224, device='cuda')
+    ops.split_columns_scaled(x, 0, C, whole, inv)
+    grown = torch.zeros(R, 224, device='cuda')
+    panel = torch.zeros(R, C, device='cuda')
+    for c0, c1 in ((0, 13), (13, 14), (14, 100), (100, 200)):   # ragged pieces: groups are re-converted from the panel
+        panel[:, c0:c1] = x[:, c0:c1]
+        g0 = c0 // 8 * 8
+        ops.split_columns_scaled(panel, g0, c1 - g0, grown, inv)
+    assert torch.equal(whole, grown)
+    assert bool((whole[:, 200:] == 0).all())
+    back = unsplit(whole, inv, C)
+    err = (back.double() - x.double()).abs() / x.abs().amax(1, keepdim=True).double()
+    assert float(err.max()) < 2.0 ** -20                      # 1000x loose bound: still far below fp32 rounding of a dot product
+    lib_err = None
+    try:
+        ops.split_columns_scaled(x, 4, 8, whole, inv)
+    except ValueError as e:
+        lib_err = str(e)
+    assert lib_err and 'multiple of 8' in lib_err

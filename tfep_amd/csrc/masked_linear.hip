@@ -447,7 +447,7 @@ int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
     g.tile_order = d->tile_order; g.aux = d->elu_grad_of; g.ldaux = d->ld_elu_grad_of; g.accumulate = d->accumulate;
     g.tile_live = d->tile_live; g.pre_add = d->pre_add; g.ld_pre_add = d->ld_pre_add;
     if (d->k_split > 1) {
-        TFEP_REQUIRE(!d->split && !d->accumulate && !d->tile_order && !d->tile_live && !d->elu_grad_of && d->act == 0,
+        TFEP_REQUIRE(!d->split_out && !d->accumulate && !d->tile_order && !d->tile_live && !d->elu_grad_of && d->act == 0,
                      "masked_linear_gemm: k_split needs a plain linear product (no activation / accumulate / tile_order / tile_live)");
         TFEP_REQUIRE(d->k_split <= 64 && d->slab_stride > 0, "masked_linear_gemm: bad k_split / slab_stride");
         g.ksplit = d->k_split; g.slab_stride = d->slab_stride;

@@ -116,6 +116,32 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
     }
 }
 
+// Columns [g0 * 8, (g0 + n_groups) * 8) of fp32 rows -> the same columns of split rows, with a scale the CALLER fixed
+// beforehand (inv_scale[row], a power of two): the hidden-activation panels of the blocked inverse grow by a few columns
+// per block, so their row scale has to be known before the values are (a bound; see flows/autoregressive.py).
+__global__ void __launch_bounds__(256) split_columns_scaled_kernel(const float* __restrict__ src, int64_t ld_src, int64_t rows,
+                                                                   int64_t g0, int64_t n_groups, uint4* __restrict__ dst,
+                                                                   int64_t ld_dst, const float* __restrict__ inv_scale) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * n_groups) return;
+    const int64_t row = idx / n_groups, g8 = g0 + idx % n_groups;
+    const float s = 1.0f / inv_scale[row];
+    const float4* sr = reinterpret_cast<const float4*>(src + row * ld_src + g8 * 8);
+    const float4 lo4 = sr[0], hi4 = sr[1];
+    const float v[8] = {lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y, hi4.z, hi4.w};
+    f16x8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float t = v[j] * s;
+        const _Float16 h = (_Float16)t;
+        hi[j] = h;
+        lo[j] = (_Float16)(t - (float)h);
+    }
+    uint4* dr = dst + row * (ld_dst / 4) + g8 * 2;
+    dr[0] = *reinterpret_cast<uint4*>(&hi);
+    dr[1] = *reinterpret_cast<uint4*>(&lo);
+}
+
 // Masked weight preparation straight into split rows (masked_linear.hip's weight_prepare_kernel + split_rows in one
 // pass over the weights).  One wave per output row: the row of v is read once coalesced for the weight-norm, then
 // gathered in PACKED column order (in_of_col: packed column -> input column; the row sits in L2 by then) so that
@@ -318,7 +344,17 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int mt, ntp;
     if (!map_block(g, mt, ntp)) return;
-    const int nt = g.tile_order ? g.tile_order[ntp] : ntp;
+    int nt = g.tile_order ? g.tile_order[ntp] : ntp;
+    // split-K (the short-and-wide block GEMMs of the inverse): ksplit x as many column positions, position -> (column
+    // tile, k slice); slice s writes its partial sums to y + s * slab_stride (gemm_common.h)
+    int k_slice = 0;
+    if constexpr (EPI == EPI_LINEAR) {              // (compile-time: the fused instantiations stay exactly as they were)
+        if (g.ksplit > 1) {
+            const int n_real = g.n_tiles / g.ksplit;
+            k_slice = nt / n_real;
+            nt -= k_slice * n_real;
+        }
+    }
     if (g.tile_live && !g.tile_live[(int64_t)mt * g.n_tiles + nt]) return;
     const int m0 = mt * T::BM, n0 = nt * T::BN;
     const unsigned long long t_start = (g.diag & 16) ? __builtin_readcyclecounter() : 0ull;
@@ -328,6 +364,13 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
     if (g.k_ranges) {
         kb = g.k_ranges[2 * nt];
         ke = g.k_ranges[2 * nt + 1];
+    }
+    if constexpr (EPI == EPI_LINEAR) {
+        if (g.ksplit > 1) {
+            const int per = (((ke - kb) / SBK + g.ksplit - 1) / g.ksplit) * SBK;   // k per slice, whole tiles
+            kb = min(ke, kb + k_slice * per);
+            ke = min(ke, kb + per);
+        }
     }
 
     f32x4 acc[NREP][SMREP];
@@ -507,7 +550,7 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
             constexpr int n = ic.value / SMREP, m = ic.value % SMREP;
             out[n][m] = acc[n][m] * rs[m];
         });
-        gemm_epilogue<SMREP, NREP, EPI, P, KSPL>(g, out, nt, n0, wrow0, lane);
+        gemm_epilogue<SMREP, NREP, EPI, P, KSPL>(g, out, nt, n0, wrow0, lane, k_slice);
     }
     if (EPI == EPI_SPLINE && (g.diag & 16) && threadIdx.x == 0) {
         const unsigned long long t_end = __builtin_readcyclecounter();
@@ -567,7 +610,8 @@ static int launch_split(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStr
     }
     GemmArgs ga = g;
     ga.m_tiles = (g.B + T::BM - 1) / T::BM;
-    ga.n_tiles = n_col_tiles;
+    if (g.ksplit > 1 && EPI != EPI_LINEAR) return fail(TFEP_ERR_INVALID_ARGUMENT, "split gemm: k_split needs the linear epilogue");
+    ga.n_tiles = n_col_tiles * (g.ksplit > 1 ? g.ksplit : 1);
     ga.map_mode = block_map_mode();
     ga.diag = env_int("TFEP_DIAG", 0);
     const long long blocks = gemm_grid_blocks(ga.map_mode, ga.m_tiles, ga.n_tiles);
@@ -635,6 +679,23 @@ int tfep_split_rows(const float* src, int64_t ld_src, int64_t rows, int64_t cols
     }
     split_rows_kernel<<<blocks, 256, 0, s>>>(src, ld_src, rows, cols, (uint4*)dst, ld_dst, cols_padded, inv_scale, max_bits);
     return check_launch("split_rows_kernel");
+}
+
+int tfep_split_columns_scaled(const float* src, int64_t ld_src, int64_t rows, int64_t col0, int64_t cols, void* dst,
+                              int64_t ld_dst, const float* inv_scale, void* stream) {
+    TFEP_REQUIRE(rows >= 0 && cols >= 0 && col0 >= 0, "split_columns_scaled: negative size");
+    if (rows == 0 || cols == 0) return TFEP_OK;
+    TFEP_REQUIRE(src && dst && inv_scale, "split_columns_scaled: NULL pointer");
+    TFEP_REQUIRE(col0 % 8 == 0, "split_columns_scaled: col0=%lld must be a multiple of 8", (long long)col0);
+    const int64_t n_groups = (cols + 7) / 8;
+    TFEP_REQUIRE(ld_src % 4 == 0 && ld_dst % 4 == 0 && col0 + n_groups * 8 <= ld_src && col0 + n_groups * 8 <= ld_dst,
+                 "split_columns_scaled: the 8-column groups covering [col0, col0 + cols) must lie inside both rows");
+    TFEP_REQUIRE((uintptr_t)dst % 16 == 0 && (uintptr_t)src % 16 == 0, "split_columns_scaled: src and dst must be 16-byte aligned");
+    const int64_t n = rows * n_groups;
+    TFEP_REQUIRE((n + 255) / 256 <= 0x7fffffffLL, "split_columns_scaled: grid too large");
+    split_columns_scaled_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(src, ld_src, rows, col0 / 8, n_groups,
+                                                                                          (uint4*)dst, ld_dst, inv_scale);
+    return check_launch("split_columns_scaled_kernel");
 }
 
 // Read and reset the TFEP_DIAG=16 cycle counters: out[0] k-loop, out[1] epilogue (shader cycles summed over workgroups), out[2] workgroups, out[3] lifetimes (100 MHz ticks).

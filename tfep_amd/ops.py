@@ -249,6 +249,24 @@ def split_rows(x, cols_padded, per_tensor=False, out=None, inv_scale=None):
     return out, inv_scale
 
 
+def split_columns_scaled(x, col0, cols, out, inv_scale):
+    """Columns ``[col0, col0 + cols)`` (whole groups of 8; ``col0 % 8 == 0``) of the fp32 rows ``x`` into the same columns
+    of the split rows ``out``, with the caller's per-row ``inv_scale`` (powers of two): for operands filled incrementally
+    (``tfep_split_columns_scaled``)."""
+    x, ldx = rows(x, 'x')
+    call('tfep_split_columns_scaled', ptr(x), ldx, x.shape[0], int(col0), int(cols), ptr(out), out.shape[1], ptr(inv_scale),
+         stream_of(x))
+    return out
+
+
+def pow2_inv_scale(bound):
+    """1 / s for the power of two s that puts ``bound`` (> 0, per row) into [2^14, 2^15): the inverse scale of a split row
+    whose entries are known to stay below ``bound`` (the split format keeps an absolute error of 2^-40 of the scaled
+    maximum, so a loose bound costs nothing)."""
+    e = torch.floor(torch.log2(bound.clamp_min(1e-30).double()))
+    return torch.exp2(e - 14.0).float()
+
+
 def masked_weight_prepare_split(weight_v, weight_g, mask, row_of_out, in_of_col, out, inv_scale):
     """Effective masked weight written directly as split-f16 rows into ``out`` (n_rows_padded, k_padded), whose
     padding rows must already be zero (``tfep_masked_weight_prepare_split``).  ``inv_scale``: 4 floats --
@@ -265,14 +283,16 @@ def masked_weight_prepare_split(weight_v, weight_g, mask, row_of_out, in_of_col,
 
 
 def masked_linear_split(x_split, x_inv_scale, w_split, w_inv_scale, bias, n_out, k_ranges=None, act=0, out=None,
-                        tile_order=None, split_out=False, bias_absmax=None):
+                        tile_order=None, split_out=False, bias_absmax=None, k_split=1):
     """``masked_linear_packed`` on split-f16 operands; the output is ordinary fp32, or -- ``split_out`` with
     ``act=1`` -- the ELU activations as split rows for the next layer: returns ``(rows, inv_scale)`` then.
-    ``w_inv_scale`` is the 4-float buffer of ``masked_weight_prepare_split`` (its entry 2 bounds the outputs)."""
+    ``w_inv_scale`` is the 4-float buffer of ``masked_weight_prepare_split`` (its entry 2 bounds the outputs).
+    ``k_split`` > 1 (plain linear product only): the k range is cut into that many slices whose partial sums go to the
+    slabs ``out[s]`` of an ``(k_split, B, n_out)`` output (bias in slab 0); the caller adds them."""
     B = x_split.shape[0]
     n_rows_w, k_padded = w_split.shape
     if out is None:
-        out = torch.empty(B, n_out, dtype=torch.float32, device=x_split.device)
+        out = torch.empty((B, n_out) if k_split <= 1 else (k_split, B, n_out), dtype=torch.float32, device=x_split.device)
     d = _lib.GemmDesc()
     if split_out:
         if bias_absmax is None:
@@ -286,9 +306,11 @@ def masked_linear_split(x_split, x_inv_scale, w_split, w_inv_scale, bias, n_out,
     d.k_ranges = k_ranges.data_ptr() if k_ranges is not None else None
     d.tile_order = tile_order.data_ptr() if tile_order is not None else None
     d.col_map = None
-    d.y, d.ldy = out.data_ptr(), out.shape[1]
+    d.y, d.ldy = out.data_ptr(), out.shape[-1]
     d.B, d.N, d.n_rows_w, d.k_padded, d.act, d.accumulate = B, n_out, n_rows_w, k_padded, int(act), 0
     d.split, d.x_inv_scale, d.w_inv_scale = 1, x_inv_scale.data_ptr(), w_inv_scale.data_ptr()
+    if k_split > 1:
+        d.k_split, d.slab_stride = int(k_split), out.shape[-2] * out.shape[-1]
     call('tfep_masked_linear_gemm', ctypes.byref(d), stream_of(x_split))
     return (out, y_inv) if split_out else out
 
