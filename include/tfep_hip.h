@@ -282,6 +282,10 @@ int tfep_split_tile_k(void);
 int tfep_split_rows(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int64_t ld_dst,
                     int64_t cols_padded, float* inv_scale, int per_tensor, void* stream);
 
+/* |.| reductions used for row-scale bounds (stream-ordered kernels only: no memset, no workspace -- safe to capture in a
+ * HIP graph).  mode 0: out[row] = max_k |src[row, k]| (rows floats);  mode 1: out[0] = max_row sum_k |src[row, k]|. */
+int tfep_abs_reduce(const float* src, int64_t ld_src, int64_t rows, int64_t cols, int mode, float* out, void* stream);
+
 /* Columns [col0, col0 + cols) (col0 % 8 == 0; whole groups of 8 are converted) of fp32 rows into the same columns of split
  * rows, with the per-row scale given by the caller (inv_scale[row], a power of two, e.g. from a bound on the row): for
  * operands that are filled incrementally -- the hidden-activation panels of the blocked inverse

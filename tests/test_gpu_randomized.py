@@ -275,3 +275,48 @@ def test_random_medium_size_block_kernel_kinds(seed):
     assert float(d.max()) < 2e-4 and torch.allclose(lf, ls, rtol=1e-4, atol=2e-3)
     assert float(dx.max()) < 5e-3
     assert torch.allclose(lf + l, torch.zeros_like(l), atol=5e-3 + 1e-5 * D)
+
+
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('TFEP_RANDOM_SPLIT_INVERSE_SEEDS', 8)))))
+def test_random_medium_size_split_inverse(seed):
+    """The blocked inverse with the output-layer block GEMM on split-f16 operands (bound-based row scale of the
+    incrementally filled activation panel) against the same inverse on exact-fp32 GEMMs, and against the forward map:
+    plain / circular splines, conditioning features, periodic embedding, 1-3 hidden layers, ragged batches."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.embeddings import PeriodicEmbedding
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    rng = np.random.default_rng(40_000 + seed)
+    D = int(rng.integers(40, 300))
+    B = int(rng.integers(1, 600))
+    n_cond = int(rng.integers(0, 3))
+    cond = sorted(rng.choice(D, size=n_cond, replace=False).tolist()) if n_cond else None
+    hidden = [int(rng.integers(600, 1700)) for _ in range(int(rng.integers(1, 4)))]
+    circular = bool(seed % 3 == 1)
+    torch.manual_seed(seed)
+    n_free = D - n_cond
+    lo, hi = (0.0, 2.0) if circular else (-4.0, 4.0)
+    per = sorted(rng.choice(D, size=max(1, D // 3), replace=False).tolist())
+    emb = PeriodicEmbedding(D, limits=[lo, hi], periodic_indices=per) if circular else None
+    maf = MAF(generate_degrees(D, str(rng.choice(['ascending', 'descending', 'random'])), conditioning_indices=cond),
+              transformer=NeuralSplineTransformer(torch.full((n_free,), lo), torch.full((n_free,), hi), 8, circular=circular),
+              embedding=emb, hidden_layers=hidden, weight_norm=bool(rng.random() < 0.7), initialize_identity=False).cuda()
+    gen = torch.Generator().manual_seed(seed)
+    x = (torch.rand(B, D, generator=gen) * 2.0 if circular else torch.randn(B, D, generator=gen) * 1.5).cuda()
+    with torch.no_grad():
+        y, l = maf(x)
+        maf.split_inverse = True
+        assert maf._split_inverse_bound(x.device) is not None
+        xs, ls = maf.inverse(y)
+        assert maf._blocked_plan(x.device)['fused'] is not None
+        xs2, ls2 = maf.inverse(y)
+        assert torch.equal(xs, xs2) and torch.equal(ls, ls2)          # deterministic
+        maf.split_inverse = False
+        maf._dev.clear()
+        xf, lf = maf.inverse(y)
+    d, dx = (xs - xf).abs(), (xs - x).abs()
+    if circular:
+        d, dx = torch.minimum(d, 2.0 - d), torch.minimum(dx, 2.0 - dx)
+    assert float(d.max()) < 2e-4 and torch.allclose(ls, lf, rtol=1e-4, atol=2e-3)
+    assert float(dx.max()) < 5e-3
+    assert torch.allclose(ls + l, torch.zeros_like(l), atol=5e-3 + 1e-5 * D)

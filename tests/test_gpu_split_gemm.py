@@ -248,3 +248,16 @@ def test_split_columns_with_a_caller_fixed_scale():
     except ValueError as e:
         lib_err = str(e)
     assert lib_err and 'multiple of 8' in lib_err
+
+
+def test_abs_reduce_row_maxima_and_infinity_norm():
+    from tfep_amd import ops
+    torch.manual_seed(5)
+    x = torch.randn(301, 1237, device='cuda') * torch.logspace(-4, 4, 301, device='cuda')[:, None]
+    assert torch.equal(ops.abs_reduce(x, 'row_max'), x.abs().amax(dim=1))
+    got = ops.abs_reduce(x, 'max_row_sum')
+    ref = x.double().abs().sum(dim=1).max()
+    assert got.shape == (1,) and abs(float(got) - float(ref)) <= 1e-5 * float(ref)
+    view = x[:, 100:300]                                         # strided rows
+    assert torch.equal(ops.abs_reduce(view, 'row_max'), view.abs().amax(dim=1))
+    assert float(ops.abs_reduce(torch.zeros(1, 0, device='cuda'), 'max_row_sum')) == 0.0

@@ -364,6 +364,20 @@ static int check_gemm_operands(const float* a, int64_t lda, const float* w, int6
 
 }  // namespace tfep
 
+namespace tfep {
+// p[0 .. n) = 0 (grid-stride; see tfep_masked_weight_prepare for why not hipMemsetAsync)
+__global__ void __launch_bounds__(256) fill_zero_kernel(float* __restrict__ p, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n && ((uintptr_t)(p + i) & 15) == 0) {
+            *reinterpret_cast<float4*>(p + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            for (size_t j = i; j < n && j < i + 4; ++j) p[j] = 0.f;
+        }
+    }
+}
+}  // namespace tfep
+
 using namespace tfep;
 
 extern "C" {
@@ -382,8 +396,15 @@ int tfep_masked_weight_prepare(const float* weight_v, const float* weight_g, con
     TFEP_REQUIRE(out_features >= 0 && in_features >= 0, "masked_weight_prepare: negative size");
     TFEP_REQUIRE(n_rows_padded >= out_features && ldw >= in_features, "masked_weight_prepare: output too small");
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(w_out, 0, (size_t)n_rows_padded * (size_t)ldw * sizeof(float), s);
-    if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipMemsetAsync: %s", hipGetErrorString(e));
+    // Cleared by a kernel, not hipMemsetAsync: captured in a HIP graph a memset becomes a memset node, and those were seen
+    // to leave garbage behind on replay (the padding rows of this buffer read back as ~1e36 by a later kernel of the same
+    // graph, while eager runs were clean; an earlier 4-byte case was traced to the same node type).
+    const size_t n_clear = (size_t)n_rows_padded * (size_t)ldw;
+    if (n_clear > 0) {
+        fill_zero_kernel<<<(unsigned)((n_clear + 1023) / 1024 < 65535 * 16 ? (n_clear + 1023) / 1024 : 65535 * 16), 256, 0, s>>>(w_out, n_clear);
+        int rc = check_launch("fill_zero_kernel");
+        if (rc) return rc;
+    }
     if (out_features == 0 || in_features == 0) return TFEP_OK;
     weight_prepare_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, s>>>(weight_v, weight_g, mask, out_features,
                                                                               in_features, row_of_out, col_of_in, w_out, ldw);

@@ -116,6 +116,29 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
     }
 }
 
+// |.| reductions for row-scale bounds, one wave per row.  mode 0: out[row] = max_k |src[row, k]|;  mode 1: out[0] =
+// max_row sum_k |src[row, k]| (the infinity norm; out[0] cleared by zero_u32_kernel first; non-negative floats order
+// like their bit patterns, so the maximum is an integer atomicMax -- exact and order-independent).
+__global__ void __launch_bounds__(256) abs_reduce_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int64_t cols,
+                                                         int mode, float* __restrict__ out) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* sr = src + row * ld;
+    float acc = 0.f;
+    if (mode == 0) {
+        for (int64_t i = lane; i < cols; i += 64) acc = fmaxf(acc, fabsf(sr[i]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc = fmaxf(acc, __shfl_xor(acc, off, 64));
+        if (lane == 0) out[row] = acc;
+    } else {
+        for (int64_t i = lane; i < cols; i += 64) acc += fabsf(sr[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(acc));
+    }
+}
+
 // Columns [g0 * 8, (g0 + n_groups) * 8) of fp32 rows -> the same columns of split rows, with a scale the CALLER fixed
 // beforehand (inv_scale[row], a power of two): the hidden-activation panels of the blocked inverse grow by a few columns
 // per block, so their row scale has to be known before the values are (a bound; see flows/autoregressive.py).
@@ -679,6 +702,20 @@ int tfep_split_rows(const float* src, int64_t ld_src, int64_t rows, int64_t cols
     }
     split_rows_kernel<<<blocks, 256, 0, s>>>(src, ld_src, rows, cols, (uint4*)dst, ld_dst, cols_padded, inv_scale, max_bits);
     return check_launch("split_rows_kernel");
+}
+
+int tfep_abs_reduce(const float* src, int64_t ld_src, int64_t rows, int64_t cols, int mode, float* out, void* stream) {
+    TFEP_REQUIRE(rows >= 0 && cols >= 0, "abs_reduce: negative size");
+    TFEP_REQUIRE(mode == 0 || mode == 1, "abs_reduce: mode must be 0 (row maxima) or 1 (maximum row sum)");
+    TFEP_REQUIRE(out && (src || rows == 0 || cols == 0), "abs_reduce: NULL pointer");
+    TFEP_REQUIRE(ld_src >= cols, "abs_reduce: ld_src < cols");
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 1) zero_u32_kernel<<<1, 1, 0, s>>>(reinterpret_cast<uint32_t*>(out), 1);
+    if (rows > 0) {
+        TFEP_REQUIRE((rows + 3) / 4 <= 0x7fffffffLL, "abs_reduce: grid too large");
+        abs_reduce_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(src, ld_src, rows, cols, mode, out);
+    }
+    return check_launch("abs_reduce_kernel");
 }
 
 int tfep_split_columns_scaled(const float* src, int64_t ld_src, int64_t rows, int64_t col0, int64_t cols, void* dst,

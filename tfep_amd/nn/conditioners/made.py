@@ -278,7 +278,7 @@ class MADE(Conditioner):
             buf = torch.empty(n_rows, plan['k_pad'][li], dtype=torch.float32, device=v.device)
             plan[key] = buf
         ops.masked_weight_prepare(v, g, lin.mask, row_of_out, plan['col_of_in'][li], n_rows, plan['k_pad'][li], out=buf)
-        bias = torch.zeros(1, n_rows, dtype=torch.float32, device=v.device)
+        bias = ops.zeros(1, n_rows, dtype=torch.float32, device=v.device)
         if row_of_out is None:
             bias[0, :lin.out_features] = lin.bias.detach()
         else:
@@ -288,7 +288,7 @@ class MADE(Conditioner):
         return buf, bias[0]
 
     def _pack_bias(self, lin, row_of_out, n_rows):
-        bias = torch.zeros(1, n_rows, dtype=torch.float32, device=lin.bias.device)
+        bias = ops.zeros(1, n_rows, dtype=torch.float32, device=lin.bias.device)
         if row_of_out is None:
             bias[0, :lin.out_features] = lin.bias.detach()
         else:
@@ -322,13 +322,13 @@ class MADE(Conditioner):
         buf = plan.get(key)
         if buf is None:
             # zero once: the kernel writes the real rows only, padding rows / columns stay zero for good
-            buf = (torch.zeros(n_rows, plan['k_pad'][li], dtype=torch.float32, device=v.device),
-                   torch.zeros(4, dtype=torch.float32, device=v.device))
+            buf = (ops.zeros(n_rows, plan['k_pad'][li], dtype=torch.float32, device=v.device),
+                   ops.zeros(4, dtype=torch.float32, device=v.device))
             plan[key] = buf
         in_of_col = plan['in_of_col'][li]
         ops.masked_weight_prepare_split(v, g, lin.mask, row_of_out, in_of_col, buf[0], buf[1])
         bias = self._pack_bias(lin, row_of_out, n_rows)
-        res = (buf[0], buf[1], bias, bias.abs().max().reshape(1))
+        res = (buf[0], buf[1], bias, ops.abs_reduce(bias.reshape(1, -1), 'row_max'))
         if self._frozen:
             plan[('packed_split', li, n_rows)] = res
         return res

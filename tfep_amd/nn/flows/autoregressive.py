@@ -282,7 +282,7 @@ class AutoregressiveFlow(torch.nn.Module):
         if self._blocked_ok():
             return self._inverse_blocked(y)
         t = self._tables(y.device)
-        x = torch.zeros(y.shape, dtype=y.dtype, device=y.device)
+        x = ops.zeros(*y.shape, dtype=y.dtype, device=y.device)
         if self.has_fixed_indices:
             ops.scatter_columns(ops.gather_columns(y, t['fixed']), t['fixed'], x)
             y = ops.gather_columns(y, t['tr'])
@@ -508,6 +508,33 @@ class AutoregressiveFlow(torch.nn.Module):
     #: Run the per-degree chain of each block in ONE kernel (``tfep_inverse_block``) when the layer qualifies.
     fused_inverse = True
 
+    #: The wide output-layer GEMM of every block (40 % of a cfg2 inverse) on split-f16 operands: None = when the forward
+    #: uses them (``_use_split_gemm``) and a bound on |x| is known beforehand (see ``_split_inverse_bound``).
+    split_inverse = None
+
+    def _split_inverse_bound(self, device):
+        """max |x| the inverse can produce, as a device scalar, or None when it is not known in advance.
+
+        The last hidden panel of the blocked inverse is filled block by block, so the row scale of its split-f16 copy
+        must be fixed before the values exist: |h| is bounded layer by layer from a bound on the conditioner inputs.
+        A spline with fixed bounds and the same domain and codomain maps y inside the domain to x inside it and is the
+        identity outside, so |x| <= max(|y|, |x0|, |xf|); affine / Moebius outputs have no such bound (fp32 GEMMs)."""
+        if self.split_inverse is False or not self.fused_inverse:
+            return None
+        if self.split_inverse is None and not self._use_split_gemm():
+            return None
+        key = ('split_inverse', str(device))
+        if key not in self._dev:
+            tr = self._transformer
+            bound = None
+            if type(tr) is NeuralSplineTransformer:
+                hst = tr.host()
+                if not (hst['learn_lower'] or hst['learn_upper']) and bool(torch.equal(tr.x0, tr._y0)) and \
+                        bool(torch.equal(tr.xf, tr._yf)):
+                    bound = torch.maximum(tr.x0.abs().max(), tr.xf.abs().max()).to(device=device, dtype=torch.float32)
+            self._dev[key] = bound
+        return self._dev[key]
+
     def _fused_inverse_supported(self, L):
         if not self.fused_inverse or L > 4:
             return False
@@ -563,7 +590,10 @@ class AutoregressiveFlow(torch.nn.Module):
 
         def dev_i32(v):
             return torch.tensor(v + [0], dtype=torch.int32).to(i32['device'])
+        # units of every layer that THIS block computes: packed columns [lo, hi) of the activation panels
+        unit_range = [(max(c0[l], r_hi(l, d0 - 2)), r_hi(l, d1 - 2)) for l in range(L)]
         return dict(wide0=wide0, c0=c0, n_old=n_old, cache_need=cache_need, n_feats=max(len(in_cols), 1), n_steps=len(steps),
+                    unit_range=unit_range,
                     steps=torch.tensor(steps, dtype=torch.int32).reshape(-1, n_ints).to(i32['device']),
                     cols=dev_i32(cols), sel=dev_i32(selv), feat_in=dev_i32(feat_in), feat_per=dev_i32(feat_per),
                     in_cols=dev_i32(in_cols))
@@ -610,8 +640,8 @@ class AutoregressiveFlow(torch.nn.Module):
         with made.frozen_weights():
             packs = [made._pack_layer(mplan, l, lins[l]) for l in range(L)]
             w_out, b_out = made._pack_layer(mplan, L, lins[L], row_of_out=bp['row_inv'], n_rows=bp['n_rows_out'])
-            x = torch.zeros(B, D, **f32)
-            xpad = torch.zeros(B, mplan['k_pad'][0], **f32)          # conditioner input, zero padded
+            x = ops.zeros(B, D, **f32)
+            xpad = ops.zeros(B, mplan['k_pad'][0], **f32)          # conditioner input, zero padded
             if self.has_fixed_indices:
                 fixed = ops.gather_columns(y, tables['fixed'])
                 ops.scatter_columns(fixed, tables['fixed'], x)
@@ -621,10 +651,10 @@ class AutoregressiveFlow(torch.nn.Module):
                 y_tr = ops.gather_columns(y, tables['tr'])
             else:
                 y_tr = y
-            h = [torch.zeros(B, mplan['n_pad'][l], **f32) for l in range(L)]
+            h = [ops.zeros(B, mplan['n_pad'][l], **f32) for l in range(L)]
             z = [None] + [torch.empty(B, mplan['n_pad'][l], **f32) for l in range(1, L)]   # partial pre-activations
             zout = torch.empty(B, bp['n_rows_out'], **f32)
-            ldj = torch.zeros(B, **f32)
+            ldj = ops.zeros(B, **f32)
             fused = bp['fused']
             if fused is not None:
                 # The block GEMMs are short and wide (B x ~100 rows of W over up to 15 000 k): too few output tiles for
@@ -663,6 +693,28 @@ class AutoregressiveFlow(torch.nn.Module):
                 d.spline = ctypes.cast(ctypes.pointer(spl), ctypes.c_void_p) if spl is not None else None
                 d.emb_lower, d.emb_upper = self._input_columns()[2]
                 stream = _lib.stream_of(y)
+                # ---- the output-layer block GEMM on split-f16 operands (see _split_inverse_bound)
+                xmax = self._split_inverse_bound(dev)
+                hs = None
+                if xmax is not None:
+                    ws_out, winv_out, _, _ = made._pack_layer_split(mplan, L, lins[L], row_of_out=bp['row_inv'],
+                                                                     n_rows=bp['n_rows_out'])
+                    # |inputs| <= max(|y|, domain, 1) (1: the cos / sin of a periodic embedding); per layer
+                    # |ELU(x W^T + b)| <= max(1, max|x| max_j sum_k |w_jk| + max|b|)
+                    # (reductions through the library: plain kernels, nothing that becomes a memset node in a HIP
+                    # graph -- torch's multi-block reductions clear their semaphores with hipMemsetAsync; see ops.zeros)
+                    bound = torch.clamp(torch.maximum(ops.abs_reduce(y, 'row_max'), xmax), min=1.0)
+                    for l in range(L):
+                        bound = torch.clamp(bound * ops.abs_reduce(packs[l][0], 'max_row_sum') +
+                                            ops.abs_reduce(packs[l][1].reshape(1, -1), 'row_max'), min=1.0)
+                    hs_inv = ops.pow2_inv_scale(bound)
+                    hs = ops.zeros(B, h[L - 1].shape[1], **f32)              # split copy of h[L - 1], filled per block
+                    tm_s = _lib.load().tfep_masked_linear_tile_m()
+                    tn_s = _lib.load().tfep_masked_linear_tile_n()
+                    pos = max(1, ((B + tm_s - 1) // tm_s) * ((wzout + tn_s - 1) // tn_s))
+                    S_out = int(min(8, max(1, 256 // pos), max(1, mplan['k_pad'][L] // 512)))
+                    zout = torch.empty(S_out, B, ops.round_up(wzout, 4), **f32)
+                    d.ldzout, d.zout_slabs, d.zout_slab_stride = zout.shape[-1], S_out, B * zout.shape[-1]
             for blk in bp['blocks']:
                 # ---- contribution of all earlier degrees to the whole block, once
                 ow = blk['out_wide']
@@ -673,7 +725,19 @@ class AutoregressiveFlow(torch.nn.Module):
                         l = wd['layer']
                         launch(h[l - 1] if l > 0 else xpad, packs[l][0], packs[l][1], wd, z[l], 0, act=0, k_split=S)
                         d.z[l] = z[l].data_ptr() - 4 * wd['row0']       # the kernel indexes by packed row
-                    launch(h[L - 1], w_out, b_out, ow, zout, 0, act=0, wide=ow['n_rows'] > 4 * narrow, k_split=S)
+                    if hs is not None:
+                        gd = _lib.GemmDesc()
+                        gd.split, gd.x_inv_scale, gd.w_inv_scale = 1, hs_inv.data_ptr(), winv_out.data_ptr()
+                        gd.x, gd.ldx = hs.data_ptr(), hs.shape[1]
+                        gd.w, gd.ldw = ws_out.data_ptr() + 4 * ow['row0'] * ws_out.shape[1], ws_out.shape[1]
+                        gd.bias, gd.k_ranges = b_out.data_ptr() + 4 * ow['row0'], krs[ow['kr']].data_ptr()
+                        gd.y, gd.ldy = zout.data_ptr(), zout.shape[-1]
+                        gd.B, gd.N, gd.n_rows_w, gd.k_padded = B, ow['n_rows'], ow['n_rows'], ws_out.shape[1]
+                        if S_out > 1:
+                            gd.k_split, gd.slab_stride = S_out, B * zout.shape[-1]
+                        _lib.call('tfep_masked_linear_gemm', ctypes.byref(gd), stream)
+                    else:
+                        launch(h[L - 1], w_out, b_out, ow, zout, 0, act=0, wide=ow['n_rows'] > 4 * narrow, k_split=S)
                     d.zout = zout.data_ptr() - 4 * ow['row0']
                 else:
                     for wd in blk['wide']:
@@ -687,6 +751,11 @@ class AutoregressiveFlow(torch.nn.Module):
                     for l in range(L):
                         d.cache_col0[l], d.cache_n_old[l] = fb['c0'][l], fb['n_old'][l]
                     _lib.call('tfep_inverse_block', ctypes.byref(d), stream)
+                    if hs is not None:                      # the block's new units of the last hidden layer, as split rows
+                        lo, hi = fb['unit_range'][L - 1]
+                        if hi > lo:
+                            g0 = lo // 8 * 8
+                            ops.split_columns_scaled(h[L - 1], g0, hi - g0, hs, hs_inv)
                     continue
                 # ---- the block's own degrees, one after the other
                 for st in blk['steps']:

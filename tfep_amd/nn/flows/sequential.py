@@ -30,7 +30,7 @@ def _run_chain(layers, method, x):
         x, log_det_J = getattr(layer, method)(x)
         total = log_det_J if total is None else total + log_det_J
     if total is None:                                   # no layers: the identity map
-        total = torch.zeros(x.shape[0], dtype=x.dtype, device=x.device)
+        total = torch.full((x.shape[0],), 0.0, dtype=x.dtype, device=x.device)   # (a kernel, not a memset: ops.zeros)
     return x, total
 
 

@@ -61,7 +61,7 @@ def volume_preserving_shift(x, shift, periodic_mask=None, limits=(0.0, 1.0), inv
     call('tfep_volume_preserving_shift', ptr(x), ldx, ptr(shift), lds,
          ptr(periodic_mask), float(limits[0]), float(limits[1]), -1 if inverse else 1,
          ptr(y), max(D, 1), B, D, stream_of(x))
-    return y, torch.zeros(B, dtype=x.dtype, device=x.device)
+    return y, zeros(B, dtype=x.dtype, device=x.device)
 
 
 # ----------------------------------------------------------------------------- spline
@@ -159,7 +159,7 @@ def pad_columns(x, k_padded):
     B, K = x.shape
     if K == k_padded and x.stride(0) == K and x.data_ptr() % 16 == 0:
         return x
-    out = torch.zeros(B, k_padded, dtype=x.dtype, device=x.device)
+    out = zeros(B, k_padded, dtype=x.dtype, device=x.device)
     out[:, :K] = x
     return out
 
@@ -249,6 +249,15 @@ def split_rows(x, cols_padded, per_tensor=False, out=None, inv_scale=None):
     return out, inv_scale
 
 
+def zeros(*shape, dtype=torch.float32, device=None):
+    """``torch.zeros`` as a fill KERNEL.  ``torch.zeros`` clears with ``hipMemsetAsync``; captured in a HIP graph that becomes
+    a memset node, and memset nodes were seen to leave garbage behind on replay (ROCm 7.0 / MI355X: the padding of a packed
+    weight buffer cleared by ``hipMemsetAsync`` read back as ~1e36 by a later kernel of the same graph while eager runs
+    were clean -- the replayed blocked inverse differed from the eager one from the second block on; earlier, a 4-byte
+    memset was corrupted by a second capture).  Everything on a capturable path clears its buffers with kernels."""
+    return torch.full(tuple(shape), 0.0, dtype=dtype, device=device)
+
+
 def split_columns_scaled(x, col0, cols, out, inv_scale):
     """Columns ``[col0, col0 + cols)`` (whole groups of 8; ``col0 % 8 == 0``) of the fp32 rows ``x`` into the same columns
     of the split rows ``out``, with the caller's per-row ``inv_scale`` (powers of two): for operands filled incrementally
@@ -256,6 +265,17 @@ def split_columns_scaled(x, col0, cols, out, inv_scale):
     x, ldx = rows(x, 'x')
     call('tfep_split_columns_scaled', ptr(x), ldx, x.shape[0], int(col0), int(cols), ptr(out), out.shape[1], ptr(inv_scale),
          stream_of(x))
+    return out
+
+
+def abs_reduce(x, what):
+    """``what='row_max'``: max_k |x[row, k]| per row;  ``'max_row_sum'``: max_row sum_k |x[row, k]| as a 1-element tensor
+    (``tfep_abs_reduce``: plain kernels, capturable in a HIP graph, unlike torch's multi-block reductions whose semaphores are
+    cleared with a small memset)."""
+    x, ldx = rows(x, 'x')
+    mode = {'row_max': 0, 'max_row_sum': 1}[what]
+    out = torch.empty(x.shape[0] if mode == 0 else 1, dtype=torch.float32, device=x.device)
+    call('tfep_abs_reduce', ptr(x), ldx, x.shape[0], x.shape[1], mode, ptr(out), stream_of(x))
     return out
 
 
@@ -296,7 +316,7 @@ def masked_linear_split(x_split, x_inv_scale, w_split, w_inv_scale, bias, n_out,
     d = _lib.GemmDesc()
     if split_out:
         if bias_absmax is None:
-            bias_absmax = bias.abs().max().reshape(1) if bias is not None else torch.zeros(1, device=out.device)
+            bias_absmax = abs_reduce(bias.reshape(1, -1), 'row_max') if bias is not None else zeros(1, device=out.device)
         y_inv = torch.empty(max(B, 1), dtype=torch.float32, device=out.device)
         d.split_out, d.y_inv_scale = 1, y_inv.data_ptr()
         d.w_l1max, d.bias_absmax = w_inv_scale.data_ptr() + 8, bias_absmax.data_ptr()

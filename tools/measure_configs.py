@@ -79,8 +79,12 @@ if 'cfg2inv' in which:
     with torch.no_grad():
         gi = GraphedFlow(flow, B, D, inverse=True, warmup=1)
         dt, (xg, lg) = timeit(lambda: gi(y), 1, 2)
+    dg = (xg - xi).detach().abs()
+    extra = {} if float(dg.max()) == 0 else dict(max_abs_diff=float(dg.max()), rows_differing=int((dg > 0).any(1).sum()),
+                                                  first_cols=torch.nonzero((dg > 0).any(0)).flatten()[:6].tolist(),
+                                                  ldj_equal=bool(torch.equal(lg, li)))
     report('cfg2 ONE layer inverse (blocked), HIP-graph replay', B, dt, equals_eager=bool(torch.equal(xg, xi)),
-           peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
+           peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), **extra)
 
 if 'train' in which:
     from tfep_amd.loss import BoltzmannKLDivLoss
