@@ -194,6 +194,10 @@ def main():
                          'peak_basis': ('fp32-equivalent flops; dense fp16 MFMA peak 2516.6 TFLOP/s / 3 MFMAs per product'
                                         if split else 'dense fp32 MFMA peak'),
                          'vs_fp32_mfma_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
+                         # what the matrix pipes sustain on this board with nothing else in flight (pure-register
+                         # 16x16x32 f16 MFMA loop on toggling operands: 1914 TFLOP/s at the power limit, / 3)
+                         'vs_power_limited_mfma_ceiling': (achieved / (1914.0 / 3.0)) if split else None,
+                         'power_limited_ceiling_source': 'profiles/r01_mfma_shape_probe.txt' if split else None,
                          'flops_per_launch': kern_flops[0], 'avg_launch_ms': float(np.mean(kern_ms)),
                          'whole_step_tflops': 2.0 * sum(nnz_all) * B * args.steps / elapsed / 1e12},
             'delta_f_estimate': float(out[2]),
