@@ -598,6 +598,32 @@ class AutoregressiveFlow(torch.nn.Module):
                     cols=dev_i32(cols), sel=dev_i32(selv), feat_in=dev_i32(feat_in), feat_per=dev_i32(feat_per),
                     in_cols=dev_i32(in_cols))
 
+    def _split_inverse_state(self, y, bp, mplan, lins, packs, h_last, n_out_max):
+        """Operands of the split-f16 output-layer block GEMM, or None when the layer does not qualify:
+        ``(hs, hs_inv, w_split, w_inv, k_split)`` -- the (zeroed) split copy of the last hidden panel ``h_last`` with its
+        bound-based per-row inverse scales, the split output weights in the inverse's row order, the number of slabs."""
+        dev = y.device
+        xmax = self._split_inverse_bound(dev)
+        if xmax is None:
+            return None
+        made = self._conditioner
+        L = bp['L']
+        w_split, w_inv, _, _ = made._pack_layer_split(mplan, L, lins[L], row_of_out=bp['row_inv'], n_rows=bp['n_rows_out'])
+        # |inputs| <= max(|y|, domain, 1) (1: the cos / sin of a periodic embedding); per layer
+        # |ELU(x W^T + b)| <= max(1, max|x| max_j sum_k |w_jk| + max|b|).  Reductions through the library: plain kernels,
+        # nothing that becomes a memset node in a HIP graph (torch's multi-block reductions clear their semaphores with
+        # hipMemsetAsync; see ops.zeros)
+        bound = torch.clamp(torch.maximum(ops.abs_reduce(y, 'row_max'), xmax), min=1.0)
+        for l in range(L):
+            bound = torch.clamp(bound * ops.abs_reduce(packs[l][0], 'max_row_sum') +
+                                ops.abs_reduce(packs[l][1].reshape(1, -1), 'row_max'), min=1.0)
+        hs = ops.zeros(*h_last.shape, dtype=torch.float32, device=dev)          # filled block by block
+        lib = _lib.load()
+        tm, tn = lib.tfep_masked_linear_tile_m(), lib.tfep_masked_linear_tile_n()
+        positions = max(1, ((y.shape[0] + tm - 1) // tm) * ((n_out_max + tn - 1) // tn))
+        k_split = int(min(8, max(1, 256 // positions), max(1, mplan['k_pad'][L] // 512)))
+        return hs, ops.pow2_inv_scale(bound), w_split, w_inv, k_split
+
     def _inverse_blocked(self, y):
         from ._backward import _gemm
         y, _ = _lib.rows(y, 'y')
@@ -613,11 +639,15 @@ class AutoregressiveFlow(torch.nn.Module):
         f32 = dict(dtype=torch.float32, device=dev)
         kr_all = bp['k_ranges']
 
-        def launch(x_in, w, bias, desc, out, out_col0, act, pre=None, pre_col0=0, wide=False, k_split=1):
+        def launch(x_in, w, bias, desc, out, out_col0, act, pre=None, pre_col0=0, wide=False, k_split=1, split=None):
             """out[:, out_col0 : +n] = act(x_in W[row0 : row0+n]^T + bias[row0:] (+ pre[:, pre_col0 : +n]));
-            ``k_split`` > 1: ``out`` is (k_split, B, cols) and receives the partial sums of the k slices."""
+            ``k_split`` > 1: ``out`` is (k_split, B, cols) and receives the partial sums of the k slices;
+            ``split = (x_inv_scale, w_inv_scale)``: ``x_in`` and ``w`` are split-f16 rows (wide tile only)."""
             n, row0 = desc['n_rows'], desc['row0']
             d = _lib.GemmDesc()
+            if split is not None:
+                d.split, d.x_inv_scale, d.w_inv_scale = 1, split[0].data_ptr(), split[1].data_ptr()
+                wide = True
             d.x, d.ldx = x_in.data_ptr(), x_in.shape[1]
             d.w, d.ldw = w.data_ptr() + 4 * row0 * w.shape[1], w.shape[1]
             d.bias = (bias.data_ptr() + 4 * row0) if bias is not None else None
@@ -694,25 +724,10 @@ class AutoregressiveFlow(torch.nn.Module):
                 d.emb_lower, d.emb_upper = self._input_columns()[2]
                 stream = _lib.stream_of(y)
                 # ---- the output-layer block GEMM on split-f16 operands (see _split_inverse_bound)
-                xmax = self._split_inverse_bound(dev)
                 hs = None
-                if xmax is not None:
-                    ws_out, winv_out, _, _ = made._pack_layer_split(mplan, L, lins[L], row_of_out=bp['row_inv'],
-                                                                     n_rows=bp['n_rows_out'])
-                    # |inputs| <= max(|y|, domain, 1) (1: the cos / sin of a periodic embedding); per layer
-                    # |ELU(x W^T + b)| <= max(1, max|x| max_j sum_k |w_jk| + max|b|)
-                    # (reductions through the library: plain kernels, nothing that becomes a memset node in a HIP
-                    # graph -- torch's multi-block reductions clear their semaphores with hipMemsetAsync; see ops.zeros)
-                    bound = torch.clamp(torch.maximum(ops.abs_reduce(y, 'row_max'), xmax), min=1.0)
-                    for l in range(L):
-                        bound = torch.clamp(bound * ops.abs_reduce(packs[l][0], 'max_row_sum') +
-                                            ops.abs_reduce(packs[l][1].reshape(1, -1), 'row_max'), min=1.0)
-                    hs_inv = ops.pow2_inv_scale(bound)
-                    hs = ops.zeros(B, h[L - 1].shape[1], **f32)              # split copy of h[L - 1], filled per block
-                    tm_s = _lib.load().tfep_masked_linear_tile_m()
-                    tn_s = _lib.load().tfep_masked_linear_tile_n()
-                    pos = max(1, ((B + tm_s - 1) // tm_s) * ((wzout + tn_s - 1) // tn_s))
-                    S_out = int(min(8, max(1, 256 // pos), max(1, mplan['k_pad'][L] // 512)))
+                sp = self._split_inverse_state(y, bp, mplan, lins, packs, h[L - 1], wzout)
+                if sp is not None:
+                    hs, hs_inv, ws_out, winv_out, S_out = sp
                     zout = torch.empty(S_out, B, ops.round_up(wzout, 4), **f32)
                     d.ldzout, d.zout_slabs, d.zout_slab_stride = zout.shape[-1], S_out, B * zout.shape[-1]
             for blk in bp['blocks']:
@@ -726,16 +741,7 @@ class AutoregressiveFlow(torch.nn.Module):
                         launch(h[l - 1] if l > 0 else xpad, packs[l][0], packs[l][1], wd, z[l], 0, act=0, k_split=S)
                         d.z[l] = z[l].data_ptr() - 4 * wd['row0']       # the kernel indexes by packed row
                     if hs is not None:
-                        gd = _lib.GemmDesc()
-                        gd.split, gd.x_inv_scale, gd.w_inv_scale = 1, hs_inv.data_ptr(), winv_out.data_ptr()
-                        gd.x, gd.ldx = hs.data_ptr(), hs.shape[1]
-                        gd.w, gd.ldw = ws_out.data_ptr() + 4 * ow['row0'] * ws_out.shape[1], ws_out.shape[1]
-                        gd.bias, gd.k_ranges = b_out.data_ptr() + 4 * ow['row0'], krs[ow['kr']].data_ptr()
-                        gd.y, gd.ldy = zout.data_ptr(), zout.shape[-1]
-                        gd.B, gd.N, gd.n_rows_w, gd.k_padded = B, ow['n_rows'], ow['n_rows'], ws_out.shape[1]
-                        if S_out > 1:
-                            gd.k_split, gd.slab_stride = S_out, B * zout.shape[-1]
-                        _lib.call('tfep_masked_linear_gemm', ctypes.byref(gd), stream)
+                        launch(hs, ws_out, b_out, ow, zout, 0, act=0, k_split=S_out, split=(hs_inv, winv_out))
                     else:
                         launch(h[L - 1], w_out, b_out, ow, zout, 0, act=0, wide=ow['n_rows'] > 4 * narrow, k_split=S)
                     d.zout = zout.data_ptr() - 4 * ow['row0']
