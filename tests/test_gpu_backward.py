@@ -226,3 +226,48 @@ def test_partial_flow_semantics_and_gradients():
     with torch.no_grad():
         x6 = torch.randn(5, len(prop), device='cuda')
         assert torch.equal(pf0(x6)[0], inner(x6)[0])
+
+
+@pytest.mark.parametrize('split', [False, True])
+@pytest.mark.parametrize('embedding', [False, True])
+def test_backward_in_several_batch_chunks_equals_one_chunk(monkeypatch, split, embedding):
+    """The backward processes the batch in chunks sized by ``_CHUNK_BYTES`` (one chunk for everything the other tests
+    run): force 4 ragged chunks and compare every gradient with the one-chunk result; gradients accumulate over chunks in
+    a fixed order, so two runs agree bit for bit."""
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.embeddings import PeriodicEmbedding
+    from tfep_amd.nn.flows import MAF, _backward as bw
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    from tfep_amd import ops
+    torch.manual_seed(11)
+    D, B = 70, 900
+    emb = PeriodicEmbedding(D, limits=[0.0, 2.0], periodic_indices=list(range(0, D, 3))) if embedding else None
+    lo, hi = (0.0, 2.0) if embedding else (-4.0, 4.0)
+    maf = MAF(generate_degrees(D, 'ascending'), transformer=NeuralSplineTransformer(torch.full((D,), lo), torch.full((D,), hi), 8,
+                                                                                   circular=embedding),
+              embedding=emb, hidden_layers=[150, 130], initialize_identity=False).cuda()
+    maf.split_gemm = split
+    x0 = (torch.rand(B, D) * 2.0 if embedding else torch.randn(B, D) * 1.2).cuda()
+    c = torch.linspace(0.1, 0.4, D, device='cuda')
+
+    def grads():
+        for p in maf.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        y, l = maf(x)
+        BoltzmannKLDivLoss()((c * y ** 2).sum(dim=1), l).backward()
+        return [x.grad.clone()] + [p.grad.clone() for p in maf.parameters()]
+
+    one = grads()
+    tm = ops.tile_sizes()[0]
+    n_out_pad = ops.round_up(25 * D, ops.tile_sizes()[2])
+    monkeypatch.setattr(bw, '_CHUNK_BYTES', 4 * n_out_pad * tm)          # chunk = one row tile: ceil(900 / tm) chunks
+    assert B > 3 * tm
+    many = grads()
+    again = grads()
+    names = ['x'] + [n for n, _ in maf.named_parameters()]
+    for n, a, b, b2 in zip(names, one, many, again):
+        scale = float(a.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, n
+        assert torch.equal(b, b2), n

@@ -18,6 +18,8 @@ PyTorch's role is the autograd graph between layers, the loss and the optimiser.
 """
 import ctypes
 
+import os
+
 import torch
 
 from ... import _lib, ops
@@ -28,8 +30,10 @@ from ..transformers.mixed import MixedTransformer
 from ..transformers.moebius import MoebiusTransformer
 from ..transformers.spline import NeuralSplineTransformer
 
-# ~2 GiB of transformer parameters per chunk
-_CHUNK_BYTES = 1 << 31
+# bytes of transformer parameters per batch chunk of the backward (TFEP_BACKWARD_CHUNK_GIB, default 8:
+# sized for 288 GB of HBM -- fewer, larger chunks mean fewer read-modify-write passes over the gradient of the 4.5 GB
+# output-layer weight and longer k in the grad_weight GEMMs; 2 -> 8 GiB: 348 -> 315 ms per cfg2 layer at B=16384)
+_CHUNK_BYTES = int(float(os.environ.get('TFEP_BACKWARD_CHUNK_GIB', 8)) * (1 << 30))
 
 
 def supported(layer):
