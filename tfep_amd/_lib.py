@@ -7,7 +7,7 @@ which is what makes ``tensor.data_ptr()`` and the current stream valid on our si
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_void_p
 
 import torch
 

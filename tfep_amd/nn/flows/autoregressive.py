@@ -625,7 +625,6 @@ class AutoregressiveFlow(torch.nn.Module):
         return hs, ops.pow2_inv_scale(bound), w_split, w_inv, k_split
 
     def _inverse_blocked(self, y):
-        from ._backward import _gemm
         y, _ = _lib.rows(y, 'y')
         B, D = y.shape
         dev = y.device
