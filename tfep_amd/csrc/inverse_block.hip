@@ -74,7 +74,9 @@ __host__ __device__ inline int ib_round4(int n) { return (n + 3) & ~3; }
 // staging cost ~2 v_mov per packed FMA to pair the operands).  Columns per group: the longest dot of the launch.
 __host__ __device__ inline int ib_round8(int n) { return (n + 7) & ~7; }
 __host__ __device__ inline int ib_stage_cols(int cache_len, int max_feats) {
-    return ib_round8(cache_len > max_feats ? cache_len : max_feats);
+    // + 1: the four 8-row groups then start 8 banks apart (a multiple of 8 columns would put them all on bank 0; the
+    // matrix-core path of the spline parameters reads one element of all 32 rows per instruction)
+    return ib_round8(cache_len > max_feats ? cache_len : max_feats) + 1;
 }
 constexpr int IB_LDS_SLACK = 12 * 64;    // floats after the weight stage: the one-slice-ahead reads of dot_staged stay in bounds
 constexpr int IB_Z_PITCH = 72;           // floats per value of the pre-activation stage [IB_STAGE_ROWS values][64 sample rows + 8]
@@ -245,6 +247,61 @@ __device__ __forceinline__ void dot_staged(float (&acc)[8], const float* __restr
     }
 }
 
+typedef float ib_f16v __attribute__((ext_vector_type(16)));
+
+// The P <= 32 parameters of one feature for the wave's 64 sample rows on the matrix cores:
+//   D^T[parameter m][sample n] = z[m][n] + sum_k W[m][k] act[k][n]   as two 32 x 32 tiles (samples 0..31 / 32..63) of
+// v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate): A = the staged weights (lane l: row l % 32, column
+// k + l / 32), B = the activations from the [unit][64 samples] cache, C = the staged pre-activations.  A lane ends up
+// with D[8 (r / 4) + 4 (l / 32) + r % 4][l % 32] in register r of each tile: half the parameters of sample l % 32 and of
+// sample 32 + l % 32.  v_permlane32_swap exchanges the halves, after which lane l holds all 32 parameters of ITS sample.
+// 2 MFMAs per 2 columns instead of 32 packed FMAs + 20 LDS reads per 8: the out dot was 25 % of the kernel.
+__device__ __forceinline__ void out_dot_mfma(float (&prm)[IB_MAX_P], const float* __restrict__ stg, int gstride,
+                                             const float* __restrict__ zso, const float* __restrict__ act, int len, int P,
+                                             int lane) {
+    const int half = lane >> 5, col = lane & 31;
+    ib_f16v d0, d1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = (r >> 2) * 8 + half * 4 + (r & 3);
+        const bool on = m < P;                                 // rows past P: never staged (stale LDS), keep them zero
+        d0[r] = on ? zso[m * IB_Z_PITCH + col] : 0.f;
+        d1[r] = on ? zso[m * IB_Z_PITCH + 32 + col] : 0.f;
+    }
+    const float* wp = stg + (col >> 3) * gstride + half * 8 + (col & 7);       // element (row col, column k + half)
+    const float* ap = act + half * 64 + col;
+    const bool row_on = col < P;
+    // len is a multiple of 8: four column pairs per iteration, their 12 LDS reads issued before the first MFMA; the reads
+    // of the next iteration are issued before this iteration's MFMAs so that they land behind them
+    float w[4], b0[4], b1[4];
+    auto load = [&](int k) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            w[q] = row_on ? wp[(k + 2 * q) * 8] : 0.f;
+            b0[q] = ap[(k + 2 * q) * 64];
+            b1[q] = ap[(k + 2 * q) * 64 + 32];
+        }
+    };
+    load(0);
+    for (int k = 0; k < len; k += 8) {
+        float wc[4], b0c[4], b1c[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { wc[q] = w[q]; b0c[q] = b0[q]; b1c[q] = b1[q]; }
+        load(k + 8);                                    // (one slice past the end on the last pass: inside the LDS slack)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            d0 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[q], b0c[q], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[q], b1c[q], d1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0[r]), __float_as_uint(d1[r]), false, false);
+        prm[(r >> 2) * 8 + (r & 3)] = __uint_as_float(sw[0]);
+        prm[(r >> 2) * 8 + 4 + (r & 3)] = __uint_as_float(sw[1]);
+    }
+}
+
 // Step record: per layer l  [row0, n, kb, ke]: units [row0, row0 + n) of layer l are computed from the inputs
 //   l == 0: the first `ke` conditioner-input entries of the block (in_cols order);  l >= 1: packed columns [kb, ke) of layer l - 1
 // then [out_row0, n_d, out_kb, out_ke, feat_off, 0].
@@ -353,20 +410,24 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
             float prm[MAXP];
             stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, n_d, a.P, okb, oke, lane);   // the feature's P rows at once
             stage_z(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, n_d, a.P, a.zout_slabs, a.zout_slab_stride, lane);
+            if constexpr (KIND == 1) {
+                out_dot_mfma(prm, stg, gstride, zs, cp, olen, a.P, lane);
+            } else {
 #pragma unroll
-            for (int p0 = 0; p0 < MAXP; p0 += 8) {
-                float acc[8];
+                for (int p0 = 0; p0 < MAXP; p0 += 8) {
+                    float acc[8];
 #pragma unroll
-                for (int g = 0; g < 8; ++g) acc[g] = 0.f;
-                if (p0 < a.P) {                                         // wave-uniform
-                    const int np = min(8, a.P - p0);
+                    for (int g = 0; g < 8; ++g) acc[g] = 0.f;
+                    if (p0 < a.P) {                                         // wave-uniform
+                        const int np = min(8, a.P - p0);
 #pragma unroll
-                    for (int g = 0; g < 8; ++g)
-                        if (g < np) acc[g] = zs[(p0 + g) * IB_Z_PITCH + lane];
-                    dot_staged(acc, stg + (p0 >> 3) * gstride, cp, olen, lane);
+                        for (int g = 0; g < 8; ++g)
+                            if (g < np) acc[g] = zs[(p0 + g) * IB_Z_PITCH + lane];
+                        dot_staged(acc, stg + (p0 >> 3) * gstride, cp, olen, lane);
+                    }
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) prm[p0 + g] = acc[g];
                 }
-#pragma unroll
-                for (int g = 0; g < 8; ++g) prm[p0 + g] = acc[g];
             }
             const int sel = a.feat_sel[foff + f];
             const float yv = a.y[r * a.ldy + sel];
