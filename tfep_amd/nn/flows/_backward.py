@@ -142,6 +142,60 @@ class MAFLayerFunction(torch.autograd.Function):
         return (None, gx, *gparams)
 
 
+class TransformerFunction(torch.autograd.Function):
+    """``y, log_det_J = transformer(x, theta)`` on the HIP kernels as one graph node; the backward is the transformer
+    VJP kernel (``transformer_vjp``).  Used by ``generic_forward``: everything AROUND the transformer -- a user-supplied
+    conditioner, an embedding that is not a ``MAFEmbedding``, a conditioner fed from a subset of the features -- is
+    then differentiated by ordinary autograd, as the reference does for the whole layer."""
+
+    @staticmethod
+    def forward(ctx, tr, x, theta):
+        x, theta = x.detach().contiguous(), theta.detach().contiguous()
+        with torch.no_grad():
+            y, ldj = tr(x, theta)
+        ctx.tr = tr
+        ctx.save_for_backward(x, theta)
+        return y, ldj
+
+    @staticmethod
+    def backward(ctx, gy, gldj):
+        x, theta = ctx.saved_tensors
+        B, D = x.shape
+        f32 = dict(dtype=torch.float32, device=x.device)
+        gy = ops.zeros(B, D, **f32) if gy is None else gy.contiguous()
+        gl = ops.zeros(B, **f32) if gldj is None else gldj.contiguous()
+        gtheta = ops.zeros(*theta.shape, **f32)
+        gx = torch.empty(B, D, **f32)
+        with torch.no_grad():
+            transformer_vjp(ctx.tr, x, theta, 0, theta.shape[1], gy, gl, gtheta, gx, _lib.stream_of(x))
+        return None, gx, gtheta
+
+
+def generic_supported(layer):
+    """Layers whose backward is not the fused HIP one but whose transformer has a VJP kernel."""
+    return _transformer_supported(layer._transformer)
+
+
+def generic_forward(layer, x):
+    """Differentiable forward of a layer that ``supported`` rejects: the conditioner runs under autograd (a MADE through
+    its ``MaskedLinear`` modules, reference masked.py:279-302 semantics; anything else as the torch module it is), the
+    transformer through ``TransformerFunction``, the index plumbing through the differentiable gather / replace of
+    ``flows/partial.py``.  Slower than the fused path (the (B, P D) parameters are materialised and kept for the
+    backward) -- the point is that training works for every configuration the reference can train."""
+    from .partial import _GatherColumns, _ReplaceColumns
+    t = layer._tables(x.device)
+    cond_in = _GatherColumns.apply(x, t['cond']) if len(layer._conditioner_indices) > 0 else x
+    made = layer._conditioner
+    if isinstance(made, MADE):
+        theta = made.layers(made._embed(cond_in))
+    else:
+        theta = made(cond_in)
+    if layer.has_fixed_indices:
+        y_tr, ldj = TransformerFunction.apply(layer._transformer, _GatherColumns.apply(x, t['tr']), theta)
+        return _ReplaceColumns.apply(x, y_tr, t['tr']), ldj
+    return TransformerFunction.apply(layer._transformer, x, theta)
+
+
 class UnsupportedBackward(torch.autograd.Function):
     """Forward works for every configuration; differentiating an unsupported one fails loudly."""
 
@@ -153,9 +207,8 @@ class UnsupportedBackward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gldj):
         raise NotImplementedError(
-            'tfep_amd: backward is implemented for MAF layers with a MADE conditioner (optionally with a '
-            'MAFEmbedding) and affine / fixed-bound neural-spline / Moebius / volume-preserving / mixed '
-            'transformers.')
+            'tfep_amd: backward needs a transformer with a VJP kernel: affine / neural-spline / Moebius / '
+            'volume-preserving / mixed transformers.')
 
 
 def _gemm(x, w, y, B, N, n_rows_w, bias=None, k_ranges=None, act=0, accumulate=0, elu_grad_of=None, tile_live=None,
@@ -251,9 +304,8 @@ def layer_backward(layer, x, gy, gldj):
     """Returns (gx, [grads in trainable_tensors() order])."""
     if not supported(layer):
         raise NotImplementedError(
-            'tfep_amd: backward is implemented for MAF layers with a MADE conditioner (optionally with a '
-            'MAFEmbedding) and affine / fixed-bound neural-spline / Moebius / volume-preserving / mixed '
-            'transformers.')
+            'tfep_amd: backward needs a transformer with a VJP kernel: affine / neural-spline / Moebius / '
+            'volume-preserving / mixed transformers.')
     x, _ = _lib.rows(x, 'x')
     gy = gy.contiguous().float()
     gldj = gldj.contiguous().float() if gldj is not None else None

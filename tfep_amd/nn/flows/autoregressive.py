@@ -251,6 +251,8 @@ class AutoregressiveFlow(torch.nn.Module):
             if x.requires_grad or any(p.requires_grad for p in params):
                 if _backward.supported(self):
                     return _backward.MAFLayerFunction.apply(self, x, *params)
+                if _backward.generic_supported(self):
+                    return _backward.generic_forward(self, x)          # conditioner by autograd, transformer VJP kernel
                 return _backward.UnsupportedBackward.apply(self, x, *params)
         return self._forward_impl(x)
 
