@@ -515,12 +515,15 @@ class AutoregressiveFlow(torch.nn.Module):
     split_inverse = None
 
     def _split_inverse_bound(self, device):
-        """max |x| the inverse can produce, as a device scalar, or None when it is not known in advance.
+        """What is needed to bound |x| of the inverse before it is computed -- ``dict(dom, x0, xf, tail_slope)`` on the
+        device -- or None when no bound is known in advance.
 
         The last hidden panel of the blocked inverse is filled block by block, so the row scale of its split-f16 copy
         must be fixed before the values exist: |h| is bounded layer by layer from a bound on the conditioner inputs.
-        A spline with fixed bounds and the same domain and codomain maps y inside the domain to x inside it and is the
-        identity outside, so |x| <= max(|y|, |x0|, |xf|); affine / Moebius outputs have no such bound (fp32 GEMMs)."""
+        A spline with fixed bounds and the same domain and codomain maps y inside [x0, xf] to x inside it; outside, the
+        map is linear with the boundary slope >= min_slope (spline.py:599-607: sentinel bins that continue the boundary
+        slopes; slope 1 with identity boundary slopes), so |x| <= max(|x0|, |xf|) + (distance of y from the domain) /
+        tail_slope.  Affine / Moebius outputs have no such bound (fp32 GEMMs)."""
         if self.split_inverse is False or not self.fused_inverse:
             return None
         if self.split_inverse is None and not self._use_split_gemm():
@@ -528,13 +531,16 @@ class AutoregressiveFlow(torch.nn.Module):
         key = ('split_inverse', str(device))
         if key not in self._dev:
             tr = self._transformer
-            bound = None
+            info = None
             if type(tr) is NeuralSplineTransformer:
                 hst = tr.host()
-                if not (hst['learn_lower'] or hst['learn_upper']) and bool(torch.equal(tr.x0, tr._y0)) and \
-                        bool(torch.equal(tr.xf, tr._yf)):
-                    bound = torch.maximum(tr.x0.abs().max(), tr.xf.abs().max()).to(device=device, dtype=torch.float32)
-            self._dev[key] = bound
+                tail = 1.0 if (hst['identity'] or hst['circular']) else hst['min_slope']
+                if not (hst['learn_lower'] or hst['learn_upper']) and tail > 1e-8 and \
+                        bool(torch.equal(tr.x0, tr._y0)) and bool(torch.equal(tr.xf, tr._yf)):
+                    f32 = dict(device=device, dtype=torch.float32)
+                    info = dict(dom=torch.maximum(tr.x0.abs().max(), tr.xf.abs().max()).to(**f32),
+                                x0=tr.x0.to(**f32).contiguous(), xf=tr.xf.to(**f32).contiguous(), tail_slope=float(tail))
+            self._dev[key] = info
         return self._dev[key]
 
     def _fused_inverse_supported(self, L):
@@ -600,22 +606,26 @@ class AutoregressiveFlow(torch.nn.Module):
                     cols=dev_i32(cols), sel=dev_i32(selv), feat_in=dev_i32(feat_in), feat_per=dev_i32(feat_per),
                     in_cols=dev_i32(in_cols))
 
-    def _split_inverse_state(self, y, bp, mplan, lins, packs, h_last, n_out_max):
+    def _split_inverse_state(self, y, bp, mplan, lins, packs, h_last, n_out_max, y_tr=None):
         """Operands of the split-f16 output-layer block GEMM, or None when the layer does not qualify:
         ``(hs, hs_inv, w_split, w_inv, k_split)`` -- the (zeroed) split copy of the last hidden panel ``h_last`` with its
         bound-based per-row inverse scales, the split output weights in the inverse's row order, the number of slabs."""
         dev = y.device
-        xmax = self._split_inverse_bound(dev)
-        if xmax is None:
+        info = self._split_inverse_bound(dev)
+        if info is None:
             return None
         made = self._conditioner
         L = bp['L']
         w_split, w_inv, _, _ = made._pack_layer_split(mplan, L, lins[L], row_of_out=bp['row_inv'], n_rows=bp['n_rows_out'])
-        # |inputs| <= max(|y|, domain, 1) (1: the cos / sin of a periodic embedding); per layer
+        # |inputs| <= max(x bound, |fixed / conditioning features of y|, 1) (1: the cos / sin of a periodic embedding); per layer
         # |ELU(x W^T + b)| <= max(1, max|x| max_j sum_k |w_jk| + max|b|).  Reductions through the library: plain kernels,
         # nothing that becomes a memset node in a HIP graph (torch's multi-block reductions clear their semaphores with
         # hipMemsetAsync; see ops.zeros)
-        bound = torch.clamp(torch.maximum(ops.abs_reduce(y, 'row_max'), xmax), min=1.0)
+        y_tr = y if y_tr is None else y_tr
+        outside = torch.clamp(torch.maximum(y_tr - info['xf'], info['x0'] - y_tr), min=0.0)     # distance from the domain
+        x_bound = torch.maximum(ops.abs_reduce(y, 'row_max'), info['dom']) + \
+            ops.abs_reduce(outside, 'row_max') * (1.0 / info['tail_slope'])
+        bound = torch.clamp(x_bound, min=1.0)
         for l in range(L):
             bound = torch.clamp(bound * ops.abs_reduce(packs[l][0], 'max_row_sum') +
                                 ops.abs_reduce(packs[l][1].reshape(1, -1), 'row_max'), min=1.0)
@@ -726,7 +736,7 @@ class AutoregressiveFlow(torch.nn.Module):
                 stream = _lib.stream_of(y)
                 # ---- the output-layer block GEMM on split-f16 operands (see _split_inverse_bound)
                 hs = None
-                sp = self._split_inverse_state(y, bp, mplan, lins, packs, h[L - 1], wzout)
+                sp = self._split_inverse_state(y, bp, mplan, lins, packs, h[L - 1], wzout, y_tr=y_tr)
                 if sp is not None:
                     hs, hs_inv, ws_out, winv_out, S_out = sp
                     zout = torch.empty(S_out, B, ops.round_up(wzout, 4), **f32)
