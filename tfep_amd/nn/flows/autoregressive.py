@@ -703,6 +703,7 @@ class AutoregressiveFlow(torch.nn.Module):
                 tm = ops.tile_sizes()[0]
                 m_tiles = (B + tm - 1) // tm
                 S = int(min(8, max(1, 256 // max(1, 2 * m_tiles)), max(1, max(mplan['k_pad']) // 512)))   # >= 512 k per slice
+                S = int(os.environ.get('TFEP_INV_SLABS', S))
                 # slabs hold only the block's own rows: column c of a slab is packed row (first row of the block + c)
                 wz = [1] * L
                 wzout = 1
