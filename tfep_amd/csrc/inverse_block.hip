@@ -13,7 +13,9 @@
 //     global_load_dwordx4 per lane = 8 weight rows x 32 columns per instruction, up to 16 instructions in flight) into
 //     an LDS stage and reads them back as same-address (broadcast) ds_read_b128.  Wave-uniform loads straight from
 //     HBM/L2 cost one ~600-cycle round trip per 4 columns on this latency-bound chain; the stage pays one per dot;
-//   fp32 FMA -- the arithmetic is ~20 kFLOP per row per block, nothing for the matrix cores to do;
+//   the pre-activations (wide-GEMM slabs) are fetched cooperatively too (8 rows x 8 values per instruction) and
+//     transposed through LDS;
+//   hidden units: packed fp32 FMA; the 25 spline parameters of a feature: two 32 x 32 fp32 MFMA tiles (out_dot_mfma);
 //   the transformer inverse is spline.h's rq_spline_element / moebius.h's moebius_vector (same code as the stand-alone
 //     kernels) or the affine map.
 #include "common.h"
@@ -58,13 +60,6 @@ struct InverseBlockArgs {
 };
 
 __device__ inline float elu_ib(float v) { return v > 0.f ? v : expm1f(v); }
-
-// sum of the split-K slabs of one pre-activation (fixed order: deterministic)
-__device__ __forceinline__ float slab_sum(const float* p, int slabs, int64_t stride) {
-    float v = p[0];
-    for (int s = 1; s < slabs; ++s) v += p[s * stride];
-    return v;
-}
 
 constexpr int IB_STAGE_ROWS = 32;      // weight rows staged at once (>= the 25 spline parameters of a feature)
 
