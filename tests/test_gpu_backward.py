@@ -157,6 +157,52 @@ def test_generic_autograd_path_matches_the_fused_backward(name):
         assert float((u - v).abs().max()) <= 2e-4 * scale + 1e-6
 
 
+def test_user_supplied_torch_transformer_and_conditioner_train_by_autograd():
+    """any user-supplied transformer / conditioner must still work.  Both written in torch: the layer runs the
+    unfused path and autograd differentiates everything; against the same model in float64."""
+    from tfep_amd.nn.conditioners.conditioner import Conditioner
+    from tfep_amd.nn.flows import AutoregressiveFlow
+    from tfep_amd.nn.transformers.transformer import Transformer
+
+    class Lin(Conditioner):
+        def __init__(self, d):
+            super().__init__()
+            self.lin = torch.nn.Linear(d, d)
+
+        def forward(self, x):
+            return self.lin(x)
+
+        def set_output(self, output):
+            self.lin.bias.data = output
+
+    class Shift(Transformer):                       # y = x + tanh(theta), volume preserving
+        def forward(self, x, parameters):
+            return x + torch.tanh(parameters), torch.zeros(x.shape[0], device=x.device)
+
+        def inverse(self, y, parameters):
+            return y - torch.tanh(parameters), torch.zeros(y.shape[0], device=y.device)
+
+        def get_identity_parameters(self, n_features):
+            return torch.zeros(n_features)
+
+        def get_degrees_out(self, degrees_in):
+            return degrees_in
+
+    torch.manual_seed(4)
+    D, B = 5, 21
+    flow = AutoregressiveFlow(D, [[i] for i in range(D)], Lin(D), Shift(), initialize_identity=False).cuda()
+    x = torch.randn(B, D, device='cuda', requires_grad=True)
+    y, ldj = flow(x)
+    (y ** 3).sum().backward()
+    ref = torch.nn.Linear(D, D).double().cuda()
+    ref.load_state_dict({k: v.double() for k, v in flow._conditioner.lin.state_dict().items()})
+    xr = x.detach().double().requires_grad_(True)
+    ((xr + torch.tanh(ref(xr))) ** 3).sum().backward()
+    assert rel(x.grad.cpu(), xr.grad.cpu()) < 1e-5
+    for p, q in zip(flow._conditioner.lin.parameters(), ref.parameters()):
+        assert rel(p.grad.cpu(), q.grad.cpu()) < 1e-5
+
+
 def test_unsupported_backward_fails_loudly():
     """A transformer without a VJP kernel: the forward works, .backward() raises."""
     from tfep_amd.nn.conditioners.conditioner import Conditioner

@@ -171,9 +171,16 @@ class TransformerFunction(torch.autograd.Function):
         return None, gx, gtheta
 
 
+_HIP_TRANSFORMERS = (AffineTransformer, MoebiusTransformer, VolumePreservingShiftTransformer, NeuralSplineTransformer,
+                     MixedTransformer)
+
+
 def generic_supported(layer):
-    """Layers whose backward is not the fused HIP one but whose transformer has a VJP kernel."""
-    return _transformer_supported(layer._transformer)
+    """Layers whose backward is not the fused HIP one but can still be differentiated: the transformer has a VJP kernel,
+    or it is a user-supplied torch module that autograd differentiates by itself.  (A SUBCLASS of one of this package's
+    transformers may have changed the map but still runs the HIP forward, which autograd cannot see: not supported.)"""
+    tr = layer._transformer
+    return _transformer_supported(tr) or not isinstance(tr, _HIP_TRANSFORMERS)
 
 
 def generic_forward(layer, x):
@@ -190,10 +197,17 @@ def generic_forward(layer, x):
         theta = made.layers(made._embed(cond_in))
     else:
         theta = made(cond_in)
+    tr = layer._transformer
+    if _transformer_supported(tr):
+        def apply(x_tr):
+            return TransformerFunction.apply(tr, x_tr, theta)
+    else:                                                    # a user's torch transformer: plain autograd
+        def apply(x_tr):
+            return tr(x_tr, theta)
     if layer.has_fixed_indices:
-        y_tr, ldj = TransformerFunction.apply(layer._transformer, _GatherColumns.apply(x, t['tr']), theta)
+        y_tr, ldj = apply(_GatherColumns.apply(x, t['tr']))
         return _ReplaceColumns.apply(x, y_tr, t['tr']), ldj
-    return TransformerFunction.apply(layer._transformer, x, theta)
+    return apply(x)
 
 
 class UnsupportedBackward(torch.autograd.Function):
@@ -207,8 +221,9 @@ class UnsupportedBackward(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, gldj):
         raise NotImplementedError(
-            'tfep_amd: backward needs a transformer with a VJP kernel: affine / neural-spline / Moebius / '
-            'volume-preserving / mixed transformers.')
+            'tfep_amd: backward needs a transformer with a VJP kernel (affine / neural-spline / Moebius / '
+            'volume-preserving / mixed) or a torch transformer that autograd can differentiate; a subclass of a HIP-backed '
+            'transformer is neither.')
 
 
 def _gemm(x, w, y, B, N, n_rows_w, bias=None, k_ranges=None, act=0, accumulate=0, elu_grad_of=None, tile_live=None,
@@ -304,8 +319,9 @@ def layer_backward(layer, x, gy, gldj):
     """Returns (gx, [grads in trainable_tensors() order])."""
     if not supported(layer):
         raise NotImplementedError(
-            'tfep_amd: backward needs a transformer with a VJP kernel: affine / neural-spline / Moebius / '
-            'volume-preserving / mixed transformers.')
+            'tfep_amd: backward needs a transformer with a VJP kernel (affine / neural-spline / Moebius / '
+            'volume-preserving / mixed) or a torch transformer that autograd can differentiate; a subclass of a HIP-backed '
+            'transformer is neither.')
     x, _ = _lib.rows(x, 'x')
     gy = gy.contiguous().float()
     gldj = gldj.contiguous().float() if gldj is not None else None
