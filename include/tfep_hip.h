@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFEP_HIP_ABI_VERSION 3
+#define TFEP_HIP_ABI_VERSION 4
 
 typedef enum tfep_status {
     TFEP_OK = 0,
@@ -298,9 +298,12 @@ int tfep_split_columns_scaled(const float* src, int64_t ld_src, int64_t rows, in
  * of tfep_masked_weight_prepare's col_of_in), or NULL for the identity.  Only the out_features real rows are
  * written (all k_padded columns of each): padding rows of w_split_out must already be zero.
  * inv_scale: 4 floats: [0] = 1/scale, [1] = scratch, [2] = max_j sum_k |w_jk| (row-L1 maximum of the effective
- * weights, used to bound the next layer's activations: tfep_gemm_desc.split_out), [3] unused. */
+ * weights, used to bound the next layer's activations: tfep_gemm_desc.split_out), [3] unused.
+ * col_cut (or NULL): when every mask row is a PREFIX in packed column order -- packed columns are sorted by the degree of
+ * their input, so mask[o][in_of_col[c]] == (c < col_cut[o]) for the autoregressive masks of made.py:308-309 -- the mask
+ * is not read at all (a third of the kernel's HBM traffic); the caller checks the prefix property once per mask. */
 int tfep_masked_weight_prepare_split(const float* weight_v, const float* weight_g, const float* mask, int out_features,
-                                     int in_features, const int32_t* row_of_out, const int32_t* in_of_col,
+                                     int in_features, const int32_t* row_of_out, const int32_t* in_of_col, const int32_t* col_cut,
                                      void* w_split_out, int64_t ldw, int k_padded, float* inv_scale, void* stream);
 
 /* tfep_fused_output_transformer_forward on split operands: h_split (B rows, per-row h_inv_scale) and w_split (one

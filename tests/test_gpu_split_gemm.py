@@ -261,3 +261,48 @@ def test_abs_reduce_row_maxima_and_infinity_norm():
     view = x[:, 100:300]                                         # strided rows
     assert torch.equal(ops.abs_reduce(view, 'row_max'), view.abs().amax(dim=1))
     assert float(ops.abs_reduce(torch.zeros(1, 0, device='cuda'), 'max_row_sum')) == 0.0
+
+
+@pytest.mark.parametrize('order', ['ascending', 'descending', 'random'])
+def test_weight_prepare_without_reading_a_prefix_mask(order):
+    """Packed columns are sorted by input degree, so an autoregressive mask row is a prefix of them: the re-pack with
+    ``col_cut`` (mask not read) must write exactly the bits of the re-pack that reads the mask; a mask that is not of that
+    form is detected and read."""
+    from tfep_amd import ops
+    from tfep_amd.nn.conditioners import MADE, generate_degrees
+    torch.manual_seed(1)
+    D = 37
+    deg = generate_degrees(D, order)
+    made = MADE(deg, degrees_out=deg.repeat(2), hidden_layers=[90, 70]).cuda()
+    plan = made.plan(torch.device('cuda'))
+    lins = made._linears()
+    n_prefix = 0
+    for li, lin in enumerate(lins):
+        cut = made._mask_prefix_cuts(plan, li, lin)
+        n_rows = plan['n_pad'][li]
+        with_mask = (torch.zeros(n_rows, plan['k_pad'][li], device='cuda'), torch.zeros(4, device='cuda'))
+        ops.masked_weight_prepare_split(lin.weight_v.detach(), lin.weight_g.detach(), lin.mask, plan['row_of_out'][li],
+                                        plan['in_of_col'][li], *with_mask)
+        if cut is None:
+            continue
+        n_prefix += 1
+        assert cut.dtype == torch.int32 and cut.shape == (lin.out_features,)
+        assert torch.equal(cut.long(), lin.mask.sum(dim=1).long())
+        no_mask = (torch.zeros(n_rows, plan['k_pad'][li], device='cuda'), torch.zeros(4, device='cuda'))
+        ops.masked_weight_prepare_split(lin.weight_v.detach(), lin.weight_g.detach(), lin.mask, plan['row_of_out'][li],
+                                        plan['in_of_col'][li], *no_mask, col_cut=cut)
+        assert torch.equal(with_mask[0].view(torch.int32), no_mask[0].view(torch.int32))
+        assert torch.equal(with_mask[1][[0, 2]], no_mask[1][[0, 2]])
+    assert n_prefix >= 2                                        # every layer fed by degree-sorted hidden units
+    # a mask with a hole is not a prefix: detected (per mask version), and the mask is read
+    lin = lins[1]
+    with torch.no_grad():
+        row = int(lin.mask.sum(dim=1).argmax())
+        col = int(plan['in_of_col'][1][0])                      # first packed column: set in every non-empty row
+        lin.mask[row, col] = 0.0
+    assert made._mask_prefix_cuts(plan, 1, lin) is None
+    x = torch.randn(5, D, device='cuda')
+    with torch.no_grad():
+        a = made(x, split=True)
+        b = made(x, split=False)
+    assert float((a - b).abs().max()) < 1e-5 * (float(b.abs().max()) + 1.0)

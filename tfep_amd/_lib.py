@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TFEP_HIP_LIB') or os.path.join(_HERE, 'lib', 'libtfep_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -94,7 +94,7 @@ _SIGNATURES = {
                                                       _P, _P, c_int, _P, _P, c_int,
                                                       c_int, c_int, c_int, _P]),
     'tfep_split_tile_k': (c_int, []),
-    'tfep_masked_weight_prepare_split': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int64, c_int, _P, _P]),
+    'tfep_masked_weight_prepare_split': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int64, c_int, _P, _P]),
     'tfep_split_rows': (c_int, [_P, c_int64, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P]),
     'tfep_abs_reduce': (c_int, [_P, c_int64, c_int64, c_int64, c_int, _P, _P]),
     'tfep_split_columns_scaled': (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P, _P]),

@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(256) weight_prepare_split_kernel(const float* 
                                                                    const float* __restrict__ mask, int N, int K,
                                                                    const int32_t* __restrict__ row_of_out,
                                                                    const int32_t* __restrict__ in_of_col,
+                                                                   const int32_t* __restrict__ col_cut,
                                                                    uint4* __restrict__ w_out, int64_t ldw, int k_padded,
                                                                    const uint32_t* __restrict__ max_bits,
                                                                    float* __restrict__ inv_scale) {
@@ -181,7 +182,9 @@ __global__ void __launch_bounds__(256) weight_prepare_split_kernel(const float* 
     if (o >= N) return;
     const int lane = threadIdx.x & 63;
     const float* vr = v + (int64_t)o * K;
-    const float* mr = mask ? mask + (int64_t)o * K : nullptr;
+    // col_cut: the mask row is the prefix [0, cut) of the packed columns -- nothing to read
+    const int cut = col_cut ? col_cut[o] : 0;
+    const float* mr = (mask && !col_cut) ? mask + (int64_t)o * K : nullptr;
     float wn = 1.0f;
     if (g) {
         float ss = 0.f;
@@ -202,7 +205,8 @@ __global__ void __launch_bounds__(256) weight_prepare_split_kernel(const float* 
             float val = 0.f;
             if (c < K) {
                 const int i = in_of_col ? in_of_col[c] : c;
-                if (!(mr && mr[i] == 0.0f)) val = g ? vr[i] * wn : (mr ? vr[i] * mr[i] : vr[i]);
+                const bool on = col_cut ? c < cut : !(mr && mr[i] == 0.0f);
+                if (on) val = g ? vr[i] * wn : (mr ? vr[i] * mr[i] : vr[i]);
             }
             l1 += fabsf(val);
             val *= s;
@@ -746,7 +750,7 @@ int tfep_diag_split_cycles(unsigned long long* out) {
 }
 
 int tfep_masked_weight_prepare_split(const float* weight_v, const float* weight_g, const float* mask, int out_features,
-                                     int in_features, const int32_t* row_of_out, const int32_t* in_of_col,
+                                     int in_features, const int32_t* row_of_out, const int32_t* in_of_col, const int32_t* col_cut,
                                      void* w_split_out, int64_t ldw, int k_padded, float* inv_scale, void* stream) {
     TFEP_REQUIRE(weight_v && w_split_out && inv_scale, "masked_weight_prepare_split: NULL pointer");
     TFEP_REQUIRE(out_features >= 0 && in_features >= 0, "masked_weight_prepare_split: negative size");
@@ -762,8 +766,8 @@ int tfep_masked_weight_prepare_split(const float* weight_v, const float* weight_
     else if (in_features > 0)
         absmax_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, s>>>(weight_v, in_features, out_features, in_features, max_bits);
     weight_prepare_split_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, s>>>(
-        weight_v, weight_g, mask, out_features, in_features, row_of_out, in_of_col, (uint4*)w_split_out, ldw, k_padded,
-        max_bits, inv_scale);
+        weight_v, weight_g, mask, out_features, in_features, row_of_out, in_of_col, col_cut, (uint4*)w_split_out, ldw,
+        k_padded, max_bits, inv_scale);
     return check_launch("weight_prepare_split_kernel");
 }
 

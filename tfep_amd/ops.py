@@ -287,17 +287,18 @@ def pow2_inv_scale(bound):
     return torch.exp2(e - 14.0).float()
 
 
-def masked_weight_prepare_split(weight_v, weight_g, mask, row_of_out, in_of_col, out, inv_scale):
+def masked_weight_prepare_split(weight_v, weight_g, mask, row_of_out, in_of_col, out, inv_scale, col_cut=None):
     """Effective masked weight written directly as split-f16 rows into ``out`` (n_rows_padded, k_padded), whose
     padding rows must already be zero (``tfep_masked_weight_prepare_split``).  ``inv_scale``: 4 floats --
-    [1/scale, scratch, max_j sum_k |w_jk|, unused]."""
+    [1/scale, scratch, max_j sum_k |w_jk|, unused].  ``col_cut`` (int32 per output row): the mask rows are prefixes of the
+    packed columns, ``mask[o, in_of_col[c]] == (c < col_cut[o])`` -- the mask is then not read."""
     check_device_tensor(weight_v, 'weight')
     if inv_scale.numel() < 4:
         raise ValueError('inv_scale must have 4 entries')
     N, K = weight_v.shape
     call('tfep_masked_weight_prepare_split', ptr(weight_v.contiguous()),
          ptr(None if weight_g is None else weight_g.contiguous()),
-         ptr(None if mask is None else mask.contiguous()), N, K, ptr(row_of_out), ptr(in_of_col),
+         ptr(None if mask is None else mask.contiguous()), N, K, ptr(row_of_out), ptr(in_of_col), ptr(col_cut),
          ptr(out), out.shape[1], out.shape[1], ptr(inv_scale), stream_of(weight_v))
     return out, inv_scale
 
