@@ -201,6 +201,9 @@ def test_weight_prepack_on_side_stream_is_transparent_and_never_stale():
     """SequentialFlow packs layer i+1's weights on a side stream while layer i computes: same results as without the
     overlap, and weights packed ahead are discarded when a parameter changed in the meantime."""
     import os
+    if os.environ.get('TFEP_SPLIT_GEMM', '1') == '0' or os.environ.get('TFEP_OVERLAP_PACK', '1') == '0':
+        pytest.skip('needs the default split-GEMM forward with side-stream packing')
+    import os
     from tfep_amd.nn.flows.sequential import _side_stream
     from tfep_amd.nn.conditioners import generate_degrees
     from tfep_amd.nn.flows import MAF, SequentialFlow
