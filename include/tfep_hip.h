@@ -68,12 +68,15 @@ typedef struct tfep_param_layout {
  *   weight_g == NULL :  W[o,i] = v[o,i] * mask[o,i]      (masked.py:270; mask may be NULL)
  * The result is written permuted and zero-padded for the GEMM kernels:
  *   w_out[row_of_out[o] * ldw + col_of_in[i]] = W[o,i]
- * row_of_out / col_of_in may be NULL (identity).  Padding rows/cols of w_out
- * (n_rows_padded x ldw) that no (o,i) maps to are set to 0.
+ * row_of_out / col_of_in may be NULL (identity).  clear != 0: padding rows/cols of w_out (n_rows_padded x ldw) that no
+ * (o,i) maps to are set to 0 first (a kernel, not hipMemsetAsync); clear == 0: the caller zeroed the buffer once and only
+ * ever packs the same layer into it (every mapped entry is rewritten, the padding is never touched).
+ * col_cut (or NULL): mask rows that are prefixes of the packed columns, mask[o][i] == (col_of_in[i] < col_cut[o]), as in
+ * tfep_masked_weight_prepare_split: the mask is not read.
  */
 int tfep_masked_weight_prepare(const float* weight_v, const float* weight_g, const float* mask,
                                int out_features, int in_features,
-                               const int32_t* row_of_out, const int32_t* col_of_in,
+                               const int32_t* row_of_out, const int32_t* col_of_in, const int32_t* col_cut, int clear,
                                float* w_out, int n_rows_padded, int64_t ldw, void* stream);
 
 /*

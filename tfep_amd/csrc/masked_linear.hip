@@ -32,12 +32,14 @@ __global__ void __launch_bounds__(256) weight_prepare_kernel(const float* __rest
                                                              const float* __restrict__ mask, int N, int K,
                                                              const int32_t* __restrict__ row_of_out,
                                                              const int32_t* __restrict__ col_of_in,
+                                                             const int32_t* __restrict__ col_cut,
                                                              float* __restrict__ w_out, int64_t ldw) {
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (o >= N) return;
     const int lane = threadIdx.x & 63;
     const float* vr = v + (int64_t)o * K;
-    const float* mr = mask ? mask + (int64_t)o * K : nullptr;
+    const int cut = col_cut ? col_cut[o] : 0;         // prefix mask: packed columns [0, cut) are on, nothing to read
+    const float* mr = (mask && !col_cut) ? mask + (int64_t)o * K : nullptr;
     float scale = 1.0f;
     if (g) {
         float ss = 0.f;
@@ -48,12 +50,13 @@ __global__ void __launch_bounds__(256) weight_prepare_kernel(const float* __rest
     const int64_t orow = row_of_out ? row_of_out[o] : o;
     float* wr = w_out + orow * ldw;
     for (int i = lane; i < K; i += 64) {
+        const int c = col_of_in ? col_of_in[i] : i;
         float val;
-        if (mr && mr[i] == 0.0f)
+        if (col_cut ? c >= cut : (mr && mr[i] == 0.0f))
             val = 0.0f;                    // _ApplyMask: exact zero, also where v*scale is NaN
         else
             val = g ? vr[i] * scale : (mr ? vr[i] * mr[i] : vr[i]);
-        wr[col_of_in ? col_of_in[i] : i] = val;
+        wr[c] = val;
     }
 }
 
@@ -390,8 +393,8 @@ int tfep_masked_linear_narrow_tile_n(void) { return Tile<LIN_MREP, NARROW_NREP>:
 int tfep_fused_tile_features(void) { return FUSED_TILE_FEATURES; }
 
 int tfep_masked_weight_prepare(const float* weight_v, const float* weight_g, const float* mask, int out_features,
-                               int in_features, const int32_t* row_of_out, const int32_t* col_of_in, float* w_out,
-                               int n_rows_padded, int64_t ldw, void* stream) {
+                               int in_features, const int32_t* row_of_out, const int32_t* col_of_in, const int32_t* col_cut,
+                               int clear, float* w_out, int n_rows_padded, int64_t ldw, void* stream) {
     TFEP_REQUIRE(weight_v && w_out, "masked_weight_prepare: NULL pointer");
     TFEP_REQUIRE(out_features >= 0 && in_features >= 0, "masked_weight_prepare: negative size");
     TFEP_REQUIRE(n_rows_padded >= out_features && ldw >= in_features, "masked_weight_prepare: output too small");
@@ -400,14 +403,14 @@ int tfep_masked_weight_prepare(const float* weight_v, const float* weight_g, con
     // to leave garbage behind on replay (the padding rows of this buffer read back as ~1e36 by a later kernel of the same
     // graph, while eager runs were clean; an earlier 4-byte case was traced to the same node type).
     const size_t n_clear = (size_t)n_rows_padded * (size_t)ldw;
-    if (n_clear > 0) {
+    if (clear && n_clear > 0) {
         fill_zero_kernel<<<(unsigned)((n_clear + 1023) / 1024 < 65535 * 16 ? (n_clear + 1023) / 1024 : 65535 * 16), 256, 0, s>>>(w_out, n_clear);
         int rc = check_launch("fill_zero_kernel");
         if (rc) return rc;
     }
     if (out_features == 0 || in_features == 0) return TFEP_OK;
     weight_prepare_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, s>>>(weight_v, weight_g, mask, out_features,
-                                                                              in_features, row_of_out, col_of_in, w_out, ldw);
+                                                                              in_features, row_of_out, col_of_in, col_cut, w_out, ldw);
     return check_launch("weight_prepare_kernel");
 }
 

@@ -273,14 +273,18 @@ class MADE(Conditioner):
             v, g = lin.weight_v.detach(), lin.weight_g.detach()
         else:
             v, g = lin._parameters['weight'].detach(), None
-        key = ('w', li, n_rows)
+        # one buffer per (layer, row order): zeroed once -- the kernel rewrites every mapped entry and never touches the
+        # padding, so later packs skip the clear (a 4.5 GB write for the cfg2 output layer)
+        key = ('w', li, n_rows, None if row_of_out is None else row_of_out.data_ptr())
         if self._frozen and ('packed', li, n_rows) in plan:
             return plan[('packed', li, n_rows)]
-        buf = plan.get(key)
-        if buf is None or buf.shape != (n_rows, plan['k_pad'][li]):
-            buf = torch.empty(n_rows, plan['k_pad'][li], dtype=torch.float32, device=v.device)
-            plan[key] = buf
-        ops.masked_weight_prepare(v, g, lin.mask, row_of_out, plan['col_of_in'][li], n_rows, plan['k_pad'][li], out=buf)
+        entry = plan.get(key)
+        if entry is None:
+            # (the entry keeps row_of_out alive: its address, part of the key, cannot be recycled for another mapping)
+            entry = plan[key] = (ops.zeros(n_rows, plan['k_pad'][li], dtype=torch.float32, device=v.device), row_of_out)
+        buf = entry[0]
+        ops.masked_weight_prepare(v, g, lin.mask, row_of_out, plan['col_of_in'][li], n_rows, plan['k_pad'][li], out=buf,
+                                  col_cut=self._mask_prefix_cuts(plan, li, lin), clear=False)
         bias = ops.zeros(1, n_rows, dtype=torch.float32, device=v.device)
         if row_of_out is None:
             bias[0, :lin.out_features] = lin.bias.detach()
@@ -325,8 +329,9 @@ class MADE(Conditioner):
         buf = plan.get(key)
         if buf is None:
             # zero once: the kernel writes the real rows only, padding rows / columns stay zero for good
+            # (row_of_out rides along so that its address, part of the key, cannot be recycled for another mapping)
             buf = (ops.zeros(n_rows, plan['k_pad'][li], dtype=torch.float32, device=v.device),
-                   ops.zeros(4, dtype=torch.float32, device=v.device))
+                   ops.zeros(4, dtype=torch.float32, device=v.device), row_of_out)
             plan[key] = buf
         in_of_col = plan['in_of_col'][li]
         ops.masked_weight_prepare_split(v, g, lin.mask, row_of_out, in_of_col, buf[0], buf[1],

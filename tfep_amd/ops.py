@@ -165,8 +165,10 @@ def pad_columns(x, k_padded):
 
 
 def masked_weight_prepare(weight_v, weight_g=None, mask=None, row_of_out=None, col_of_in=None,
-                          n_rows_padded=None, k_padded=None, out=None):
-    """Effective masked weight, permuted + zero padded (reference masked.py:369-371, :433-439, :270)."""
+                          n_rows_padded=None, k_padded=None, out=None, col_cut=None, clear=True):
+    """Effective masked weight, permuted + zero padded (reference masked.py:369-371, :433-439, :270).  ``col_cut``:
+    prefix mask rows (see ``masked_weight_prepare_split``); ``clear=False``: ``out`` was zeroed once and always holds the
+    same layer, so its padding needs no clearing."""
     check_device_tensor(weight_v, 'weight')
     N, K = weight_v.shape
     tk = tile_sizes()[2]
@@ -176,8 +178,8 @@ def masked_weight_prepare(weight_v, weight_g=None, mask=None, row_of_out=None, c
         out = torch.empty(n_rows_padded, k_padded, dtype=torch.float32, device=weight_v.device)
     call('tfep_masked_weight_prepare', ptr(weight_v.contiguous()),
          ptr(None if weight_g is None else weight_g.contiguous()),
-         ptr(None if mask is None else mask.contiguous()), N, K, ptr(row_of_out), ptr(col_of_in),
-         ptr(out), n_rows_padded, k_padded, stream_of(weight_v))
+         ptr(None if mask is None else mask.contiguous()), N, K, ptr(row_of_out), ptr(col_of_in), ptr(col_cut),
+         int(bool(clear)), ptr(out), n_rows_padded, k_padded, stream_of(weight_v))
     return out
 
 
