@@ -238,3 +238,35 @@ def test_weight_prepack_on_side_stream_is_transparent_and_never_stale():
         layer.prepack_async(x.device, _side_stream(x.device))
         got2 = layer(h)
         assert torch.equal(got2[0], ref[0]) and torch.equal(got2[1], ref[1])
+
+
+@pytest.mark.parametrize('split', [False, True])
+def test_graph_replay_of_the_blocked_inverse_equals_the_eager_inverse(split):
+    """HIP-graph replay of the blocked inverse (block kernel, split-K block GEMMs, and -- ``split`` -- the split-f16
+    output-layer GEMM with its bound-based row scales) gives the bits of the eager call, replay after replay, also for a
+    second graph captured later.  (Memset nodes broke exactly this once: ``ops.zeros`` / ``fill_zero_kernel``.)"""
+    from tfep_amd.graphs import GraphedFlow
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF, SequentialFlow
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    torch.manual_seed(3)
+    D, B = 150, 333
+    flow = SequentialFlow(*[MAF(generate_degrees(D, o), transformer=NeuralSplineTransformer(torch.full((D,), -4.0), torch.full((D,), 4.0), 8),
+                                hidden_layers=[1100, 1300], initialize_identity=False) for o in ('ascending', 'descending')]).cuda()
+    for layer in flow:
+        layer.split_inverse = split
+    x = torch.randn(B, D, device='cuda') * 1.3
+    y, _ = flow(x)                                   # (grad mode on: like a training script that then samples)
+    xe, le = flow.inverse(y)
+    with torch.no_grad():
+        for layer in flow:
+            assert layer._blocked_plan(y.device)['fused'] is not None
+            assert (layer._split_inverse_bound(y.device) is not None) == split
+        g1 = GraphedFlow(flow, B, D, inverse=True, warmup=1)
+        outs = [g1(y) for _ in range(3)]             # back to back
+        g2 = GraphedFlow(flow, B, D, inverse=True, warmup=1)
+        outs.append(g2(y))
+        outs.append(g1(y))                           # the first graph again, after the second capture
+    for xg, lg in outs:
+        assert torch.equal(xg, xe) and torch.equal(lg, le)
+    assert float((xe - x).abs().max()) < 5e-3
