@@ -547,28 +547,53 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
             }
             so[m][i] = s_out;
         });
-        // Lanes 2j and 2j+1 hold adjacent columns: the even lane stores both halves' pairs as 32-bit words (half as
-        // many, aligned stores; g.N is even and a pair never straddles a group of 8 columns).
-        static_for<0, NREP>([&](auto nc) __attribute__((always_inline)) {
-            constexpr int n = nc.value;
-            const int col = n0 + n * 16 + cj;
-            const bool in_range = col < g.N;
-            const float bv = (in_range && g.bias) ? g.bias[col] : 0.f;
-            const int64_t cbyte = (int64_t)(col >> 3) * 32 + (col & 7) * 2;            // hi half; lo half 16 bytes on
-            static_for<0, SMREP * 4>([&](auto ic) __attribute__((always_inline)) {
-                constexpr int m = ic.value / 4, i = ic.value % 4;
-                const int row = wrow0 + m * 16 + rq + i;
-                const float v = elu_f(acc[n][m][i] * rs[m][i] + bv) * so[m][i];
-                const _Float16 h = (_Float16)v;
-                const _Float16 l = (_Float16)(v - (float)h);
-                const uint32_t mine = (uint32_t)__builtin_bit_cast(uint16_t, h) | ((uint32_t)__builtin_bit_cast(uint16_t, l) << 16);
-                const uint32_t next = (uint32_t)__shfl_xor((int)mine, 1, 64);           // the odd neighbour's (hi, lo)
-                if (!(cj & 1) && in_range && row < g.B) {
-                    uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(g.y) + (int64_t)row * g.ldy * 4 + cbyte);
-                    dst[0] = (mine & 0xffffu) | (next << 16);                            // hi of col, hi of col + 1
-                    dst[4] = (mine >> 16) | (next & 0xffff0000u);                        // lo of col, lo of col + 1
-                }
+        // The accumulator layout (a lane: 4 rows x 1 column per tile) would store 2 bytes at a time; the tile goes through
+        // LDS instead, 64 columns at a time, and leaves as whole 32-byte groups (8 hi halves, 8 lo halves) -- 8 lanes write
+        // 256 contiguous bytes of a row.  (4-byte pair-packed stores ran this epilogue at 1.5 TB/s: 17 % of the K = 3008
+        // hidden layer.)
+        constexpr int EP_PITCH = 68;                    // floats per staged row: 64 columns + 4 so that the 4 row groups
+                                                        // of a tile write to different banks
+        static_assert(NREP % 4 == 0, "the split-row epilogue stages 4 column tiles at a time");
+        static_assert(SWAVES * 64 * EP_PITCH * 4 <= T::LDS_BYTES, "epilogue stage does not fit in LDS");
+        __syncthreads();                                // every wave is done with the operand stages: LDS is reused below
+        float* stage = reinterpret_cast<float*>(slds + wave * (64 * EP_PITCH * 4));
+        static_for<0, NREP / 4>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = qc.value;
+            static_for<0, 4>([&](auto n4c) __attribute__((always_inline)) {
+                constexpr int n = 4 * q + n4c.value;
+                const int col = n0 + n * 16 + cj;
+                const bool in_range = col < g.N;
+                const float bv = (in_range && g.bias) ? g.bias[col] : 0.f;
+                static_for<0, SMREP * 4>([&](auto ic) __attribute__((always_inline)) {
+                    constexpr int m = ic.value / 4, i = ic.value % 4;
+                    const float v = in_range ? elu_f(acc[n][m][i] * rs[m][i] + bv) * so[m][i] : 0.f;
+                    stage[(m * 16 + rq + i) * EP_PITCH + n4c.value * 16 + cj] = v;
+                });
             });
+            __builtin_amdgcn_wave_barrier();            // (one wave per stage: LDS is in order, this pins the compiler)
+            const int grp = lane & 7;
+            const int colg = n0 + q * 64 + grp * 8;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row_l = it * 8 + (lane >> 3);
+                const int row = wrow0 + row_l;
+                const f32x4_alias lo4 = *reinterpret_cast<const f32x4_alias*>(stage + row_l * EP_PITCH + grp * 8);
+                const f32x4_alias hi4 = *reinterpret_cast<const f32x4_alias*>(stage + row_l * EP_PITCH + grp * 8 + 4);
+                const float v8[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                f16x8 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const _Float16 h = (_Float16)v8[j];
+                    hi[j] = h;
+                    lo[j] = (_Float16)(v8[j] - (float)h);
+                }
+                if (row < g.B && colg < g.N) {
+                    uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(g.y) + (int64_t)row * g.ldy * 4 + (int64_t)(colg >> 3) * 32);
+                    dst[0] = *reinterpret_cast<uint4*>(&hi);
+                    dst[1] = *reinterpret_cast<uint4*>(&lo);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         });
     } else {
         // the other epilogues get a copy they may index from unrolled loops
