@@ -84,7 +84,7 @@ def main():
     ap.add_argument('--batch', type=int, default=65536, help='samples per GPU')
     ap.add_argument('--layers', type=int, default=4)
     ap.add_argument('--bins', type=int, default=8)
-    ap.add_argument('--cpu-chunk', type=int, default=1024)
+    ap.add_argument('--cpu-chunk', type=int, default=2048)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
