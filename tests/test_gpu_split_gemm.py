@@ -309,3 +309,31 @@ def test_weight_prepare_without_reading_a_prefix_mask(order):
         a = made(x, split=True)
         b = made(x, split=False)
     assert float((a - b).abs().max()) < 1e-5 * (float(b.abs().max()) + 1.0)
+
+
+def test_elu_of_the_gemm_epilogues_is_fp32_accurate():
+    """The ELU of the GEMM epilogues (gemm_common.h: expm1f on the negative branch) against float64:
+    through a GEMM with an identity weight, over 30 decades of negative inputs, plus -0, -inf, NaN."""
+    from tfep_amd import ops
+    tm, tn, tk = ops.tile_sizes()
+    n = 256
+    xs = torch.cat([-torch.logspace(-30, 2, 4000, dtype=torch.float64), -torch.linspace(0, 20, 4000, dtype=torch.float64),
+                    torch.tensor([-0.0, 0.5, 3.0, -float('inf'), float('nan')], dtype=torch.float64)])
+    pad = (-len(xs)) % n
+    xs = torch.cat([xs, torch.zeros(pad, dtype=torch.float64)])
+    a = xs.float().reshape(-1, n).cuda()                                  # each row: n values, identity weight keeps them
+    w = ops.masked_weight_prepare(torch.eye(n, device='cuda'), None, None, n_rows_padded=n, k_padded=n)
+    bias = torch.zeros(n, device='cuda')
+    y32 = ops.masked_linear_packed(a, w, bias, n, act=1)                 # exact-fp32 MFMA kernel, ELU epilogue
+    as_, ainv = ops.split_rows(a, n)
+    ws_, winv = ops.split_rows(w, n, per_tensor=True)
+    ys = ops.masked_linear_split(as_, ainv, ws_, winv, bias, n, act=1)   # split kernel, same epilogue code
+    ref = torch.where(a.double() > 0, a.double(), torch.expm1(a.double()))
+    for y in (y32, ys):
+        finite = torch.isfinite(ref) & torch.isfinite(a)
+        rows_ok = torch.isfinite(a).all(dim=1)                           # the NaN / inf row pollutes its own GEMM row only
+        m = finite & rows_ok[:, None] & (ref != 0)
+        rel = ((y.double() - ref).abs() / ref.abs())[m]
+        assert float(rel.max()) < 2.5e-7
+        assert bool((y[(ref == 0) & rows_ok[:, None]] == 0).all())
+    assert torch.isnan(y32[~rows_ok]).any()                              # NaN in -> NaN out (not -1)
