@@ -195,6 +195,21 @@ def test_new_entry_points_reject_bad_arguments():
         _lib.call('tfep_bootstrap_fep', _lib.ptr(work), None, None, _lib.ptr(wts), 16, 2, 16, 0.0, _lib.ptr(res),
                   _lib.stream_of(work))
     assert ops.tile_sizes()[2] == _lib.load().tfep_split_tile_k() == 32
+    # reductions / incremental split conversion / inverse-block sizes
+    with pytest.raises(ValueError, match='mode must be 0'):
+        _lib.call('tfep_abs_reduce', _lib.ptr(a), 64, 8, 64, 2, _lib.ptr(inv), _lib.stream_of(a))
+    with pytest.raises(ValueError, match='ld_src < cols'):
+        _lib.call('tfep_abs_reduce', _lib.ptr(a), 32, 8, 64, 0, _lib.ptr(inv), _lib.stream_of(a))
+    with pytest.raises(ValueError, match='must lie inside both rows'):
+        _lib.call('tfep_split_columns_scaled', _lib.ptr(a), 64, 8, 56, 16, _lib.ptr(out), 64, _lib.ptr(inv), _lib.stream_of(a))
+    lib = _lib.load()
+    assert lib.tfep_inverse_block_lds_bytes(0, 10, 10) == -1 and lib.tfep_inverse_block_lds_bytes(2, -1, 10) == -1
+    small, big = lib.tfep_inverse_block_lds_bytes(2, 100, 16), lib.tfep_inverse_block_lds_bytes(2, 400, 64)
+    assert 0 < small < 160 * 1024 < big                      # the second one must make the planner shrink its blocks
+    ib2 = _lib.InverseBlockDesc()
+    ib2.B, ib2.n_layers, ib2.n_steps, ib2.kind = 8, 1, 1, 3
+    with pytest.raises(ValueError, match='kind must be 0'):
+        _lib.call('tfep_inverse_block', ctypes.byref(ib2), _lib.stream_of(a))
 
 
 def test_weight_prepack_on_side_stream_is_transparent_and_never_stale():
