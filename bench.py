@@ -158,7 +158,7 @@ def main():
         # dense fp16 peak
         peak = PEAK_F16_MFMA_TFLOPS / 3.0
         kernel = 'split_gemm_kernel<25,EPI_SPLINE> (fused MADE output layer + RQ spline + log-det; 3 x v_mfma_f32_16x16x32_f16 per fp32 product)'
-        tname = 'r01_split_pmc_traffic.json'
+        tname = 'r01_final_pmc_traffic.json'             # counters of the final build of round 1 (profiles/README.md)
     else:
         peak = PEAK_FP32_MFMA_TFLOPS
         kernel = 'gemm_kernel<2,25,EPI_SPLINE> (fused MADE output layer + RQ spline + log-det; v_mfma_f32_16x16x4_f32)'
