@@ -199,6 +199,9 @@ def main():
                          'vs_power_limited_mfma_ceiling': (achieved / (1914.0 / 3.0)) if split else None,
                          'power_limited_ceiling_source': 'profiles/r01_mfma_shape_probe.txt' if split else None,
                          'flops_per_launch': kern_flops[0], 'avg_launch_ms': float(np.mean(kern_ms)),
+                         # the same launches counted as dense GEMMs (no credit for skipping the masked half)
+                         'dense_equivalent_tflops': achieved * sum(float(l._conditioner.layers[-1].mask.numel()) for l in flow)
+                         / sum(nnz_out),
                          'whole_step_tflops': 2.0 * sum(nnz_all) * B * args.steps / elapsed / 1e12},
             'delta_f_estimate': float(out[2]),
         }
