@@ -1,19 +1,23 @@
 #!/usr/bin/env python
-"""Headline benchmark: samples/s of forward + log|det J| for the cfg2 flow of BASELINE.json
+"""Headline benchmark: samples/s of forward + log|det J| for the cfg2 / cfg3 flow of BASELINE.json
 (4-layer MAF + RQ-spline(8 bins), 3x1000 atoms = 3000 features, batch 65536, fp32) on N MI355X.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch: for each of the 4 MAF layers the masked
+One "step" = one pass of the hot path over the 65536-sample batch: for each of the 4 MAF layers the masked
 weight-norm re-pack (the reference recomputes it on every forward) and its conversion to split-f16
 rows, the conversion of each layer's activations, the two hidden GEMMs (+ELU) and the fused
 output-GEMM + spline + log-det kernel (split-f16 MFMA by default, exact-fp32 MFMA with
-TFEP_SPLIT_GEMM=0), then the TFEP free-energy
-estimator over the batch's log-weights (sufficient statistics + one RCCL all-gather of 9 scalars
-per rank when N > 1).  Inputs are resident in HBM before the timed region.  Weak scaling: every
-rank processes its own full batch with a full weight replica; there is no collective on the data
-path.  Rank 0 prints ONE JSON line.
+TFEP_SPLIT_GEMM=0), then the TFEP free-energy estimator over the batch's log-weights (sufficient statistics + one
+RCCL all-gather of 9 scalars per rank when N > 1).  Inputs are resident in HBM before the timed region.
+
+N > 1 is BASELINE config 3: the SAME 65536-sample batch sharded by rows over the ranks (8192 per GPU at N = 8,
+``tfep_amd.distributed.shard_rows``), a full weight replica per rank, no collective on the data path: STRONG scaling
+(``--scaling weak`` gives every rank its own 65536 rows instead).  Rank 0 prints ONE JSON line.  After the timed
+headline region the same process also times (a) the step with the packed weights cached across forwards
+(``cached_repack``; the headline re-packs every step), (b) the step on the exact-fp32 MFMA GEMMs (``exact_fp32``) and
+(c), on rank 0 at N = 1, the CPU restatement of the path on the host cores (``cpu_baseline``).
 """
 import argparse
 import json
@@ -47,32 +51,39 @@ def build_flow(D, n_layers, n_bins, device, seed=0):
     return SequentialFlow(*layers).to(device)
 
 
-def cpu_baseline(flow, D, n_bins, chunk, budget_s=30.0):
-    """Time the numpy oracle (fp32) for ONE MAF layer on `chunk` samples and scale to all layers.
-    kind 'port': the CPU restatement of the reference algorithm, not the reference itself."""
-    from oracle import flows as oflows, made as omade
-    import threadpoolctl
+def cpu_baseline(flow, D, n_bins, chunk):
+    """Time the torch-CPU restatement of the path (``oracle/torch_cpu.py``: fp32, no autograd, every host core through
+    torch's intra-op pool / MKL) for ONE MAF layer on a ``chunk``-sample chunk and scale to all layers (BASELINE.md
+    section 3).  kind 'port': the CPU restatement of the reference algorithm, not the reference itself."""
+    from oracle import torch_cpu
     cores = os.cpu_count() or 1
-    layer0 = flow[0]
-    sd = {k: v.detach().cpu().numpy() for k, v in layer0._conditioner.state_dict().items()}
-    layer = dict(degrees_in=omade.generate_degrees(D, 'ascending'),
-                 transformer=dict(type='spline', x0=np.full(D, -5.0, np.float32), xf=np.full(D, 5.0, np.float32),
-                                  n_bins=n_bins),
-                 embedding=None, made=omade.made_layers_from_state(sd))
-    x = np.random.default_rng(1234).standard_normal((chunk, D)).astype(np.float32).clip(-4.9, 4.9)
+    threads = torch.get_num_threads()
+    sd = flow[0]._conditioner.state_dict()
+    made = [{k: sd[f'layers.{2 * i}.{k}'].detach().cpu() for k in ('bias', 'mask', 'weight_g', 'weight_v')}
+            for i in range(3)]
+    x0, xf = torch.full((D,), -5.0), torch.full((D,), 5.0)
+    x = torch.randn(chunk, D, generator=torch.Generator().manual_seed(1234)).clamp_(-4.9, 4.9)
+    torch_cpu.maf_forward(x[:16], made, x0, xf, n_bins)          # page the weights in, spin the thread pool up
     t0 = time.perf_counter()
-    y, ldj = oflows.maf_forward(x, layer)
+    y, ldj = torch_cpu.maf_forward(x, made, x0, xf, n_bins)
     dt = time.perf_counter() - t0
     n_layers = len(flow)
-    try:
-        threads = max(i.get('num_threads', 1) for i in threadpoolctl.threadpool_info()) or cores
-    except Exception:
-        threads = cores
     return {
         'value': chunk / (dt * n_layers), 'unit': 'samples/s', 'cores': int(threads), 'kind': 'port',
-        'sample': f'numpy fp32 oracle, 1 of {n_layers} MAF layers (weight-norm + 3 masked linears + RQ spline) on a '
-                  f'{chunk}-sample chunk in {dt:.1f} s, scaled by 1/{n_layers}; host has {cores} logical cores',
-    }, (x, y, ldj)
+        'sample': f'torch-CPU fp32 restatement (oracle/torch_cpu.py), 1 of {n_layers} MAF layers (weight-norm + 3 masked '
+                  f'linears + RQ spline) on a {chunk}-sample chunk in {dt:.1f} s, scaled by 1/{n_layers}; '
+                  f'{threads} torch threads on {cores} logical cores',
+    }, (x.numpy(), y.numpy(), ldj.numpy())
+
+
+def rows_for_rank(batch, rank, world, scaling='strong'):
+    """Rows ``[row0, row1)`` of the global batch that ``rank`` maps, and the global batch size.  strong (BASELINE
+    cfg3): ``batch`` rows sharded contiguously (8192 per GPU at N = 8); weak: ``batch`` rows on every rank."""
+    from tfep_amd.distributed import shard_rows
+    if scaling == 'strong':
+        row0, row1 = shard_rows(batch, rank, world)
+        return row0, row1, batch
+    return rank * batch, (rank + 1) * batch, world * batch
 
 
 def main():
@@ -81,11 +92,14 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--features', type=int, default=3000)
-    ap.add_argument('--batch', type=int, default=65536, help='samples per GPU')
+    ap.add_argument('--batch', type=int, default=65536, help='GLOBAL batch (row-sharded over the ranks)')
+    ap.add_argument('--scaling', choices=['strong', 'weak'], default='strong',
+                    help='strong (BASELINE cfg3): the batch is sharded over the ranks; weak: --batch rows per rank')
     ap.add_argument('--layers', type=int, default=4)
     ap.add_argument('--bins', type=int, default=8)
-    ap.add_argument('--cpu-chunk', type=int, default=2048)
+    ap.add_argument('--cpu-chunk', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extra-arms', action='store_true', help='skip the cached-repack and exact-fp32 arms')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -104,7 +118,9 @@ def main():
         dist.init_process_group('nccl', device_id=device)
 
     from tfep_amd.analysis import fep_estimator
-    D, B = args.features, args.batch
+    D = args.features
+    row0, row1, global_batch = rows_for_rank(args.batch, rank, world, args.scaling)
+    B = row1 - row0
     flow = build_flow(D, args.layers, args.bins, device)
     # Synthetic inputs: x ~ N(0,1) clipped to the spline domain, a
     # different stream per rank; u_B, u_A synthetic reduced potentials for the log-weights.
@@ -130,67 +146,100 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for _ in range(args.warmup):
-        step()
-    sync()
-    for l in flow:
-        l._profile_events = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t)
+    def timed(n_warmup, n_steps):
+        """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks.  Returns
+        (seconds, last output, HIP-event ms of every fused-kernel launch, its flops per launch)."""
+        for _ in range(n_warmup):
+            step()
+        sync()
+        for l in flow:
+            l._profile_events = []
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            out = step()
+        sync()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = [ev0.elapsed_time(ev1) for l in flow for ev0, ev1 in l._profile_events]
+        fl = [2.0 * nnz_out[i] * B for i, l in enumerate(flow) for _ in l._profile_events]
+        for l in flow:
+            l._profile_events = None
+        return float(t), out, ms, fl
 
-    # dominant kernel: fused output GEMM + spline (one launch per layer per step)
-    kern_ms = [ev0.elapsed_time(ev1) for l in flow for ev0, ev1 in l._profile_events]
-    kern_flops = [2.0 * nnz_out[i] * B for i, l in enumerate(flow) for _ in l._profile_events]
+    # ---------------------------------------------------------------- headline: weights re-packed every step
+    elapsed, out, kern_ms, kern_flops = timed(args.warmup, args.steps)
     achieved = sum(kern_flops) / (sum(kern_ms) * 1e-3) / 1e12
+    split = all(l._use_split_gemm() for l in flow)
+
+    # ---------------------------------------------------------------- extra arms (same process, same device)
+    extra = {}
+    if not args.no_extra_arms:
+        for l in flow:
+            l._conditioner.cache_packed_weights = True
+        t_c, _, ms_c, fl_c = timed(1, args.steps)
+        extra['cached_repack'] = {
+            'value': global_batch * args.steps / t_c, 'ms_per_step': 1e3 * t_c / args.steps,
+            'note': 'packed split-f16 weights kept across forwards while no parameter / mask version changed '
+                    '(MADE.cache_packed_weights; SURVEY.md 8b); the headline value re-packs on every step'}
+        for l in flow:
+            l._conditioner.cache_packed_weights = False
+            l._conditioner.invalidate_plan()            # frees the cached packs
+            l.split_gemm = False
+        n_exact = min(3, args.steps)
+        t_e, _, ms_e, fl_e = timed(1, n_exact)
+        tf_e = sum(fl_e) / (sum(ms_e) * 1e-3) / 1e12
+        extra['exact_fp32'] = {
+            'value': global_batch * n_exact / t_e, 'ms_per_step': 1e3 * t_e / n_exact, 'steps': n_exact,
+            'fused_kernel_tflops': tf_e, 'frac_of_157.3': tf_e / PEAK_FP32_MFMA_TFLOPS,
+            'whole_step_tflops': 2.0 * sum(nnz_all) * B * world * n_exact / t_e / 1e12 / world,
+            'kernel': 'gemm_kernel<2,25,EPI_SPLINE> (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate)'}
+        for l in flow:
+            l.split_gemm = None
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
     # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/README.md).
-    split = all(l._use_split_gemm() for l in flow)
     if split:
         # three fp16 MFMAs per fp32 product: the matrix-pipe bound for fp32-equivalent flops is a third of the
         # dense fp16 peak
         peak = PEAK_F16_MFMA_TFLOPS / 3.0
         kernel = 'split_gemm_kernel<25,EPI_SPLINE> (fused MADE output layer + RQ spline + log-det; 3 x v_mfma_f32_16x16x32_f16 per fp32 product)'
-        tname = 'r01_final_pmc_traffic.json'             # counters of the final build of round 1 (profiles/README.md)
+        tnames = ('r02_pmc_traffic.json', 'r01_final_pmc_traffic.json')
     else:
         peak = PEAK_FP32_MFMA_TFLOPS
         kernel = 'gemm_kernel<2,25,EPI_SPLINE> (fused MADE output layer + RQ spline + log-det; v_mfma_f32_16x16x4_f32)'
-        tname = 'r01_pmc_traffic.json'
-    traffic = None
-    tpath = os.path.join(ROOT, 'profiles', tname)
-    if D == 3000 and B == 65536 and args.layers == 4 and os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath))['hbm_bytes_per_launch']
-        except Exception:
-            traffic = None
+        tnames = ('r01_pmc_traffic.json',)
+    traffic, traffic_src = None, None
+    if D == 3000 and B == 65536 and args.layers == 4:
+        for tname in tnames:
+            tpath = os.path.join(ROOT, 'profiles', tname)
+            try:
+                traffic, traffic_src = json.load(open(tpath))['hbm_bytes_per_launch'], 'profiles/' + tname
+                break
+            except Exception:
+                continue
 
     if rank == 0:
         res = {
             'metric': 'samples/s (fwd+log|detJ|) MAF+RQ-spline, 3N=3000, batch 64k',
-            'value': world * B * args.steps / elapsed,
+            'value': global_batch * args.steps / elapsed,
             'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic', 'repack': 'every_step',
             'gemm_arithmetic': ('fp32 operands as fp16 hi+lo halves, 3 fp16 MFMAs per product, fp32 accumulate '
                                 '(fp32-equivalent; spline / log-det in fp64)' if split else
                                 'fp32 MFMA, fp32 accumulate (spline / log-det in fp64)'),
-            'config': {'workload': f'cfg2: {args.layers}-layer MAF + RQ neural-spline ({args.bins} bins), '
-                                   f'{D} features (3x{D // 3} atoms), batch {B} per GPU, fp32, '
-                                   'forward + log|det J| + TFEP estimator',
-                       'global_batch': world * B, 'features': D, 'layers': args.layers,
+            'config': {'workload': f'cfg{2 if world == 1 else 3}: {args.layers}-layer MAF + RQ neural-spline ({args.bins} bins), '
+                                   f'{D} features (3x{D // 3} atoms), global batch {global_batch} '
+                                   f'({B} rows per GPU), fp32, forward + log|det J| + TFEP estimator',
+                       'global_batch': global_batch, 'rows_per_gpu': B, 'features': D, 'layers': args.layers,
                        'hidden_width': int(flow[0]._conditioner.dimensions_hidden[0]),
-                       'parallelism': f'dp{world} (batch-sharded replicas, 9-scalar RCCL all-gather)'},
+                       'parallelism': f'dp{world} (row-sharded batch, weight replicas, 9-scalar RCCL all-gather)'},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': traffic, 'kernel': kernel,
+                         'frac': achieved / peak, 'traffic': traffic, 'traffic_source': traffic_src, 'kernel': kernel,
                          'peak_basis': ('fp32-equivalent flops; dense fp16 MFMA peak 2516.6 TFLOP/s / 3 MFMAs per product'
                                         if split else 'dense fp32 MFMA peak'),
                          'vs_fp32_mfma_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
@@ -205,6 +254,7 @@ def main():
                          'whole_step_tflops': 2.0 * sum(nnz_all) * B * args.steps / elapsed / 1e12},
             'delta_f_estimate': float(out[2]),
         }
+        res.update(extra)
         if not args.no_cpu_baseline and world == 1:
             try:
                 base, (xs, ys, ls) = cpu_baseline(flow, D, args.bins, args.cpu_chunk)
@@ -213,7 +263,9 @@ def main():
                 with torch.no_grad():
                     yg, lg = flow[0](torch.from_numpy(xs).to(device))
                 res['cpu_check'] = {'rel_l2_y': float(np.linalg.norm(yg.cpu().numpy() - ys) / np.linalg.norm(ys)),
-                                    'max_abs_ldj': float(np.abs(lg.cpu().numpy() - ls).max())}
+                                    'max_abs_ldj': float(np.abs(lg.cpu().numpy() - ls).max()),
+                                    'note': 'GPU layer 0 vs the fp32 CPU restatement on the CPU chunk; the asserted fp64 '
+                                            'comparison at this width is tests/test_gpu_parity.py::test_cfg2_layer_vs_fp64_oracle'}
             except Exception as e:                              # the headline number must still print
                 res['cpu_baseline'] = {'value': None, 'unit': 'samples/s', 'cores': os.cpu_count(), 'kind': 'port',
                                        'sample': f'failed: {type(e).__name__}: {e}'}

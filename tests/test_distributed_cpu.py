@@ -95,7 +95,7 @@ def _worker(rank, world, port, q):
         lin = torch.nn.Linear(5, 3)
         for i, p in enumerate(lin.parameters()):
             p.grad = torch.full_like(p, float(rank + 1 + i))
-        allreduce_gradients(lin, bucket_bytes=40)
+        allreduce_gradients(lin, bucket_bytes=40, average=True)
         gavg = [float(p.grad.flatten()[0]) for p in lin.parameters()]
         q.put((rank, float(loss), float(df), gavg))
     finally:
@@ -120,6 +120,67 @@ def test_two_rank_gloo_allreduce_of_tfep_statistics():
         np.testing.assert_allclose(df, oloss.fep_estimator(uB - ldj - uA), rtol=1e-6)
         assert gavg == [1.5, 2.5]                           # mean over ranks of (rank + 1 + i)
     assert res[0][1:] == res[1][1:]
+
+
+def _stats_cpu(uB, ldj, uA, lw, bias, kT=1.0, ignore_nan=False):
+    """CPU stand-in for ops.tfep_reduce in the loss (the HIP reduction cannot run here): same 9 statistics."""
+    def a(t):
+        return None if t is None else t.detach().double().numpy()
+    uB_, ldj_, uA_ = a(uB), a(ldj), a(uA)
+    z = np.zeros_like(uB_)
+    return torch.tensor(shard_stats(uB_, z if ldj_ is None else ldj_, z if uA_ is None else uA_, a(lw), a(bias),
+                                    kT=kT, ignore_nan=ignore_nan))
+
+
+def _loss_grad_worker(rank, world, port, q, weighted):
+    """Distributed loss + gradient sync: every rank must end with the gradient of the GLOBAL-batch loss."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import tfep_amd.loss as tl
+        tl.ops.tfep_reduce = _stats_cpu                      # this process only
+        torch.manual_seed(0)
+        n = 11                                               # ragged shards (6 + 5)
+        x = torch.randn(n, 4, dtype=torch.float64)
+        lw = torch.randn(n, dtype=torch.float64) if weighted else None
+        lin = torch.nn.Linear(4, 2).double()                 # same replica on every rank (seeded)
+        b, e = shard_rows(n, rank, world)
+        out = lin(x[b:e])
+        loss = tl.BoltzmannKLDivLoss(distributed=True)(out[:, 0], out[:, 1], None if lw is None else lw[b:e])
+        loss.backward()
+        allreduce_gradients(lin, bucket_bytes=40)            # default: SUM
+        q.put((rank, float(loss), [p.grad.flatten().tolist() for p in lin.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('weighted', [False, True])
+def test_two_rank_gloo_loss_and_gradient_sync_match_single_process(weighted):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_loss_grad_worker, args=(r, world, port, q, weighted)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process, full batch, plain torch (reference loss.py:125-140)
+    torch.manual_seed(0)
+    n = 11
+    x = torch.randn(n, 4, dtype=torch.float64)
+    lw = torch.randn(n, dtype=torch.float64) if weighted else None
+    lin = torch.nn.Linear(4, 2).double()
+    out = lin(x)
+    r = out[:, 0] - out[:, 1]
+    loss = (torch.softmax(lw, 0) * r).sum() if weighted else r.mean()
+    loss.backward()
+    for _, l, grads in res:
+        np.testing.assert_allclose(l, float(loss), rtol=1e-6)      # the statistics round r to float32
+        for g, p in zip(grads, lin.parameters()):
+            np.testing.assert_allclose(g, p.grad.flatten().numpy(), rtol=1e-10, atol=1e-14)
 
 
 def _log_worker(rank, world, port, q, log_dir):
@@ -161,3 +222,44 @@ def test_two_rank_gloo_gather_of_per_sample_logs(tmp_path):
     assert res[0]['potential'] == [i * 0.5 - 1.0 for i in range(7)]
     back = TFEPLogger(save_dir_path=str(tmp_path / 'log')).read_eval_tensors(step_idx=0)
     assert back['dataset_sample_index'].tolist() == list(range(7)) and back['potential'].tolist() == res[0]['potential']
+
+
+def _bench_shard_worker(rank, world, port, q):
+    """bench.py's cfg3 sharding on gloo: every rank reduces ITS rows of the one global batch; the all-gathered
+    statistics give every rank the estimate of the whole 64k-row batch (the numbers, not the GPU kernels, are under test)."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import bench
+        n = 65536
+        row0, row1, glob = bench.rows_for_rank(n, rank, world, 'strong')
+        work = np.random.default_rng(7).standard_normal(n)             # the same global batch on every rank
+        z = np.zeros(row1 - row0)
+        local = torch.tensor(shard_stats(work[row0:row1], z, z, None, None))
+        _, df = finalize(allreduce_stats(local).numpy(), weighted=False, biased=False)
+        q.put((rank, row0, row1, glob, float(df)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_strong_scaling_shards_one_global_batch():
+    import bench
+    assert bench.rows_for_rank(65536, 3, 8, 'strong') == (3 * 8192, 4 * 8192, 65536)      # BASELINE cfg3
+    assert bench.rows_for_rank(65536, 0, 1, 'strong') == (0, 65536, 65536)                # N = 1: cfg2 unchanged
+    assert bench.rows_for_rank(65536, 3, 8, 'weak') == (3 * 65536, 4 * 65536, 8 * 65536)
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bench_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2], r[3]) for r in res] == [(0, 32768, 65536), (32768, 65536, 65536)]
+    work = np.random.default_rng(7).standard_normal(65536)
+    ref = oloss.fep_estimator(work.astype(np.float32).astype(np.float64))
+    for r in res:
+        np.testing.assert_allclose(r[4], ref, rtol=1e-6)

@@ -285,3 +285,56 @@ def test_graph_replay_of_the_blocked_inverse_equals_the_eager_inverse(split):
     for xg, lg in outs:
         assert torch.equal(xg, xe) and torch.equal(lg, le)
     assert float((xe - x).abs().max()) < 5e-3
+
+
+@pytest.mark.parametrize('transformer', ['spline', 'affine'])
+def test_checkpoint_from_another_degree_order_loads_into_consistent_plans(transformer):
+    """Two MAFs built with different random degree orders; after ``load_state_dict`` the second must compute what the
+    first computes -- forward (fused + generic), blocked inverse and pass-per-degree inverse -- also when its plans
+    were already built for its own degrees before the load (stale k-ranges / blocked plan)."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF, SequentialFlow
+    from tfep_amd.nn.transformers import AffineTransformer, NeuralSplineTransformer
+    D = 23
+
+    def build(seed):
+        torch.manual_seed(seed)
+        tr = (lambda: NeuralSplineTransformer(torch.full((D,), -4.0), torch.full((D,), 4.0), 8)) \
+            if transformer == 'spline' else AffineTransformer
+        return SequentialFlow(*[MAF(generate_degrees(D, 'random'), transformer=tr(), initialize_identity=False)
+                                for _ in range(2)]).cuda()
+    a, b = build(3), build(11)
+    x = (torch.randn(70, D, generator=torch.Generator().manual_seed(2)) * 1.3).cuda()
+    with torch.no_grad():
+        b(x), b.inverse(x)                               # plans of b's OWN degrees exist before the load
+        b.load_state_dict(a.state_dict(), strict=True)
+        ya, la = a(x)
+        xa, lia = a.inverse(ya)
+        for fused in (True, False):
+            for layer in b:
+                layer.fused = fused
+            yb, lb = b(x)
+            assert torch.equal(ya, yb) and torch.equal(la, lb)
+        assert all(layer._blocked_ok() for layer in b)
+        xb, lib = b.inverse(ya)
+        assert torch.equal(xa, xb) and torch.equal(lia, lib)
+        for layer in b:
+            layer.blocked_inverse = False
+        xr, lir = b.inverse(ya)
+        assert torch.allclose(xr, xa, rtol=1e-5, atol=2e-5) and torch.allclose(lir, lia, rtol=1e-5, atol=1e-4)
+        assert torch.allclose(xa, x, atol=2e-4)
+
+
+def test_inverse_under_autograd_fails_loudly_at_backward():
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    torch.manual_seed(0)
+    maf = MAF(generate_degrees(6, 'ascending'), initialize_identity=False).cuda()
+    y = torch.randn(9, 6, device='cuda')
+    x, l = maf.inverse(y)                                 # values are computed ...
+    assert x.requires_grad and torch.isfinite(x).all()
+    with pytest.raises(NotImplementedError):
+        (x.sum() + l.sum()).backward()                    # ... differentiating them raises
+    with torch.no_grad():
+        x2, _ = maf.inverse(y)
+    assert not x2.requires_grad and torch.equal(x2, x.detach())

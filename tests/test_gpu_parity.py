@@ -55,8 +55,27 @@ def test_affine_volpres():
     # float32 wrap of a float32 sum: compare against the reference's own float32 result exactly-ish
     np.testing.assert_allclose(y.cpu().numpy(), g['volpres/y_f32'], rtol=0, atol=1e-6)
     assert torch.all(l == 0)
-    x, _ = t.inverse(dev(g['volpres/y_f32']), dev(g['volpres/par']))
-    assert x.shape == y.shape
+    x, li = t.inverse(dev(g['volpres/y_f32']), dev(g['volpres/par']))
+    assert x.shape == y.shape and torch.all(li == 0)
+    # value check of the inverse: x = (y - b) wrapped into the period on the periodic columns (affine.py:414-456), in
+    # float64 from the same float32 inputs; on the circle a value within rounding of a period boundary may land on
+    # either end, so periodic columns are compared modulo the period
+    xr = g['volpres/y_f32'].astype(np.float64) - g['volpres/par'].astype(np.float64)
+    pidx = g['volpres/periodic_indices'].astype(np.int64)
+    lo, hi = (float(v) for v in g['volpres/periodic_limits'])
+    xr[:, pidx] = np.mod(xr[:, pidx], hi - lo) + lo
+    d = np.abs(x.cpu().numpy().astype(np.float64) - xr)
+    d[:, pidx] = np.minimum(d[:, pidx], (hi - lo) - d[:, pidx])
+    assert d.max() < 2e-6
+    if 'volpres/xinv_f64' in g.files:                      # the reference's own float64 inverse, when the fixture has it
+        d = np.abs(x.cpu().numpy().astype(np.float64) - g['volpres/xinv_f64'])
+        d[:, pidx] = np.minimum(d[:, pidx], (hi - lo) - d[:, pidx])
+        assert d.max() < 2e-6
+    # and forward(inverse(y)) == y on the circle
+    y2, _ = t(x, dev(g['volpres/par']))
+    d = (y2 - dev(g['volpres/y_f32'])).abs().cpu().numpy()
+    d[:, pidx] = np.minimum(d[:, pidx], (hi - lo) - d[:, pidx])
+    assert d.max() < 2e-6
 
 
 def _spline_names():
@@ -371,9 +390,64 @@ def test_cfg2_size_properties():
     assert torch.allclose(li + l[:256], torch.zeros(256, device='cuda'), atol=2e-3)
 
 
+@pytest.mark.parametrize('split', [True, False])
+def test_cfg2_layer_vs_fp64_oracle(split):
+    """One MAF + RQ-8 layer at the BASELINE cfg2 width (D=3000, H=14998, P*D=75000) on 512 rows against the float64
+    oracle (same float32 weights and inputs), with the documented tolerances ASSERTED: rel L2(y) <= 1e-5 and
+    per sample |d ldj| <= max(1e-5 max(1, |ldj|), 4 x the float32 oracle's own error vs float64 on the same data)
+    -- for the split-f16 GEMMs (the default forward) and for the exact-fp32 MFMA GEMMs."""
+    from oracle import made as omade, transformers as otr
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    D, B, K = 3000, 512, 8
+    torch.manual_seed(0)
+    with torch.device('cuda'):
+        layer = MAF(generate_degrees(D, 'ascending'),
+                    transformer=NeuralSplineTransformer(torch.full((D,), -5.0), torch.full((D,), 5.0), K),
+                    initialize_identity=False)
+    layer.split_gemm = split
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(1234)).clamp_(-4.9, 4.9)
+    with torch.no_grad():
+        y, l = layer(x.cuda())
+    y, l = y.cpu().numpy().astype(np.float64), l.cpu().numpy().astype(np.float64)
+
+    def oracle(dtype):
+        # oracle/made.py row-chunked over the output units (weight norm is per row): the float64 copy of the
+        # 75000 x 14998 output layer would not fit otherwise
+        h = x.numpy().astype(dtype)
+        lins = list(layer._conditioner.layers[::2])
+        for li, lin in enumerate(lins):
+            outs = []
+            for r0 in range(0, lin.out_features, 8192):
+                sl = slice(r0, r0 + 8192)
+                mask = lin.mask[sl].cpu().numpy().astype(dtype)
+                w = omade.weight_norm_effective(lin.weight_g[sl].detach().cpu().numpy().astype(dtype),
+                                                lin.weight_v[sl].detach().cpu().numpy().astype(dtype), mask)
+                outs.append(omade.masked_linear(h, w, lin.bias[sl].detach().cpu().numpy().astype(dtype), mask))
+            h = np.concatenate(outs, axis=1)
+            if li + 1 < len(lins):
+                h = omade.elu(h)
+        return otr.spline_forward(x.numpy().astype(dtype), h, np.full(D, -5.0, dtype), np.full(D, 5.0, dtype), K)
+
+    y64, l64 = oracle(np.float64)
+    y32, l32 = oracle(np.float32)
+    noise_y = np.linalg.norm(y32 - y64) / np.linalg.norm(y64)
+    noise_l = np.abs(l32.astype(np.float64) - l64).max()
+    rel = np.linalg.norm(y - y64) / np.linalg.norm(y64)
+    err_l = np.abs(l - l64)
+    tol_l = np.maximum(1e-5 * np.maximum(1.0, np.abs(l64)), 4.0 * noise_l)
+    print(f'cfg2 layer vs fp64 oracle ({"split-f16" if split else "exact-fp32"} GEMMs): rel L2(y) {rel:.2e} '
+          f'(fp32 oracle {noise_y:.2e}), max |d ldj| {err_l.max():.2e} (fp32 oracle {noise_l:.2e}, |ldj| median '
+          f'{np.median(np.abs(l64)):.1f}), max |dy| {np.abs(y - y64).max():.2e}')
+    assert rel <= 1e-5
+    assert bool((err_l <= tol_l).all()), (err_l.max(), tol_l.min())
+    assert err_l.max() <= 1e-5 * max(1.0, np.abs(l64).max()) + 4.0 * noise_l
+
+
 def test_cfg4_size_properties():
-    """Circular RQ-8 + periodic embedding on 512 torsions, batch 131072: outputs stay in the period,
-    the map is periodic (x and x + period agree), and the inverse round-trips on a slice."""
+    """Circular RQ-8 + periodic embedding on 512 torsions, batch 131072, all 4 layers of BASELINE cfg4-i: outputs stay
+    in the period, the map is periodic (x and x + period agree), and the inverse round-trips on a slice."""
     from tfep_amd.nn.conditioners import generate_degrees
     from tfep_amd.nn.embeddings import PeriodicEmbedding
     from tfep_amd.nn.flows import MAF, SequentialFlow
@@ -384,7 +458,7 @@ def test_cfg4_size_properties():
         flow = SequentialFlow(*[
             MAF(generate_degrees(D, 'ascending' if i % 2 == 0 else 'descending'),
                 transformer=NeuralSplineTransformer(torch.zeros(D), torch.ones(D), 8, circular=True),
-                embedding=PeriodicEmbedding(D, limits=[0.0, 1.0]), initialize_identity=False) for i in range(2)])
+                embedding=PeriodicEmbedding(D, limits=[0.0, 1.0]), initialize_identity=False) for i in range(4)])
     x = torch.rand(B, D, device='cuda', generator=torch.Generator('cuda').manual_seed(2))
     y, l = flow(x)
     assert bool(((y >= 0) & (y <= 1)).all()) and torch.isfinite(l).all()
@@ -397,6 +471,38 @@ def test_cfg4_size_properties():
     d = torch.minimum(d, 1.0 - d)                      # distance on the circle
     assert float(d.max()) < 2e-4
     assert torch.allclose(li + l[:512], torch.zeros(512, device='cuda'), atol=5e-3)
+
+
+def test_cfg4_moebius_size_properties():
+    """BASELINE cfg4-ii at size: 4-layer MAF with Moebius(d=2, unit sphere) on 512 torsions as unit 2-vectors (1024
+    features, ``repeats=2`` degrees), batch 131072.  Size-independent properties: outputs stay on the unit circle, row
+    independence bit for bit, run-to-run determinism, and the blocked inverse round-trips with cancelling log-dets."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF, SequentialFlow
+    from tfep_amd.nn.transformers import MoebiusTransformer
+    n_vec, B = 512, 131072
+    D = 2 * n_vec
+    torch.manual_seed(0)
+    with torch.device('cuda'):
+        flow = SequentialFlow(*[
+            MAF(generate_degrees(D, 'ascending' if i % 2 == 0 else 'descending', repeats=2),
+                transformer=MoebiusTransformer(dimension=2, unit_sphere=True), initialize_identity=False)
+            for i in range(4)])
+    theta = torch.rand(B, n_vec, device='cuda', generator=torch.Generator('cuda').manual_seed(3)) * (2 * np.pi)
+    x = torch.stack([torch.cos(theta), torch.sin(theta)], dim=-1).reshape(B, D)
+    with torch.no_grad():
+        y, l = flow(x)
+        assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(l).all())
+        r = y.reshape(B, n_vec, 2).norm(dim=-1)
+        assert float((r - 1).abs().max()) < 1e-4                                  # unit circle preserved through 4 layers
+        y2, l2 = flow(x)
+        assert torch.equal(y, y2) and torch.equal(l, l2)
+        for lo, hi in ((0, 200), (77777, 77777 + 131), (B - 64, B)):
+            ys, ls = flow(x[lo:hi].clone())
+            assert torch.equal(ys, y[lo:hi]) and torch.equal(ls, l[lo:hi]), (lo, hi)
+        xi, li = flow.inverse(y[5000:5000 + 512])
+        assert float((xi - x[5000:5000 + 512]).abs().max()) < 5e-4
+        assert torch.allclose(li + l[5000:5000 + 512], torch.zeros(512, device='cuda'), atol=5e-3)
 
 
 def test_circular_spline_fixed_points_and_periodicity():

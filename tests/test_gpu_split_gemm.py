@@ -71,6 +71,51 @@ def test_split_gemm_matches_float64(B, K, N, act):
     assert torch.equal(y, y2)
 
 
+def test_split_gemm_rows_spanning_ten_decades_under_a_triangular_mask():
+    """MADE's structure at its worst for a per-row scale: activations whose magnitude grows by 10 decades along k and a
+    prefix (autoregressive) mask, so that early outputs see ONLY the tiny entries while the row scale is set by the
+    largest one.  What the split format promises -- and what is asserted -- is an ABSOLUTE error of ~2^-22 of
+    (row maximum) x sum_k |w_jk| per output (fp32-equivalent norm-wise per row); the exact-fp32 MFMA kernel is also
+    accurate COMPONENT-wise (error relative to sum_k |a_k w_jk| of the visible entries).  Both are measured and
+    printed side by side; the component-wise loss of the split path on the outputs that see only entries below
+    ~2^-19 of the row maximum is the documented limit (use ``split_gemm=False`` for such data)."""
+    from tfep_amd import ops
+    tm, tn, tk = ops.tile_sizes()
+    torch.manual_seed(5)
+    B, K, N = 256, 1024, 1024
+    decades = 10.0 * torch.arange(K, device='cuda') / (K - 1) - 10.0             # 1e-10 ... 1 along k
+    a = torch.randn(B, K, device='cuda') * torch.pow(10.0, decades)[None, :]
+    w = torch.randn(N, K, device='cuda') / K ** 0.5
+    deg_in = torch.arange(K, device='cuda')
+    deg_out = torch.sort(torch.randint(1, K + 1, (N,), device='cuda')).values
+    mask = (deg_out[:, None] > deg_in[None, :]).float()                          # row j sees the prefix k < deg_out[j]
+    npad = ops.round_up(N, tk)
+    wp = ops.masked_weight_prepare(w, None, mask, n_rows_padded=npad, k_padded=K)
+    bias = torch.zeros(npad, device='cuda')
+    wm = (w * mask).double()
+    ref = a.double() @ wm.T
+    comp = a.double().abs() @ wm.abs().T                                        # sum_k |a_k w_jk| over the visible k
+    rowmax = a.double().abs().max(dim=1, keepdim=True).values * wm.abs().sum(dim=1)[None, :]
+    as_, ainv = ops.split_rows(a.contiguous(), K)
+    ws_, winv = ops.split_rows(wp, K, per_tensor=True)
+    y_split = ops.masked_linear_split(as_, ainv, ws_, winv, bias, N, act=0).double()
+    y_fp32 = ops.masked_linear_packed(a.contiguous(), wp, bias, N, act=0).double()
+    seen = comp > 0
+    cw_split = float(((y_split - ref).abs() / comp)[seen].max())
+    cw_fp32 = float(((y_fp32 - ref).abs() / comp)[seen].max())
+    nw_split = float(((y_split - ref).abs() / rowmax)[seen].max())
+    nw_fp32 = float(((y_fp32 - ref).abs() / rowmax)[seen].max())
+    # outputs whose visible entries are all within 2^-12 of the row maximum keep fp32-like component-wise accuracy
+    big = seen & (comp > rowmax * 2.0 ** -12)
+    cw_split_big = float(((y_split - ref).abs() / comp)[big].max())
+    print(f'10-decade rows, prefix mask: component-wise max error split {cw_split:.2e} / exact-fp32 {cw_fp32:.2e}; '
+          f'relative to (row max x sum|w|): split {nw_split:.2e} / exact-fp32 {nw_fp32:.2e}; '
+          f'split, outputs within 2^-12 of the row scale: {cw_split_big:.2e}')
+    assert cw_fp32 < 2e-6                         # exact fp32 products: accurate component-wise
+    assert nw_split < 1e-6                        # split: fp32-equivalent relative to the row scale ...
+    assert cw_split_big < 1e-3                    # ... and component-wise wherever the entries are not dwarfed
+
+
 def test_split_gemm_with_mask_k_ranges_and_tile_order():
     """Block-triangular mask (sorted MADE degrees): k-ranges in units of 32 skip tiles; results as the dense product."""
     from tfep_amd import ops

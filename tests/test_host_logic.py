@@ -176,3 +176,28 @@ def test_inverse_masks_and_indices_buffers():
     assert maf._inverse_masks.int().tolist() == [[0, 1, 1, 0, 0, 0], [0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 0, 1]]
     maf = MAF(degrees_in=[0, 1, 2])
     assert maf._transformer_indices.numel() == 0 and not maf.has_fixed_indices
+
+
+@pytest.mark.parametrize('hidden', [2, [20, 17]])
+def test_load_state_dict_rederives_degrees_from_the_loaded_buffers(hidden):
+    """A checkpoint saved from a model with another (random) degree order replaces the masks; the host copy of the
+    degrees that drives the execution plans / blocked inverse must follow (reference: everything derives from buffers)."""
+    def build(seed, order='random'):
+        torch.manual_seed(seed)
+        return MAF(generate_degrees(7, order, conditioning_indices=[2]), transformer=AffineTransformer(),
+                   hidden_layers=hidden)
+    a, b = build(1), build(5)
+    assert not torch.equal(a._conditioner._degrees[0], b._conditioner._degrees[0])
+    b.load_state_dict(a.state_dict(), strict=True)
+    assert b._conditioner._degrees_stale
+    b._sync_conditioner()
+    for da, db in zip(a._conditioner._degrees, b._conditioner._degrees):
+        assert torch.equal(da, db)
+    assert b._conditioner._degrees_ok and not b._conditioner._degrees_stale
+    assert b._blocked_ok()
+    # masks that no degree assignment reproduces: degree shortcuts off, nothing raises
+    c = build(5)
+    c._conditioner.layers[2].mask[0, :] = 1.0 - c._conditioner.layers[2].mask[0, :]
+    c._conditioner.invalidate_plan()
+    c._sync_conditioner()
+    assert not c._conditioner._degrees_ok and not c._blocked_ok()

@@ -143,7 +143,7 @@ def load():
         # Not a fallback: compile the HIP sources in-tree (hipcc, ~10 s) if the library did not travel.
         try:
             from . import build as _build
-            _build.build(force=True, verbose=False)
+            _build.build(verbose=False)          # under a file lock, atomic rename: safe with one process per GPU
         except Exception as e:  # noqa: BLE001
             raise TfepHipError(
                 f'{LIB_PATH} not found and building it failed ({e}); run `python -m tfep_amd.build` '

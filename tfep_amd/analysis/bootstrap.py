@@ -25,7 +25,6 @@ def bootstrap(data, statistic, *, confidence_level=0.95, n_resamples=9999, boots
     n_samples = len(data)
     if bayesian and generator is not None:
         raise ValueError('Bayesian bootstrapping does not support random number generators.')
-    single = bootstrap_sample_size is None or isinstance(bootstrap_sample_size, int)
     if bootstrap_sample_size is None:
         sizes = [n_samples]
     else:
@@ -33,6 +32,7 @@ def bootstrap(data, statistic, *, confidence_level=0.95, n_resamples=9999, boots
             raise ValueError('With Bayesian bootstrapping, specifying a bootstrap_sample_size '
                              'is supported only when take_first_only is True.')
         sizes = [bootstrap_sample_size] if isinstance(bootstrap_sample_size, int) else list(bootstrap_sample_size)
+    single = len(sizes) == 1                  # also a one-element list (reference bootstrap.py: len(...) == 1)
     if method not in ('percentile', 'basic'):
         raise ValueError("method must be 'percentile' or 'basic'")
     if isinstance(generator, int):

@@ -1,4 +1,10 @@
-"""Build libtfep_hip.so (gfx950) in-tree with hipcc.  ``python -m tfep_amd.build``."""
+"""Build libtfep_hip.so (gfx950) in-tree with hipcc.  ``python -m tfep_amd.build``.
+
+Safe under the one-process-per-GPU launch: the whole build runs under an exclusive file lock, objects are only
+recompiled when their source (or any header) is newer, and the library is linked to a temporary name and moved into
+place with ``os.replace`` -- a concurrent ``dlopen`` sees the old file or the new one, never a half-written one.
+"""
+import fcntl
 import os
 import subprocess
 import sys
@@ -17,12 +23,17 @@ def _hipcc():
     raise RuntimeError('hipcc not found')
 
 
+def _headers():
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    deps.append(os.path.join(os.path.dirname(HERE), 'include', 'tfep_hip.h'))
+    return deps
+
+
 def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-    deps.append(os.path.join(os.path.dirname(HERE), 'include', 'tfep_hip.h'))
+    deps = [os.path.join(CSRC, f) for f in SOURCES] + _headers()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -31,23 +42,47 @@ def build(force=False, verbose=True):
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    objs = []
-    procs = []
+    with open(os.path.join(LIB_DIR, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():      # another process built it while this one waited for the lock
+                return LIB_PATH
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
+    t_hdr = max(os.path.getmtime(h) for h in _headers())
+    objs, procs = [], []
     for src in SOURCES:
+        path = os.path.join(CSRC, src)
         obj = os.path.join(LIB_DIR, src.replace('.hip', '.o'))
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(path), t_hdr):
+            continue
+        tmp = obj + f'.{os.getpid()}.tmp'
         cmd = [_hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc',
-               '-Wno-unused-result', '-c', os.path.join(CSRC, src), '-o', obj]
+               '-Wno-unused-result', '-c', path, '-o', tmp]
         if verbose:
             print(' '.join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd)))
-        objs.append(obj)
-    for src, p in procs:
+        procs.append((src, tmp, obj, subprocess.Popen(cmd)))
+    failed = []
+    for src, tmp, obj, p in procs:
         if p.wait() != 0:
-            raise RuntimeError(f'hipcc failed on {src}')
-    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+            failed.append(src)
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        else:
+            os.replace(tmp, obj)
+    if failed:
+        raise RuntimeError(f'hipcc failed on {", ".join(failed)}')
+    tmp = LIB_PATH + f'.{os.getpid()}.tmp'
+    cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', tmp] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 

@@ -47,8 +47,13 @@ def shard_rows(n_rows, rank, world_size):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def allreduce_gradients(module, group=None, bucket_bytes=1 << 30, average=True, reduce_scatter=None):
-    """Data-parallel training: sum (average) the ``.grad`` of every parameter across ranks.
+def allreduce_gradients(module, group=None, bucket_bytes=1 << 30, average=False, reduce_scatter=None):
+    """Data-parallel training: SUM the ``.grad`` of every parameter across ranks.
+
+    The sum is what pairs with ``BoltzmannKLDivLoss(distributed=True)``: that loss is the loss of the GLOBAL batch and
+    its backward already weights every local sample by ``1/N_global`` (or by the global softmax weight), so the
+    gradient of the reported loss is the sum of the ranks' local gradients.  ``average=True`` divides by the world
+    size afterwards -- only for a loss that each rank normalises by its LOCAL batch (``distributed=False``).
 
     Gradients are copied into a few large flat buckets (default 1 GiB: the 22 GB of cfg2 gradients
     go out as ~22 collectives, each long enough to run at link bandwidth on the point-to-point

@@ -143,8 +143,14 @@ class MADE(Conditioner):
 
         # Host-side copy of the degrees (drives the degree sort of the execution plan).
         self._degrees = [d.detach().cpu().clone() for d in (degrees_in, *degrees_hidden, degrees_out)]
+        self._degrees_stale = False    # set when the mask buffers are replaced (load_state_dict, in-place edits)
+        self._degrees_ok = True        # False: the masks are not those of any degree assignment we can recover
         self._plans = {}
         self._frozen = False
+        #: Keep the packed (weight-normed, masked, permuted, split) weights across forwards while no parameter or mask
+        #: has been updated in place (``Tensor._version``); default off: re-pack on every forward like the reference's
+        #: pre-hook (masked.py:397-398).  SURVEY.md section 8(b) sanctions caches invalidated by parameter version.
+        self.cache_packed_weights = False
         self._packed_ahead = None      # split weights packed on a side stream for the next forward (prepack_split_async)
 
     # ------------------------------------------------------------------ reference API
@@ -218,6 +224,77 @@ class MADE(Conditioner):
     def invalidate_plan(self):
         """Drop cached permutations / k-ranges (call after replacing a ``mask`` buffer)."""
         self._plans = {}
+        self._packed_ahead = None
+        self._degrees_stale = True
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        # A checkpoint replaces the mask buffers (e.g. one saved from a model built with another random degree order):
+        # everything derived from the degrees -- the host copy, the plans, packed weights -- is re-derived from the
+        # loaded buffers on the next use (reference: every quantity derives from the buffers, made.py:286-329).
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate_plan()
+
+    def _mask_versions(self):
+        return tuple(lin.mask._version for lin in self._linears())
+
+    def _masks_of(self, degrees):
+        """True when ``degrees`` (one tensor per layer, inputs first) reproduce every mask buffer."""
+        lins = self._linears()
+        if len(degrees) != len(lins) + 1:
+            return False
+        for li, lin in enumerate(lins):
+            d_in, d_out = degrees[li].to(lin.mask.device), degrees[li + 1].to(lin.mask.device)
+            if (len(d_out), len(d_in)) != tuple(lin.mask.shape):
+                return False
+            strict = li == len(lins) - 1
+            for r0 in range(0, len(d_out), 4096):                       # row chunks: the cfg2 masks are 4.5 GB
+                a = d_out[r0:r0 + 4096, None]
+                m = (a > d_in[None, :]) if strict else (a >= d_in[None, :])
+                if not bool(torch.equal(m, lin.mask[r0:r0 + 4096] != 0)):
+                    return False
+        return True
+
+    def _sync_degrees(self, degrees_in=None):
+        """Make the host copy of the degrees agree with the (possibly just loaded) mask buffers.
+
+        ``degrees_in``: the input degrees when the caller knows them (``AutoregressiveFlow`` derives them from its
+        ``_inverse_masks`` buffer).  Hidden and output degrees are re-derived from the masks: a unit's degree is the
+        largest degree it is connected to (+1 for the strict output layer) -- exact for MADE, whose hidden degrees
+        are drawn from the input degrees (made.py:388-422).  If no assignment reproduces the masks the degree-based
+        shortcuts (blocked inverse) are switched off; the GEMMs always take their k-ranges from the actual masks."""
+        if not self._degrees_stale:
+            return
+        self._degrees_stale = False
+        self._plans = {}
+        self._packed_ahead = None
+        if degrees_in is not None:
+            degrees_in = ensure_tensor_sequence(degrees_in, dtype=int).detach().cpu()
+        current = list(self._degrees)
+        if degrees_in is not None and len(degrees_in) == len(current[0]):
+            current[0] = degrees_in
+        with torch.no_grad():
+            if self._masks_of(current):
+                self._degrees, self._degrees_ok = [d.clone() for d in current], True
+                return
+            lins = self._linears()
+            derived = [current[0]]
+            for li, lin in enumerate(lins):
+                prev = derived[-1].to(lin.mask.device)
+                if len(prev) != lin.mask.shape[1]:
+                    self._degrees_ok = False
+                    return
+                low = int(prev.min()) - 1
+                rows = []
+                for r0 in range(0, lin.mask.shape[0], 4096):
+                    m = lin.mask[r0:r0 + 4096] != 0
+                    rows.append(torch.where(m, prev[None, :], torch.full_like(prev[None, :], low)).max(dim=1).values)
+                d = torch.cat(rows)
+                if li == len(lins) - 1:
+                    d = d + 1
+                derived.append(d.cpu())
+            self._degrees_ok = self._masks_of(derived)
+            if self._degrees_ok:
+                self._degrees = derived
 
     def _apply(self, fn, *args, **kwargs):
         self._plans = {}
@@ -227,13 +304,18 @@ class MADE(Conditioner):
     def plan(self, device):
         """Per-device plan: hidden-unit permutations, padded sizes, k-ranges, work buffers."""
         key = str(device)
-        if key in self._plans:
-            return self._plans[key]
+        cached = self._plans.get(key)
+        if cached is not None and cached['mask_versions'] != self._mask_versions():
+            self.invalidate_plan()                      # a mask was edited in place
+            cached = None
+        self._sync_degrees()
+        if cached is not None:
+            return cached
         tm, tn, tk = ops.tile_sizes()
         lins = self._linears()
         n_lin = len(lins)
         plan = {'row_of_out': [], 'col_of_in': [], 'in_of_col': [], 'n_pad': [], 'k_pad': [], 'k_ranges': [], 'tile_order': [],
-                'w': [None] * n_lin, 'bias': [None] * n_lin}
+                'w': [None] * n_lin, 'bias': [None] * n_lin, 'mask_versions': self._mask_versions()}
         col_of_in = None
         for li, lin in enumerate(lins):
             is_out = li == n_lin - 1
@@ -242,7 +324,10 @@ class MADE(Conditioner):
                 row_of_out = None
                 n_pad = lin.out_features
             else:
-                deg = self._degrees[li + 1].cpu()
+                if self._degrees_ok:
+                    deg = self._degrees[li + 1].cpu()
+                else:       # masks of unknown origin: fewer connections first (any order is correct, see k_ranges below)
+                    deg = torch.count_nonzero(lin.mask, dim=1).cpu()
                 order = torch.argsort(deg, stable=True)              # packed position -> hidden unit
                 row = torch.empty_like(order)
                 row[order] = torch.arange(len(order), device='cpu')                # hidden unit -> packed position
@@ -276,8 +361,10 @@ class MADE(Conditioner):
         # one buffer per (layer, row order): zeroed once -- the kernel rewrites every mapped entry and never touches the
         # padding, so later packs skip the clear (a 4.5 GB write for the cfg2 output layer)
         key = ('w', li, n_rows, None if row_of_out is None else row_of_out.data_ptr())
-        if self._frozen and ('packed', li, n_rows) in plan:
-            return plan[('packed', li, n_rows)]
+        ckey = ('packed',) + key[1:]
+        keep = self._keep_packed(plan)
+        if keep and ckey in plan:
+            return plan[ckey]
         entry = plan.get(key)
         if entry is None:
             # (the entry keeps row_of_out alive: its address, part of the key, cannot be recycled for another mapping)
@@ -290,8 +377,8 @@ class MADE(Conditioner):
             bias[0, :lin.out_features] = lin.bias.detach()
         else:
             ops.scatter_columns(lin.bias.detach()[None, :], row_of_out, bias)
-        if self._frozen:
-            plan[('packed', li, n_rows)] = (buf, bias[0])
+        if keep:
+            plan[ckey] = (buf, bias[0])
         return buf, bias[0]
 
     def _pack_bias(self, lin, row_of_out, n_rows):
@@ -307,8 +394,10 @@ class MADE(Conditioner):
         for the matrix).  Returns ``(w_split, w_inv_scale, bias)``."""
         row_of_out = plan['row_of_out'][li] if row_of_out is None else row_of_out
         n_rows = plan['n_pad'][li] if n_rows is None else n_rows
-        if self._frozen and ('packed_split', li, n_rows) in plan:
-            return plan[('packed_split', li, n_rows)]
+        ckey = ('packed_split', li, n_rows, None if row_of_out is None else row_of_out.data_ptr())
+        keep = self._keep_packed(plan)
+        if keep and ckey in plan:
+            return plan[ckey]
         ahead = self._packed_ahead
         if ahead is not None and ahead['versions'] != self._param_versions():
             ahead = self._packed_ahead = None                     # parameters changed since: pack again
@@ -338,9 +427,23 @@ class MADE(Conditioner):
                                         col_cut=self._mask_prefix_cuts(plan, li, lin))
         bias = self._pack_bias(lin, row_of_out, n_rows)
         res = (buf[0], buf[1], bias, ops.abs_reduce(bias.reshape(1, -1), 'row_max'))
-        if self._frozen:
-            plan[('packed_split', li, n_rows)] = res
+        if keep:
+            plan[ckey] = res
         return res
+
+    def _keep_packed(self, plan):
+        """True when packed weights may be kept in (and served from) ``plan``: inside ``frozen_weights()``, or with
+        ``cache_packed_weights`` while every parameter / mask still has the version the cache was filled at."""
+        if self._frozen:
+            return True
+        if not self.cache_packed_weights or torch.cuda.is_current_stream_capturing():
+            return False
+        versions = self._param_versions()
+        if plan.get('packed_versions') != versions:
+            for k in [k for k in plan if isinstance(k, tuple) and k[0] in ('packed', 'packed_split')]:
+                del plan[k]
+            plan['packed_versions'] = versions
+        return True
 
     def _mask_prefix_cuts(self, plan, li, lin):
         """``col_cut`` of ``tfep_masked_weight_prepare_split`` for layer ``li``, or None.
@@ -381,6 +484,8 @@ class MADE(Conditioner):
         plan = self.plan(device)
         lins = self._linears()
         self._packed_ahead = None
+        if self.cache_packed_weights and not self._frozen:
+            return                                 # the cache already holds (or the forward will fill) the packed weights
         stream.wait_stream(torch.cuda.current_stream(device))
         items = {}
         with torch.cuda.stream(stream):
