@@ -361,3 +361,29 @@ def build_embedding(cfg, module):
                                      embedding_layers=[build_embedding(c, module) for c in cfg['layers']],
                                      embedded_indices=cfg['embedded_indices'])
     raise ValueError(kind)
+
+
+def continuous_configs():
+    """The EGNN dynamics configurations of ``continuous.npz`` (the same table ``tools/gen_golden.py`` generated from)."""
+    return {
+        'tiny': dict(node_types=[0, 0, 1, 2, 1], r_cutoff=50.0, time_feat_dim=4, node_feat_dim=8, distance_feat_dim=6,
+                     n_layers=2, speed_factor=1.0, batch=7, x_scale=1.0, seed=11),
+        'cutoff': dict(node_types=[0, 1, 1, 0, 2, 2, 0], r_cutoff=1.6, time_feat_dim=3, node_feat_dim=16,
+                       distance_feat_dim=8, n_layers=3, speed_factor=0.7, batch=9, x_scale=0.9, seed=12),
+        'default': dict(node_types=[0, 1, 1, 0, 2, 2, 0, 3, 1, 0, 2, 1], r_cutoff=2.5, time_feat_dim=16, node_feat_dim=64,
+                        distance_feat_dim=64, n_layers=4, speed_factor=1.0, batch=5, x_scale=1.2, seed=13),
+        'pair': dict(node_types=[0, 0], r_cutoff=10.0, time_feat_dim=2, node_feat_dim=4, distance_feat_dim=3,
+                     n_layers=1, speed_factor=1.0, batch=3, x_scale=1.0, seed=14),
+    }
+
+
+def continuous_state(npz, name, dtype=None):
+    """The reference ``state_dict`` of one EGNN dynamics fixture as torch tensors (float64 unless ``dtype``)."""
+    import torch
+    dtype = torch.float64 if dtype is None else dtype
+    out = {}
+    for k in npz.files:
+        if k.startswith(f'{name}/sd/'):
+            t = torch.from_numpy(np.ascontiguousarray(npz[k]))
+            out[k[len(f'{name}/sd/'):]] = t.to(dtype) if t.is_floating_point() else t
+    return out

@@ -106,7 +106,7 @@ class AutoregressiveFlow(torch.nn.Module):
             for d_, m_ in enumerate(self._inverse_masks.cpu()):
                 deg_x[m_] = d_
             emb = getattr(made, 'embedding', None)
-            hint = deg_x if emb is None else emb.get_degrees_out(deg_x)
+            hint = deg_x if emb is None else emb.get_degrees_out(deg_x.to(self._inverse_masks.device)).cpu()
         made._sync_degrees(hint)
 
     # ------------------------------------------------------------------ device-side index tables

@@ -952,6 +952,149 @@ def gen_logger():
     TFEPLogger(save_dir_path=sorted_root).read_eval_tensors(step_idx=7, sort_by='trajectory_sample_index')
 
 
+# -----------------------------------------------------------------------------
+# 12. config 5: EGNN dynamics, radial bases, graph helpers, trace estimators of the continuous flow
+# -----------------------------------------------------------------------------
+
+def continuous_configs():
+    """Small EGNN dynamics configurations (constructor arguments + batch); also imported by tests/golden_util.py."""
+    return {
+        # every pair inside the cutoff, two layers, tiny widths
+        'tiny': dict(node_types=[0, 0, 1, 2, 1], r_cutoff=50.0, time_feat_dim=4, node_feat_dim=8, distance_feat_dim=6,
+                     n_layers=2, speed_factor=1.0, batch=7, x_scale=1.0, seed=11),
+        # a cutoff that prunes about half of the pairs; speed_factor != 1
+        'cutoff': dict(node_types=[0, 1, 1, 0, 2, 2, 0], r_cutoff=1.6, time_feat_dim=3, node_feat_dim=16,
+                       distance_feat_dim=8, n_layers=3, speed_factor=0.7, batch=9, x_scale=0.9, seed=12),
+        # the default widths of EGNNDynamics (egnn.py:73-81) on 12 nodes, 4 layers
+        'default': dict(node_types=[0, 1, 1, 0, 2, 2, 0, 3, 1, 0, 2, 1], r_cutoff=2.5, time_feat_dim=16, node_feat_dim=64,
+                        distance_feat_dim=64, n_layers=4, speed_factor=1.0, batch=5, x_scale=1.2, seed=13),
+        # a single node pair and one node type (degenerate sizes)
+        'pair': dict(node_types=[0, 0], r_cutoff=10.0, time_feat_dim=2, node_feat_dim=4, distance_feat_dim=3,
+                     n_layers=1, speed_factor=1.0, batch=3, x_scale=1.0, seed=14),
+    }
+
+
+def gen_continuous():
+    from tfep.nn.dynamics.egnn import EGNNDynamics
+    from tfep.nn.embeddings.radial import BehlerParrinelloRadialExpansion, GaussianBasisExpansion
+    from tfep.nn.flows.continuous import ContinuousFlow
+    from tfep.nn import graph as rgraph
+    out = {}
+
+    # ---- radial bases (embeddings/radial.py:90-130, 269-291)
+    r = torch.cat([torch.tensor([0.0, 1e-3, 2.0, 2.0 + 1e-6, 3.5]), torch.rand(40, generator=gen(1)) * 2.4]).float()
+    for dname, dt in (('f64', torch.float64), ('f32', torch.float32)):
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dt)
+        try:
+            gb = GaussianBasisExpansion.from_range(n_gaussians=5, max_mean=1.0, trainable_stds=True)
+            bp = BehlerParrinelloRadialExpansion.from_range(r_cutoff=2.0, n_gaussians=6, max_mean=2.0, trainable_stds=True)
+            bp2 = BehlerParrinelloRadialExpansion(r_cutoff=2.0, means=torch.tensor([0.1, 0.7, 1.9]),
+                                                  stds=torch.tensor([0.3, 0.2, 0.5]), force_zero_after_cutoff=False)
+            with torch.no_grad():
+                out[f'radial/gauss_{dname}'] = npy(gb(r.to(dt)))
+                out[f'radial/bp_{dname}'] = npy(bp(r.to(dt)))
+                out[f'radial/bp_nozero_{dname}'] = npy(bp2(r.to(dt)))
+            if dname == 'f64':
+                out['radial/gauss_means'], out['radial/gauss_log_gammas'] = npy(gb._means), npy(gb._log_gammas)
+                out['radial/bp_means'], out['radial/bp_log_gammas'] = npy(bp._means), npy(bp._log_gammas)
+                out['radial/bp2_means'], out['radial/bp2_log_gammas'] = npy(bp2._means), npy(bp2._log_gammas)
+        finally:
+            torch.set_default_dtype(old)
+    out['radial/r'] = npy(r)
+
+    # ---- graph helpers (graph.py:119-316)
+    for n in (1, 2, 4):
+        out[f'graph/edges_n{n}_b1'] = npy(rgraph.get_all_edges(1, n)).astype(np.int64)
+        out[f'graph/edges_n{n}_b3'] = npy(rgraph.get_all_edges(3, n)).astype(np.int64)
+    mask = torch.tensor([[0., 1, 0], [1, 0, 1], [1, 1, 0]])
+    out['graph/mask'] = npy(mask)
+    out['graph/edges_masked_b2'] = npy(rgraph.get_all_edges(2, 3, mask)).astype(np.int64)
+    xg = torch.randn(8, 3, generator=gen(2), dtype=torch.float64)
+    eg = rgraph.get_all_edges(2, 4)
+    for norm in (False, True):
+        d, v = rgraph.compute_edge_distances(xg, eg, normalize_directions=norm)
+        out[f'graph/dist_norm{int(norm)}'], out[f'graph/dir_norm{int(norm)}'] = npy(d), npy(v)
+    d, v = rgraph.compute_edge_distances(xg, eg, normalize_directions=True)
+    pe, pd, pv = rgraph.prune_long_edges(1.5, eg, d, v)
+    out['graph/x'], out['graph/pruned_edges'], out['graph/pruned_dist'], out['graph/pruned_dir'] = \
+        npy(xg), npy(pe).astype(np.int64), npy(pd), npy(pv)
+    data = torch.randn(len(d), 3, generator=gen(3), dtype=torch.float64)
+    out['graph/seg_data'] = npy(data)
+    out['graph/seg_sum'] = npy(rgraph.unsorted_segment_sum(data, eg[1], 8))
+
+    # ---- EGNN dynamics, ODE function (velocity, trace, regularisation) with stored eps
+    for name, cfg in continuous_configs().items():
+        kw = {k: cfg[k] for k in ('node_types', 'r_cutoff', 'time_feat_dim', 'node_feat_dim', 'distance_feat_dim',
+                                  'n_layers', 'speed_factor')}
+        n_nodes, B = len(cfg['node_types']), cfg['batch']
+        g = gen(cfg['seed'])
+        x32 = (torch.randn(B, 3 * n_nodes, generator=g) * cfg['x_scale']).float()
+        t32 = torch.rand(1, generator=g).float()
+        eps32 = torch.randn(3, B, 3 * n_nodes, generator=g).float()
+        torch.manual_seed(cfg['seed'])
+        dyn32 = EGNNDynamics(initialize_identity=False, **kw)
+        # spread every parameter (biases are small, the log-gammas identical at init) -- still float32-rounded
+        with torch.no_grad():
+            for prm in dyn32.parameters():
+                prm.add_(0.05 * torch.randn(prm.shape, generator=g))
+        sd32 = dyn32.state_dict()
+        out.update({f'{name}/sd/{k}': npy(v) for k, v in sd32.items()})
+        out[f'{name}/x'], out[f'{name}/t'], out[f'{name}/eps'] = npy(x32), npy(t32), npy(eps32)
+        for dname, dt in (('f64', torch.float64), ('f32', torch.float32)):
+            old = torch.get_default_dtype()
+            torch.set_default_dtype(dt)
+            try:
+                dyn = EGNNDynamics(initialize_identity=False, **kw)
+                dyn.load_state_dict({k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd32.items()})
+                x, t, eps = x32.to(dt), t32.to(dt), eps32.to(dt)
+                with torch.no_grad():
+                    out[f'{name}/vel_{dname}'] = npy(dyn(t[0], x))
+                    if dname == 'f64':
+                        # node embedding and the state after every layer (egnn.py:158-176)
+                        h = dyn._create_node_embedding(t[0], B)
+                        out[f'{name}/h0_f64'] = npy(h)
+                        pos = x.view(B * n_nodes, 3)
+                        edges = dyn.get_edges(B)
+                        for li in range(cfg['n_layers']):
+                            h, pos = dyn._modules['graph_layer_' + str(li)](h, pos, edges)
+                            out[f'{name}/h{li + 1}_f64'], out[f'{name}/pos{li + 1}_f64'] = npy(h), npy(pos)
+                # the integrands of the ODE function (continuous.py:231-278) with the stored eps
+                for est, n_hut, reg in (('hutchinson', 1, True), ('hutchinson', 3, True), ('hutchinson', 1, False),
+                                        ('exact', 1, True), ('exact', 1, False)):
+                    flow = ContinuousFlow(dyn, trace_estimator=est, n_hutchinson_samples=n_hut, regularization=reg,
+                                          requires_backward=False)
+                    f = flow.ode_func
+                    if est == 'hutchinson':
+                        f._eps = eps[:n_hut]
+                    else:
+                        f._cached_eye = torch.eye(x.shape[1])
+                    xx = x.clone()
+                    state = (xx, xx.new_zeros(B), xx.new_zeros(B)) if reg else (xx, xx.new_zeros(B))
+                    res = f(t[0], state)
+                    key = f'{name}/{est}{n_hut}_{"reg" if reg else "noreg"}'
+                    out[f'{key}/vel_{dname}'] = npy(res[0])
+                    out[f'{key}/trace_{dname}'] = npy(res[1])
+                    if reg:
+                        out[f'{key}/reg_{dname}'] = npy(res[2])
+                if dname == 'f64':
+                    # the full Jacobian d vel / d x of every sample (pins JVP / VJP products of any direction)
+                    jac = torch.stack([torch.autograd.functional.jacobian(lambda z: dyn(t[0], z[None])[0], x[b])
+                                       for b in range(B)])
+                    out[f'{name}/jacobian_f64'] = npy(jac)
+            finally:
+                torch.set_default_dtype(old)
+
+    # ---- identity initialisation: zero velocity (egnn.py:136-138)
+    torch.manual_seed(0)
+    dyn = EGNNDynamics(node_types=[0, 1, 0], r_cutoff=5.0, time_feat_dim=2, node_feat_dim=4, distance_feat_dim=3, n_layers=2)
+    xi = torch.randn(4, 9, generator=gen(5))
+    with torch.no_grad():
+        out['identity/vel_max_abs'] = np.asarray(float(dyn(torch.tensor(0.3), xi).abs().max()))
+    out.update({f'identity/sd/{k}': npy(v) for k, v in dyn.state_dict().items()})
+    np.savez_compressed(os.path.join(OUT, 'continuous.npz'), **out)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
     if len(sys.argv) > 1:
@@ -969,5 +1112,6 @@ if __name__ == '__main__':
     gen_embeddings()
     gen_bootstrap()
     gen_logger()
+    gen_continuous()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
