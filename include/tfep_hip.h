@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFEP_HIP_ABI_VERSION 4
+#define TFEP_HIP_ABI_VERSION 5
 
 typedef enum tfep_status {
     TFEP_OK = 0,
@@ -474,6 +474,136 @@ int tfep_tfep_reduce_workspace_doubles(int N);
  */
 int tfep_bootstrap_fep(const float* work, const float* bias, const int64_t* indices, const float* weights,
                        int64_t n_data, int64_t n_resamples, int64_t sample_size, float kT, double* out, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Config 5: EGNN dynamics of the continuous flow (tfep/nn/dynamics/egnn.py,   */
+/* tfep/nn/graph.py, tfep/nn/embeddings/radial.py, tfep/nn/flows/continuous.py) */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Tile count nt (feature tile = 16 nt) of the fused EGNN kernels for a (node_feat_dim, distance_feat_dim) pair:
+ * 1, 2 or 4; 0 = unsupported (a dimension above 64).  Node-level arrays (h, P, Q, aggregated messages) are
+ * (B, n_nodes, 16 nt) float32, zero in the padding.
+ */
+int tfep_egnn_tile(int node_feat_dim, int distance_feat_dim);
+/* Floats of one packed layer (tfep_egnn_pack_layer) for a tile count; -1 if nt is not 1, 2 or 4. */
+int64_t tfep_egnn_packed_floats(int nt);
+
+/* The parameter tensors of one _EGLayer (egnn.py:225-270), reference shapes, row-major. */
+typedef struct tfep_egnn_layer_params {
+    int32_t F, G;                   /* node_feat_dim, distance_feat_dim */
+    const float* dist_means;        /* (G)  distance_embedding._means = linspace(0, r_cutoff, G)  (radial.py:132-137) */
+    const float* dist_log_gammas;   /* (G)  distance_embedding._log_gammas                        (radial.py:57-62) */
+    const float* msg0_w;            /* (F, 2F+G) message_mlp.0.weight: columns [h_src | h_dest | rbf] (egnn.py:312) */
+    const float* msg0_b;            /* (F) */
+    const float* msg2_w;            /* (F, F)  message_mlp.2 */
+    const float* msg2_b;            /* (F) */
+    const float* att_w;             /* (1, F)  attention_mlp.0 */
+    const float* att_b;             /* (1) */
+    const float* ux0_w;             /* (F, F)  update_x_mlp.0 */
+    const float* ux0_b;             /* (F) */
+    const float* ux2_w;             /* (1, F)  update_x_mlp.2 (no bias) */
+    const float* uh0_w;             /* (F, 2F) update_h_mlp.0: columns [h | aggregated messages] (egnn.py:336) */
+    const float* uh0_b;             /* (F) */
+    const float* uh2_w;             /* (F, F)  update_h_mlp.2 */
+    const float* uh2_b;             /* (F) */
+} tfep_egnn_layer_params;
+
+/*
+ * Re-pack the parameters of one layer for the kernels below (every forward, like the masked weights): the six F x F
+ * blocks as "lane-linear" MFMA operand images (csrc/egnn.hip), the vectors zero-padded to 16 nt, exp(log_gamma).
+ * packed: tfep_egnn_packed_floats(nt) floats.
+ */
+int tfep_egnn_pack_layer(const tfep_egnn_layer_params* params, int nt, float* packed, void* stream);
+
+/*
+ * EGNNDynamics._create_node_embedding (egnn.py:196-219) and the node-level part of the first layer's message MLP:
+ *   h0[i] = W_emb [one_hot(type_i), exp(-exp(log_gamma_k) (t - mean_k)^2)] + b_emb      (the same for every sample)
+ *   P0[i] = W1[:, 0:F] h0[i],   Q0[i] = W1[:, F:2F] h0[i] + b1                           (message_mlp.0 split by input)
+ * one_hot: (n_nodes, n_types); w_emb: (F, n_types + time_dim); h0, P0, Q0: (n_nodes, 16 nt).
+ */
+int tfep_egnn_embed(const float* one_hot, int n_nodes, int n_types, float t, const float* time_means,
+                    const float* time_log_gammas, int time_dim, const float* w_emb, const float* b_emb,
+                    const tfep_egnn_layer_params* layer0, int nt, float* h0, float* P0, float* Q0, void* stream);
+
+/*
+ * One _EGLayer.forward without its node MLP (egnn.py:272-369): for every sample and every destination node j
+ *   nm[j]      = sum_{i != j, |x_j - x_i| <= r_cutoff} m_ij              (_create_edge_messages + segment sum, :294-331)
+ *   pos_out[j] = pos[j] + speed_factor sum_i (x_j - x_i)/|x_j - x_i| tanh(x2 . SiLU(X1 m_ij + d1))      (:344-364)
+ *   m_ij = m2 sigmoid(wa . m2 + ba),  m2 = SiLU(W2 SiLU(P[i] + Q[j] + W1c rbf(|x_j - x_i|)) + b2)
+ * with the Behler-Parrinello radial basis rbf (radial.py:269-291).  No edge list, no scatter_add (graph.py:119-316):
+ * see csrc/egnn.hip.  With dpos != NULL the directional derivative along (dpos, dP, dQ) is carried through the same
+ * pass: dpos_out, dnm.  P, Q: (B, n_nodes, 16 nt) with pq_bstride = n_nodes, or (n_nodes, 16 nt) shared by all samples
+ * with pq_bstride = 0 (layer 0); dP / dQ NULL = zero (layer 0).  nm NULL: the aggregated messages are not needed (last
+ * layer: the velocity depends on the positions only).
+ */
+typedef struct tfep_egnn_edge_args {
+    int32_t B, n_nodes, nt;
+    float r_cutoff, speed_factor;
+    const float* packed;
+    const float* pos;
+    const float* dpos;
+    const float* P;
+    const float* Q;
+    int64_t pq_bstride;
+    const float* dP;
+    const float* dQ;
+    float* pos_out;
+    float* dpos_out;
+    float* nm;
+    float* dnm;
+} tfep_egnn_edge_args;
+int tfep_egnn_edge(const tfep_egnn_edge_args* args, void* stream);
+
+/*
+ * Node update between layer l and l + 1: h' = h + U2 SiLU(U1 [h, nm] + c1) + c2 (_update_h, egnn.py:327-342) with the
+ * packed weights of layer l, then P' = W1[:, 0:F] h', Q' = W1[:, F:2F] h' + b1 with those of layer l + 1; tangents
+ * alongside when dnm != NULL (dh NULL = zero).  h: (B, n_nodes, 16 nt) with h_bstride = n_nodes or shared, 0.
+ */
+typedef struct tfep_egnn_node_args {
+    int32_t B, n_nodes, nt;
+    const float* packed;
+    const float* packed_next;
+    const float* h;
+    int64_t h_bstride;
+    const float* dh;
+    const float* nm;
+    const float* dnm;
+    float* h_out;
+    float* dh_out;
+    float* P_out;
+    float* Q_out;
+    float* dP_out;
+    float* dQ_out;
+} tfep_egnn_node_args;
+int tfep_egnn_node(const tfep_egnn_node_args* args, void* stream);
+
+/*
+ * End of EGNNDynamics.forward (egnn.py:178-193): vel = (pos - x) - mean_nodes(pos - x), (B, 3 n_nodes).  With a tangent
+ * (dpos, eps): jvp = (dpos - eps) - mean = J eps, and the quadratic forms of the trace estimators
+ * (continuous.py:285-324):  trace[b] += scale eps . (J eps),  frob[b] += scale |J eps|^2.  vel_sq[b] = |vel|^2
+ * (continuous.py:281-282).  vel, jvp, trace, frob, vel_sq may be NULL.
+ */
+int tfep_egnn_finish(const float* pos, const float* x, const float* dpos, const float* eps, int B, int n_nodes,
+                     float* vel, float* jvp, float scale, float* trace, float* frob, float* vel_sq, void* stream);
+
+/*
+ * GaussianBasisExpansion.forward (radial.py:110-130): out[e, k] = exp(-exp(log_gamma_k) (r_e - mean_k)^2); with
+ * switching != 0 times the Behler-Parrinello cosine switch 0.5 cos(pi r / r_cutoff) + 0.5, zero beyond the cutoff if
+ * force_zero_after_cutoff (radial.py:161-176, 269-291).  r: (n); out: (n, n_basis).
+ */
+int tfep_radial_expansion(const float* r, int64_t n, const float* means, const float* log_gammas, int n_basis,
+                          float r_cutoff, int switching, int force_zero_after_cutoff, float* out, void* stream);
+
+/* unsorted_segment_sum (graph.py:304-316): out[s, :] = sum_{rows with segment_ids == s} data[row, :]; out is cleared
+ * first; float atomics (the fused EGNN kernels do not use this). */
+int tfep_segment_sum(const float* data, const int64_t* segment_ids, int64_t n_rows, int n_cols, int64_t n_segments,
+                     float* out, void* stream);
+
+/* y = x + sum_{k < n_terms} a[k] v[k]  (x may be NULL = 0; n_terms <= 4; v, a: HOST arrays of device pointers /
+ * coefficients): the stage combinations of the fixed-grid ODE steppers that replace torchdiffeq's
+ * (continuous.py:136-169). */
+int tfep_ode_axpy(const float* x, const float* const* v, const float* a, int n_terms, int64_t n, float* y, void* stream);
 
 #ifdef __cplusplus
 }

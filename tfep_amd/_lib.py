@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TFEP_HIP_LIB') or os.path.join(_HERE, 'lib', 'libtfep_hip.so')
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 
@@ -57,6 +57,26 @@ class SplineDesc(Structure):
                 ('n_bins', c_int32), ('circular', c_int32), ('identity_boundary_slopes', c_int32),
                 ('learn_lower_bound', c_int32), ('learn_upper_bound', c_int32),
                 ('min_bin_size', c_float), ('min_slope', c_float)]
+
+
+class EgnnLayerParams(Structure):
+    _fields_ = [('F', c_int32), ('G', c_int32)] + [(k, c_void_p) for k in (
+        'dist_means', 'dist_log_gammas', 'msg0_w', 'msg0_b', 'msg2_w', 'msg2_b', 'att_w', 'att_b', 'ux0_w', 'ux0_b',
+        'ux2_w', 'uh0_w', 'uh0_b', 'uh2_w', 'uh2_b')]
+
+
+class EgnnEdgeArgs(Structure):
+    _fields_ = [('B', c_int32), ('n_nodes', c_int32), ('nt', c_int32), ('r_cutoff', c_float), ('speed_factor', c_float),
+                ('packed', c_void_p), ('pos', c_void_p), ('dpos', c_void_p), ('P', c_void_p), ('Q', c_void_p),
+                ('pq_bstride', c_int64), ('dP', c_void_p), ('dQ', c_void_p), ('pos_out', c_void_p), ('dpos_out', c_void_p),
+                ('nm', c_void_p), ('dnm', c_void_p)]
+
+
+class EgnnNodeArgs(Structure):
+    _fields_ = [('B', c_int32), ('n_nodes', c_int32), ('nt', c_int32), ('packed', c_void_p), ('packed_next', c_void_p),
+                ('h', c_void_p), ('h_bstride', c_int64), ('dh', c_void_p), ('nm', c_void_p), ('dnm', c_void_p),
+                ('h_out', c_void_p), ('dh_out', c_void_p), ('P_out', c_void_p), ('Q_out', c_void_p),
+                ('dP_out', c_void_p), ('dQ_out', c_void_p)]
 
 
 _P = c_void_p
@@ -125,6 +145,17 @@ _SIGNATURES = {
     'tfep_tfep_reduce': (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P]),
     'tfep_tfep_reduce_workspace_doubles': (c_int, [c_int]),
     'tfep_bootstrap_fep': (c_int, [_P, _P, _P, _P, c_int64, c_int64, c_int64, c_float, _P, _P]),
+    'tfep_egnn_tile': (c_int, [c_int, c_int]),
+    'tfep_egnn_packed_floats': (c_int64, [c_int]),
+    'tfep_egnn_pack_layer': (c_int, [POINTER(EgnnLayerParams), c_int, _P, _P]),
+    'tfep_egnn_embed': (c_int, [_P, c_int, c_int, c_float, _P, _P, c_int, _P, _P, POINTER(EgnnLayerParams), c_int,
+                                _P, _P, _P, _P]),
+    'tfep_egnn_edge': (c_int, [POINTER(EgnnEdgeArgs), _P]),
+    'tfep_egnn_node': (c_int, [POINTER(EgnnNodeArgs), _P]),
+    'tfep_egnn_finish': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P]),
+    'tfep_radial_expansion': (c_int, [_P, c_int64, _P, _P, c_int, c_float, c_int, c_int, _P, _P]),
+    'tfep_segment_sum': (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P]),
+    'tfep_ode_axpy': (c_int, [_P, POINTER(c_void_p), POINTER(c_float), c_int, c_int64, _P, _P]),
 }
 
 EXPORTED_SYMBOLS = tuple(sorted(_SIGNATURES))

@@ -1,0 +1,767 @@
+// Config 5 of BASELINE.json: the EGNN dynamics of the continuous normalizing flow, forward + directional derivative
+// (Jacobian-vector product) in one pass, on the matrix cores of gfx950.
+//
+// Reference: tfep/nn/dynamics/egnn.py (EGNNDynamics.forward :143-194, _EGLayer :222-369), tfep/nn/graph.py (all-pairs
+// edges :119-163, distances :222-263, cutoff pruning :266-301, scatter-add segment sum :304-316),
+// tfep/nn/embeddings/radial.py (Gaussian / Behler-Parrinello bases :110-130, :161-176, :269-291) and the trace
+// estimators of tfep/nn/flows/continuous.py (:285-361).
+//
+// What the reference does per layer: build the (batch * n * (n-1)) edge list, gather h / x per edge, a 192 -> 64 -> 64
+// message MLP, attention, scatter_add of messages and displacements.  What this file does instead:
+//   * edges are never materialised: a workgroup owns 16 DESTINATION nodes of one sample and walks all source nodes;
+//     one MFMA column group = the 16 edges (source i -> the 16 destinations);
+//   * the edge MLPs run TRANSPOSED on v_mfma_f32_16x16x4_f32 (exact fp32): features are matrix rows, edges are columns.
+//     In that orientation the accumulator layout of one product (lane = edge column, registers = 4 consecutive
+//     features) IS the B-operand layout of the next one, so the whole chain rbf -> W1 -> SiLU -> W2 -> SiLU ->
+//     attention -> X1 -> SiLU -> tanh stays in registers: no LDS round trip, no transposes;
+//   * the first linear is split by input block: W1 [h_src, h_dest, rbf] = P_i + Q_j + W1c rbf with the node-level
+//     products P = W1a h, Q = W1b h + b1 computed once per node (egnn_node_kernel), not once per edge;
+//   * the sum over sources (the reference's scatter_add to edges[1]) is a register accumulation -- the destination is
+//     the lane -- finished by a fixed-order cross-wave reduction in LDS: no atomics, bit-reproducible;
+//   * pruned edges (distance > cutoff, graph.py:297) are masked; a column group with no live edge is skipped entirely;
+//   * the tangent (dx -> d velocity) rides along: every product is issued twice with the same weight fragment, the
+//     activations carry their derivatives.  e . (J e) is the Hutchinson trace estimate of continuous.py:307-324 (the
+//     reference forms (e^T J) . e by a reverse pass -- the same number).
+// Weights are re-packed from the reference parameter tensors on every call (tfep_egnn_pack_layer) into "lane-linear"
+// images: the 16 bytes lane l needs for 4 consecutive MFMA k-steps of a row tile are contiguous, a wave reads 1 KB per
+// ds_read_b128 without bank conflicts.
+#include "common.h"
+
+namespace tfep {
+namespace {
+
+using f4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int EDGE_WAVES = 8;            // waves per workgroup of the edge kernel (2 per SIMD)
+constexpr int NODE_WAVES = 4;
+
+__host__ __device__ inline int64_t img_floats(int nt) { return (int64_t)nt * nt * 256; }       // (16 nt)^2
+// layout of a packed layer (floats)
+struct PackedLayout {
+    int64_t w1c, w2, x1, b2, d1, wa, x2, mu, gamma, scal, u1a, u1b, u2, c1, c2, w1a, w1b, b1, total;
+};
+__host__ __device__ inline PackedLayout packed_layout(int nt) {
+    PackedLayout L;
+    const int64_t I = img_floats(nt), V = 16 * nt;
+    int64_t o = 0;
+    L.w1c = o; o += I; L.w2 = o; o += I; L.x1 = o; o += I;
+    L.b2 = o; o += V; L.d1 = o; o += V; L.wa = o; o += V; L.x2 = o; o += V; L.mu = o; o += V; L.gamma = o; o += V;
+    L.scal = o; o += 4;
+    L.u1a = o; o += I; L.u1b = o; o += I; L.u2 = o; o += I; L.c1 = o; o += V; L.c2 = o; o += V;
+    L.w1a = o; o += I; L.w1b = o; o += I; L.b1 = o; o += V;
+    L.total = o;
+    return L;
+}
+constexpr int EDGE_CONST_VECS = 6;       // b2, d1, wa, x2, mu, gamma follow the three edge images contiguously
+
+__device__ inline f4 mfma4(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// acc[tp] += W[tp][:] x  (and the same for the tangent dx with the SAME weight fragment), W as a lane-linear LDS image
+template <int NT, bool TAN>
+__device__ inline void chain_gemm(const f4* __restrict__ img, const f4 (&x)[NT], const f4 (&dx)[NT], f4 (&acc)[NT],
+                                  f4 (&dacc)[NT], int lane) {
+#pragma unroll
+    for (int tp = 0; tp < NT; ++tp) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f4 a = img[(tp * NT + t) * 64 + lane];
+            acc[tp] = mfma4(a.x, x[t].x, acc[tp]);
+            if (TAN) dacc[tp] = mfma4(a.x, dx[t].x, dacc[tp]);
+            acc[tp] = mfma4(a.y, x[t].y, acc[tp]);
+            if (TAN) dacc[tp] = mfma4(a.y, dx[t].y, dacc[tp]);
+            acc[tp] = mfma4(a.z, x[t].z, acc[tp]);
+            if (TAN) dacc[tp] = mfma4(a.z, dx[t].z, dacc[tp]);
+            acc[tp] = mfma4(a.w, x[t].w, acc[tp]);
+            if (TAN) dacc[tp] = mfma4(a.w, dx[t].w, dacc[tp]);
+        }
+    }
+}
+
+// SiLU and its derivative (torch.nn.SiLU: x * sigmoid(x)), elementwise on a tile; dz <- silu'(z) dz, z <- silu(z)
+template <int NT, bool TAN>
+__device__ inline void silu_tile(f4 (&z)[NT], f4 (&dz)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = z[t][r];
+            const float sig = 1.0f / (1.0f + expf(-v));
+            z[t][r] = v * sig;
+            if (TAN) dz[t][r] *= sig * (1.0f + v * (1.0f - sig));
+        }
+    }
+}
+
+// sum over the four 16-lane groups of a wave (the lanes that hold the same edge column)
+__device__ inline float sum_over_q(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight re-pack: reference parameter tensors of one _EGLayer -> packed layer
+// ---------------------------------------------------------------------------------------------------------------
+__device__ inline float img_entry(const float* w, int ldw, int col0, int n_rows, int n_cols, int nt, int64_t idx) {
+    // idx = ((tp * nt + t) * 64 + l) * 4 + r  ->  W[16 tp + (l & 15)][col0 + 16 t + 4 (l >> 4) + r]
+    const int r = (int)(idx & 3), l = (int)((idx >> 2) & 63);
+    const int tt = (int)(idx >> 8);
+    const int t = tt % nt, tp = tt / nt;
+    const int row = 16 * tp + (l & 15), col = 16 * t + 4 * (l >> 4) + r;
+    return (row < n_rows && col < n_cols) ? w[(int64_t)row * ldw + col0 + col] : 0.0f;
+}
+__device__ inline float vec_entry(const float* v, int n, int64_t i) { return (v != nullptr && i < n) ? v[i] : 0.0f; }
+
+__global__ void egnn_pack_kernel(tfep_egnn_layer_params p, int nt, float* __restrict__ out) {
+    const PackedLayout L = packed_layout(nt);
+    const int64_t I = img_floats(nt), V = 16 * nt;
+    const int F = p.F, G = p.G;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.total; i += (int64_t)gridDim.x * blockDim.x) {
+        float v;
+        if (i < L.w2) v = img_entry(p.msg0_w, 2 * F + G, 2 * F, F, G, nt, i - L.w1c);
+        else if (i < L.x1) v = img_entry(p.msg2_w, F, 0, F, F, nt, i - L.w2);
+        else if (i < L.b2) v = img_entry(p.ux0_w, F, 0, F, F, nt, i - L.x1);
+        else if (i < L.d1) v = vec_entry(p.msg2_b, F, i - L.b2);
+        else if (i < L.wa) v = vec_entry(p.ux0_b, F, i - L.d1);
+        else if (i < L.x2) v = vec_entry(p.att_w, F, i - L.wa);
+        else if (i < L.mu) v = vec_entry(p.ux2_w, F, i - L.x2);
+        else if (i < L.gamma) v = vec_entry(p.dist_means, G, i - L.mu);
+        else if (i < L.scal) v = (i - L.gamma < G) ? expf(p.dist_log_gammas[i - L.gamma]) : 0.0f;   // radial.py:127
+        else if (i < L.u1a) v = (i == L.scal) ? p.att_b[0] : 0.0f;
+        else if (i < L.u1b) v = img_entry(p.uh0_w, 2 * F, 0, F, F, nt, i - L.u1a);
+        else if (i < L.u2) v = img_entry(p.uh0_w, 2 * F, F, F, F, nt, i - L.u1b);
+        else if (i < L.c1) v = img_entry(p.uh2_w, F, 0, F, F, nt, i - L.u2);
+        else if (i < L.c2) v = vec_entry(p.uh0_b, F, i - L.c1);
+        else if (i < L.w1a) v = vec_entry(p.uh2_b, F, i - L.c2);
+        else if (i < L.w1b) v = img_entry(p.msg0_w, 2 * F + G, 0, F, F, nt, i - L.w1a);
+        else if (i < L.b1) v = img_entry(p.msg0_w, 2 * F + G, F, F, F, nt, i - L.w1b);
+        else v = vec_entry(p.msg0_b, F, i - L.b1);
+        out[i] = v;
+        (void)I; (void)V;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// node embedding + the source / destination terms of layer 0 (the same for every sample: h0 depends on t only)
+//   h0 = W_emb [one_hot(type), exp(-gamma (t - mu)^2)] + b_emb        (egnn.py:196-219, radial.py:110-130)
+//   P0 = W1a h0,  Q0 = W1b h0 + b1                                     (first linear of message_mlp, egnn.py:246)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void egnn_embed_kernel(const float* __restrict__ one_hot, int n_nodes, int n_types, float t,
+                                  const float* __restrict__ time_means, const float* __restrict__ time_log_gammas,
+                                  int time_dim, const float* __restrict__ w_emb, const float* __restrict__ b_emb, int F,
+                                  const float* __restrict__ msg0_w, const float* __restrict__ msg0_b, int G, int f_pad,
+                                  float* __restrict__ h0, float* __restrict__ P0, float* __restrict__ Q0) {
+    extern __shared__ float smem[];           // h0 of this node (F)
+    const int node = blockIdx.x;
+    const int K = n_types + time_dim;
+    for (int f = threadIdx.x; f < f_pad; f += blockDim.x) {
+        float acc = 0.0f;
+        if (f < F) {
+            acc = b_emb[f];
+            for (int k = 0; k < n_types; ++k) acc += w_emb[f * K + k] * one_hot[node * n_types + k];
+            for (int k = 0; k < time_dim; ++k) {
+                const float d = t - time_means[k];
+                acc += w_emb[f * K + n_types + k] * expf(-expf(time_log_gammas[k]) * d * d);
+            }
+        }
+        smem[f] = acc;
+        h0[(int64_t)node * f_pad + f] = acc;
+    }
+    __syncthreads();
+    const int ldw = 2 * F + G;
+    for (int f = threadIdx.x; f < f_pad; f += blockDim.x) {
+        float p = 0.0f, q = 0.0f;
+        if (f < F) {
+            q = msg0_b[f];
+            for (int k = 0; k < F; ++k) {
+                p += msg0_w[f * ldw + k] * smem[k];
+                q += msg0_w[f * ldw + F + k] * smem[k];
+            }
+        }
+        P0[(int64_t)node * f_pad + f] = p;
+        Q0[(int64_t)node * f_pad + f] = q;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// edge kernel: one _EGLayer without its node MLP (egnn.py:272-369)
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT, bool TAN>
+__global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn_edge_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int FP = 16 * NT;
+    constexpr int IMG4 = NT * NT * 64;                    // f4 per image
+    const PackedLayout L = packed_layout(NT);
+    const int n = a.n_nodes;
+    const int n_blk = (n + 15) / 16;
+    const int b = blockIdx.x / n_blk, jb = blockIdx.x % n_blk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, c = lane & 15;
+
+    // ---- LDS: [3 images][6 vectors][pos n*3][dpos n*3][reduction]
+    f4* const w_img = reinterpret_cast<f4*>(smem);
+    float* const vecs = smem + 3 * IMG4 * 4;
+    float* const s_pos = vecs + EDGE_CONST_VECS * FP;
+    float* const s_dpos = s_pos + ((3 * n + 3) & ~3);
+    float* const s_red = s_dpos + (TAN ? ((3 * n + 3) & ~3) : 0);
+    {
+        const f4* src = reinterpret_cast<const f4*>(a.packed + L.w1c);
+        const int n4 = 3 * IMG4 + EDGE_CONST_VECS * FP / 4;
+        for (int i = tid; i < n4; i += EDGE_WAVES * 64) w_img[i] = src[i];
+        const float* px = a.pos + (int64_t)b * 3 * n;
+        for (int i = tid; i < 3 * n; i += EDGE_WAVES * 64) s_pos[i] = px[i];
+        if (TAN) {
+            const float* pdx = a.dpos + (int64_t)b * 3 * n;
+            for (int i = tid; i < 3 * n; i += EDGE_WAVES * 64) s_dpos[i] = pdx[i];
+        }
+    }
+    const float att_b = a.packed[L.scal];
+    __syncthreads();
+    const f4* const img_w1c = w_img;
+    const f4* const img_w2 = w_img + IMG4;
+    const f4* const img_x1 = w_img + 2 * IMG4;
+    const f4* const v_b2 = reinterpret_cast<const f4*>(vecs);
+    const f4* const v_d1 = v_b2 + FP / 4;
+    const f4* const v_wa = v_d1 + FP / 4;
+    const f4* const v_x2 = v_wa + FP / 4;
+    const f4* const v_mu = v_x2 + FP / 4;
+    const f4* const v_ga = v_mu + FP / 4;
+
+    // ---- per-lane destination state
+    const int j = jb * 16 + c;
+    const bool j_ok = j < n;
+    const int jc = j_ok ? j : 0;
+    const float xj0 = s_pos[3 * jc], xj1 = s_pos[3 * jc + 1], xj2 = s_pos[3 * jc + 2];
+    float dxj0 = 0.f, dxj1 = 0.f, dxj2 = 0.f;
+    if (TAN) { dxj0 = s_dpos[3 * jc]; dxj1 = s_dpos[3 * jc + 1]; dxj2 = s_dpos[3 * jc + 2]; }
+    const int64_t pq_b = (int64_t)b * a.pq_bstride;
+    f4 Qj[NT], dQj[NT];
+    {
+        const f4* Qp = reinterpret_cast<const f4*>(a.Q + (pq_b + jc) * FP);
+        const f4* dQp = (TAN && a.dQ != nullptr) ? reinterpret_cast<const f4*>(a.dQ + ((int64_t)b * n + jc) * FP) : nullptr;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            Qj[t] = Qp[4 * t + q];
+            dQj[t] = dQp != nullptr ? dQp[4 * t + q] : f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    f4 nm[NT], dnm[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { nm[t] = f4{0.f, 0.f, 0.f, 0.f}; dnm[t] = f4{0.f, 0.f, 0.f, 0.f}; }
+    float disp0 = 0.f, disp1 = 0.f, disp2 = 0.f, dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
+    const float rc = a.r_cutoff, pi_rc = 3.14159265358979323846f / rc;
+    const float* const Pb = a.P + pq_b * FP;
+    const float* const dPb = (TAN && a.dP != nullptr) ? a.dP + (int64_t)b * n * FP : nullptr;
+
+    for (int i = wave; i < n; i += EDGE_WAVES) {
+        // ---- geometry of the 16 edges (i -> j0 + c); the four q-groups compute it redundantly (a few dozen VALU)
+        const float v0 = xj0 - s_pos[3 * i], v1 = xj1 - s_pos[3 * i + 1], v2 = xj2 - s_pos[3 * i + 2];
+        const float d = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);              // graph.py:257
+        const bool keep = j_ok && (j != i) && (d <= rc);                 // graph.py:297 (and no self edges, :143)
+        if (__ballot(keep) == 0ull) continue;                            // wave-uniform: nothing survives the cutoff
+        const float inv_d = keep ? 1.0f / d : 0.0f;
+        const float u0 = v0 * inv_d, u1 = v1 * inv_d, u2 = v2 * inv_d;   // normalised direction (graph.py:260)
+        float ddist = 0.f, du0 = 0.f, du1 = 0.f, du2 = 0.f;
+        if (TAN) {
+            const float w0 = dxj0 - s_dpos[3 * i], w1 = dxj1 - s_dpos[3 * i + 1], w2 = dxj2 - s_dpos[3 * i + 2];
+            ddist = u0 * w0 + u1 * w1 + u2 * w2;
+            du0 = (w0 - u0 * ddist) * inv_d; du1 = (w1 - u1 * ddist) * inv_d; du2 = (w2 - u2 * ddist) * inv_d;
+        }
+        float sn, cs;
+        sincosf(pi_rc * d, &sn, &cs);
+        const float sw = 0.5f * cs + 0.5f;                                // radial.py:173
+        const float dsw = -0.5f * pi_rc * sn;                             // d sw / d dist
+        f4 rbf[NT], drbf[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f4 mu = v_mu[4 * t + q], ga = v_ga[4 * t + q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dm = d - mu[r];
+                const float g = expf(-ga[r] * dm * dm);                   // radial.py:126-128
+                rbf[t][r] = g * sw;                                       // radial.py:291
+                if (TAN) drbf[t][r] = ddist * g * (dsw - 2.0f * ga[r] * dm * sw);
+            }
+        }
+        // ---- message MLP: z1 = P_i + Q_j + W1c rbf (egnn.py:246-251 with the first linear split by input block)
+        f4 z[NT], dz[NT];
+        {
+            const f4* Pp = reinterpret_cast<const f4*>(Pb + (int64_t)i * FP);
+            const f4* dPp = dPb != nullptr ? reinterpret_cast<const f4*>(dPb + (int64_t)i * FP) : nullptr;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                z[t] = Pp[4 * t + q] + Qj[t];
+                if (TAN) dz[t] = dPp != nullptr ? dPp[4 * t + q] + dQj[t] : dQj[t];
+            }
+        }
+        chain_gemm<NT, TAN>(img_w1c, rbf, drbf, z, dz, lane);
+        silu_tile<NT, TAN>(z, dz);
+        f4 y[NT], dy[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { y[t] = v_b2[4 * t + q]; dy[t] = f4{0.f, 0.f, 0.f, 0.f}; }
+        chain_gemm<NT, TAN>(img_w2, z, dz, y, dy, lane);
+        silu_tile<NT, TAN>(y, dy);
+        // ---- attention (egnn.py:254-257, 323-325): m = m2 * sigmoid(wa . m2 + ba)
+        float s = 0.f, ds = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f4 wa = v_wa[4 * t + q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s += wa[r] * y[t][r];
+                if (TAN) ds += wa[r] * dy[t][r];
+            }
+        }
+        s = sum_over_q(s) + att_b;
+        const float att = keep ? 1.0f / (1.0f + expf(-s)) : 0.0f;         // pruned edges carry no message
+        float datt = 0.f;
+        if (TAN) datt = att * (1.0f - att) * sum_over_q(ds);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (TAN) { dy[t][r] = dy[t][r] * att + y[t][r] * datt; dnm[t][r] += dy[t][r]; }
+                y[t][r] *= att;
+                nm[t][r] += y[t][r];                                      // segment sum over the sources (egnn.py:331)
+            }
+        }
+        // ---- displacement magnitude (egnn.py:260-267, 347-361): tanh(x2 . SiLU(X1 m + d1))
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { z[t] = v_d1[4 * t + q]; dz[t] = f4{0.f, 0.f, 0.f, 0.f}; }
+        chain_gemm<NT, TAN>(img_x1, y, dy, z, dz, lane);
+        silu_tile<NT, TAN>(z, dz);
+        s = 0.f; ds = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f4 x2 = v_x2[4 * t + q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s += x2[r] * z[t][r];
+                if (TAN) ds += x2[r] * dz[t][r];
+            }
+        }
+        const float mag = tanhf(sum_over_q(s));
+        const float k = keep ? a.speed_factor : 0.0f;
+        disp0 += k * u0 * mag; disp1 += k * u1 * mag; disp2 += k * u2 * mag;
+        if (TAN) {
+            const float dmag = (1.0f - mag * mag) * sum_over_q(ds);
+            dd0 += k * (du0 * mag + u0 * dmag); dd1 += k * (du1 * mag + u1 * dmag); dd2 += k * (du2 * mag + u2 * dmag);
+        }
+    }
+
+    // ---- cross-wave reduction in a fixed order (no atomics), then the node outputs
+    constexpr int NM4 = NT * 64;                                          // f4 per wave of the message partials
+    f4* const r_nm = reinterpret_cast<f4*>(s_red);
+    f4* const r_dnm = r_nm + EDGE_WAVES * NM4;
+    float* const r_disp = reinterpret_cast<float*>(r_dnm + (TAN ? EDGE_WAVES * NM4 : 0));
+    __syncthreads();                                                      // (the weight images are no longer read)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        r_nm[wave * NM4 + t * 64 + lane] = nm[t];
+        if (TAN) r_dnm[wave * NM4 + t * 64 + lane] = dnm[t];
+    }
+    if (q == 0) {
+        float* p = r_disp + (wave * 16 + c) * 6;
+        p[0] = disp0; p[1] = disp1; p[2] = disp2; p[3] = dd0; p[4] = dd1; p[5] = dd2;
+    }
+    __syncthreads();
+    if (a.nm != nullptr) {
+        for (int it = tid; it < NM4 * (TAN ? 2 : 1); it += EDGE_WAVES * 64) {
+            const bool tan = it >= NM4;
+            const int e = tan ? it - NM4 : it;
+            const f4* src = tan ? r_dnm : r_nm;
+            f4 sum = src[e];
+#pragma unroll
+            for (int w = 1; w < EDGE_WAVES; ++w) sum += src[w * NM4 + e];
+            const int t = e >> 6, l = e & 63;
+            const int jj = jb * 16 + (l & 15);
+            if (jj < n) {
+                float* dst = (tan ? a.dnm : a.nm) + ((int64_t)b * n + jj) * FP;
+                reinterpret_cast<f4*>(dst)[4 * t + (l >> 4)] = sum;
+            }
+        }
+    }
+    if (tid < 16 * (TAN ? 6 : 3)) {
+        const int comp = tid % (TAN ? 6 : 3), cc = tid / (TAN ? 6 : 3);
+        const int jj = jb * 16 + cc;
+        if (jj < n) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < EDGE_WAVES; ++w) sum += r_disp[(w * 16 + cc) * 6 + comp];
+            if (comp < 3) a.pos_out[((int64_t)b * n + jj) * 3 + comp] = s_pos[3 * jj + comp] + sum;      // egnn.py:364
+            else a.dpos_out[((int64_t)b * n + jj) * 3 + comp - 3] = s_dpos[3 * jj + comp - 3] + sum;
+        }
+    }
+}
+
+template <int NT, bool TAN>
+size_t edge_lds_bytes(int n) {
+    const size_t fp = 16 * NT, img4 = (size_t)NT * NT * 64;
+    size_t fl = 3 * img4 * 4 + EDGE_CONST_VECS * fp + (size_t)((3 * n + 3) & ~3) * (TAN ? 2 : 1);
+    fl += (size_t)EDGE_WAVES * NT * 64 * 4 * (TAN ? 2 : 1) + EDGE_WAVES * 16 * 6;
+    return fl * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// node kernel between two layers: h' = h + U2 SiLU(U1 [h, nm] + c1) + c2 (egnn.py:327-342) of layer l, then the
+// source / destination terms P = W1a h', Q = W1b h' + b1 of layer l + 1 -- the same transposed MFMA chain, 16 nodes
+// per column group.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT, bool TAN>
+__global__ __launch_bounds__(NODE_WAVES * 64) void egnn_node_kernel(tfep_egnn_node_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int FP = 16 * NT;
+    constexpr int IMG4 = NT * NT * 64;
+    const PackedLayout L = packed_layout(NT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    // LDS: U1a, U1b, U2 (+ c1, c2) of this layer; W1a, W1b (+ b1) of the next
+    f4* const post = reinterpret_cast<f4*>(smem);
+    f4* const pre = post + 3 * IMG4 + 2 * FP / 4;
+    {
+        const f4* s0 = reinterpret_cast<const f4*>(a.packed + L.u1a);
+        for (int i = tid; i < 3 * IMG4 + 2 * FP / 4; i += NODE_WAVES * 64) post[i] = s0[i];
+        const f4* s1 = reinterpret_cast<const f4*>(a.packed_next + L.w1a);
+        for (int i = tid; i < 2 * IMG4 + FP / 4; i += NODE_WAVES * 64) pre[i] = s1[i];
+    }
+    __syncthreads();
+    const f4 *img_u1a = post, *img_u1b = post + IMG4, *img_u2 = post + 2 * IMG4;
+    const f4 *v_c1 = post + 3 * IMG4, *v_c2 = v_c1 + FP / 4;
+    const f4 *img_w1a = pre, *img_w1b = pre + IMG4, *v_b1 = pre + 2 * IMG4;
+    const int64_t n_total = (int64_t)a.B * a.n_nodes;
+    const int64_t n_groups = (n_total + 15) / 16;
+    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t g = (int64_t)blockIdx.x * NODE_WAVES + wave; g < n_groups; g += (int64_t)gridDim.x * NODE_WAVES) {
+        const int64_t node = g * 16 + c;
+        const bool ok = node < n_total;
+        const int64_t nd = ok ? node : 0;
+        const int64_t hb = (nd / a.n_nodes) * a.h_bstride + (nd % a.n_nodes);
+        f4 h[NT], dh[NT], m[NT], dm[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            h[t] = reinterpret_cast<const f4*>(a.h + hb * FP)[4 * t + q];
+            m[t] = reinterpret_cast<const f4*>(a.nm + nd * FP)[4 * t + q];
+            dh[t] = (TAN && a.dh != nullptr) ? reinterpret_cast<const f4*>(a.dh + nd * FP)[4 * t + q] : zero4;
+            dm[t] = TAN ? reinterpret_cast<const f4*>(a.dnm + nd * FP)[4 * t + q] : zero4;
+        }
+        f4 z[NT], dz[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { z[t] = v_c1[4 * t + q]; dz[t] = zero4; }
+        chain_gemm<NT, TAN>(img_u1a, h, dh, z, dz, lane);
+        chain_gemm<NT, TAN>(img_u1b, m, dm, z, dz, lane);
+        silu_tile<NT, TAN>(z, dz);
+        f4 y[NT], dy[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { y[t] = v_c2[4 * t + q] + h[t]; dy[t] = dh[t]; }      // residual (egnn.py:342)
+        chain_gemm<NT, TAN>(img_u2, z, dz, y, dy, lane);
+        f4 P[NT], dP[NT], Q[NT], dQ[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { P[t] = zero4; dP[t] = zero4; Q[t] = v_b1[4 * t + q]; dQ[t] = zero4; }
+        chain_gemm<NT, TAN>(img_w1a, y, dy, P, dP, lane);
+        chain_gemm<NT, TAN>(img_w1b, y, dy, Q, dQ, lane);
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                reinterpret_cast<f4*>(a.h_out + node * FP)[4 * t + q] = y[t];
+                reinterpret_cast<f4*>(a.P_out + node * FP)[4 * t + q] = P[t];
+                reinterpret_cast<f4*>(a.Q_out + node * FP)[4 * t + q] = Q[t];
+                if (TAN) {
+                    reinterpret_cast<f4*>(a.dh_out + node * FP)[4 * t + q] = dy[t];
+                    reinterpret_cast<f4*>(a.dP_out + node * FP)[4 * t + q] = dP[t];
+                    reinterpret_cast<f4*>(a.dQ_out + node * FP)[4 * t + q] = dQ[t];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// velocity (egnn.py:178-193): vel = (pos_L - x) - mean over nodes; with a tangent also d vel = (dpos_L - e) - mean and
+// the quadratic forms the trace estimators need: e . (J e) and |J e|^2 (continuous.py:307-324, :285-304).
+// One workgroup per sample.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void egnn_finish_kernel(const float* __restrict__ pos, const float* __restrict__ x,
+                                   const float* __restrict__ dpos, const float* __restrict__ eps, int n_nodes,
+                                   float* __restrict__ vel, float* __restrict__ jvp, float scale,
+                                   float* __restrict__ trace, float* __restrict__ frob, float* __restrict__ vel_sq) {
+    __shared__ double red[8][4];
+    const int b = blockIdx.x, D = 3 * n_nodes;
+    const float* p = pos + (int64_t)b * D;
+    const float* xx = x + (int64_t)b * D;
+    const bool tan = dpos != nullptr;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n_nodes; i += blockDim.x) {
+        for (int k = 0; k < 3; ++k) {
+            s[k] += (double)(p[3 * i + k] - xx[3 * i + k]);
+            if (tan) s[3 + k] += (double)(dpos[(int64_t)b * D + 3 * i + k] - eps[(int64_t)b * D + 3 * i + k]);
+        }
+    }
+    __shared__ double mean[6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    for (int k = 0; k < 6; ++k) {
+        const double v = wave_sum(s[k]);
+        if (lane == 0) red[wave][k & 3] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0;
+            for (int w = 0; w < n_waves; ++w) tot += red[w][k & 3];
+            mean[k] = tot / n_nodes;
+        }
+        __syncthreads();
+    }
+    double tr = 0, fr = 0, vs = 0;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        const int k = i % 3;
+        const float v = (float)((double)(p[i] - xx[i]) - mean[k]);
+        if (vel != nullptr) vel[(int64_t)b * D + i] = v;
+        vs += (double)v * v;
+        if (tan) {
+            const float e = eps[(int64_t)b * D + i];
+            const float dv = (float)((double)(dpos[(int64_t)b * D + i] - e) - mean[3 + k]);
+            if (jvp != nullptr) jvp[(int64_t)b * D + i] = dv;
+            tr += (double)e * dv;
+            fr += (double)dv * dv;
+        }
+    }
+    double out[3] = {tr, fr, vs};
+    for (int k = 0; k < 3; ++k) {
+        const double v = wave_sum(out[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t0 = 0, t1 = 0, t2 = 0;
+        for (int w = 0; w < n_waves; ++w) { t0 += red[w][0]; t1 += red[w][1]; t2 += red[w][2]; }
+        if (tan && trace != nullptr) trace[b] += scale * (float)t0;
+        if (tan && frob != nullptr) frob[b] += scale * (float)t1;
+        if (vel_sq != nullptr) vel_sq[b] = (float)t2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// stand-alone helpers of the public API
+// ---------------------------------------------------------------------------------------------------------------
+// Gaussian basis (radial.py:110-130) with the optional Behler-Parrinello cosine switch (radial.py:161-176, 269-291)
+__global__ void radial_kernel(const float* __restrict__ r, int64_t n, const float* __restrict__ means,
+                              const float* __restrict__ log_gammas, int n_basis, float r_cutoff, int switching,
+                              int force_zero, float* __restrict__ out) {
+    const int64_t total = n * n_basis;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i / n_basis;
+        const int k = (int)(i % n_basis);
+        const float d = r[e], dm = d - means[k];
+        float v = expf(-expf(log_gammas[k]) * dm * dm);
+        if (switching) {
+            float sw = 0.5f * cosf(3.14159265358979323846f / r_cutoff * d) + 0.5f;
+            if (force_zero && d > r_cutoff) sw = 0.0f;
+            v *= sw;
+        }
+        out[i] = v;
+    }
+}
+
+// scatter-add of rows into segments (graph.py:304-316); float atomics: the order of the additions is not fixed
+__global__ void segment_sum_kernel(const float* __restrict__ data, const int64_t* __restrict__ ids, int64_t n_rows,
+                                   int n_cols, int64_t n_segments, float* __restrict__ out) {
+    const int64_t total = n_rows * n_cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / n_cols, seg = ids[row];
+        if (seg >= 0 && seg < n_segments) atomicAdd(out + seg * n_cols + (i % n_cols), data[i]);
+    }
+}
+
+__global__ void fill_kernel(float* __restrict__ p, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+// y = x + sum_k a_k v_k  (the stage combinations of the fixed-grid Runge-Kutta steppers)
+__global__ void axpy_kernel(const float* __restrict__ x, const float* v0, const float* v1, const float* v2,
+                            const float* v3, float a0, float a1, float a2, float a3, int64_t n, float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float acc = x != nullptr ? x[i] : 0.0f;
+        if (v0 != nullptr) acc += a0 * v0[i];
+        if (v1 != nullptr) acc += a1 * v1[i];
+        if (v2 != nullptr) acc += a2 * v2[i];
+        if (v3 != nullptr) acc += a3 * v3[i];
+        y[i] = acc;
+    }
+}
+
+inline int grid_for(int64_t n, int block) { return (int)std::min<int64_t>((n + block - 1) / block, 65536); }
+
+template <typename K>
+int allow_lds(K kernel, size_t bytes, const char* what) {
+    if (bytes > 160 * 1024) return fail(TFEP_ERR_UNSUPPORTED, "%s needs %zu bytes of LDS (> 160 KiB)", what, bytes);
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+    }
+    return TFEP_OK;
+}
+
+template <int NT, bool TAN>
+int launch_edge(const tfep_egnn_edge_args& a, hipStream_t st) {
+    const size_t lds = edge_lds_bytes<NT, TAN>(a.n_nodes);
+    int rc = allow_lds(egnn_edge_kernel<NT, TAN>, lds, "tfep_egnn_edge");
+    if (rc != TFEP_OK) return rc;
+    const int64_t blocks = (int64_t)a.B * ((a.n_nodes + 15) / 16);
+    TFEP_REQUIRE(blocks < (1ll << 31), "tfep_egnn_edge: too many workgroups");
+    hipLaunchKernelGGL((egnn_edge_kernel<NT, TAN>), dim3((unsigned)blocks), dim3(EDGE_WAVES * 64), lds, st, a);
+    return check_launch("tfep_egnn_edge");
+}
+
+template <int NT, bool TAN>
+int launch_node(const tfep_egnn_node_args& a, hipStream_t st) {
+    const size_t lds = ((size_t)5 * NT * NT * 64 * 4 + 3 * 16 * NT) * sizeof(float);
+    int rc = allow_lds(egnn_node_kernel<NT, TAN>, lds, "tfep_egnn_node");
+    if (rc != TFEP_OK) return rc;
+    const int64_t groups = ((int64_t)a.B * a.n_nodes + 15) / 16;
+    const int blocks = (int)std::min<int64_t>((groups + NODE_WAVES - 1) / NODE_WAVES, 256 * 8);
+    hipLaunchKernelGGL((egnn_node_kernel<NT, TAN>), dim3(blocks), dim3(NODE_WAVES * 64), lds, st, a);
+    return check_launch("tfep_egnn_node");
+}
+
+}  // namespace
+}  // namespace tfep
+
+using namespace tfep;
+
+extern "C" {
+
+int tfep_egnn_tile(int node_feat_dim, int distance_feat_dim) {
+    const int m = node_feat_dim > distance_feat_dim ? node_feat_dim : distance_feat_dim;
+    if (node_feat_dim < 1 || distance_feat_dim < 1 || m > 64) return 0;
+    const int nt = (m + 15) / 16;
+    return nt == 3 ? 4 : nt;
+}
+
+int64_t tfep_egnn_packed_floats(int nt) {
+    if (nt != 1 && nt != 2 && nt != 4) return -1;
+    return packed_layout(nt).total;
+}
+
+int tfep_egnn_pack_layer(const tfep_egnn_layer_params* p, int nt, float* packed, void* stream) {
+    TFEP_REQUIRE(p != nullptr && packed != nullptr, "tfep_egnn_pack_layer: null argument");
+    TFEP_REQUIRE(nt == 1 || nt == 2 || nt == 4, "tfep_egnn_pack_layer: nt must be 1, 2 or 4");
+    TFEP_REQUIRE(p->F >= 1 && p->G >= 1 && p->F <= 16 * nt && p->G <= 16 * nt,
+                 "tfep_egnn_pack_layer: feature sizes (%d, %d) do not fit a tile of %d", p->F, p->G, 16 * nt);
+    TFEP_REQUIRE(p->dist_means && p->dist_log_gammas && p->msg0_w && p->msg0_b && p->msg2_w && p->msg2_b && p->att_w &&
+                 p->att_b && p->ux0_w && p->ux0_b && p->ux2_w && p->uh0_w && p->uh0_b && p->uh2_w && p->uh2_b,
+                 "tfep_egnn_pack_layer: null parameter tensor");
+    const int64_t total = packed_layout(nt).total;
+    hipLaunchKernelGGL(egnn_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, *p, nt, packed);
+    return check_launch("tfep_egnn_pack_layer");
+}
+
+int tfep_egnn_embed(const float* one_hot, int n_nodes, int n_types, float t, const float* time_means,
+                    const float* time_log_gammas, int time_dim, const float* w_emb, const float* b_emb,
+                    const tfep_egnn_layer_params* layer0, int nt, float* h0, float* P0, float* Q0, void* stream) {
+    TFEP_REQUIRE(one_hot && time_means && time_log_gammas && w_emb && b_emb && layer0 && h0 && P0 && Q0,
+                 "tfep_egnn_embed: null argument");
+    TFEP_REQUIRE(n_nodes >= 1 && n_types >= 1 && time_dim >= 1, "tfep_egnn_embed: bad sizes");
+    TFEP_REQUIRE(nt == 1 || nt == 2 || nt == 4, "tfep_egnn_embed: nt must be 1, 2 or 4");
+    TFEP_REQUIRE(layer0->F <= 16 * nt, "tfep_egnn_embed: node_feat_dim %d does not fit the tile", layer0->F);
+    const int fp = 16 * nt;
+    hipLaunchKernelGGL(egnn_embed_kernel, dim3(n_nodes), dim3(64), fp * sizeof(float), (hipStream_t)stream, one_hot, n_nodes,
+                       n_types, t, time_means, time_log_gammas, time_dim, w_emb, b_emb, layer0->F, layer0->msg0_w,
+                       layer0->msg0_b, layer0->G, fp, h0, P0, Q0);
+    return check_launch("tfep_egnn_embed");
+}
+
+int tfep_egnn_edge(const tfep_egnn_edge_args* a, void* stream) {
+    TFEP_REQUIRE(a != nullptr, "tfep_egnn_edge: null argument");
+    TFEP_REQUIRE(a->B >= 1 && a->n_nodes >= 1 && a->n_nodes <= 4096, "tfep_egnn_edge: bad sizes (B=%d, n_nodes=%d)", a->B,
+                 a->n_nodes);
+    TFEP_REQUIRE(a->packed && a->pos && a->P && a->Q && a->pos_out, "tfep_egnn_edge: null tensor");
+    TFEP_REQUIRE(a->r_cutoff > 0.0f, "tfep_egnn_edge: r_cutoff must be positive");
+    TFEP_REQUIRE(a->pq_bstride == 0 || a->pq_bstride == a->n_nodes, "tfep_egnn_edge: pq_bstride must be 0 or n_nodes");
+    const bool tan = a->dpos != nullptr;
+    if (tan) {
+        TFEP_REQUIRE(a->dpos_out != nullptr, "tfep_egnn_edge: dpos_out missing");
+        TFEP_REQUIRE((a->dP == nullptr) == (a->dQ == nullptr), "tfep_egnn_edge: dP and dQ go together");
+        TFEP_REQUIRE(a->nm == nullptr || a->dnm != nullptr, "tfep_egnn_edge: dnm missing");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (a->nt * 2 + (tan ? 1 : 0)) {
+        case 2: return launch_edge<1, false>(*a, st);
+        case 3: return launch_edge<1, true>(*a, st);
+        case 4: return launch_edge<2, false>(*a, st);
+        case 5: return launch_edge<2, true>(*a, st);
+        case 8: return launch_edge<4, false>(*a, st);
+        case 9: return launch_edge<4, true>(*a, st);
+    }
+    return fail(TFEP_ERR_INVALID_ARGUMENT, "tfep_egnn_edge: nt must be 1, 2 or 4 (got %d)", a->nt);
+}
+
+int tfep_egnn_node(const tfep_egnn_node_args* a, void* stream) {
+    TFEP_REQUIRE(a != nullptr, "tfep_egnn_node: null argument");
+    TFEP_REQUIRE(a->B >= 1 && a->n_nodes >= 1, "tfep_egnn_node: bad sizes");
+    TFEP_REQUIRE(a->packed && a->packed_next && a->h && a->nm && a->h_out && a->P_out && a->Q_out,
+                 "tfep_egnn_node: null tensor");
+    TFEP_REQUIRE(a->h_bstride == 0 || a->h_bstride == a->n_nodes, "tfep_egnn_node: h_bstride must be 0 or n_nodes");
+    const bool tan = a->dnm != nullptr;
+    if (tan) TFEP_REQUIRE(a->dh_out && a->dP_out && a->dQ_out, "tfep_egnn_node: tangent outputs missing");
+    hipStream_t st = (hipStream_t)stream;
+    switch (a->nt * 2 + (tan ? 1 : 0)) {
+        case 2: return launch_node<1, false>(*a, st);
+        case 3: return launch_node<1, true>(*a, st);
+        case 4: return launch_node<2, false>(*a, st);
+        case 5: return launch_node<2, true>(*a, st);
+        case 8: return launch_node<4, false>(*a, st);
+        case 9: return launch_node<4, true>(*a, st);
+    }
+    return fail(TFEP_ERR_INVALID_ARGUMENT, "tfep_egnn_node: nt must be 1, 2 or 4 (got %d)", a->nt);
+}
+
+int tfep_egnn_finish(const float* pos, const float* x, const float* dpos, const float* eps, int B, int n_nodes,
+                     float* vel, float* jvp, float scale, float* trace, float* frob, float* vel_sq, void* stream) {
+    TFEP_REQUIRE(pos && x && B >= 1 && n_nodes >= 1, "tfep_egnn_finish: bad arguments");
+    TFEP_REQUIRE((dpos == nullptr) == (eps == nullptr), "tfep_egnn_finish: dpos and eps go together");
+    const int block = n_nodes >= 256 ? 256 : 64;
+    hipLaunchKernelGGL(egnn_finish_kernel, dim3(B), dim3(block), 0, (hipStream_t)stream, pos, x, dpos, eps, n_nodes, vel,
+                       jvp, scale, trace, frob, vel_sq);
+    return check_launch("tfep_egnn_finish");
+}
+
+int tfep_radial_expansion(const float* r, int64_t n, const float* means, const float* log_gammas, int n_basis,
+                          float r_cutoff, int switching, int force_zero_after_cutoff, float* out, void* stream) {
+    TFEP_REQUIRE(n >= 0 && n_basis >= 1, "tfep_radial_expansion: bad sizes");
+    if (n == 0) return TFEP_OK;
+    TFEP_REQUIRE(r && means && log_gammas && out, "tfep_radial_expansion: null tensor");
+    TFEP_REQUIRE(!switching || r_cutoff > 0.0f, "tfep_radial_expansion: r_cutoff must be positive");
+    hipLaunchKernelGGL(radial_kernel, dim3(grid_for(n * n_basis, 256)), dim3(256), 0, (hipStream_t)stream, r, n, means,
+                       log_gammas, n_basis, r_cutoff, switching, force_zero_after_cutoff, out);
+    return check_launch("tfep_radial_expansion");
+}
+
+int tfep_segment_sum(const float* data, const int64_t* segment_ids, int64_t n_rows, int n_cols, int64_t n_segments,
+                     float* out, void* stream) {
+    TFEP_REQUIRE(n_rows >= 0 && n_cols >= 1 && n_segments >= 0, "tfep_segment_sum: bad sizes");
+    if (n_segments == 0) return TFEP_OK;
+    TFEP_REQUIRE(out != nullptr, "tfep_segment_sum: null output");
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n_segments * n_cols, 256)), dim3(256), 0, (hipStream_t)stream, out,
+                       n_segments * n_cols, 0.0f);
+    if (n_rows == 0) return check_launch("tfep_segment_sum");
+    TFEP_REQUIRE(data && segment_ids, "tfep_segment_sum: null tensor");
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(grid_for(n_rows * n_cols, 256)), dim3(256), 0, (hipStream_t)stream, data,
+                       segment_ids, n_rows, n_cols, n_segments, out);
+    return check_launch("tfep_segment_sum");
+}
+
+int tfep_ode_axpy(const float* x, const float* const* v, const float* a, int n_terms, int64_t n, float* y, void* stream) {
+    TFEP_REQUIRE(n >= 0 && n_terms >= 0 && n_terms <= 4 && y != nullptr, "tfep_ode_axpy: bad arguments");
+    if (n == 0) return TFEP_OK;
+    const float* vv[4] = {nullptr, nullptr, nullptr, nullptr};
+    float aa[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < n_terms; ++k) {
+        TFEP_REQUIRE(v != nullptr && a != nullptr && v[k] != nullptr, "tfep_ode_axpy: null term");
+        vv[k] = v[k];
+        aa[k] = a[k];
+    }
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, vv[0], vv[1], vv[2], vv[3],
+                       aa[0], aa[1], aa[2], aa[3], n, y);
+    return check_launch("tfep_ode_axpy");
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+"""E(n)-equivariant graph network dynamics with the ``tfep.nn.dynamics.egnn`` API on gfx950 kernels.
+
+Mirrors reference ``tfep/nn/dynamics/egnn.py``: ``EGNNDynamics`` (:28-219) with the same constructor, submodule /
+parameter names (``time_embedding._log_gammas``, ``h_embedding.{weight,bias}``, ``graph_layer_{i}.{distance_embedding.
+_log_gammas, message_mlp.{0,2}, attention_mlp.0, update_x_mlp.{0,2}, update_h_mlp.{0,2}}``), the ``_node_types_one_hot``
+buffer and the identity initialisation (:136-138).  The torch submodules only HOLD the parameters (same construction
+order, so the same seed gives the reference's initial values); the arithmetic is ``csrc/egnn.hip``:
+
+  ``forward(t, x)``   velocity ``(batch, 3 n_nodes)``                                   (egnn.py:143-194)
+  ``jvp(t, x, v)``    velocity and the directional derivative ``J v`` in the same pass -- what the trace estimators of
+                      the continuous flow are built from (``e . (J e)`` is the Hutchinson estimate, continuous.py:307-324)
+
+Per call: the parameters are re-packed (``tfep_egnn_pack_layer``), one embedding kernel, one edge kernel per layer, one
+node kernel between layers, one finishing kernel.  No edge list, no scatter_add.  There is no CPU path and no autograd
+through the kernels: differentiating the outputs raises.
+"""
+import ctypes
+
+import torch
+
+from ... import _lib
+from ..embeddings.radial import BehlerParrinelloRadialExpansion, GaussianBasisExpansion
+from ..graph import FixedGraph
+
+
+class _EGLayer(torch.nn.Module):
+    """Parameters of one equivariant layer under the reference's names (egnn.py:225-270)."""
+
+    def __init__(self, r_cutoff, node_feat_dim, distance_feat_dim, speed_factor):
+        super().__init__()
+        self.speed_factor = speed_factor
+        self.distance_embedding = BehlerParrinelloRadialExpansion.from_range(
+            r_cutoff=r_cutoff, n_gaussians=distance_feat_dim, max_mean=r_cutoff, trainable_stds=True,
+            force_zero_after_cutoff=False)
+        F = node_feat_dim
+        self.message_mlp = torch.nn.Sequential(
+            torch.nn.Linear(2 * F + distance_feat_dim, F), torch.nn.SiLU(), torch.nn.Linear(F, F), torch.nn.SiLU())
+        self.attention_mlp = torch.nn.Sequential(torch.nn.Linear(F, 1), torch.nn.Sigmoid())
+        self.update_x_mlp = torch.nn.Sequential(
+            torch.nn.Linear(F, F), torch.nn.SiLU(), torch.nn.Linear(F, 1, bias=False), torch.nn.Tanh())
+        self.update_h_mlp = torch.nn.Sequential(torch.nn.Linear(2 * F, F), torch.nn.SiLU(), torch.nn.Linear(F, F))
+
+    def forward(self, *args, **kwargs):
+        raise RuntimeError('_EGLayer holds parameters only; EGNNDynamics runs the layers on the HIP kernels')
+
+
+class EGNNDynamics(FixedGraph):
+    """Velocity field of a continuous normalizing flow (Satorras et al. 2021, as varied by tfep).  Arguments as
+    reference egnn.py:73-128."""
+
+    def __init__(
+        self,
+        node_types,
+        r_cutoff,
+        time_feat_dim=16,
+        node_feat_dim=64,
+        distance_feat_dim=64,
+        n_layers=4,
+        speed_factor=1.0,
+        initialize_identity=True,
+    ):
+        super().__init__(node_types=node_types)
+        self.time_embedding = GaussianBasisExpansion.from_range(n_gaussians=time_feat_dim, max_mean=1.0,
+                                                                trainable_stds=True)
+        self.h_embedding = torch.nn.Linear(in_features=len(self._node_types_one_hot[1]) + time_feat_dim,
+                                           out_features=node_feat_dim)
+        self._n_layers = n_layers
+        for layer_idx in range(n_layers):
+            eg_layer = _EGLayer(r_cutoff=r_cutoff, node_feat_dim=node_feat_dim, distance_feat_dim=distance_feat_dim,
+                                speed_factor=speed_factor)
+            if initialize_identity:
+                eg_layer.update_x_mlp[-2].weight.data.fill_(0.0)
+            self.add_module('graph_layer_' + str(layer_idx), eg_layer)
+        self._dims = (int(time_feat_dim), int(node_feat_dim), int(distance_feat_dim))
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, t, x):
+        """Velocity ``(batch_size, n_nodes*3)`` at time ``t`` and positions ``x``."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _NotDifferentiable.apply(self, t, x, *[p for p in self.parameters() if p.requires_grad])
+        return self._run(t, x)[0]
+
+    def jvp(self, t, x, v, trace=None, frobenius=None, scale=1.0, velocity_squared_norm=None, need_jvp=True):
+        """``(velocity, J v)`` with ``J = d velocity / d x``; optionally ``trace += scale v . (J v)``,
+        ``frobenius += scale |J v|^2`` and ``velocity_squared_norm = |velocity|^2`` (all ``(batch,)``, in place)."""
+        return self._run(t, x, v, trace, frobenius, scale, velocity_squared_norm, need_jvp)
+
+    # ------------------------------------------------------------------ execution
+    def _layers(self):
+        return [self._modules['graph_layer_' + str(i)] for i in range(self._n_layers)]
+
+    def _tile(self):
+        nt = _lib.load().tfep_egnn_tile(self._dims[1], self._dims[2])
+        if nt == 0:
+            raise NotImplementedError(f'EGNNDynamics kernels support node_feat_dim, distance_feat_dim <= 64 '
+                                      f'(got {self._dims[1]}, {self._dims[2]})')
+        return nt
+
+    def _layer_params(self, layer, device):
+        """ctypes view of one layer's parameter tensors (kept alive by the returned list)."""
+        def f32(p):
+            p = p.detach()
+            if p.device != device or p.dtype != torch.float32 or not p.is_contiguous():
+                p = p.to(device=device, dtype=torch.float32).contiguous()
+            return p
+        tensors = dict(
+            dist_means=f32(layer.distance_embedding._means), dist_log_gammas=f32(layer.distance_embedding._log_gammas),
+            msg0_w=f32(layer.message_mlp[0].weight), msg0_b=f32(layer.message_mlp[0].bias),
+            msg2_w=f32(layer.message_mlp[2].weight), msg2_b=f32(layer.message_mlp[2].bias),
+            att_w=f32(layer.attention_mlp[0].weight), att_b=f32(layer.attention_mlp[0].bias),
+            ux0_w=f32(layer.update_x_mlp[0].weight), ux0_b=f32(layer.update_x_mlp[0].bias),
+            ux2_w=f32(layer.update_x_mlp[2].weight),
+            uh0_w=f32(layer.update_h_mlp[0].weight), uh0_b=f32(layer.update_h_mlp[0].bias),
+            uh2_w=f32(layer.update_h_mlp[2].weight), uh2_b=f32(layer.update_h_mlp[2].bias))
+        p = _lib.EgnnLayerParams()
+        p.F, p.G = self._dims[1], self._dims[2]
+        for k, v in tensors.items():
+            setattr(p, k, v.data_ptr())
+        return p, tensors
+
+    def _run(self, t, x, v=None, trace=None, frob=None, scale=1.0, vel_sq=None, need_jvp=True):
+        _lib.check_device_tensor(x, 'x')
+        x, _ = _lib.rows(x, 'x')
+        x = x.contiguous()
+        B, D = x.shape
+        n = self.n_nodes
+        if D != 3 * n:
+            raise ValueError(f'x must have shape (batch_size, {3 * n}), got {tuple(x.shape)}')
+        tan = v is not None
+        if tan:
+            _lib.check_device_tensor(v, 'v')
+            v = v.contiguous()
+            if v.shape != x.shape:
+                raise ValueError('v must have the shape of x')
+        for name, acc in (('trace', trace), ('frobenius', frob), ('velocity_squared_norm', vel_sq)):
+            if acc is not None:
+                _lib.check_device_tensor(acc, name)
+                if acc.shape != (B,) or not acc.is_contiguous():
+                    raise ValueError(f'{name} must be a contiguous (batch,) tensor')
+        dev, stream = x.device, _lib.stream_of(x)
+        nt = self._tile()
+        fp = 16 * nt
+        f32 = dict(dtype=torch.float32, device=dev)
+        layers = self._layers()
+        L = len(layers)
+        t = float(t)
+
+        # ---- re-pack the parameters (every call, like the masked weights of the MAF path)
+        n_packed = _lib.load().tfep_egnn_packed_floats(nt)
+        packed = torch.empty(L, n_packed, **f32)
+        keep = []
+        params0 = None
+        for li, layer in enumerate(layers):
+            p, tensors = self._layer_params(layer, dev)
+            keep.append(tensors)
+            params0 = p if li == 0 else params0
+            _lib.call('tfep_egnn_pack_layer', ctypes.byref(p), nt, _lib.ptr(packed[li]), stream)
+
+        # ---- node embedding and layer-0 source / destination terms (the same for every sample)
+        emb = torch.empty(3, n, fp, **f32)
+        one_hot = self._node_types_one_hot.detach().to(**f32).contiguous()
+        tm = self.time_embedding._means.detach().to(**f32).contiguous()
+        tg = self.time_embedding._log_gammas.detach().to(**f32).contiguous()
+        we = self.h_embedding.weight.detach().to(**f32).contiguous()
+        be = self.h_embedding.bias.detach().to(**f32).contiguous()
+        _lib.call('tfep_egnn_embed', _lib.ptr(one_hot), n, one_hot.shape[1], t, _lib.ptr(tm), _lib.ptr(tg), len(tm),
+                  _lib.ptr(we), _lib.ptr(be), ctypes.byref(params0), nt, _lib.ptr(emb[0]), _lib.ptr(emb[1]),
+                  _lib.ptr(emb[2]), stream)
+
+        big = None
+        if L > 1:       # h, nm, P, Q (+ tangents): (B, n, fp) each, reused by every layer
+            big = torch.empty(8 if tan else 4, B, n, fp, **f32)
+        pos, dpos = x, v
+        h, h_bstride, dh = emb[0], 0, None
+        P, Q, dP, dQ, pq_bstride = emb[1], emb[2], None, None, 0
+        r_cutoff = float(layers[0].distance_embedding.r_cutoff)
+        for li, layer in enumerate(layers):
+            last = li == L - 1
+            a = _lib.EgnnEdgeArgs()
+            a.B, a.n_nodes, a.nt = B, n, nt
+            a.r_cutoff, a.speed_factor = float(layer.distance_embedding.r_cutoff), float(layer.speed_factor)
+            a.packed = packed[li].data_ptr()
+            a.pos, a.dpos = pos.data_ptr(), (dpos.data_ptr() if tan else None)
+            a.P, a.Q, a.pq_bstride = P.data_ptr(), Q.data_ptr(), pq_bstride
+            a.dP, a.dQ = (dP.data_ptr() if dP is not None else None), (dQ.data_ptr() if dQ is not None else None)
+            pos_out = torch.empty(B, D, **f32)
+            dpos_out = torch.empty(B, D, **f32) if tan else None
+            a.pos_out, a.dpos_out = pos_out.data_ptr(), (dpos_out.data_ptr() if tan else None)
+            if not last:
+                a.nm, a.dnm = big[1].data_ptr(), (big[5].data_ptr() if tan else None)
+            _lib.call('tfep_egnn_edge', ctypes.byref(a), stream)
+            if not last:
+                # (each wave of the node kernel reads a node's h completely before writing it: in place from layer 1 on)
+                na = _lib.EgnnNodeArgs()
+                na.B, na.n_nodes, na.nt = B, n, nt
+                na.packed, na.packed_next = packed[li].data_ptr(), packed[li + 1].data_ptr()
+                na.h, na.h_bstride, na.dh = h.data_ptr(), h_bstride, (dh.data_ptr() if dh is not None else None)
+                na.nm, na.dnm = big[1].data_ptr(), (big[5].data_ptr() if tan else None)
+                na.h_out, na.P_out, na.Q_out = big[0].data_ptr(), big[2].data_ptr(), big[3].data_ptr()
+                if tan:
+                    na.dh_out, na.dP_out, na.dQ_out = big[4].data_ptr(), big[6].data_ptr(), big[7].data_ptr()
+                _lib.call('tfep_egnn_node', ctypes.byref(na), stream)
+                h, h_bstride, P, Q, pq_bstride = big[0], n, big[2], big[3], n
+                if tan:
+                    dh, dP, dQ = big[4], big[6], big[7]
+            pos, dpos = pos_out, dpos_out
+        vel = torch.empty(B, D, **f32)
+        jv = torch.empty(B, D, **f32) if (tan and need_jvp) else None
+        _lib.call('tfep_egnn_finish', _lib.ptr(pos), _lib.ptr(x), _lib.ptr(dpos), _lib.ptr(v) if tan else None, B, n,
+                  _lib.ptr(vel), _lib.ptr(jv), float(scale), _lib.ptr(trace), _lib.ptr(frob), _lib.ptr(vel_sq), stream)
+        del keep, r_cutoff
+        return vel, jv
+
+
+class _NotDifferentiable(torch.autograd.Function):
+    """The velocity under autograd: the values are computed, differentiating them raises (no backward kernels yet)."""
+
+    @staticmethod
+    def forward(ctx, module, t, x, *params):
+        with torch.no_grad():
+            return module._run(t, x)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError('tfep_amd: EGNNDynamics has no backward on the HIP path (forward, Jacobian-vector '
+                                  'products and the flow trace are available); call it under torch.no_grad().')
