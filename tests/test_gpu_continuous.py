@@ -153,3 +153,160 @@ def test_radial_and_segment_sum_helpers():
     out = graph.unsorted_segment_sum(dev(g['graph/seg_data']), e[1], 8)
     np.testing.assert_allclose(out.cpu().numpy(), g['graph/seg_sum'], rtol=1e-6, atol=1e-6)
     assert graph.unsorted_segment_sum(torch.zeros(0, 3, device='cuda'), torch.zeros(0, dtype=torch.int64), 4).abs().sum() == 0
+
+
+# ------------------------------------------------------------------ the continuous flow
+
+def oracle_dynamics(name, g):
+    cfg = gu.continuous_configs()[name]
+    sd = gu.continuous_state(g, name)
+    return (lambda t, x: oe.egnn_dynamics(t, x, sd, cfg)), cfg
+
+
+@pytest.mark.parametrize('name,method,n_steps', [('tiny', 'rk4', 5), ('cutoff', 'rk4', 4), ('cutoff', 'midpoint', 8),
+                                                 ('pair', 'euler', 10), ('default', 'rk4', 2)])
+@pytest.mark.parametrize('estimator', ['hutchinson', 'exact'])
+def test_flow_matches_float64_oracle_on_the_same_grid(name, method, n_steps, estimator):
+    """ContinuousFlow over the HIP dynamics against the float64 oracle integrating with the same scheme, grid and
+    Hutchinson noise (the ODE stepping has no reference golden -- torchdiffeq is absent: parity unpinned -- but the
+    integrands are pinned by the goldens, see test_jvp_and_trace_match_reference_jacobian)."""
+    from tfep_amd.nn.flows import ContinuousFlow
+    g = gu.load('continuous.npz')
+    dyn, cfg = build_dynamics(name, g)
+    odyn, _ = oracle_dynamics(name, g)
+    x32 = g[f'{name}/x'][:4]
+    eps32 = g[f'{name}/eps'][:2, :4]
+    if estimator == 'exact' and name == 'default':
+        pytest.skip('36 coordinates x 4 layers x 8 stages in the float64 oracle: covered by the smaller fixtures')
+    flow = ContinuousFlow(dyn, trace_estimator=estimator, solver=method, solver_options={'step_size': 1.0 / n_steps},
+                          n_hutchinson_samples=2, regularization=True)
+    flow.ode_func.fixed_noise = dev(eps32)
+    with torch.no_grad():
+        y, tr, reg = flow(dev(x32))
+    assert flow.last_solver_stats['n_steps'] == n_steps
+    yo, tro, rego = oe.continuous_flow(odyn, torch.from_numpy(x32).double(), n_steps, method, estimator=estimator,
+                                       eps=torch.from_numpy(eps32).double(), regularization=True, frobenius_from='jvp')
+    assert rel_l2(y, yo.numpy()) <= REL
+    np.testing.assert_allclose(tr.cpu().numpy(), tro.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(reg.cpu().numpy(), rego.numpy(), rtol=1e-4, atol=2e-5)
+    # without the regularisation term the state has two components and the same y / trace
+    flow.regularization = False
+    with torch.no_grad():
+        y2, tr2 = flow(dev(x32))
+    assert torch.equal(y2, y) and torch.equal(tr2, tr)
+    # inverse: integrates back from t = 1, the trace comes out negated (continuous.py:176-180)
+    with torch.no_grad():
+        xb, trb = flow.inverse(y)
+    xo, tbo = oe.continuous_flow(odyn, yo, n_steps, method, inverse=True, estimator=estimator,
+                                 eps=torch.from_numpy(eps32).double(), regularization=False)
+    assert rel_l2(xb, xo.numpy()) <= REL
+    np.testing.assert_allclose(trb.cpu().numpy(), tbo.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_flow_round_trip_and_adaptive_solver():
+    """tests/nn/flows/test_continuous.py:221-260 on the HIP dynamics: inverse(forward(x)) == x with cancelling traces
+    (exact estimator), for the fixed-grid rk4 and the adaptive dopri5; dopri5 agrees with a fine rk4 grid to its
+    tolerance and reports its step counts."""
+    from tfep_amd.nn.flows import ContinuousFlow
+    g = gu.load('continuous.npz')
+    dyn, cfg = build_dynamics('cutoff', g)
+    x = dev(g['cutoff/x'])
+    fine = ContinuousFlow(dyn, trace_estimator='exact', solver='rk4', solver_options={'step_size': 1 / 32}, regularization=False)
+    with torch.no_grad():
+        y_ref, tr_ref = fine(x)
+        xb, trb = fine.inverse(y_ref)
+    assert float((xb - x).abs().max()) < 2e-5 and float((tr_ref + trb).abs().max()) < 2e-4
+    flow = ContinuousFlow(dyn, trace_estimator='exact', regularization=False)          # solver='dopri5', the default
+    with torch.no_grad():
+        y, tr = flow(x)
+        stats = dict(flow.last_solver_stats)
+        xi, tri = flow.inverse(y)
+    assert stats['n_steps'] >= 1 and stats['n_evaluations'] >= 7
+    # rtol = atol = 1e-4 on an RMS norm over the whole batch: individual coordinates end a few 1e-3 off (the reference's
+    # own round-trip test uses atol 1e-3 on a much smoother toy dynamics)
+    assert float((y - y_ref).abs().max()) < 5e-3 and float((tr - tr_ref).abs().max()) < 1e-2
+    assert float((xi - x).abs().max()) < 5e-3 and float((tr + tri).abs().max()) < 1e-2
+    # fresh noise per integration unless fixed (continuous.py:223-229)
+    hut = ContinuousFlow(dyn, solver='euler', solver_options={'step_size': 0.5}, regularization=False)
+    with torch.no_grad():
+        _, t1 = hut(x)
+        _, t2 = hut(x)
+        hut.ode_func.fixed_noise = torch.randn(1, *x.shape, device='cuda')
+        _, t3 = hut(x)
+        _, t4 = hut(x)
+    assert not torch.equal(t1, t2) and torch.equal(t3, t4)
+
+
+def test_flow_api_schema_and_errors():
+    from tfep_amd.nn.dynamics import EGNNDynamics
+    from tfep_amd.nn.flows import ContinuousFlow
+    dyn = EGNNDynamics([0, 1], r_cutoff=3.0, time_feat_dim=2, node_feat_dim=4, distance_feat_dim=3, n_layers=1)
+    flow = ContinuousFlow(dyn)
+    assert all(k.startswith('ode_func.dynamics.') for k in flow.state_dict())
+    assert flow.ode_func.trace_estimator == 'hutchinson' and flow.solver == 'dopri5' and flow.regularization
+    with pytest.raises(ValueError):
+        ContinuousFlow(dyn, trace_estimator='foo')
+    flow = flow.cuda()
+    x = torch.randn(3, 6, device='cuda')
+    y, tr, reg = flow(x)                                      # identity initialisation: nothing moves
+    assert torch.equal(y.detach(), x) and float(tr.abs().max()) == 0.0 and float(reg.abs().max()) == 0.0
+    with pytest.raises(NotImplementedError):
+        y.sum().backward()                                   # loud, not silent
+    with pytest.raises(ValueError):
+        ContinuousFlow(dyn, solver='adams')(x.detach())
+    with pytest.raises(_lib_error()):
+        flow(x.cpu())                                        # no CPU fallback
+    with pytest.raises(NotImplementedError):
+        EGNNDynamics([0, 1], r_cutoff=3.0, node_feat_dim=65).cuda()(0.0, x.detach())
+
+
+def _lib_error():
+    from tfep_amd._lib import TfepHipError
+    return TfepHipError
+
+
+class DynamicsMLP(torch.nn.Module):
+    """A user-supplied torch dynamics (the one the reference's own tests use, test_continuous.py:82-103)."""
+
+    def __init__(self, n_features):
+        super().__init__()
+        self.mlp = torch.nn.Sequential(
+            torch.nn.Linear(n_features + 1, n_features), torch.nn.SiLU(), torch.nn.Linear(n_features, n_features),
+            torch.nn.SiLU(), torch.nn.Linear(n_features, n_features, bias=False), torch.nn.Tanh())
+
+    def forward(self, t, x):
+        if len(x.shape) > 1:
+            t = t.reshape(1, 1).expand(x.shape[0], 1)
+        return self.mlp(torch.cat([t, x], dim=-1))
+
+
+def test_user_supplied_torch_dynamics_through_autograd():
+    """Any ``dynamics(t, x)`` module still works: velocity and vector-Jacobian products by autograd on
+    the device.  Exact trace / Frobenius norm against the full autograd Jacobian, Hutchinson in expectation, round trip,
+    identity flow with a stable backward (test_continuous.py:125-260)."""
+    from tfep_amd.nn.flows import ContinuousFlow
+    torch.manual_seed(2)
+    D, B = 9, 5
+    dyn = DynamicsMLP(D).cuda().double()
+    x = torch.randn(B, D, device='cuda', dtype=torch.float64)
+    t = torch.tensor(0.3, device='cuda', dtype=torch.float64)
+    jac = torch.stack([torch.autograd.functional.jacobian(lambda z: dyn(t, z[None])[0], x[b]) for b in range(B)])
+    flow = ContinuousFlow(dyn, trace_estimator='exact', solver='rk4', solver_options={'step_size': 0.1}, requires_backward=False)
+    vel, tr, reg = flow.ode_func(t, (x, x.new_zeros(B), x.new_zeros(B)))
+    assert torch.allclose(tr, torch.diagonal(jac, dim1=1, dim2=2).sum(-1))
+    assert torch.allclose(reg, (vel ** 2).sum(-1) + (jac ** 2).sum((1, 2)))
+    hut = ContinuousFlow(dyn, n_hutchinson_samples=4000, requires_backward=False)
+    hut.ode_func.before_odeint(x)
+    _, trh, regh = hut.ode_func(t, (x, x.new_zeros(B), x.new_zeros(B)))
+    assert torch.allclose(trh, tr, atol=5e-2) and torch.allclose(regh, reg, atol=5e-2)
+    with torch.no_grad():
+        y, tr1, _ = flow(x)
+        xb, tr2, _ = flow.inverse(y)
+    assert torch.allclose(xb, x, atol=1e-5) and torch.allclose(tr1 + tr2, torch.zeros_like(tr1), atol=1e-5)
+    # identity dynamics: y == x, zero trace, gradient of sum(y) w.r.t. x is one (test_identity_flow)
+    dyn.mlp[-2].weight.data.fill_(0.0)
+    xg = x.clone().requires_grad_(True)
+    y, tr, reg = ContinuousFlow(dyn, trace_estimator='exact', solver='rk4', solver_options={'step_size': 0.25})(xg)
+    assert torch.allclose(y, xg) and torch.allclose(tr, torch.zeros_like(tr))
+    y.sum().backward()
+    assert torch.allclose(xg.grad, torch.ones_like(xg.grad))

@@ -4,3 +4,4 @@ from .sequential import SequentialFlow  # noqa: F401
 from .partial import PartialFlow  # noqa: F401
 from .centroid import CenteredCentroidFlow  # noqa: F401
 from .oriented import OrientedFlow  # noqa: F401
+from .continuous import ContinuousFlow  # noqa: F401

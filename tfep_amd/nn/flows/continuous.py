@@ -1,0 +1,223 @@
+"""Continuous normalizing flow with the ``tfep.nn.flows.continuous`` API (reference ``tfep/nn/flows/continuous.py``).
+
+``ContinuousFlow`` (:29-181) keeps the constructor, ``forward`` / ``inverse`` -> ``(y, trace[, reg])`` (the trace of the
+inverse negated, :176-180), the ``ode_func`` submodule (``ode_func.dynamics.*`` in the ``state_dict``) and
+``before_odeint``'s fresh Hutchinson noise per integration (:223-229).  Two execution paths:
+
+* dynamics with a Jacobian-vector-product kernel (``tfep_amd.nn.dynamics.EGNNDynamics``): the integrands come from the
+  HIP kernels -- velocity, ``e . (J e)`` (Hutchinson, :307-324; equal to the reference's ``(e^T J) . e``) or
+  ``sum_k e_k . (J e_k)`` (exact, :285-304), and the regulariser ``|v|^2 + |J|_F^2`` (:262-268).  The exact Frobenius norm
+  is ``sum_k |J e_k|^2``; the Hutchinson Frobenius estimate is formed from ``|J e|^2`` -- the same expectation as the
+  reference's ``|e^T J|^2`` but not the same number for a given ``e`` (a reverse pass through the kernels does not exist
+  yet).  Not differentiable: backward raises.
+* any other ``dynamics(t, x)`` torch module: velocity and vector-Jacobian products by autograd on the device, as the
+  reference does; differentiable with ``adjoint=False`` semantics (plain backpropagation through the steps).
+
+The ODE is integrated by ``_odeint.odeint`` (torchdiffeq is absent: "ODE-solve parity unpinned", see there).
+"""
+import ctypes
+import enum
+
+import torch
+
+from ... import _lib
+from . import _odeint
+
+
+class ContinuousFlow(torch.nn.Module):
+    """Continuous normalizing flow (Chen et al. 2018; Hutchinson trace as in FFJORD; regularisation as in Finlay et
+    al. 2020).  Arguments as reference continuous.py:29-112; ``solver`` is one of ``euler``, ``midpoint``, ``rk4``
+    (with ``solver_options={'step_size': h}``) or ``dopri5`` (``rtol = atol = 1e-4`` as in the reference)."""
+
+    def __init__(
+            self,
+            dynamics,
+            trace_estimator='hutchinson',
+            solver='dopri5',
+            solver_options=None,
+            n_hutchinson_samples=1,
+            adjoint=True,
+            regularization=True,
+            vmap=False,
+            requires_backward=True,
+    ):
+        super().__init__()
+        self.ode_func = _ODEFunc(dynamics, trace_estimator, n_hutchinson_samples, vmap, requires_backward)
+        self.solver = solver
+        self.solver_options = solver_options
+        self.adjoint = adjoint
+        self.regularization = regularization
+        self.last_solver_stats = {}
+
+    def forward(self, x):
+        """``(y, trace[, reg])``: mapped coordinates, log|det J| of the flow, regularisation integral."""
+        return self._pass(x, inverse=False)
+
+    def inverse(self, y):
+        return self._pass(y, inverse=True)
+
+    def _pass(self, x, inverse):
+        t0, t1 = (1.0, 0.0) if inverse else (0.0, 1.0)
+        f = self.ode_func
+        hip = f.uses_kernels()
+        # kernels: float32 HIP tensors; a user-supplied torch dynamics: any floating dtype, but still on the device
+        _lib.check_device_tensor(x, 'x', dtype=torch.float32 if hip else x.dtype)
+        if hip and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            params = [p for p in self.parameters() if p.requires_grad]
+            return list(_FlowNotDifferentiable.apply(self, x, inverse, *params))
+        return self._integrate(x, t0, t1, hip)
+
+    def _integrate(self, x, t0, t1, hip):
+        f = self.ode_func
+        trace = torch.full((x.shape[0],), 0.0, dtype=x.dtype, device=x.device)
+        f.before_odeint(x)
+        state = (x, trace, trace.clone()) if self.regularization else (x, trace)
+        stats = {}
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not hip):
+            out = _odeint.odeint(f, state, t0, t1, method=self.solver, options=self.solver_options, rtol=1e-4, atol=1e-4,
+                                 axpy=_axpy_kernel if hip else _axpy_torch, stats=stats)
+        self.last_solver_stats = stats
+        out = list(out)
+        out[1] = -out[1]             # the integration started from a zero trace (continuous.py:176-180)
+        return out
+
+
+class _ODEFunc(torch.nn.Module):
+    """``(t, state) -> integrands`` for the stepper (reference continuous.py:188-278)."""
+
+    class TraceEstimators(enum.Enum):
+        exact, hutchinson = range(2)
+
+    def __init__(self, dynamics, trace_estimator, n_hutchinson_samples, vmap, requires_backward):
+        super().__init__()
+        self.dynamics = dynamics
+        self.trace_estimator = trace_estimator
+        self.n_hutchinson_samples = n_hutchinson_samples
+        self.vmap = vmap
+        self.requires_backward = requires_backward
+        self._eps = None
+        #: Set to a ``(n_hutchinson_samples, batch, features)`` tensor to use THAT noise instead of fresh normal
+        #: samples in the next integrations (reproducible traces; the reference redraws on every call).
+        self.fixed_noise = None
+
+    @property
+    def trace_estimator(self):
+        return self._trace_estimator.name
+
+    @trace_estimator.setter
+    def trace_estimator(self, new_trace_estimator):
+        try:
+            self._trace_estimator = getattr(self.TraceEstimators, new_trace_estimator)
+        except AttributeError:
+            raise ValueError('trace_estimator must be one of {}'.format([e.name for e in self.TraceEstimators]))
+
+    def uses_kernels(self):
+        return callable(getattr(self.dynamics, 'jvp', None)) and hasattr(self.dynamics, '_run')
+
+    def before_odeint(self, x):
+        """New Hutchinson noise for a new integration (continuous.py:223-229)."""
+        if self._trace_estimator == self.TraceEstimators.hutchinson:
+            if self.fixed_noise is not None:
+                eps = self.fixed_noise.to(device=x.device, dtype=x.dtype)
+                if eps.shape != (self.n_hutchinson_samples, *x.shape):
+                    raise ValueError('fixed_noise must have shape (n_hutchinson_samples, batch_size, n_features)')
+                self._eps = eps.contiguous()
+            else:
+                self._eps = torch.randn(self.n_hutchinson_samples, *x.shape, dtype=x.dtype, device=x.device)
+
+    def forward(self, t, state):
+        regularization = len(state) == 3
+        x = state[0]
+        if self.uses_kernels():
+            return self._kernel_integrands(float(t), x, regularization)
+        return self._autograd_integrands(t, x, regularization)
+
+    # ------------------------------------------------------------------ HIP kernels
+    def _kernel_integrands(self, t, x, regularization):
+        dyn = self.dynamics
+        B, D = x.shape
+        zeros = dict(dtype=torch.float32, device=x.device)
+        trace = torch.full((B,), 0.0, **zeros)
+        frob = torch.full((B,), 0.0, **zeros) if regularization else None
+        vsq = torch.full((B,), 0.0, **zeros) if regularization else None
+        vel = None
+        if self._trace_estimator == self.TraceEstimators.hutchinson:
+            S = len(self._eps)
+            for s in range(S):
+                v, _ = dyn.jvp(t, x, self._eps[s], trace=trace, frobenius=frob, scale=1.0 / S,
+                               velocity_squared_norm=vsq if s == 0 else None, need_jvp=False)
+                vel = v if vel is None else vel
+        else:
+            for k in range(D):                   # one unit tangent per coordinate (the reference: D reverse passes)
+                e = torch.full((B, D), 0.0, **zeros)
+                e[:, k] = 1.0
+                v, _ = dyn.jvp(t, x, e, trace=trace, frobenius=frob, scale=1.0,
+                               velocity_squared_norm=vsq if k == 0 else None, need_jvp=False)
+                vel = v if vel is None else vel
+        if regularization:
+            return vel, trace, _axpy_kernel(vsq, [(1.0, frob)])
+        return vel, trace
+
+    # ------------------------------------------------------------------ any torch dynamics: autograd on the device
+    def _autograd_integrands(self, t, x, regularization):
+        create_graph = bool(self.requires_backward) and torch.is_grad_enabled()
+        t = torch.as_tensor(t, dtype=x.dtype, device=x.device)
+        with torch.enable_grad():
+            if not x.requires_grad:
+                x = x.detach().requires_grad_(True) if not create_graph else x.requires_grad_(True)
+            vel = self.dynamics(t, x)
+            if self._trace_estimator == self.TraceEstimators.hutchinson:
+                rows = torch.stack([torch.autograd.grad(vel, x, e, create_graph=create_graph, retain_graph=True)[0]
+                                    for e in self._eps])                         # e^T J per noise sample
+                trace = (rows * self._eps).sum(dim=-1).mean(dim=0)
+                frob = (rows * rows).sum(dim=-1).mean(dim=0)
+            else:
+                D = x.shape[1]
+                summed = vel.sum(dim=0)
+                trace, frob = 0.0, 0.0
+                for k in range(D):
+                    sel = torch.zeros(D, dtype=x.dtype, device=x.device)
+                    sel[k] = 1.0
+                    row = torch.autograd.grad(summed, x, sel, create_graph=create_graph, retain_graph=True)[0]
+                    trace = trace + row[:, k]
+                    frob = frob + (row * row).sum(dim=-1)
+        if not create_graph:
+            vel, trace, frob = vel.detach(), trace.detach(), frob.detach()
+        if regularization:
+            return vel, trace, (vel * vel).sum(dim=-1) + frob
+        return vel, trace
+
+
+def _axpy_torch(x, terms):
+    out = x
+    for a, v in terms:
+        out = out + a * v
+    return out
+
+
+def _axpy_kernel(x, terms):
+    """``x + sum a_k v_k`` by ``tfep_ode_axpy`` (float32 HIP tensors of one shape; at most 4 terms per launch)."""
+    x = x.contiguous()
+    out = x
+    for i in range(0, max(len(terms), 1), 4):
+        chunk = terms[i:i + 4]
+        vs = [v.contiguous() for _, v in chunk]
+        ptrs = (ctypes.c_void_p * 4)(*[v.data_ptr() for v in vs], *([None] * (4 - len(vs))))
+        coef = (ctypes.c_float * 4)(*[float(a) for a, _ in chunk], *([0.0] * (4 - len(vs))))
+        y = torch.empty_like(x)
+        _lib.call('tfep_ode_axpy', _lib.ptr(out), ptrs, coef, len(vs), x.numel(), _lib.ptr(y), _lib.stream_of(x))
+        out = y
+    return out
+
+
+class _FlowNotDifferentiable(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, flow, x, inverse, *params):
+        t0, t1 = (1.0, 0.0) if inverse else (0.0, 1.0)
+        with torch.no_grad():
+            return tuple(flow._integrate(x, t0, t1, True))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError('tfep_amd: a ContinuousFlow over HIP dynamics has no backward yet (forward, inverse and '
+                                  'the trace are available); call it under torch.no_grad().')
