@@ -77,6 +77,12 @@ __device__ inline void chain_gemm(const f4* __restrict__ img, const f4 (&x)[NT],
     }
 }
 
+// exp and 1/x on the transcendental unit (v_exp_f32 / v_rcp_f32, 1 ulp each; the argument scaling x * log2(e) adds
+// |x| 6e-8 of relative error): the library expf / IEEE division cost ~10 instructions each, and the edge kernel evaluates
+// 64 of each per 16 edges and layer.  Measured against the float64 goldens the velocities keep their 6e-7 relative error.
+__device__ inline float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ inline float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
 // SiLU and its derivative (torch.nn.SiLU: x * sigmoid(x)), elementwise on a tile; dz <- silu'(z) dz, z <- silu(z)
 template <int NT, bool TAN>
 __device__ inline void silu_tile(f4 (&z)[NT], f4 (&dz)[NT]) {
@@ -85,7 +91,7 @@ __device__ inline void silu_tile(f4 (&z)[NT], f4 (&dz)[NT]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v = z[t][r];
-            const float sig = 1.0f / (1.0f + expf(-v));
+            const float sig = fast_rcp(1.0f + fast_exp(-v));
             z[t][r] = v * sig;
             if (TAN) dz[t][r] *= sig * (1.0f + v * (1.0f - sig));
         }
@@ -194,7 +200,16 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
     const PackedLayout L = packed_layout(NT);
     const int n = a.n_nodes;
     const int n_blk = (n + 15) / 16;
-    const int b = blockIdx.x / n_blk, jb = blockIdx.x % n_blk;
+    // Workgroup ids go round-robin over the 8 XCDs (each with its own L2): remap so that an XCD works through a
+    // CONTIGUOUS range of (sample, destination block) pairs -- the 16 blocks of a sample then share one L2 for the
+    // sample's positions and source terms (bijective for any grid size; a different placement only costs speed).
+    int blk;
+    {
+        const int total = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q8 = total >> 3, r8 = total & 7;
+        blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int b = blk / n_blk, jb = blk % n_blk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane >> 4, c = lane & 15;
 
@@ -203,7 +218,9 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
     float* const vecs = smem + 3 * IMG4 * 4;
     float* const s_pos = vecs + EDGE_CONST_VECS * FP;
     float* const s_dpos = s_pos + ((3 * n + 3) & ~3);
-    float* const s_red = s_dpos + (TAN ? ((3 * n + 3) & ~3) : 0);
+    f4* const s_q = reinterpret_cast<f4*>(s_dpos + (TAN ? ((3 * n + 3) & ~3) : 0));      // Q of the 16 destinations
+    f4* const s_dq = s_q + NT * 64;
+    float* const s_red = reinterpret_cast<float*>(s_dq + (TAN ? NT * 64 : 0));
     {
         const f4* src = reinterpret_cast<const f4*>(a.packed + L.w1c);
         const int n4 = 3 * IMG4 + EDGE_CONST_VECS * FP / 4;
@@ -214,6 +231,20 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
             const float* pdx = a.dpos + (int64_t)b * 3 * n;
             for (int i = tid; i < 3 * n; i += EDGE_WAVES * 64) s_dpos[i] = pdx[i];
         }
+    }
+    // destination terms Q_j (+ tangent) of the block, lane-linear: entry (4t + q) * 16 + c is Q[j0 + c][16t + 4q ..]
+    const int64_t pq_b = (int64_t)blk / n_blk * a.pq_bstride;
+    for (int e = tid; e < NT * 64 * (TAN ? 2 : 1); e += EDGE_WAVES * 64) {
+        const bool tan = e >= NT * 64;
+        const int ee = tan ? e - NT * 64 : e;
+        const int cc = ee & 15, tq = ee >> 4;
+        const int jj = jb * 16 + cc;
+        f4 v = f4{0.f, 0.f, 0.f, 0.f};
+        if (jj < n) {
+            if (!tan) v = reinterpret_cast<const f4*>(a.Q + (pq_b + jj) * FP)[tq];
+            else if (a.dQ != nullptr) v = reinterpret_cast<const f4*>(a.dQ + ((int64_t)b * n + jj) * FP)[tq];
+        }
+        (tan ? s_dq : s_q)[ee] = v;
     }
     const float att_b = a.packed[L.scal];
     __syncthreads();
@@ -234,17 +265,6 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
     const float xj0 = s_pos[3 * jc], xj1 = s_pos[3 * jc + 1], xj2 = s_pos[3 * jc + 2];
     float dxj0 = 0.f, dxj1 = 0.f, dxj2 = 0.f;
     if (TAN) { dxj0 = s_dpos[3 * jc]; dxj1 = s_dpos[3 * jc + 1]; dxj2 = s_dpos[3 * jc + 2]; }
-    const int64_t pq_b = (int64_t)b * a.pq_bstride;
-    f4 Qj[NT], dQj[NT];
-    {
-        const f4* Qp = reinterpret_cast<const f4*>(a.Q + (pq_b + jc) * FP);
-        const f4* dQp = (TAN && a.dQ != nullptr) ? reinterpret_cast<const f4*>(a.dQ + ((int64_t)b * n + jc) * FP) : nullptr;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            Qj[t] = Qp[4 * t + q];
-            dQj[t] = dQp != nullptr ? dQp[4 * t + q] : f4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
     f4 nm[NT], dnm[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) { nm[t] = f4{0.f, 0.f, 0.f, 0.f}; dnm[t] = f4{0.f, 0.f, 0.f, 0.f}; }
@@ -252,8 +272,35 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
     const float rc = a.r_cutoff, pi_rc = 3.14159265358979323846f / rc;
     const float* const Pb = a.P + pq_b * FP;
     const float* const dPb = (TAN && a.dP != nullptr) ? a.dP + (int64_t)b * n * FP : nullptr;
+    // source terms P_i (+ tangent) of the NEXT source are fetched one iteration ahead: with two waves per SIMD nothing
+    // else hides an L2 / HBM round trip
+    f4 Pn[NT], dPn[NT];
+    auto fetch_source = [&](int i) {
+        const int ic = i < n ? i : 0;
+        const f4* Pp = reinterpret_cast<const f4*>(Pb + (int64_t)ic * FP);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) Pn[t] = Pp[4 * t + q];
+        if (TAN) {
+            if (dPb != nullptr) {
+                const f4* dPp = reinterpret_cast<const f4*>(dPb + (int64_t)ic * FP);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dPn[t] = dPp[4 * t + q];
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) dPn[t] = f4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    fetch_source(wave);
 
     for (int i = wave; i < n; i += EDGE_WAVES) {
+        f4 z[NT], dz[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {                                    // z1 starts as P_i + Q_j
+            z[t] = Pn[t] + s_q[(4 * t + q) * 16 + c];
+            if (TAN) dz[t] = dPn[t] + s_dq[(4 * t + q) * 16 + c];
+        }
+        fetch_source(i + EDGE_WAVES);
         // ---- geometry of the 16 edges (i -> j0 + c); the four q-groups compute it redundantly (a few dozen VALU)
         const float v0 = xj0 - s_pos[3 * i], v1 = xj1 - s_pos[3 * i + 1], v2 = xj2 - s_pos[3 * i + 2];
         const float d = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);              // graph.py:257
@@ -278,22 +325,12 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float dm = d - mu[r];
-                const float g = expf(-ga[r] * dm * dm);                   // radial.py:126-128
+                const float g = fast_exp(-ga[r] * dm * dm);               // radial.py:126-128
                 rbf[t][r] = g * sw;                                       // radial.py:291
                 if (TAN) drbf[t][r] = ddist * g * (dsw - 2.0f * ga[r] * dm * sw);
             }
         }
         // ---- message MLP: z1 = P_i + Q_j + W1c rbf (egnn.py:246-251 with the first linear split by input block)
-        f4 z[NT], dz[NT];
-        {
-            const f4* Pp = reinterpret_cast<const f4*>(Pb + (int64_t)i * FP);
-            const f4* dPp = dPb != nullptr ? reinterpret_cast<const f4*>(dPb + (int64_t)i * FP) : nullptr;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                z[t] = Pp[4 * t + q] + Qj[t];
-                if (TAN) dz[t] = dPp != nullptr ? dPp[4 * t + q] + dQj[t] : dQj[t];
-            }
-        }
         chain_gemm<NT, TAN>(img_w1c, rbf, drbf, z, dz, lane);
         silu_tile<NT, TAN>(z, dz);
         f4 y[NT], dy[NT];
@@ -398,6 +435,7 @@ template <int NT, bool TAN>
 size_t edge_lds_bytes(int n) {
     const size_t fp = 16 * NT, img4 = (size_t)NT * NT * 64;
     size_t fl = 3 * img4 * 4 + EDGE_CONST_VECS * fp + (size_t)((3 * n + 3) & ~3) * (TAN ? 2 : 1);
+    fl += (size_t)NT * 64 * 4 * (TAN ? 2 : 1);                       // Q / dQ of the destination block
     fl += (size_t)EDGE_WAVES * NT * 64 * 4 * (TAN ? 2 : 1) + EDGE_WAVES * 16 * 6;
     return fl * sizeof(float);
 }
