@@ -139,7 +139,7 @@ def _loss_grad_worker(rank, world, port, q, weighted):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         import tfep_amd.loss as tl
-        tl.ops.tfep_reduce = _stats_cpu                      # this process only
+        tl.reduce_stats = _stats_cpu                         # this process only (the HIP reduction cannot run here)
         torch.manual_seed(0)
         n = 11                                               # ragged shards (6 + 5)
         x = torch.randn(n, 4, dtype=torch.float64)

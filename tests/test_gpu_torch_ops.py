@@ -1,0 +1,151 @@
+"""The kernels as custom torch ops (``torch.ops.tfep.*``): schema / fake-tensor / autograd-registration / AOT checks by
+``torch.library.opcheck``, gradients through the registered formulas, tracing under fake tensors, and that the Module
+API really goes through the dispatcher."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _spline_args(D, K=8, circular=False, identity=False, lower=False, upper=False):
+    x0, xf = torch.full((D,), -2.0, device='cuda'), torch.full((D,), 3.0, device='cuda')
+    return (x0, xf, x0.clone(), xf.clone(), K, circular, identity, lower, upper, 1e-4, 1e-4)
+
+
+def _n_par(K, circular, identity, lower, upper):
+    n = 3 * K + 1 + int(lower) + int(upper)
+    if identity:
+        n -= 1 if circular else 2
+    return n
+
+
+def _samples():
+    import tfep_amd.torch_ops  # noqa: F401
+    g = torch.Generator(device='cuda').manual_seed(0)
+    B, D = 7, 6
+
+    def r(*shape, grad=False):
+        return torch.randn(*shape, device='cuda', generator=g).requires_grad_(grad)
+    out = {}
+    out['affine_forward'] = [(r(B, D, grad=True), r(B, 2 * D, grad=True))]
+    out['affine_inverse'] = [(r(B, D), r(B, 2 * D))]
+    out['affine_backward'] = [(r(B, D), r(B, 2 * D), r(B, D), r(B))]
+    for flags in ((False, False, False, False), (True, False, False, False), (False, True, True, True)):
+        cfg = _spline_args(D, 5, *flags)
+        P = _n_par(5, *flags)
+        out.setdefault('spline_forward', []).append((r(B, D, grad=True), r(B, P * D, grad=True), *cfg))
+        out.setdefault('spline_inverse', []).append((r(B, D), r(B, P * D), *cfg))
+        out.setdefault('spline_backward', []).append((r(B, D), r(B, P * D), r(B, D), r(B), *cfg))
+    x = r(B, D)
+    x = x / x.reshape(B, 3, 2).norm(dim=-1).repeat_interleave(2, dim=1)
+    out['moebius_forward'] = [(x.clone().requires_grad_(True), r(B, D, grad=True), 2, 0.99, True),
+                              (r(B, D, grad=True), r(B, D, grad=True), 3, 0.9, False)]
+    out['moebius_inverse'] = [(x.clone(), r(B, D), 2, 0.99, True)]
+    out['moebius_backward'] = [(x.clone(), r(B, D), r(B, D), r(B), 2, 0.99, True)]
+    mask = (torch.rand(5, D, device='cuda', generator=g) > 0.4).float()
+    mask[2] = 0.0                                                     # a fully masked row (NaN-safe weight norm)
+    out['masked_linear'] = [
+        (r(B, D, grad=True), r(5, D, grad=True), r(5, grad=True), mask, r(5, 1, grad=True)),
+        (r(3, B, D, grad=True), r(5, D, grad=True), None, None, None)]
+    out['masked_linear_backward'] = [(r(B, 5), r(B, D), r(5, D), mask, r(5, 1)), (r(B, 5), r(B, D), r(5, D), None, None)]
+    out['tfep_reduce'] = [(r(100), r(100), r(100), r(100), None, 1.0, False), (r(100), None, None, None, r(100), 2.5, True)]
+    return out
+
+
+def test_every_op_is_registered_with_a_fake_and_passes_opcheck():
+    import tfep_amd.torch_ops as to
+    samples = _samples()
+    for name in to.OPS:
+        op = getattr(torch.ops.tfep, name).default
+        if name == 'fused_output_transformer':
+            continue                                                  # exercised through the Module API below
+        assert name in samples, name
+        for args in samples[name]:
+            torch.library.opcheck(op, args)
+
+
+def test_ops_are_differentiable_and_match_the_module_backward():
+    """Stand-alone transformers are differentiable through the registered autograd formulas (the reference's are, by
+    eager autograd): gradients against the float64 torch restatement of the same maps."""
+    from tfep_amd.nn.transformers import AffineTransformer, NeuralSplineTransformer
+    g = torch.Generator(device='cuda').manual_seed(1)
+    B, D = 11, 5
+    x = torch.randn(B, D, device='cuda', generator=g, requires_grad=True)
+    p = torch.randn(B, 2 * D, device='cuda', generator=g, requires_grad=True)
+    y, l = AffineTransformer()(x, p)
+    (y.square().sum() + (l * l).sum()).backward()
+    x64, p64 = x.detach().double().requires_grad_(True), p.detach().double().requires_grad_(True)
+    y64 = x64 * torch.exp(p64[:, D:]) + p64[:, :D]
+    l64 = p64[:, D:].sum(1)
+    (y64.square().sum() + (l64 * l64).sum()).backward()
+    assert torch.allclose(x.grad.double(), x64.grad, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(p.grad.double(), p64.grad, rtol=1e-5, atol=1e-5)
+    # spline: against central differences of the op itself in the parameters
+    t = NeuralSplineTransformer(torch.full((D,), -3.0), torch.full((D,), 3.0), 4).cuda()
+    P = t.n_parameters_per_feature
+    par = torch.randn(B, P * D, device='cuda', generator=g, requires_grad=True)
+    xs = (torch.rand(B, D, device='cuda', generator=g) * 5 - 2.5).requires_grad_(True)
+    y, l = t(xs, par)
+    w = torch.randn(B, D, device='cuda', generator=g)
+    ((y * w).sum() + l.sum()).backward()
+    with torch.no_grad():
+        h = 1e-2
+        for (bi, ci) in ((0, 0), (3, 7), (10, P * D - 1)):
+            pp, pm = par.detach().clone(), par.detach().clone()
+            pp[bi, ci] += h
+            pm[bi, ci] -= h
+            fp = t(xs.detach(), pp)
+            fm = t(xs.detach(), pm)
+            fd = (((fp[0] - fm[0]) * w).sum() + (fp[1] - fm[1]).sum()) / (2 * h)
+            assert abs(float(fd) - float(par.grad[bi, ci])) < 2e-3 * max(1.0, abs(float(fd)))
+
+
+def test_modules_dispatch_through_torch_ops_and_trace_under_fake_tensors():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from torch.fx.experimental.proxy_tensor import make_fx
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    D, B = 4, 9
+    t = NeuralSplineTransformer(torch.full((D,), -1.0), torch.full((D,), 1.0), 3).cuda()
+    args = t._op_args(torch.device('cuda'))
+
+    def fn(x, par, u, x0, xf, y0, yf):
+        y, l = torch.ops.tfep.spline_forward(x, par, x0, xf, y0, yf, *args[4:])
+        s = torch.ops.tfep.tfep_reduce(u, l, None, None, None, 1.0, False)
+        return y, s[1] / s[0]
+    x = torch.rand(B, D, device='cuda') * 2 - 1
+    par = torch.randn(B, 10 * D, device='cuda')
+    u = torch.randn(B, device='cuda')
+    gm = make_fx(fn, tracing_mode='fake')(x, par, u, *args[:4])        # traces through the fake implementations
+    targets = [str(n.target) for n in gm.graph.nodes if n.op == 'call_function']
+    assert any('tfep.spline_forward' in s for s in targets) and any('tfep.tfep_reduce' in s for s in targets)
+    y, loss = gm(x, par, u, *args[:4])
+    y2, l2 = t(x, par)
+    assert torch.equal(y, y2) and torch.allclose(loss, BoltzmannKLDivLoss()(u, l2), rtol=1e-6)
+    with FakeTensorMode():
+        e = [torch.empty(D, device='cuda') for _ in range(4)]
+        fy, fl = torch.ops.tfep.spline_forward(torch.empty(B, D, device='cuda'), torch.empty(B, 10 * D, device='cuda'),
+                                               *e, *args[4:])
+        assert fy.shape == (B, D) and fl.shape == (B,)
+    # a flow forward goes through tfep::fused_output_transformer (seen by the dispatcher)
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    class Spy(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            self.seen.append(str(func))
+            return func(*args, **(kwargs or {}))
+    flow = gu.build_flow('rq4', gu.load('flows.npz'))
+    xin = torch.from_numpy(gu.load('flows.npz')['rq4/x'][:8]).cuda()
+    with torch.no_grad(), Spy() as spy:
+        flow(xin)
+    assert sum('tfep.fused_output_transformer' in s for s in spy.seen) == len(flow)
+    # CPU tensors never reach a kernel: no CPU implementation is registered
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.tfep.affine_forward(torch.zeros(2, 2), torch.zeros(2, 4))

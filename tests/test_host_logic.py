@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f'{name} declared in tfep_hip.h but not exported'
     # the ctypes binding covers exactly the declared entry points
     assert set(_lib.EXPORTED_SYMBOLS) == declared
-    assert _lib.load().tfep_hip_abi_version() == 4
+    assert _lib.load().tfep_hip_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_no_cpu_fallback():
@@ -201,3 +201,13 @@ def test_load_state_dict_rederives_degrees_from_the_loaded_buffers(hidden):
     c._conditioner.invalidate_plan()
     c._sync_conditioner()
     assert not c._conditioner._degrees_ok and not c._blocked_ok()
+
+
+def test_custom_torch_ops_are_registered():
+    """``torch.ops.tfep.*`` exist with schemas after importing the package's op module (no GPU needed to look)."""
+    import tfep_amd.torch_ops as to
+    for name in to.OPS:
+        op = getattr(torch.ops.tfep, name)
+        assert 'Tensor' in str(op.default._schema), name
+    s = str(torch.ops.tfep.spline_forward.default._schema)
+    assert 'n_bins' in s and 'circular' in s and '-> (Tensor, Tensor)' in s

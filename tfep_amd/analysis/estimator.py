@@ -1,8 +1,8 @@
 """(T)FEP free-energy estimator (reference ``tfep/analysis/estimator.py:24-86``)."""
 import torch
 
-from .. import ops
 from ..distributed import allreduce_stats
+from ..loss import reduce_stats
 
 
 def fep_estimator(data, kT=1.0, weights=None, vectorized=False, process_group=None, distributed=False):
@@ -42,7 +42,7 @@ def _estimate(data, kT, weights, process_group, distributed):
             extra = torch.log(weights[b].contiguous().float()) * kT
         else:
             extra = None
-        stats = ops.tfep_reduce(w, None, None, None, extra, kT=kT)
+        stats = reduce_stats(w, None, None, None, extra, kT=kT)       # torch.ops.tfep.tfep_reduce
         if distributed:
             stats = allreduce_stats(stats, process_group)
         lse = stats[5] + torch.log(stats[6])                    # logsumexp(-w/kT [+ bias/kT])

@@ -10,7 +10,7 @@ from typing import Optional
 
 import torch
 
-from . import ops
+from . import ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.tfep.*)
 from .distributed import allreduce_stats
 
 
@@ -41,8 +41,8 @@ class BoltzmannKLDivLoss(torch.nn.Module):
         return self._value(*args)[0]
 
     def _value(self, target_potentials, log_det_J, log_weights, ref_potentials):
-        stats = ops.tfep_reduce(target_potentials.detach(), _det(log_det_J), _det(ref_potentials), _det(log_weights),
-                                None, kT=1.0, ignore_nan=self.ignore_nan)
+        stats = reduce_stats(target_potentials.detach(), _det(log_det_J), _det(ref_potentials), _det(log_weights),
+                             None, kT=1.0, ignore_nan=self.ignore_nan)
         if self.distributed:
             stats = allreduce_stats(stats, self.process_group)
         if log_weights is not None:
@@ -50,6 +50,14 @@ class BoltzmannKLDivLoss(torch.nn.Module):
         else:
             loss = stats[1] / stats[0]                 # (nan)mean(r)
         return loss.to(target_potentials.dtype), stats
+
+
+def reduce_stats(target_potentials, log_det_J=None, ref_potentials=None, log_weights=None, bias=None, kT=1.0,
+                 ignore_nan=False):
+    """The 9 float64 sufficient statistics of the batch: ``torch.ops.tfep.tfep_reduce`` (``tfep_tfep_reduce``)."""
+    ops.check_device_tensor(target_potentials, 'target_potentials')
+    return torch.ops.tfep.tfep_reduce(target_potentials, log_det_J, ref_potentials, log_weights, bias, float(kT),
+                                      bool(ignore_nan))
 
 
 def _det(t):

@@ -233,23 +233,20 @@ class AutoregressiveFlow(torch.nn.Module):
         else:
             h, mplan = made.forward_hidden(x)
             w, b = made._pack_layer(mplan, fp['li'], made.layers[-1], row_of_out=fp['row_of_out'], n_rows=fp['n_rows'])
-        y = x.clone() if self.has_fixed_indices else torch.empty(B, D, dtype=x.dtype, device=x.device)
-        ldj = torch.empty(B, dtype=torch.float32, device=x.device)
-        ws = torch.empty(fp['n_slots'] // 16, B, dtype=torch.float64, device=x.device)
-        desc = self._transformer.config(x.device).desc if kind == _FUSED_SPLINE else None
         prof = getattr(self, '_profile_events', None)
         if prof is not None:                     # bench.py: HIP events around the fused launch
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record(torch.cuda.current_stream(x.device))
-        tail = (_lib.ptr(b), _lib.ptr(fp['k_ranges']), _lib.ptr(fp['tile_order']), kind,
-                ctypes.byref(desc) if desc is not None else None,
-                _lib.ptr(x), ldx, _lib.ptr(y), D, _lib.ptr(fp['feat_index']), _lib.ptr(fp['feat_tr']),
-                fp['n_slots'], _lib.ptr(ws), _lib.ptr(ldj), 0, B, fp['n_rows'], w.shape[1], _lib.stream_of(x))
-        if split:
-            _lib.call('tfep_fused_output_transformer_forward_split', _lib.ptr(h), h.shape[1], _lib.ptr(h_inv),
-                      _lib.ptr(w), w.shape[1], _lib.ptr(w_inv), *tail)
+        if kind == _FUSED_SPLINE:
+            cfg, hst = self._transformer.config(x.device), self._transformer.host()
+            spl = (cfg.x0, cfg.xf, cfg.y0, cfg.yf, hst['n_bins'], hst['circular'], hst['identity'], hst['learn_lower'],
+                   hst['learn_upper'], hst['min_bin'], hst['min_slope'])
         else:
-            _lib.call('tfep_fused_output_transformer_forward', _lib.ptr(h), h.shape[1], _lib.ptr(w), w.shape[1], *tail)
+            spl = (None, None, None, None, 0, False, False, False, False, 0.0, 0.0)
+        # torch.ops.tfep.fused_output_transformer = tfep_fused_output_transformer_forward[_split]
+        y, ldj = torch.ops.tfep.fused_output_transformer(
+            h, h_inv if split else None, w, w_inv if split else None, b, fp['k_ranges'], fp['tile_order'], kind, x,
+            x if self.has_fixed_indices else None, fp['feat_index'], fp['feat_tr'], fp['n_slots'], fp['n_rows'], *spl)
         if prof is not None:
             ev1.record(torch.cuda.current_stream(x.device))
             prof.append((ev0, ev1))

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from torch.nn.parameter import Parameter
 
-from .. import ops
+from .. import ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.tfep.*)
 
 
 # =============================================================================
@@ -92,9 +92,10 @@ class MaskedLinearFunc(torch.autograd.Function):
             grad_weight = torch.empty_like(weight)
             if weight_g is not None:
                 grad_g = torch.empty_like(weight_g)
-            _lib.call('tfep_weight_norm_backward', _lib.ptr(gw), k_pad, _lib.ptr(weight.detach().contiguous()),
-                      _lib.ptr(None if weight_g is None else weight_g.detach().contiguous()),
-                      _lib.ptr(None if mask is None else mask.contiguous()), n_out, k, None, None,
+            w_c = weight.detach().contiguous()
+            g_c = None if weight_g is None else weight_g.detach().contiguous()
+            m_c = None if mask is None else mask.contiguous()
+            _lib.call('tfep_weight_norm_backward', _lib.ptr(gw), k_pad, _lib.ptr(w_c), _lib.ptr(g_c), _lib.ptr(m_c), n_out, k, None, None,
                       _lib.ptr(grad_weight), _lib.ptr(grad_g), _lib.stream_of(xp))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             grad_bias = torch.empty(n_out, **f32)
@@ -107,7 +108,8 @@ def masked_linear(input, weight, bias=None, mask=None):
 
     ``input`` may have extra leading dimensions ``(batch, *, in_features)``.
     """
-    return MaskedLinearFunc.apply(input, weight, bias, mask)
+    ops.check_device_tensor(input, 'input')
+    return torch.ops.tfep.masked_linear(input, weight, bias, mask, None)
 
 
 # =============================================================================
@@ -162,9 +164,10 @@ class MaskedLinear(torch.nn.Linear):
         return super().__getattr__(name)
 
     def forward(self, input):
+        ops.check_device_tensor(input, 'input')
         if self.has_weight_norm:
-            return MaskedLinearFunc.apply(input, self.weight_v, self.bias, self.mask, self.weight_g)
-        return MaskedLinearFunc.apply(input, self._parameters['weight'], self.bias, self.mask)
+            return torch.ops.tfep.masked_linear(input, self.weight_v, self.bias, self.mask, self.weight_g)
+        return torch.ops.tfep.masked_linear(input, self._parameters['weight'], self.bias, self.mask, None)
 
     def extra_repr(self):
         return 'in_features={}, out_features={}, bias={}, weight_norm={}'.format(

@@ -3,7 +3,7 @@ from typing import Optional
 
 import torch
 
-from ... import ops
+from ... import ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.tfep.*)
 from .transformer import MAFTransformer
 
 
@@ -16,10 +16,12 @@ class AffineTransformer(MAFTransformer):
     n_parameters_per_feature = 2
 
     def forward(self, x, parameters):
-        return ops.affine(x, parameters, inverse=False)
+        ops.check_device_tensor(x, 'x')
+        return tuple(torch.ops.tfep.affine_forward(x, parameters))        # differentiable (tfep::affine_backward)
 
     def inverse(self, y, parameters):
-        return ops.affine(y, parameters, inverse=True)
+        ops.check_device_tensor(y, 'y')
+        return tuple(torch.ops.tfep.affine_inverse(y, parameters))
 
     def get_identity_parameters(self, n_features: int) -> torch.Tensor:
         return torch.zeros(size=(self.n_parameters_per_feature * n_features,))

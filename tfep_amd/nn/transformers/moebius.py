@@ -1,7 +1,7 @@
 """Moebius transformer (reference ``tfep/nn/transformers/moebius.py:27-190``)."""
 import torch
 
-from ... import ops
+from ... import ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.tfep.*)
 from .transformer import MAFTransformer
 
 
@@ -19,10 +19,14 @@ class MoebiusTransformer(MAFTransformer):
         self.unit_sphere = unit_sphere
 
     def forward(self, x, parameters):
-        return ops.moebius(x, parameters, self.dimension, self.max_radius, self.unit_sphere, inverse=False)
+        ops.check_device_tensor(x, 'x')
+        return tuple(torch.ops.tfep.moebius_forward(x, parameters, int(self.dimension), float(self.max_radius),
+                                                    bool(self.unit_sphere)))                   # differentiable
 
     def inverse(self, y, parameters):
-        return ops.moebius(y, parameters, self.dimension, self.max_radius, self.unit_sphere, inverse=True)
+        ops.check_device_tensor(y, 'y')
+        return tuple(torch.ops.tfep.moebius_inverse(y, parameters, int(self.dimension), float(self.max_radius),
+                                                    bool(self.unit_sphere)))
 
     def get_identity_parameters(self, n_features: int) -> torch.Tensor:
         return torch.zeros(size=(n_features,))

@@ -3,7 +3,7 @@ from typing import Optional
 
 import torch
 
-from ... import ops
+from ... import ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.tfep.*)
 from .transformer import MAFTransformer
 
 
@@ -106,11 +106,18 @@ class NeuralSplineTransformer(MAFTransformer):
                 h['min_bin'], h['min_slope'])
         return self._cfg
 
+    def _op_args(self, device):
+        cfg, h = self.config(device), self.host()
+        return (cfg.x0, cfg.xf, cfg.y0, cfg.yf, h['n_bins'], h['circular'], h['identity'], h['learn_lower'],
+                h['learn_upper'], h['min_bin'], h['min_slope'])
+
     def forward(self, x, parameters):
-        return ops.spline(x, parameters, self.config(x.device), inverse=False)
+        ops.check_device_tensor(x, 'x')
+        return tuple(torch.ops.tfep.spline_forward(x, parameters, *self._op_args(x.device)))   # differentiable
 
     def inverse(self, y, parameters):
-        return ops.spline(y, parameters, self.config(y.device), inverse=True)
+        ops.check_device_tensor(y, 'y')
+        return tuple(torch.ops.tfep.spline_inverse(y, parameters, *self._op_args(y.device)))
 
     def get_identity_parameters(self, n_features: int) -> torch.Tensor:
         """Zeros: equal bins, unit slopes, zero shift, unit domain scale (reference spline.py:263-297)."""

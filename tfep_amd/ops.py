@@ -176,9 +176,12 @@ def masked_weight_prepare(weight_v, weight_g=None, mask=None, row_of_out=None, c
     k_padded = round_up(K, tk) if k_padded is None else k_padded
     if out is None:
         out = torch.empty(n_rows_padded, k_padded, dtype=torch.float32, device=weight_v.device)
-    call('tfep_masked_weight_prepare', ptr(weight_v.contiguous()),
-         ptr(None if weight_g is None else weight_g.contiguous()),
-         ptr(None if mask is None else mask.contiguous()), N, K, ptr(row_of_out), ptr(col_of_in), ptr(col_cut),
+    # (contiguous copies live in locals until the launch is queued; a temporary freed inside the argument list could be
+    # overwritten by the next one)
+    v_c = weight_v.contiguous()
+    g_c = None if weight_g is None else weight_g.contiguous()
+    m_c = None if mask is None else mask.contiguous()
+    call('tfep_masked_weight_prepare', ptr(v_c), ptr(g_c), ptr(m_c), N, K, ptr(row_of_out), ptr(col_of_in), ptr(col_cut),
          int(bool(clear)), ptr(out), n_rows_padded, k_padded, stream_of(weight_v))
     return out
 
@@ -187,7 +190,8 @@ def mask_k_ranges(mask, tile_n, n_tiles, k_padded, row_of_out=None, col_of_in=No
     check_device_tensor(mask, 'mask')
     N, K = mask.shape
     out = torch.empty(n_tiles, 2, dtype=torch.int32, device=mask.device)
-    call('tfep_mask_k_ranges', ptr(mask.contiguous()), N, K, ptr(row_of_out), ptr(col_of_in), tile_n,
+    m_c = mask.contiguous()
+    call('tfep_mask_k_ranges', ptr(m_c), N, K, ptr(row_of_out), ptr(col_of_in), tile_n,
          tile_sizes()[2], n_tiles, k_padded, ptr(out), stream_of(mask))
     return out
 
@@ -298,9 +302,10 @@ def masked_weight_prepare_split(weight_v, weight_g, mask, row_of_out, in_of_col,
     if inv_scale.numel() < 4:
         raise ValueError('inv_scale must have 4 entries')
     N, K = weight_v.shape
-    call('tfep_masked_weight_prepare_split', ptr(weight_v.contiguous()),
-         ptr(None if weight_g is None else weight_g.contiguous()),
-         ptr(None if mask is None else mask.contiguous()), N, K, ptr(row_of_out), ptr(in_of_col), ptr(col_cut),
+    v_c = weight_v.contiguous()
+    g_c = None if weight_g is None else weight_g.contiguous()
+    m_c = None if mask is None else mask.contiguous()
+    call('tfep_masked_weight_prepare_split', ptr(v_c), ptr(g_c), ptr(m_c), N, K, ptr(row_of_out), ptr(in_of_col), ptr(col_cut),
          ptr(out), out.shape[1], out.shape[1], ptr(inv_scale), stream_of(weight_v))
     return out, inv_scale
 
