@@ -539,6 +539,8 @@ int tfep_egnn_embed(const float* one_hot, int n_nodes, int n_types, float t, con
  */
 typedef struct tfep_egnn_edge_args {
     int32_t B, n_nodes, nt;
+    int32_t split;              /* != 0: the three per-edge F x F products on split-f16 operands (3 fp16 MFMAs per fp32
+                                   product, fp32 accumulate; csrc/egnn.hip), 0: exact-fp32 MFMA */
     float r_cutoff, speed_factor;
     const float* packed;
     const float* pos;

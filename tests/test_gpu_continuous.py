@@ -18,7 +18,7 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).float().cuda()
 
 
-def build_dynamics(name, g):
+def build_dynamics(name, g, split=None):
     from tfep_amd.nn.dynamics import EGNNDynamics
     cfg = gu.continuous_configs()[name]
     kw = {k: cfg[k] for k in ('node_types', 'r_cutoff', 'time_feat_dim', 'node_feat_dim', 'distance_feat_dim', 'n_layers',
@@ -26,6 +26,7 @@ def build_dynamics(name, g):
     dyn = EGNNDynamics(initialize_identity=False, **kw)
     sd = {k: v.float() if v.is_floating_point() else v for k, v in gu.continuous_state(g, name, torch.float32).items()}
     dyn.load_state_dict(sd, strict=True)
+    dyn.split_gemm = split              # None: the default (split-f16 edge products); False: exact-fp32 MFMA
     return dyn.cuda(), cfg
 
 
@@ -34,17 +35,19 @@ def rel_l2(got, ref):
     return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-300))
 
 
+@pytest.mark.parametrize('split', [True, False])
 @pytest.mark.parametrize('name', CONFIGS)
-def test_dynamics_velocity_matches_reference(name):
+def test_dynamics_velocity_matches_reference(name, split):
     g = gu.load('continuous.npz')
-    dyn, cfg = build_dynamics(name, g)
+    dyn, cfg = build_dynamics(name, g, split)
     x, t = dev(g[f'{name}/x']), float(g[f'{name}/t'][0])
     with torch.no_grad():
         vel = dyn(torch.tensor(t), x)
     ref = g[f'{name}/vel_f64']
     noise = np.linalg.norm(g[f'{name}/vel_f32'] - ref) / np.linalg.norm(ref)
     r = rel_l2(vel, ref)
-    print(f'{name}: velocity rel L2 {r:.2e} (reference float32 vs float64: {noise:.2e})')
+    print(f'{name} ({"split-f16" if split else "exact-fp32"} edge products): velocity rel L2 {r:.2e} '
+          f'(reference float32 vs float64: {noise:.2e})')
     assert r <= REL
     # deterministic, and independent of the batch a sample sits in
     with torch.no_grad():
@@ -52,10 +55,11 @@ def test_dynamics_velocity_matches_reference(name):
         assert torch.equal(dyn(torch.tensor(t), x[1:3].clone()), vel[1:3])
 
 
+@pytest.mark.parametrize('split', [True, False])
 @pytest.mark.parametrize('name', CONFIGS)
-def test_jvp_and_trace_match_reference_jacobian(name):
+def test_jvp_and_trace_match_reference_jacobian(name, split):
     g = gu.load('continuous.npz')
-    dyn, cfg = build_dynamics(name, g)
+    dyn, cfg = build_dynamics(name, g, split)
     x, t, eps = dev(g[f'{name}/x']), float(g[f'{name}/t'][0]), dev(g[f'{name}/eps'])
     jac = g[f'{name}/jacobian_f64']
     B = x.shape[0]

@@ -66,7 +66,8 @@ class EgnnLayerParams(Structure):
 
 
 class EgnnEdgeArgs(Structure):
-    _fields_ = [('B', c_int32), ('n_nodes', c_int32), ('nt', c_int32), ('r_cutoff', c_float), ('speed_factor', c_float),
+    _fields_ = [('B', c_int32), ('n_nodes', c_int32), ('nt', c_int32), ('split', c_int32), ('r_cutoff', c_float),
+                ('speed_factor', c_float),
                 ('packed', c_void_p), ('pos', c_void_p), ('dpos', c_void_p), ('P', c_void_p), ('Q', c_void_p),
                 ('pq_bstride', c_int64), ('dP', c_void_p), ('dQ', c_void_p), ('pos_out', c_void_p), ('dpos_out', c_void_p),
                 ('nm', c_void_p), ('dnm', c_void_p)]

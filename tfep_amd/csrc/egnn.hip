@@ -38,8 +38,11 @@ constexpr int NODE_WAVES = 4;
 __host__ __device__ inline int64_t img_floats(int nt) { return (int64_t)nt * nt * 256; }       // (16 nt)^2
 // layout of a packed layer (floats)
 struct PackedLayout {
-    int64_t w1c, w2, x1, b2, d1, wa, x2, mu, gamma, scal, u1a, u1b, u2, c1, c2, w1a, w1b, b1, total;
+    int64_t w1c, w2, x1, b2, d1, wa, x2, mu, gamma, scal, u1a, u1b, u2, c1, c2, w1a, w1b, b1, s_w1c, s_w2, s_x1, total;
 };
+// A split-f16 operand image: per (row tile tp, pair of k tiles T) 64 lanes x 8 halves -- the "hi" image (fp16 of the
+// scaled weight) followed by the "lo" image (fp16 of the residual); in floats of the packed buffer.
+__host__ __device__ inline int64_t split_img_floats(int nt) { return (int64_t)nt * ((nt + 1) / 2) * 64 * 8; }
 __host__ __device__ inline PackedLayout packed_layout(int nt) {
     PackedLayout L;
     const int64_t I = img_floats(nt), V = 16 * nt;
@@ -49,6 +52,8 @@ __host__ __device__ inline PackedLayout packed_layout(int nt) {
     L.scal = o; o += 4;
     L.u1a = o; o += I; L.u1b = o; o += I; L.u2 = o; o += I; L.c1 = o; o += V; L.c2 = o; o += V;
     L.w1a = o; o += I; L.w1b = o; o += I; L.b1 = o; o += V;
+    const int64_t SI = split_img_floats(nt);
+    L.s_w1c = o; o += SI; L.s_w2 = o; o += SI; L.s_x1 = o; o += SI;
     L.total = o;
     return L;
 }
@@ -73,6 +78,54 @@ __device__ inline void chain_gemm(const f4* __restrict__ img, const f4 (&x)[NT],
             if (TAN) dacc[tp] = mfma4(a.z, dx[t].z, dacc[tp]);
             acc[tp] = mfma4(a.w, x[t].w, acc[tp]);
             if (TAN) dacc[tp] = mfma4(a.w, dx[t].w, dacc[tp]);
+        }
+    }
+}
+
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+constexpr float SPLIT_X_SCALE = 16.0f;       // activations enter the split products as x * 16: |x| < 4094 fits fp16
+
+// v * s = hi + lo with hi = fp16(v s), lo = fp16(v s - hi): 22 significant bits in two fp16 halves
+__device__ inline void split8(const f4& a, const f4& b, float s, h8& hi, h8& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float va = a[j] * s, vb = b[j] * s;
+        const _Float16 ha = (_Float16)va, hb = (_Float16)vb;
+        hi[j] = ha; hi[j + 4] = hb;
+        lo[j] = (_Float16)(va - (float)ha);
+        lo[j + 4] = (_Float16)(vb - (float)hb);
+    }
+}
+
+__device__ inline f4 mfma16(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// The same chain product on v_mfma_f32_16x16x32_f16 with every fp32 operand as two fp16 halves: hi*hi + lo*hi + hi*lo
+// (the dropped lo*lo is 2^-22 relative), fp32 accumulation.  One MFMA covers TWO of the 16-feature k tiles: k slot j of
+// lane group q is feature 16 (2T + (j >> 2)) + 4q + (j & 3) -- the accumulator registers of tiles 2T and 2T + 1.
+// acc / dacc must enter as zero; the caller un-scales (weights carry a per-matrix power of two, activations 16).
+template <int NT, bool TAN>
+__device__ inline void chain_gemm_split(const h8* __restrict__ img, const f4 (&x)[NT], const f4 (&dx)[NT], f4 (&acc)[NT],
+                                        f4 (&dacc)[NT], int lane) {
+    constexpr int NT2 = (NT + 1) / 2;
+    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+    h8 xh[NT2], xl[NT2], dxh[NT2], dxl[NT2];
+#pragma unroll
+    for (int T = 0; T < NT2; ++T) {
+        split8(x[2 * T], (2 * T + 1 < NT) ? x[(2 * T + 1 < NT) ? 2 * T + 1 : 0] : zero4, SPLIT_X_SCALE, xh[T], xl[T]);
+        if (TAN) split8(dx[2 * T], (2 * T + 1 < NT) ? dx[(2 * T + 1 < NT) ? 2 * T + 1 : 0] : zero4, SPLIT_X_SCALE, dxh[T], dxl[T]);
+    }
+    const h8* img_lo = img + NT * NT2 * 64;
+#pragma unroll
+    for (int tp = 0; tp < NT; ++tp) {
+#pragma unroll
+        for (int T = 0; T < NT2; ++T) {
+            const h8 wh = img[(tp * NT2 + T) * 64 + lane], wl = img_lo[(tp * NT2 + T) * 64 + lane];
+            acc[tp] = mfma16(wh, xh[T], acc[tp]);
+            if (TAN) dacc[tp] = mfma16(wh, dxh[T], dacc[tp]);
+            acc[tp] = mfma16(wl, xh[T], acc[tp]);
+            if (TAN) dacc[tp] = mfma16(wl, dxh[T], dacc[tp]);
+            acc[tp] = mfma16(wh, xl[T], acc[tp]);
+            if (TAN) dacc[tp] = mfma16(wh, dxl[T], dacc[tp]);
         }
     }
 }
@@ -118,11 +171,64 @@ __device__ inline float img_entry(const float* w, int ldw, int col0, int n_rows,
 }
 __device__ inline float vec_entry(const float* v, int n, int64_t i) { return (v != nullptr && i < n) ? v[i] : 0.0f; }
 
+// power-of-two scale that puts the largest |w| of a matrix block into [2^13, 2^14) (fp16 overflows at 65504; the
+// products are exact in fp32 whatever the scale)
+__global__ void egnn_scale_kernel(tfep_egnn_layer_params p, int nt, float* __restrict__ out) {
+    __shared__ float red[4];
+    const PackedLayout L = packed_layout(nt);
+    const int F = p.F, G = p.G, m = blockIdx.x;
+    const float* w = m == 0 ? p.msg0_w : (m == 1 ? p.msg2_w : p.ux0_w);
+    const int ldw = m == 0 ? 2 * F + G : F, col0 = m == 0 ? 2 * F : 0, n_cols = m == 0 ? G : F;
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < F * n_cols; i += blockDim.x) mx = fmaxf(mx, fabsf(w[(i / n_cols) * ldw + col0 + i % n_cols]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        int e = 0;
+        if (mx > 0.f && mx < 3.0e38f) { (void)frexpf(mx, &e); e = 14 - e; }      // mx * 2^e in [2^13, 2^14)
+        e = e > 60 ? 60 : (e < -60 ? -60 : e);
+        out[L.scal + 1 + m] = ldexpf(1.0f, e);
+    }
+}
+
+__device__ inline void split_img_entry(const float* w, int ldw, int col0, int n_rows, int n_cols, int nt, float scale,
+                                       int64_t idx, _Float16* hi, _Float16* lo) {
+    // idx = ((tp * nt2 + T) * 64 + l) * 8 + j  ->  W[16 tp + (l & 15)][col0 + 16 (2T + (j >> 2)) + 4 (l >> 4) + (j & 3)]
+    const int nt2 = (nt + 1) / 2;
+    const int j = (int)(idx & 7), l = (int)((idx >> 3) & 63);
+    const int tt = (int)(idx >> 9);
+    const int T = tt % nt2, tp = tt / nt2;
+    const int row = 16 * tp + (l & 15), col = 16 * (2 * T + (j >> 2)) + 4 * (l >> 4) + (j & 3);
+    const float v = (row < n_rows && col < n_cols) ? w[(int64_t)row * ldw + col0 + col] * scale : 0.0f;
+    const _Float16 h = (_Float16)v;
+    hi[idx] = h;
+    lo[idx] = (_Float16)(v - (float)h);
+}
+
+__global__ void egnn_pack_split_kernel(tfep_egnn_layer_params p, int nt, float* __restrict__ out) {
+    const PackedLayout L = packed_layout(nt);
+    const int F = p.F, G = p.G;
+    const int64_t n = (int64_t)nt * ((nt + 1) / 2) * 64 * 8;              // halves per image
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n);
+        const int64_t idx = i % n;
+        _Float16* hi = reinterpret_cast<_Float16*>(out + (m == 0 ? L.s_w1c : (m == 1 ? L.s_w2 : L.s_x1)));
+        const float scale = out[L.scal + 1 + m];
+        if (m == 0) split_img_entry(p.msg0_w, 2 * F + G, 2 * F, F, G, nt, scale, idx, hi, hi + n);
+        else if (m == 1) split_img_entry(p.msg2_w, F, 0, F, F, nt, scale, idx, hi, hi + n);
+        else split_img_entry(p.ux0_w, F, 0, F, F, nt, scale, idx, hi, hi + n);
+    }
+}
+
 __global__ void egnn_pack_kernel(tfep_egnn_layer_params p, int nt, float* __restrict__ out) {
     const PackedLayout L = packed_layout(nt);
     const int64_t I = img_floats(nt), V = 16 * nt;
     const int F = p.F, G = p.G;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.total; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L.s_w1c; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i > L.scal && i < L.u1a) continue;                       // the three split scales: egnn_scale_kernel
         float v;
         if (i < L.w2) v = img_entry(p.msg0_w, 2 * F + G, 2 * F, F, G, nt, i - L.w1c);
         else if (i < L.x1) v = img_entry(p.msg2_w, F, 0, F, F, nt, i - L.w2);
@@ -192,11 +298,12 @@ __global__ void egnn_embed_kernel(const float* __restrict__ one_hot, int n_nodes
 // ---------------------------------------------------------------------------------------------------------------
 // edge kernel: one _EGLayer without its node MLP (egnn.py:272-369)
 // ---------------------------------------------------------------------------------------------------------------
-template <int NT, bool TAN>
+template <int NT, bool TAN, bool SPLIT>
 __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn_edge_args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int FP = 16 * NT;
-    constexpr int IMG4 = NT * NT * 64;                    // f4 per image
+    // f4 (16 bytes) per operand image in LDS: fp32 lane-linear image, or split-f16 hi + lo images
+    constexpr int IMG4 = SPLIT ? NT * ((NT + 1) / 2) * 64 * 2 : NT * NT * 64;
     const PackedLayout L = packed_layout(NT);
     const int n = a.n_nodes;
     const int n_blk = (n + 15) / 16;
@@ -222,9 +329,10 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
     f4* const s_dq = s_q + NT * 64;
     float* const s_red = reinterpret_cast<float*>(s_dq + (TAN ? NT * 64 : 0));
     {
-        const f4* src = reinterpret_cast<const f4*>(a.packed + L.w1c);
-        const int n4 = 3 * IMG4 + EDGE_CONST_VECS * FP / 4;
-        for (int i = tid; i < n4; i += EDGE_WAVES * 64) w_img[i] = src[i];
+        const f4* src = reinterpret_cast<const f4*>(a.packed + (SPLIT ? L.s_w1c : L.w1c));
+        for (int i = tid; i < 3 * IMG4; i += EDGE_WAVES * 64) w_img[i] = src[i];
+        const f4* vsrc = reinterpret_cast<const f4*>(a.packed + L.b2);
+        for (int i = tid; i < EDGE_CONST_VECS * FP / 4; i += EDGE_WAVES * 64) w_img[3 * IMG4 + i] = vsrc[i];
         const float* px = a.pos + (int64_t)b * 3 * n;
         for (int i = tid; i < 3 * n; i += EDGE_WAVES * 64) s_pos[i] = px[i];
         if (TAN) {
@@ -247,6 +355,10 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
         (tan ? s_dq : s_q)[ee] = v;
     }
     const float att_b = a.packed[L.scal];
+    // split products come out scaled by (weight scale of the matrix) x 16: exact powers of two
+    const float inv1 = SPLIT ? 1.0f / (a.packed[L.scal + 1] * SPLIT_X_SCALE) : 1.0f;
+    const float inv2 = SPLIT ? 1.0f / (a.packed[L.scal + 2] * SPLIT_X_SCALE) : 1.0f;
+    const float inv3 = SPLIT ? 1.0f / (a.packed[L.scal + 3] * SPLIT_X_SCALE) : 1.0f;
     __syncthreads();
     const f4* const img_w1c = w_img;
     const f4* const img_w2 = w_img + IMG4;
@@ -257,6 +369,28 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
     const f4* const v_x2 = v_wa + FP / 4;
     const f4* const v_mu = v_x2 + FP / 4;
     const f4* const v_ga = v_mu + FP / 4;
+    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+    // out = init + W x (and dout = dinit + W dx) through the exact-fp32 or the split-f16 chain product.  `init(t)` is read
+    // only when needed (before the fp32 chain, which accumulates onto it; after the split chain, which starts from zero and
+    // is un-scaled by an exact power of two) so that it is not live across the product.
+    auto product = [&](const f4* img, const f4 (&x)[NT], const f4 (&dx)[NT], f4 (&out)[NT], f4 (&dout)[NT], float inv,
+                       auto init, auto dinit) {
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { out[t] = zero4; dout[t] = zero4; }
+            chain_gemm_split<NT, TAN>(reinterpret_cast<const h8*>(img), x, dx, out, dout, lane);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                out[t] = out[t] * inv + init(t);
+                if (TAN) dout[t] = dout[t] * inv + dinit(t);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) { out[t] = init(t); dout[t] = TAN ? dinit(t) : zero4; }
+            chain_gemm<NT, TAN>(img, x, dx, out, dout, lane);
+        }
+    };
+    auto no_tangent = [&](int) { return zero4; };
 
     // ---- per-lane destination state
     const int j = jb * 16 + c;
@@ -294,18 +428,14 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
     fetch_source(wave);
 
     for (int i = wave; i < n; i += EDGE_WAVES) {
-        f4 z[NT], dz[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {                                    // z1 starts as P_i + Q_j
-            z[t] = Pn[t] + s_q[(4 * t + q) * 16 + c];
-            if (TAN) dz[t] = dPn[t] + s_dq[(4 * t + q) * 16 + c];
-        }
-        fetch_source(i + EDGE_WAVES);
         // ---- geometry of the 16 edges (i -> j0 + c); the four q-groups compute it redundantly (a few dozen VALU)
         const float v0 = xj0 - s_pos[3 * i], v1 = xj1 - s_pos[3 * i + 1], v2 = xj2 - s_pos[3 * i + 2];
         const float d = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);              // graph.py:257
         const bool keep = j_ok && (j != i) && (d <= rc);                 // graph.py:297 (and no self edges, :143)
-        if (__ballot(keep) == 0ull) continue;                            // wave-uniform: nothing survives the cutoff
+        if (__ballot(keep) == 0ull) {                                    // wave-uniform: nothing survives the cutoff
+            fetch_source(i + EDGE_WAVES);
+            continue;
+        }
         const float inv_d = keep ? 1.0f / d : 0.0f;
         const float u0 = v0 * inv_d, u1 = v1 * inv_d, u2 = v2 * inv_d;   // normalised direction (graph.py:260)
         float ddist = 0.f, du0 = 0.f, du1 = 0.f, du2 = 0.f;
@@ -331,12 +461,14 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
             }
         }
         // ---- message MLP: z1 = P_i + Q_j + W1c rbf (egnn.py:246-251 with the first linear split by input block)
-        chain_gemm<NT, TAN>(img_w1c, rbf, drbf, z, dz, lane);
+        f4 z[NT], dz[NT];
+        product(img_w1c, rbf, drbf, z, dz, inv1,
+                [&](int t) { return Pn[t] + s_q[(4 * t + q) * 16 + c]; },
+                [&](int t) { return dPn[t] + s_dq[(4 * t + q) * 16 + c]; });
+        fetch_source(i + EDGE_WAVES);                                    // P of the next source: lands under the rest of this one
         silu_tile<NT, TAN>(z, dz);
         f4 y[NT], dy[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { y[t] = v_b2[4 * t + q]; dy[t] = f4{0.f, 0.f, 0.f, 0.f}; }
-        chain_gemm<NT, TAN>(img_w2, z, dz, y, dy, lane);
+        product(img_w2, z, dz, y, dy, inv2, [&](int t) { return v_b2[4 * t + q]; }, no_tangent);
         silu_tile<NT, TAN>(y, dy);
         // ---- attention (egnn.py:254-257, 323-325): m = m2 * sigmoid(wa . m2 + ba)
         float s = 0.f, ds = 0.f;
@@ -363,9 +495,7 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
             }
         }
         // ---- displacement magnitude (egnn.py:260-267, 347-361): tanh(x2 . SiLU(X1 m + d1))
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { z[t] = v_d1[4 * t + q]; dz[t] = f4{0.f, 0.f, 0.f, 0.f}; }
-        chain_gemm<NT, TAN>(img_x1, y, dy, z, dz, lane);
+        product(img_x1, y, dy, z, dz, inv3, [&](int t) { return v_d1[4 * t + q]; }, no_tangent);
         silu_tile<NT, TAN>(z, dz);
         s = 0.f; ds = 0.f;
 #pragma unroll
@@ -431,9 +561,9 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
     }
 }
 
-template <int NT, bool TAN>
+template <int NT, bool TAN, bool SPLIT>
 size_t edge_lds_bytes(int n) {
-    const size_t fp = 16 * NT, img4 = (size_t)NT * NT * 64;
+    const size_t fp = 16 * NT, img4 = SPLIT ? (size_t)NT * ((NT + 1) / 2) * 64 * 2 : (size_t)NT * NT * 64;
     size_t fl = 3 * img4 * 4 + EDGE_CONST_VECS * fp + (size_t)((3 * n + 3) & ~3) * (TAN ? 2 : 1);
     fl += (size_t)NT * 64 * 4 * (TAN ? 2 : 1);                       // Q / dQ of the destination block
     fl += (size_t)EDGE_WAVES * NT * 64 * 4 * (TAN ? 2 : 1) + EDGE_WAVES * 16 * 6;
@@ -638,15 +768,20 @@ int allow_lds(K kernel, size_t bytes, const char* what) {
     return TFEP_OK;
 }
 
-template <int NT, bool TAN>
-int launch_edge(const tfep_egnn_edge_args& a, hipStream_t st) {
-    const size_t lds = edge_lds_bytes<NT, TAN>(a.n_nodes);
-    int rc = allow_lds(egnn_edge_kernel<NT, TAN>, lds, "tfep_egnn_edge");
+template <int NT, bool TAN, bool SPLIT>
+int launch_edge_impl(const tfep_egnn_edge_args& a, hipStream_t st) {
+    const size_t lds = edge_lds_bytes<NT, TAN, SPLIT>(a.n_nodes);
+    int rc = allow_lds(egnn_edge_kernel<NT, TAN, SPLIT>, lds, "tfep_egnn_edge");
     if (rc != TFEP_OK) return rc;
     const int64_t blocks = (int64_t)a.B * ((a.n_nodes + 15) / 16);
     TFEP_REQUIRE(blocks < (1ll << 31), "tfep_egnn_edge: too many workgroups");
-    hipLaunchKernelGGL((egnn_edge_kernel<NT, TAN>), dim3((unsigned)blocks), dim3(EDGE_WAVES * 64), lds, st, a);
+    hipLaunchKernelGGL((egnn_edge_kernel<NT, TAN, SPLIT>), dim3((unsigned)blocks), dim3(EDGE_WAVES * 64), lds, st, a);
     return check_launch("tfep_egnn_edge");
+}
+
+template <int NT, bool TAN>
+int launch_edge(const tfep_egnn_edge_args& a, hipStream_t st) {
+    return a.split ? launch_edge_impl<NT, TAN, true>(a, st) : launch_edge_impl<NT, TAN, false>(a, st);
 }
 
 template <int NT, bool TAN>
@@ -687,8 +822,11 @@ int tfep_egnn_pack_layer(const tfep_egnn_layer_params* p, int nt, float* packed,
     TFEP_REQUIRE(p->dist_means && p->dist_log_gammas && p->msg0_w && p->msg0_b && p->msg2_w && p->msg2_b && p->att_w &&
                  p->att_b && p->ux0_w && p->ux0_b && p->ux2_w && p->uh0_w && p->uh0_b && p->uh2_w && p->uh2_b,
                  "tfep_egnn_pack_layer: null parameter tensor");
-    const int64_t total = packed_layout(nt).total;
-    hipLaunchKernelGGL(egnn_pack_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, *p, nt, packed);
+    const PackedLayout L = packed_layout(nt);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(egnn_scale_kernel, dim3(3), dim3(256), 0, st, *p, nt, packed);
+    hipLaunchKernelGGL(egnn_pack_kernel, dim3(grid_for(L.s_w1c, 256)), dim3(256), 0, st, *p, nt, packed);
+    hipLaunchKernelGGL(egnn_pack_split_kernel, dim3(grid_for(3 * split_img_floats(nt), 256)), dim3(256), 0, st, *p, nt, packed);
     return check_launch("tfep_egnn_pack_layer");
 }
 

@@ -15,6 +15,7 @@ node kernel between layers, one finishing kernel.  No edge list, no scatter_add.
 through the kernels: differentiating the outputs raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -72,6 +73,9 @@ class EGNNDynamics(FixedGraph):
                 eg_layer.update_x_mlp[-2].weight.data.fill_(0.0)
             self.add_module('graph_layer_' + str(layer_idx), eg_layer)
         self._dims = (int(time_feat_dim), int(node_feat_dim), int(distance_feat_dim))
+        #: The three per-edge F x F products on split-f16 operands (fp32-equivalent, ~3x the fp32-MFMA rate); False: exact
+        #: fp32 MFMA; None: the ``TFEP_EGNN_SPLIT`` environment switch (default on).
+        self.split_gemm = None
 
     # ------------------------------------------------------------------ reference API
     def forward(self, t, x):
@@ -140,6 +144,7 @@ class EGNNDynamics(FixedGraph):
         dev, stream = x.device, _lib.stream_of(x)
         nt = self._tile()
         fp = 16 * nt
+        split = (os.environ.get('TFEP_EGNN_SPLIT', '1') != '0') if self.split_gemm is None else bool(self.split_gemm)
         f32 = dict(dtype=torch.float32, device=dev)
         layers = self._layers()
         L = len(layers)
@@ -178,6 +183,7 @@ class EGNNDynamics(FixedGraph):
             last = li == L - 1
             a = _lib.EgnnEdgeArgs()
             a.B, a.n_nodes, a.nt = B, n, nt
+            a.split = int(split)
             a.r_cutoff, a.speed_factor = float(layer.distance_embedding.r_cutoff), float(layer.speed_factor)
             a.packed = packed[li].data_ptr()
             a.pos, a.dpos = pos.data_ptr(), (dpos.data_ptr() if tan else None)

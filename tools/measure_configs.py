@@ -33,6 +33,24 @@ def report(name, B, dt, **kw):
     print(json.dumps(dict(config=name, batch=B, ms=round(dt * 1e3, 3), samples_per_s=round(B / dt, 1), **kw)), flush=True)
 
 
+PEAK_F32, PEAK_SPLIT = 157.3, 2516.6 / 3.0          # dense fp32 MFMA; dense fp16 MFMA / 3 MFMAs per fp32 product
+
+
+def mfma_roofline(flow, B, dt, passes=1.0, note=None):
+    """Mask-aware algorithmic flops of the conditioner GEMMs (2 nnz(mask) per sample and linear) times
+    ``passes`` (1 = one forward's worth: forward, or the blocked inverse; a training step = forward + recompute +
+    grad_input + grad_weight = 4) over the measured time, against the bound of the arithmetic the layers run on."""
+    nnz = sum(float(torch.count_nonzero(lin.mask)) for layer in flow for lin in layer._conditioner.layers[::2])
+    split = all(layer._use_split_gemm() for layer in flow)
+    peak = PEAK_SPLIT if split else PEAK_F32
+    tf = 2.0 * nnz * B * passes / dt / 1e12
+    out = dict(bound='mfma', achieved=round(tf, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(tf / peak, 4),
+               flops=2.0 * nnz * B * passes, arithmetic='split-f16 (fp16 MFMA / 3)' if split else 'fp32 MFMA')
+    if note:
+        out['note'] = note
+    return out
+
+
 def order(i):
     return 'ascending' if i % 2 == 0 else 'descending'
 
@@ -47,7 +65,8 @@ if 'cfg1' in which:
     x = torch.randn(B, D, device=dev)
     with torch.no_grad():
         dt, (y, _) = timeit(lambda: flow(x), 3, 20)
-    report('cfg1 forward: 2-layer MAF + affine, D=66', B, dt)
+    report('cfg1 forward: 2-layer MAF + affine, D=66', B, dt,
+           roofline=mfma_roofline(flow, B, dt, note='27 k weights: launch / latency bound, absolute number only'))
     dt, (xi, _) = timeit(lambda: flow.inverse(y), 1, 5)
     report('cfg1 inverse (blocked)', B, dt, roundtrip_max_abs=float((xi - x).detach().abs().max()))
     from tfep_amd.graphs import GraphedFlow
@@ -71,10 +90,12 @@ if 'cfg2inv' in which:
                                   initialize_identity=False))
     x = torch.randn(B, D, device=dev).clamp_(-4.9, 4.9)
     dt, (y, lf) = timeit(lambda: flow(x), 1, 2)
-    report('cfg2 ONE layer forward', B, dt)
+    report('cfg2 ONE layer forward', B, dt, roofline=mfma_roofline(flow, B, dt))
     dt, (xi, li) = timeit(lambda: flow.inverse(y), 1, 1)
     report('cfg2 ONE layer inverse (blocked, 3000 degrees)', B, dt,
-           roundtrip_rel_l2=float((xi - x).detach().norm() / x.norm()), ldj_cancel_max_abs=float((lf + li).detach().abs().max()))
+           roundtrip_rel_l2=float((xi - x).detach().norm() / x.norm()), ldj_cancel_max_abs=float((lf + li).detach().abs().max()),
+           roofline=mfma_roofline(flow, B, dt, note='one forward of flops; the chain of 3000 degree steps is sequential: '
+                                                    'issue-rate bound block kernel (DESIGN.md section 7)'))
     from tfep_amd.graphs import GraphedFlow
     with torch.no_grad():
         gi = GraphedFlow(flow, B, D, inverse=True, warmup=1)
@@ -85,6 +106,23 @@ if 'cfg2inv' in which:
                                                   ldj_equal=bool(torch.equal(lg, li)))
     report('cfg2 ONE layer inverse (blocked), HIP-graph replay', B, dt, equals_eager=bool(torch.equal(xg, xi)),
            peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1), **extra)
+
+if 'cfg3shard' in which:
+    # BASELINE cfg3 per-GPU share: the 4-layer cfg2 flow on 8192 rows (65536 / 8), weights re-packed every step
+    D, B = 3000, 8192
+    with torch.device(dev):
+        flow = SequentialFlow(*[MAF(generate_degrees(D, order(i)),
+                                    transformer=NeuralSplineTransformer(torch.full((D,), -5.0), torch.full((D,), 5.0), 8),
+                                    initialize_identity=False) for i in range(4)])
+    x = torch.randn(B, D, device=dev).clamp_(-4.9, 4.9)
+    with torch.no_grad():
+        dt, _ = timeit(lambda: flow(x), 2, 10)
+        report('cfg3 per-GPU shard: 4-layer cfg2 flow on 8192 rows, re-pack every step', B, dt, roofline=mfma_roofline(flow, B, dt))
+        for l in flow:
+            l._conditioner.cache_packed_weights = True
+        dt, _ = timeit(lambda: flow(x), 2, 10)
+        report('cfg3 per-GPU shard: same, packed weights cached', B, dt, roofline=mfma_roofline(flow, B, dt))
+    del flow
 
 if 'train' in which:
     from tfep_amd.loss import BoltzmannKLDivLoss
@@ -107,9 +145,10 @@ if 'train' in which:
     with torch.no_grad():
         dtf, _ = timeit(lambda: flow(x), 1, 2)
     dt, loss = timeit(train_step, 1, 2)
-    report('cfg2 ONE layer forward (no grad)', B, dtf)
+    report('cfg2 ONE layer forward (no grad)', B, dtf, roofline=mfma_roofline(flow, B, dtf))
     report('cfg2 ONE layer training step (forward + backward of all parameters)', B, dt, loss=float(loss),
-           peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1))
+           peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+           roofline=mfma_roofline(flow, B, dt, passes=4.0, note='forward + recompute + grad_input + grad_weight'))
 
 if 'cfg4' in which:
     D, B = 512, 131072
@@ -121,13 +160,13 @@ if 'cfg4' in which:
     x = torch.rand(B, D, device=dev)
     dt, (y, _) = timeit(lambda: flow(x), 1, 3)
     report('cfg4-i forward: 4-layer MAF + circular RQ-8 + periodic embedding, 512 torsions', B, dt,
-           y_in_domain=bool(((y >= 0) & (y <= 1)).all()))
+           y_in_domain=bool(((y >= 0) & (y <= 1)).all()), roofline=mfma_roofline(flow, B, dt))
     Bi = 16384
     with torch.no_grad():
         dti, (xi, _) = timeit(lambda: flow.inverse(y[:Bi]), 1, 2)
     dcirc = (xi - x[:Bi]).abs()
     report('cfg4-i inverse (blocked, fused block kernel; 4 layers x 512 degrees)', Bi, dti,
-           roundtrip_circle_max=float(torch.minimum(dcirc, 1 - dcirc).max()))
+           roundtrip_circle_max=float(torch.minimum(dcirc, 1 - dcirc).max()), roofline=mfma_roofline(flow, Bi, dti))
     with torch.device(dev):
         flow = SequentialFlow(*[MAF(generate_degrees(2 * D, order(i), repeats=2),
                                     transformer=MoebiusTransformer(dimension=2, unit_sphere=True),
@@ -135,12 +174,17 @@ if 'cfg4' in which:
     ang = torch.rand(B, D, device=dev) * 2 * math.pi
     x = torch.stack([torch.cos(ang), torch.sin(ang)], dim=2).reshape(B, 2 * D)
     dt, (y, _) = timeit(lambda: flow(x), 1, 3)
+    # generic path: per layer x (4 KB) in, 3 activations / parameter rows of 1024 floats written and re-read, y out
+    hbm = B * 4 * 1024 * 4 * (2 + 2 * 3) / dt / 1e9
     report('cfg4-ii forward: 4-layer MAF + Moebius(d=2, unit sphere), 512 torsions as 1024 features', B, dt,
-           max_norm_error=float((y.reshape(B, D, 2).norm(dim=2) - 1).abs().max()))
+           max_norm_error=float((y.reshape(B, D, 2).norm(dim=2) - 1).abs().max()),
+           roofline=dict(bound='hbm', achieved=round(hbm, 1), peak=8000.0, unit='GB/s', frac=round(hbm / 8000.0, 4),
+                         note='unfused path: activations and the (B, P D) parameters round-trip HBM; 3.1 M weights'),
+           mfma=mfma_roofline(flow, B, dt))
     with torch.no_grad():
         dti, (xi, _) = timeit(lambda: flow.inverse(y[:Bi]), 1, 2)
     report('cfg4-ii inverse (blocked; 4 layers x 512 degrees)', Bi, dti,
-           roundtrip_max_abs=float((xi - x[:Bi]).abs().max()))
+           roundtrip_max_abs=float((xi - x[:Bi]).abs().max()), roofline=mfma_roofline(flow, Bi, dti))
 
 if 'hbm' in which:
     # HBM-bound kernels in isolation: algorithmic bytes / time vs the 8 TB/s HBM3E peak.
