@@ -38,6 +38,27 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def build_probe(out_path, extra_flags, verbose=True):
+    """A separate library with extra compiler flags (timing probes such as -DTFEP_PROBE_KWINDOW=128), built into its
+    own directory; select it with TFEP_HIP_LIB=<out_path>.  The shipped library is not touched."""
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix='tfep_probe_')
+    objs, procs = [], []
+    for src in SOURCES:
+        obj = os.path.join(tmp, src.replace('.hip', '.o'))
+        objs.append(obj)
+        cmd = [_hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result',
+               *extra_flags, '-c', os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f'hipcc failed on {src}')
+    subprocess.check_call([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out_path] + objs)
+    return out_path
+
+
 def build(force=False, verbose=True):
     """Compile every HIP source for gfx950 into one shared library."""
     if not force and not needs_build():
@@ -88,5 +109,9 @@ def _build_locked(force, verbose):
 
 
 if __name__ == '__main__':
-    build(force='--force' in sys.argv)
-    print(LIB_PATH)
+    if '--probe' in sys.argv:            # python -m tfep_amd.build --probe /tmp/libprobe.so -DTFEP_PROBE_KWINDOW=128
+        i = sys.argv.index('--probe')
+        print(build_probe(sys.argv[i + 1], sys.argv[i + 2:]))
+    else:
+        build(force='--force' in sys.argv)
+        print(LIB_PATH)

@@ -460,7 +460,14 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
                 bl[pc.value] = *(const f16x8*)(Bs + pc.value * 16 * ROW_BYTES + off_lo);
             }
         });
+#ifdef TFEP_PROBE_KWINDOW
+        // TIMING PROBE (wrong results): every k-tile is fetched from the first TFEP_PROBE_KWINDOW columns of the operand
+        // panels, so that the streamed operands stay resident in the XCD's L2 -- what removing the super-tile over-fetch
+        // from beyond L2 could buy at most (python -m tfep_amd.build --probe ... -DTFEP_PROBE_KWINDOW=128).
+        const int k_next = kb + (((t + 1) * SBK) % TFEP_PROBE_KWINDOW);
+#else
         const int k_next = kb + (t + 1) * SBK;
+#endif
         // The next tile's DMA goes out EARLY in this tile (a DMA issued late meets the barrier before it has landed),
         // one instruction after each group of four MFMAs -- a lone wave that issues a clump of DMA instructions
         // starves its matrix pipe meanwhile.  Weights first: their stage is free since the barrier; then the wave's
