@@ -314,3 +314,48 @@ def test_user_supplied_torch_dynamics_through_autograd():
     assert torch.allclose(y, xg) and torch.allclose(tr, torch.zeros_like(tr))
     y.sum().backward()
     assert torch.allclose(xg.grad, torch.ones_like(xg.grad))
+
+
+def test_cfg5_full_size_properties():
+    """BASELINE config 5 at size: 3 x 256 atoms, batch 16384, 10 rk4 steps, Hutchinson trace, default EGNN widths (4
+    layers, 64 features, 64 radial functions), every pair inside the cutoff.  Size-independent properties: finite outputs;
+    the centre of geometry of every sample is preserved (egnn.py:187-191); a slice pushed through alone (same noise rows)
+    reproduces its rows of the big batch bit for bit (rows are independent, the reductions have a fixed order); the
+    inverse integrates a slice back to its start with cancelling traces; the split-f16 edge products agree with the
+    exact-fp32 MFMA chain on a slice."""
+    from tfep_amd.nn.dynamics import EGNNDynamics
+    from tfep_amd.nn.flows import ContinuousFlow
+    B, n = 16384, 256
+    gen = torch.Generator(device='cuda').manual_seed(7)
+    side, a = 7, 0.215                                                   # jittered lattice at ~100 atoms / nm^3
+    grid = torch.stack(torch.meshgrid(*[torch.arange(side, dtype=torch.float32)] * 3, indexing='ij'), -1).reshape(-1, 3)[:n]
+    x = (grid.cuda()[None] * a + (torch.rand(B, n, 3, device='cuda', generator=gen) - 0.5) * 0.3 * a).reshape(B, 3 * n)
+    torch.manual_seed(0)
+    # (randomly initialised weights and 255 neighbours per atom: speed_factor keeps the velocity field smooth enough for
+    # 10 rk4 steps to resolve, so that the round trip below tests the kernels and not the truncation error)
+    dyn = EGNNDynamics(node_types=[i % 4 for i in range(n)], r_cutoff=4.0, speed_factor=0.02,
+                       initialize_identity=False).cuda()
+    flow = ContinuousFlow(dyn, solver='rk4', solver_options={'step_size': 0.1}, regularization=False)
+    eps = torch.randn(1, B, 3 * n, device='cuda', generator=gen)
+    flow.ode_func.fixed_noise = eps
+    with torch.no_grad():
+        y, tr = flow(x)
+        assert flow.last_solver_stats == dict(n_steps=10, n_rejected=0, n_evaluations=40)
+        assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(tr).all())
+        assert float((y - x).abs().max()) > 1e-4                         # the flow moves the atoms ...
+        c0, c1 = x.reshape(B, n, 3).mean(1), y.reshape(B, n, 3).mean(1)
+        assert float((c1 - c0).abs().max()) < 2e-5                       # ... but not a sample's centre of geometry
+        for lo, hi in ((0, 48), (9000, 9000 + 33)):
+            flow.ode_func.fixed_noise = eps[:, lo:hi].clone()
+            ys, ts = flow(x[lo:hi].clone())
+            assert torch.equal(ys, y[lo:hi]) and torch.equal(ts, tr[lo:hi]), (lo, hi)
+        lo, hi = 4000, 4000 + 128
+        flow.ode_func.fixed_noise = eps[:, lo:hi].clone()
+        xb, tb = flow.inverse(y[lo:hi].clone())
+        assert float((xb - x[lo:hi]).abs().max()) < 1e-4                 # rk4 forward then backward on the same grid
+        assert float((tb + tr[lo:hi]).abs().max()) < 1e-2 * max(1.0, float(tr[lo:hi].abs().max()))
+        dyn.split_gemm = False
+        ye, te = flow(x[lo:hi].clone())
+        dyn.split_gemm = None
+        assert float((ye - y[lo:hi]).norm() / y[lo:hi].norm()) < 1e-6
+        assert float((te - tr[lo:hi]).abs().max()) < 1e-3 * max(1.0, float(tr[lo:hi].abs().max()))

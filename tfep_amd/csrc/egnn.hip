@@ -97,7 +97,16 @@ __device__ inline void split8(const f4& a, const f4& b, float s, h8& hi, h8& lo)
     }
 }
 
-__device__ inline f4 mfma16(h8 a, h8 b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// acc += A B on v_mfma_f32_16x16x32_f16, accumulating IN PLACE (vDst == SrcC).  Inline asm on purpose: with the builtin,
+// hipcc (ROCm 7.2) gave destination and SrcC different registers and re-used the SrcC registers of the last products two
+// wait states later (a 64-bit shift, then the next source's global loads) while those MFMAs were still in flight -- the
+// tangent of the split chain came out different from run to run (caught by the bitwise row-independence check of
+// tests/test_gpu_continuous.py::test_cfg5_full_size_properties; the value tests against the goldens at 1e-5 passed).
+// In place there is no separate SrcC to clobber; A / B are read when the instruction issues.  hipcc pads nothing around
+// an asm statement: chain_gemm_split puts the wait states before the first product and after the last itself.
+__device__ inline void mfma16_acc(f4& acc, const h8& a, const h8& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
 
 // The same chain product on v_mfma_f32_16x16x32_f16 with every fp32 operand as two fp16 halves: hi*hi + lo*hi + hi*lo
 // (the dropped lo*lo is 2^-22 relative), fp32 accumulation.  One MFMA covers TWO of the 16-feature k tiles: k slot j of
@@ -115,19 +124,31 @@ __device__ inline void chain_gemm_split(const h8* __restrict__ img, const f4 (&x
         if (TAN) split8(dx[2 * T], (2 * T + 1 < NT) ? dx[(2 * T + 1 < NT) ? 2 * T + 1 : 0] : zero4, SPLIT_X_SCALE, dxh[T], dxl[T]);
     }
     const h8* img_lo = img + NT * NT2 * 64;
+    // the fp16 halves above come from VALU conversions: keep them (and everything else) ahead of the first product and
+    // give the VALU -> MFMA operand hazard its wait states by hand
+#pragma unroll
+    for (int tp = 0; tp < NT; ++tp) {                     // the (zero) accumulators exist in registers from here on
+        asm volatile("" : "+v"(acc[tp]));
+        if (TAN) asm volatile("" : "+v"(dacc[tp]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 3" ::: "memory");
 #pragma unroll
     for (int tp = 0; tp < NT; ++tp) {
 #pragma unroll
         for (int T = 0; T < NT2; ++T) {
             const h8 wh = img[(tp * NT2 + T) * 64 + lane], wl = img_lo[(tp * NT2 + T) * 64 + lane];
-            acc[tp] = mfma16(wh, xh[T], acc[tp]);
-            if (TAN) dacc[tp] = mfma16(wh, dxh[T], dacc[tp]);
-            acc[tp] = mfma16(wl, xh[T], acc[tp]);
-            if (TAN) dacc[tp] = mfma16(wl, dxh[T], dacc[tp]);
-            acc[tp] = mfma16(wh, xl[T], acc[tp]);
-            if (TAN) dacc[tp] = mfma16(wh, dxl[T], dacc[tp]);
+            mfma16_acc(acc[tp], wh, xh[T]);
+            if (TAN) mfma16_acc(dacc[tp], wh, dxh[T]);
+            mfma16_acc(acc[tp], wl, xh[T]);
+            if (TAN) mfma16_acc(dacc[tp], wl, dxh[T]);
+            mfma16_acc(acc[tp], wh, xl[T]);
+            if (TAN) mfma16_acc(dacc[tp], wh, dxl[T]);
         }
     }
+    // leave the matrix pipe's result latency behind before anything reads the accumulators
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // exp and 1/x on the transcendental unit (v_exp_f32 / v_rcp_f32, 1 ulp each; the argument scaling x * log2(e) adds
