@@ -304,7 +304,9 @@ int tfep_split_columns_scaled(const float* src, int64_t ld_src, int64_t rows, in
  * weights, used to bound the next layer's activations: tfep_gemm_desc.split_out), [3] unused.
  * col_cut (or NULL): when every mask row is a PREFIX in packed column order -- packed columns are sorted by the degree of
  * their input, so mask[o][in_of_col[c]] == (c < col_cut[o]) for the autoregressive masks of made.py:308-309 -- the mask
- * is not read at all (a third of the kernel's HBM traffic); the caller checks the prefix property once per mask. */
+ * is not read at all (a third of the kernel's HBM traffic); the caller checks the prefix property once per mask.  With
+ * col_cut only the live prefix [0, col_cut[o]) of each packed row (rounded up to 8 columns) is written: the rest of the
+ * row must already be zero (a buffer zeroed once and only ever used for this layer and mask). */
 int tfep_masked_weight_prepare_split(const float* weight_v, const float* weight_g, const float* mask, int out_features,
                                      int in_features, const int32_t* row_of_out, const int32_t* in_of_col, const int32_t* col_cut,
                                      void* w_split_out, int64_t ldw, int k_padded, float* inv_scale, void* stream);

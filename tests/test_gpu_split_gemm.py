@@ -340,7 +340,9 @@ def test_weight_prepare_without_reading_a_prefix_mask(order):
         ops.masked_weight_prepare_split(lin.weight_v.detach(), lin.weight_g.detach(), lin.mask, plan['row_of_out'][li],
                                         plan['in_of_col'][li], *no_mask, col_cut=cut)
         assert torch.equal(with_mask[0].view(torch.int32), no_mask[0].view(torch.int32))
-        assert torch.equal(with_mask[1][[0, 2]], no_mask[1][[0, 2]])
+        assert torch.equal(with_mask[1][0], no_mask[1][0])                       # the matrix scale
+        # (row-L1 maximum: the prefix kernel sums a row's |w| in another order -- it only feeds a bound)
+        assert torch.allclose(with_mask[1][2], no_mask[1][2], rtol=1e-5)
     assert n_prefix >= 2                                        # every layer fed by degree-sorted hidden units
     # a mask with a hole is not a prefix: detected (per mask version), and the mask is read
     lin = lins[1]

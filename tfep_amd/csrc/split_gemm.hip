@@ -76,7 +76,8 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ s
     for (int64_t i = lane; i < cols; i += 64) m = fmaxf(m, fabsf(sr[i]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    if (lane == 0) atomicMax(out_bits, __float_as_uint(m));     // non-negative floats order like their bits
+    // non-negative floats order like their bits; look before the atomic (same-address atomics serialise in L2)
+    if (lane == 0 && __float_as_uint(m) > __atomic_load_n(out_bits, __ATOMIC_RELAXED)) atomicMax(out_bits, __float_as_uint(m));
 }
 
 // One wave per row.  per_tensor: the scale comes from *tensor_max_bits (absmax_kernel) and inv_scale[0] is written
@@ -135,7 +136,10 @@ __global__ void __launch_bounds__(256) abs_reduce_kernel(const float* __restrict
         for (int64_t i = lane; i < cols; i += 64) acc += fabsf(sr[i]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-        if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(acc));
+        if (lane == 0) {                              // running maximum: look before the same-address atomic
+            unsigned int* mx = reinterpret_cast<unsigned int*>(out);
+            if (__float_as_uint(acc) > __atomic_load_n(mx, __ATOMIC_RELAXED)) atomicMax(mx, __float_as_uint(acc));
+        }
     }
 }
 
@@ -218,7 +222,107 @@ __global__ void __launch_bounds__(256) weight_prepare_split_kernel(const float* 
         dr[g8 * 2 + 1] = *reinterpret_cast<uint4*>(&lo);
     }
     l1 = wave_sum(l1);
-    if (lane == 0 && l1 < INFINITY) atomicMax(reinterpret_cast<uint32_t*>(inv_scale + 2), __float_as_uint(l1));
+    // (a running maximum: look before the atomic -- 75 000 same-address atomics serialise in L2 and were most of this kernel's
+    // time; a stale read only costs an unnecessary atomic)
+    if (lane == 0 && l1 < INFINITY) {
+        uint32_t* mx = reinterpret_cast<uint32_t*>(inv_scale + 2);
+        if (__float_as_uint(l1) > __atomic_load_n(mx, __ATOMIC_RELAXED)) atomicMax(mx, __float_as_uint(l1));
+    }
+}
+
+// The same for prefix masks (col_cut), one WORKGROUP per output row with the row of v staged in LDS: v is read exactly
+// once from HBM, fully coalesced (sum of squares on the way in), the permuted gather v[in_of_col[c]] then comes from LDS
+// (the one-wave-per-row kernel above gathers 4-byte elements through L2: 1.7 TB/s on the cfg2 output layer), and only the
+// live prefix [0, cut) of the packed row is written, in whole 32-byte groups -- the masked suffix was zeroed when the
+// buffer was allocated and nothing ever writes it (the k-ranges of the GEMMs do not even read it).
+constexpr int PFX_THREADS = 512;
+__global__ void __launch_bounds__(PFX_THREADS) weight_prepare_split_prefix_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                                          int N, int K, const int32_t* __restrict__ row_of_out,
+                                                                          const int32_t* __restrict__ in_of_col,
+                                                                          const int32_t* __restrict__ col_cut,
+                                                                          uint4* __restrict__ w_out, int64_t ldw, int k_padded,
+                                                                          const uint32_t* __restrict__ max_bits,
+                                                                          float* __restrict__ inv_scale) {
+    extern __shared__ float srow[];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const float* vr = v + (int64_t)o * K;
+    {
+        // 16-byte loads with several in flight per lane: at two workgroups per CU (the row takes 60 KB of LDS at
+        // K = 14 998) 4-byte loads leave too few bytes in flight to cover the HBM latency.  Rows start 8-byte aligned at
+        // best: a scalar head up to the first 16-byte boundary, float4 body, scalar tail.
+        const int head = min(K, (int)(((16u - (uint32_t)((uintptr_t)vr & 15u)) & 15u) >> 2));
+        const int n4 = (K - head) >> 2;
+        const float4* v4 = reinterpret_cast<const float4*>(vr + head);
+        if (tid < head) srow[tid] = vr[tid];
+        // eight loads issued before the first is consumed (the compiler does not hoist them over the LDS stores itself:
+        // one HBM round trip per 16 bytes and lane made this kernel latency-bound at 1 TB/s)
+        for (int i0 = tid; i0 < n4; i0 += 8 * PFX_THREADS) {
+            float4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * PFX_THREADS;
+                q[u] = i < n4 ? v4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * PFX_THREADS;
+                if (i < n4) {
+                    float* d = srow + head + 4 * i;
+                    d[0] = q[u].x; d[1] = q[u].y; d[2] = q[u].z; d[3] = q[u].w;
+                }
+            }
+        }
+        for (int i = head + 4 * n4 + tid; i < K; i += PFX_THREADS) srow[i] = vr[i];
+    }
+    __syncthreads();
+    float wn = 1.0f;
+    if (g) {
+        // the row norm in the summation order of weight_prepare_split_kernel (lane l: l, l + 64, ...; then the butterfly),
+        // every wave for itself from LDS: the packed bits are identical whichever kernel packs the layer
+        float ss = 0.f;
+        for (int i = tid & 63; i < K; i += 64) ss += srow[i] * srow[i];
+        ss = wave_sum(ss);
+        wn = g[o] / sqrtf(ss);             // may be inf/NaN for a fully-masked row: never used below
+    }
+    const float s = pow2_scale_for(__uint_as_float(*max_bits));
+    if (o == 0 && tid == 0) inv_scale[0] = 1.0f / s;
+    const int cut = min(col_cut[o], K);
+    const int64_t orow = row_of_out ? row_of_out[o] : o;
+    uint4* dr = w_out + orow * (ldw / 4);
+    float l1 = 0.f;
+    const int n_groups = (cut + 7) >> 3;
+    for (int g8 = tid; g8 < n_groups; g8 += PFX_THREADS) {
+        f16x8 hi, lo;
+        int idx[8];
+        if (in_of_col && g8 * 8 + 8 <= K && ((uintptr_t)in_of_col & 15u) == 0) {
+            const int4 a = reinterpret_cast<const int4*>(in_of_col)[2 * g8], b = reinterpret_cast<const int4*>(in_of_col)[2 * g8 + 1];
+            idx[0] = a.x; idx[1] = a.y; idx[2] = a.z; idx[3] = a.w; idx[4] = b.x; idx[5] = b.y; idx[6] = b.z; idx[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = g8 * 8 + j;
+                idx[j] = (in_of_col && c < K) ? in_of_col[c] : min(c, K - 1);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = g8 * 8 + j;
+            float val = 0.f;
+            if (c < cut) val = srow[idx[j]] * wn;
+            l1 += fabsf(val);
+            val *= s;
+            const _Float16 h = (_Float16)val;
+            hi[j] = h;
+            lo[j] = (_Float16)(val - (float)h);
+        }
+        dr[g8 * 2] = *reinterpret_cast<uint4*>(&hi);
+        dr[g8 * 2 + 1] = *reinterpret_cast<uint4*>(&lo);
+    }
+    l1 = wave_sum(l1);
+    if ((tid & 63) == 0 && l1 < INFINITY) {                   // look before the atomic (see weight_prepare_split_kernel)
+        uint32_t* mx = reinterpret_cast<uint32_t*>(inv_scale + 2);
+        if (__float_as_uint(l1) > __atomic_load_n(mx, __ATOMIC_RELAXED)) atomicMax(mx, __float_as_uint(l1));
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -797,6 +901,15 @@ int tfep_masked_weight_prepare_split(const float* weight_v, const float* weight_
         absmax_kernel<<<1, 256, 0, s>>>(weight_g, 0, 1, out_features, max_bits);          // one wave over the N gains
     else if (in_features > 0)
         absmax_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, s>>>(weight_v, in_features, out_features, in_features, max_bits);
+    static const bool lds_rows = env_int("TFEP_PACK_LDS", 1) != 0;            // A/B switch
+    // (short rows stay with the one-wave-per-row kernel: a workgroup per 3000-element row is mostly launch overhead)
+    if (col_cut && lds_rows && in_features >= 8192 && (size_t)in_features * 4 <= 64 * 1024) {
+        // prefix masks: the row goes through LDS once; the masked suffix of each packed row is NOT written (see the kernel)
+        weight_prepare_split_prefix_kernel<<<(unsigned)out_features, PFX_THREADS, (size_t)in_features * 4, s>>>(
+            weight_v, weight_g, out_features, in_features, row_of_out, in_of_col, col_cut, (uint4*)w_split_out, ldw, k_padded,
+            max_bits, inv_scale);
+        return check_launch("weight_prepare_split_prefix_kernel");
+    }
     weight_prepare_split_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, s>>>(
         weight_v, weight_g, mask, out_features, in_features, row_of_out, in_of_col, col_cut, (uint4*)w_split_out, ldw,
         k_padded, max_bits, inv_scale);
