@@ -166,8 +166,9 @@ __device__ inline void silu_tile(f4 (&z)[NT], f4 (&dz)[NT]) {
         for (int r = 0; r < 4; ++r) {
             const float v = z[t][r];
             const float sig = fast_rcp(1.0f + fast_exp(-v));
-            z[t][r] = v * sig;
-            if (TAN) dz[t][r] *= sig * (1.0f + v * (1.0f - sig));
+            const float sv = v * sig;
+            z[t][r] = sv;
+            if (TAN) dz[t][r] *= fmaf(sv, 1.0f - sig, sig);       // silu' = sig + silu (1 - sig)
         }
     }
 }
@@ -447,7 +448,6 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
         }
     };
     fetch_source(wave);
-
     for (int i = wave; i < n; i += EDGE_WAVES) {
         // ---- geometry of the 16 edges (i -> j0 + c); the four q-groups compute it redundantly (a few dozen VALU)
         const float v0 = xj0 - s_pos[3 * i], v1 = xj1 - s_pos[3 * i + 1], v2 = xj2 - s_pos[3 * i + 2];

@@ -124,6 +124,32 @@ if 'cfg3shard' in which:
         report('cfg3 per-GPU shard: same, packed weights cached', B, dt, roofline=mfma_roofline(flow, B, dt))
     del flow
 
+if 'variants' in which:
+    # what the unfused path costs for the spline variants the fused epilogue does not cover.  One
+    # cfg2-sized layer (D = 3000, H = 14998) at B = 32768: fused K = 8 plain spline against the K = 5 identity-slope /
+    # learnable-bound splines of MixedMAFMap (app/mixedmaf.py:770-811) on the generic path (split GEMMs, the (B, P D)
+    # parameters through HBM, stand-alone spline kernel).
+    D, B = 3000, 32768
+    x = torch.randn(B, D, device=dev).clamp_(-4.9, 4.9)
+    for name, kw in (('K=8 plain (fused epilogue)', dict(n_bins=8)),
+                     ('K=8 plain, fused=False (generic path)', dict(n_bins=8)),
+                     ('K=5 identity slopes (generic path)', dict(n_bins=5, identity_boundary_slopes=True)),
+                     ('K=5 identity slopes + learnable bounds (generic path)',
+                      dict(n_bins=5, identity_boundary_slopes=True, learn_lower_bound=True, learn_upper_bound=True))):
+        torch.manual_seed(0)
+        with torch.device(dev):
+            flow = SequentialFlow(MAF(generate_degrees(D, 'ascending'),
+                                      transformer=NeuralSplineTransformer(torch.full((D,), -5.0), torch.full((D,), 5.0), **kw),
+                                      initialize_identity=False))
+        if 'fused=False' in name:
+            flow[0].fused = False
+        with torch.no_grad():
+            dt, _ = timeit(lambda: flow(x), 1, 3)
+        P = flow[0]._transformer.n_parameters_per_feature
+        report(f'one cfg2-sized layer, {name}', B, dt, params_per_feature=P, fused=flow[0]._fused_kind() is not None,
+               param_tensor_gb=round(B * P * D * 4 / 1e9, 2), roofline=mfma_roofline(flow, B, dt))
+        del flow
+
 if 'train' in which:
     from tfep_amd.loss import BoltzmannKLDivLoss
     D = 3000
