@@ -583,6 +583,58 @@ typedef struct tfep_egnn_node_args {
 int tfep_egnn_node(const tfep_egnn_node_args* args, void* stream);
 
 /*
+ * Reverse pass (vector-Jacobian product with respect to the positions) of tfep_egnn_edge: what the reference obtains by
+ * torch.autograd.grad(vel, x, e) in its Hutchinson estimators (continuous.py:307-361).  The layer is recomputed per edge
+ * and walked backwards; run it TWICE per layer: src_owned = 0 (workgroups own destinations) writes
+ *   g_lane = g_Q (B, n, 16 nt)  and  g_pos = g_pos_out + destination-side position terms,
+ * then src_owned = 1 (workgroups own sources) writes g_lane = g_P and ADDS the source-side terms to g_pos.
+ * pos, P, Q: the layer's inputs (saved from the forward pass); g_pos_out: cotangent of its output positions;
+ * g_nm: cotangent of its aggregated messages (from tfep_egnn_node_backward; NULL = zero: last layer).
+ */
+typedef struct tfep_egnn_edge_bwd_args {
+    int32_t B, n_nodes, nt, split, src_owned;
+    float r_cutoff, speed_factor;
+    const float* packed;
+    const float* pos;
+    const float* P;
+    const float* Q;
+    int64_t pq_bstride;
+    const float* g_pos_out;
+    const float* g_nm;
+    float* g_lane;
+    float* g_pos;
+} tfep_egnn_edge_bwd_args;
+int tfep_egnn_edge_backward(const tfep_egnn_edge_bwd_args* args, void* stream);
+
+/*
+ * Reverse pass of tfep_egnn_node (same packed / packed_next): from the cotangents of its outputs (g_h_next: of h', NULL =
+ * zero; g_P, g_Q: of the next layer's source / destination terms) to those of its inputs, g_h and g_nm; h, nm: the
+ * node kernel's inputs saved from the forward pass.
+ */
+typedef struct tfep_egnn_node_bwd_args {
+    int32_t B, n_nodes, nt;
+    const float* packed;
+    const float* packed_next;
+    const float* h;
+    int64_t h_bstride;
+    const float* nm;
+    const float* g_h_next;
+    const float* g_P;
+    const float* g_Q;
+    float* g_h;
+    float* g_nm;
+} tfep_egnn_node_bwd_args;
+int tfep_egnn_node_backward(const tfep_egnn_node_bwd_args* args, void* stream);
+
+/* out = sign (in - mean over the nodes), per sample and component, (B, 3 n_nodes): the centring of the velocity
+ * (egnn.py:187-191) and, being a symmetric projector, its own reverse pass. */
+int tfep_egnn_center(const float* in, int B, int n_nodes, float sign, float* out, void* stream);
+
+/* Per row of (B, D): dot[b] += scale x[b] . y[b], sumsq[b] += scale |x[b]|^2 (either may be NULL): the trace and Frobenius
+ * estimates of continuous.py:307-361 from x = e^T J, y = e. */
+int tfep_row_dots(const float* x, const float* y, int B, int D, float scale, float* dot, float* sumsq, void* stream);
+
+/*
  * End of EGNNDynamics.forward (egnn.py:178-193): vel = (pos - x) - mean_nodes(pos - x), (B, 3 n_nodes).  With a tangent
  * (dpos, eps): jvp = (dpos - eps) - mean = J eps, and the quadratic forms of the trace estimators
  * (continuous.py:285-324):  trace[b] += scale eps . (J eps),  frob[b] += scale |J eps|^2.  vel_sq[b] = |vel|^2

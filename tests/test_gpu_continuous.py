@@ -188,16 +188,29 @@ def test_flow_matches_float64_oracle_on_the_same_grid(name, method, n_steps, est
     with torch.no_grad():
         y, tr, reg = flow(dev(x32))
     assert flow.last_solver_stats['n_steps'] == n_steps
+    # (the oracle in the reference's reverse-mode form: with the regulariser the flow runs the reverse-pass kernels)
     yo, tro, rego = oe.continuous_flow(odyn, torch.from_numpy(x32).double(), n_steps, method, estimator=estimator,
-                                       eps=torch.from_numpy(eps32).double(), regularization=True, frobenius_from='jvp')
+                                       eps=torch.from_numpy(eps32).double(), regularization=True, frobenius_from='vjp')
     assert rel_l2(y, yo.numpy()) <= REL
     np.testing.assert_allclose(tr.cpu().numpy(), tro.numpy(), rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(reg.cpu().numpy(), rego.numpy(), rtol=1e-4, atol=2e-5)
-    # without the regularisation term the state has two components and the same y / trace
+    # without the regularisation term the state has two components, the trace comes from the forward-mode kernel
+    # (e . (J e) instead of (e^T J) . e: the same number up to rounding) and y is unchanged
     flow.regularization = False
     with torch.no_grad():
         y2, tr2 = flow(dev(x32))
-    assert torch.equal(y2, y) and torch.equal(tr2, tr)
+    assert torch.equal(y2, y) and torch.allclose(tr2, tr, rtol=1e-4, atol=2e-5)
+    if estimator == 'hutchinson':
+        flow.ode_func.reverse_mode = False                # forward mode with the regulariser: |J e|^2 instead of |e^T J|^2
+        flow.regularization = True
+        with torch.no_grad():
+            y3, tr3, reg3 = flow(dev(x32))
+        _, _, rego_f = oe.continuous_flow(odyn, torch.from_numpy(x32).double(), n_steps, method, estimator=estimator,
+                                          eps=torch.from_numpy(eps32).double(), regularization=True, frobenius_from='jvp')
+        assert torch.equal(y3, y) and torch.allclose(tr3, tr, rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(reg3.cpu().numpy(), rego_f.numpy(), rtol=1e-4, atol=2e-5)
+        flow.ode_func.reverse_mode = None
+        flow.regularization = False
     # inverse: integrates back from t = 1, the trace comes out negated (continuous.py:176-180)
     with torch.no_grad():
         xb, trb = flow.inverse(y)
@@ -359,3 +372,41 @@ def test_cfg5_full_size_properties():
         dyn.split_gemm = None
         assert float((ye - y[lo:hi]).norm() / y[lo:hi].norm()) < 1e-6
         assert float((te - tr[lo:hi]).abs().max()) < 1e-3 * max(1.0, float(tr[lo:hi].abs().max()))
+
+
+@pytest.mark.parametrize('split', [True, False])
+@pytest.mark.parametrize('name', CONFIGS)
+def test_vjp_matches_reference_reverse_mode(name, split):
+    """``EGNNDynamics.vjp``: e^T J by the reverse-pass kernels against the reference's full Jacobian, and the quadratic
+    forms the reference's Hutchinson estimators build from it -- trace (e^T J) . e and |e^T J|^2 -- against its own
+    ``_trace_and_frobenious_squared_norm_hutchinson`` goldens (continuous.py:344-361), 1 and 3 noise samples."""
+    g = gu.load('continuous.npz')
+    dyn, cfg = build_dynamics(name, g, split)
+    x, t, eps = dev(g[f'{name}/x']), float(g[f'{name}/t'][0]), dev(g[f'{name}/eps'])
+    jac = g[f'{name}/jacobian_f64']
+    B = x.shape[0]
+    e64 = g[f'{name}/eps'].astype(np.float64)
+    with torch.no_grad():
+        vel0 = dyn(t, x)
+        for n_s, key in ((1, 'hutchinson1_reg'), (3, 'hutchinson3_reg')):
+            trace, frob, vsq = (torch.zeros(B, device='cuda') for _ in range(3))
+            for s_ in range(n_s):
+                vel, ej = dyn.vjp(t, x, eps[s_], trace=trace, frobenius=frob, scale=1.0 / n_s,
+                                  velocity_squared_norm=vsq if s_ == 0 else None)
+                assert torch.equal(vel, vel0)
+                ref = np.einsum('bi,bij->bj', e64[s_], jac)
+                assert rel_l2(ej, ref) <= REL, (name, s_, rel_l2(ej, ref))
+            scale = np.mean([np.abs(np.einsum('bi,bij->bj', e64[s_], jac) * e64[s_]).sum(-1) for s_ in range(n_s)], axis=0)
+            assert np.all(np.abs(trace.cpu().numpy() - g[f'{name}/{key}/trace_f64']) <= 1e-5 * np.maximum(scale, 1.0))
+            reg = (vsq + frob).cpu().numpy()
+            np.testing.assert_allclose(reg, g[f'{name}/{key}/reg_f64'], rtol=1e-4, atol=1e-6)
+        # the forward-mode and reverse-mode traces are the same number
+        tr_f = torch.zeros(B, device='cuda')
+        tr_r = torch.zeros(B, device='cuda')
+        dyn.jvp(t, x, eps[0], trace=tr_f, need_jvp=False)
+        ej1 = dyn.vjp(t, x, eps[0], trace=tr_r)[1]
+        assert torch.allclose(tr_f, tr_r, rtol=1e-4, atol=1e-4)
+        # deterministic, and independent of the batch a sample sits in
+        assert torch.equal(dyn.vjp(t, x, eps[0])[1], ej1)
+        if B > 2:
+            assert torch.equal(dyn.vjp(t, x[1:3].clone(), eps[0, 1:3].clone())[1], ej1[1:3])

@@ -80,6 +80,19 @@ class EgnnNodeArgs(Structure):
                 ('dP_out', c_void_p), ('dQ_out', c_void_p)]
 
 
+class EgnnEdgeBwdArgs(Structure):
+    _fields_ = [('B', c_int32), ('n_nodes', c_int32), ('nt', c_int32), ('split', c_int32), ('src_owned', c_int32),
+                ('r_cutoff', c_float), ('speed_factor', c_float), ('packed', c_void_p), ('pos', c_void_p),
+                ('P', c_void_p), ('Q', c_void_p), ('pq_bstride', c_int64), ('g_pos_out', c_void_p), ('g_nm', c_void_p),
+                ('g_lane', c_void_p), ('g_pos', c_void_p)]
+
+
+class EgnnNodeBwdArgs(Structure):
+    _fields_ = [('B', c_int32), ('n_nodes', c_int32), ('nt', c_int32), ('packed', c_void_p), ('packed_next', c_void_p),
+                ('h', c_void_p), ('h_bstride', c_int64), ('nm', c_void_p), ('g_h_next', c_void_p), ('g_P', c_void_p),
+                ('g_Q', c_void_p), ('g_h', c_void_p), ('g_nm', c_void_p)]
+
+
 _P = c_void_p
 _SIGNATURES = {
     'tfep_hip_abi_version': (c_int, []),
@@ -154,6 +167,10 @@ _SIGNATURES = {
     'tfep_egnn_edge': (c_int, [POINTER(EgnnEdgeArgs), _P]),
     'tfep_egnn_node': (c_int, [POINTER(EgnnNodeArgs), _P]),
     'tfep_egnn_finish': (c_int, [_P, _P, _P, _P, c_int, c_int, _P, _P, c_float, _P, _P, _P, _P]),
+    'tfep_egnn_edge_backward': (c_int, [POINTER(EgnnEdgeBwdArgs), _P]),
+    'tfep_egnn_node_backward': (c_int, [POINTER(EgnnNodeBwdArgs), _P]),
+    'tfep_egnn_center': (c_int, [_P, c_int, c_int, c_float, _P, _P]),
+    'tfep_row_dots': (c_int, [_P, _P, c_int, c_int, c_float, _P, _P, _P]),
     'tfep_radial_expansion': (c_int, [_P, c_int64, _P, _P, c_int, c_float, c_int, c_int, _P, _P]),
     'tfep_segment_sum': (c_int, [_P, _P, c_int64, c_int, c_int64, _P, _P]),
     'tfep_ode_axpy': (c_int, [_P, POINTER(c_void_p), POINTER(c_float), c_int, c_int64, _P, _P]),

@@ -38,7 +38,9 @@ constexpr int NODE_WAVES = 4;
 __host__ __device__ inline int64_t img_floats(int nt) { return (int64_t)nt * nt * 256; }       // (16 nt)^2
 // layout of a packed layer (floats)
 struct PackedLayout {
-    int64_t w1c, w2, x1, b2, d1, wa, x2, mu, gamma, scal, u1a, u1b, u2, c1, c2, w1a, w1b, b1, s_w1c, s_w2, s_x1, total;
+    int64_t w1c, w2, x1, b2, d1, wa, x2, mu, gamma, scal, u1a, u1b, u2, c1, c2, w1a, w1b, b1;
+    int64_t w1cT, w2T, x1T, w1aT, w1bT, u2T, u1aT, u1bT;        // transposed fp32 images (reverse pass)
+    int64_t s_w1c, s_w2, s_x1, s_w1cT, s_w2T, s_x1T, total;     // split-f16 images, forward and transposed
 };
 // A split-f16 operand image: per (row tile tp, pair of k tiles T) 64 lanes x 8 halves -- the "hi" image (fp16 of the
 // scaled weight) followed by the "lo" image (fp16 of the residual); in floats of the packed buffer.
@@ -52,8 +54,11 @@ __host__ __device__ inline PackedLayout packed_layout(int nt) {
     L.scal = o; o += 4;
     L.u1a = o; o += I; L.u1b = o; o += I; L.u2 = o; o += I; L.c1 = o; o += V; L.c2 = o; o += V;
     L.w1a = o; o += I; L.w1b = o; o += I; L.b1 = o; o += V;
+    L.w1cT = o; o += I; L.w2T = o; o += I; L.x1T = o; o += I;
+    L.w1aT = o; o += I; L.w1bT = o; o += I; L.u2T = o; o += I; L.u1aT = o; o += I; L.u1bT = o; o += I;
     const int64_t SI = split_img_floats(nt);
     L.s_w1c = o; o += SI; L.s_w2 = o; o += SI; L.s_x1 = o; o += SI;
+    L.s_w1cT = o; o += SI; L.s_w2T = o; o += SI; L.s_x1T = o; o += SI;
     L.total = o;
     return L;
 }
@@ -183,12 +188,16 @@ __device__ inline float sum_over_q(float v) {
 // ---------------------------------------------------------------------------------------------------------------
 // weight re-pack: reference parameter tensors of one _EGLayer -> packed layer
 // ---------------------------------------------------------------------------------------------------------------
-__device__ inline float img_entry(const float* w, int ldw, int col0, int n_rows, int n_cols, int nt, int64_t idx) {
-    // idx = ((tp * nt + t) * 64 + l) * 4 + r  ->  W[16 tp + (l & 15)][col0 + 16 t + 4 (l >> 4) + r]
+// Image entry of the block M[row][col] = W[row][col0 + col] (n_rows x n_cols) of a row-major matrix W, or of its transpose
+// (`transposed`: the image is of M^T, n_cols x n_rows -- the operand of the reverse pass).
+__device__ inline float img_entry(const float* w, int ldw, int col0, int n_rows, int n_cols, int nt, int64_t idx,
+                                  bool transposed = false) {
+    // idx = ((tp * nt + t) * 64 + l) * 4 + r  ->  entry [16 tp + (l & 15)][16 t + 4 (l >> 4) + r]
     const int r = (int)(idx & 3), l = (int)((idx >> 2) & 63);
     const int tt = (int)(idx >> 8);
     const int t = tt % nt, tp = tt / nt;
-    const int row = 16 * tp + (l & 15), col = 16 * t + 4 * (l >> 4) + r;
+    int row = 16 * tp + (l & 15), col = 16 * t + 4 * (l >> 4) + r;
+    if (transposed) { const int x = row; row = col; col = x; }
     return (row < n_rows && col < n_cols) ? w[(int64_t)row * ldw + col0 + col] : 0.0f;
 }
 __device__ inline float vec_entry(const float* v, int n, int64_t i) { return (v != nullptr && i < n) ? v[i] : 0.0f; }
@@ -217,13 +226,14 @@ __global__ void egnn_scale_kernel(tfep_egnn_layer_params p, int nt, float* __res
 }
 
 __device__ inline void split_img_entry(const float* w, int ldw, int col0, int n_rows, int n_cols, int nt, float scale,
-                                       int64_t idx, _Float16* hi, _Float16* lo) {
-    // idx = ((tp * nt2 + T) * 64 + l) * 8 + j  ->  W[16 tp + (l & 15)][col0 + 16 (2T + (j >> 2)) + 4 (l >> 4) + (j & 3)]
+                                       int64_t idx, _Float16* hi, _Float16* lo, bool transposed = false) {
+    // idx = ((tp * nt2 + T) * 64 + l) * 8 + j  ->  entry [16 tp + (l & 15)][16 (2T + (j >> 2)) + 4 (l >> 4) + (j & 3)]
     const int nt2 = (nt + 1) / 2;
     const int j = (int)(idx & 7), l = (int)((idx >> 3) & 63);
     const int tt = (int)(idx >> 9);
     const int T = tt % nt2, tp = tt / nt2;
-    const int row = 16 * tp + (l & 15), col = 16 * (2 * T + (j >> 2)) + 4 * (l >> 4) + (j & 3);
+    int row = 16 * tp + (l & 15), col = 16 * (2 * T + (j >> 2)) + 4 * (l >> 4) + (j & 3);
+    if (transposed) { const int x = row; row = col; col = x; }
     const float v = (row < n_rows && col < n_cols) ? w[(int64_t)row * ldw + col0 + col] * scale : 0.0f;
     const _Float16 h = (_Float16)v;
     hi[idx] = h;
@@ -234,14 +244,16 @@ __global__ void egnn_pack_split_kernel(tfep_egnn_layer_params p, int nt, float* 
     const PackedLayout L = packed_layout(nt);
     const int F = p.F, G = p.G;
     const int64_t n = (int64_t)nt * ((nt + 1) / 2) * 64 * 8;              // halves per image
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int m = (int)(i / n);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 6 * n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int im = (int)(i / n);                   // 0..2 forward images, 3..5 their transposes
+        const int m = im % 3;
+        const bool tr = im >= 3;
         const int64_t idx = i % n;
-        _Float16* hi = reinterpret_cast<_Float16*>(out + (m == 0 ? L.s_w1c : (m == 1 ? L.s_w2 : L.s_x1)));
+        _Float16* hi = reinterpret_cast<_Float16*>(out + L.s_w1c + (int64_t)im * split_img_floats(nt));
         const float scale = out[L.scal + 1 + m];
-        if (m == 0) split_img_entry(p.msg0_w, 2 * F + G, 2 * F, F, G, nt, scale, idx, hi, hi + n);
-        else if (m == 1) split_img_entry(p.msg2_w, F, 0, F, F, nt, scale, idx, hi, hi + n);
-        else split_img_entry(p.ux0_w, F, 0, F, F, nt, scale, idx, hi, hi + n);
+        if (m == 0) split_img_entry(p.msg0_w, 2 * F + G, 2 * F, F, G, nt, scale, idx, hi, hi + n, tr);
+        else if (m == 1) split_img_entry(p.msg2_w, F, 0, F, F, nt, scale, idx, hi, hi + n, tr);
+        else split_img_entry(p.ux0_w, F, 0, F, F, nt, scale, idx, hi, hi + n, tr);
     }
 }
 
@@ -269,7 +281,15 @@ __global__ void egnn_pack_kernel(tfep_egnn_layer_params p, int nt, float* __rest
         else if (i < L.w1a) v = vec_entry(p.uh2_b, F, i - L.c2);
         else if (i < L.w1b) v = img_entry(p.msg0_w, 2 * F + G, 0, F, F, nt, i - L.w1a);
         else if (i < L.b1) v = img_entry(p.msg0_w, 2 * F + G, F, F, F, nt, i - L.w1b);
-        else v = vec_entry(p.msg0_b, F, i - L.b1);
+        else if (i < L.w1cT) v = vec_entry(p.msg0_b, F, i - L.b1);
+        else if (i < L.w2T) v = img_entry(p.msg0_w, 2 * F + G, 2 * F, F, G, nt, i - L.w1cT, true);
+        else if (i < L.x1T) v = img_entry(p.msg2_w, F, 0, F, F, nt, i - L.w2T, true);
+        else if (i < L.w1aT) v = img_entry(p.ux0_w, F, 0, F, F, nt, i - L.x1T, true);
+        else if (i < L.w1bT) v = img_entry(p.msg0_w, 2 * F + G, 0, F, F, nt, i - L.w1aT, true);
+        else if (i < L.u2T) v = img_entry(p.msg0_w, 2 * F + G, F, F, F, nt, i - L.w1bT, true);
+        else if (i < L.u1aT) v = img_entry(p.uh2_w, F, 0, F, F, nt, i - L.u2T, true);
+        else if (i < L.u1bT) v = img_entry(p.uh0_w, 2 * F, 0, F, F, nt, i - L.u1aT, true);
+        else v = img_entry(p.uh0_w, 2 * F, F, F, F, nt, i - L.u1bT, true);
         out[i] = v;
         (void)I; (void)V;
     }
@@ -665,6 +685,433 @@ __global__ __launch_bounds__(NODE_WAVES * 64) void egnn_node_kernel(tfep_egnn_no
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Reverse pass (vector-Jacobian product) of one layer's edge part: what autograd computes for e^T J in the reference's
+// Hutchinson estimators (continuous.py:307-361).  Per live edge (source i -> destination j) the forward chain is
+// recomputed and walked backwards:
+//   g_mag = c (u . gp_j),  g_u = c mag gp_j            (c = speed_factor; gp = cotangent of the layer's output positions)
+//   g_z3 = silu'(z3) x2 (1 - mag^2) g_mag,   g_m = X1^T g_z3 + g_nm_j
+//   g_a2 = att g_m + wa att (1 - sigma(e)) (g_m . a2),   g_z2 = silu'(z2) g_a2,   g_z1 = silu'(z1) (W2^T g_z2)
+//   g_P_i += g_z1,  g_Q_j += g_z1,  g_rbf = W1c^T g_z1,  g_d = sum_k g_rbf_k d rbf_k / d d
+//   g_v = g_d u + (g_u - u (u . g_u)) / d,   g_x_j += g_v,   g_x_i -= g_v
+// The sums over sources (g_Q_j, + g_v) and over destinations (g_P_i, - g_v) cannot both be register accumulations of one
+// pass, and per-edge atomics are out of the question: the kernel runs TWICE, once owning 16 destinations per workgroup
+// (lanes = destinations, walking the sources) and once owning 16 sources (lanes = sources, walking the destinations).
+// Same transposed MFMA chain as the forward kernel, with the transposed weight images for the three reverse products.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ inline void silu_keep(f4 (&z)[NT], f4 (&ds)[NT]) {          // z <- silu(z), ds <- silu'(z)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = z[t][r];
+            const float sig = fast_rcp(1.0f + fast_exp(-v));
+            const float sv = v * sig;
+            z[t][r] = sv;
+            ds[t][r] = fmaf(sv, 1.0f - sig, sig);
+        }
+    }
+}
+
+template <int NT, bool SRC_OWNED, bool SPLIT>
+__global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_bwd_kernel(tfep_egnn_edge_bwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int FP = 16 * NT;
+    constexpr int IMG4 = SPLIT ? NT * ((NT + 1) / 2) * 64 * 2 : NT * NT * 64;
+    const PackedLayout L = packed_layout(NT);
+    const int n = a.n_nodes;
+    const int n_blk = (n + 15) / 16;
+    int blk;
+    {
+        const int total = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q8 = total >> 3, r8 = total & 7;
+        blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int b = blk / n_blk, ab = blk % n_blk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, c = lane & 15;
+
+    // ---- LDS: [3 forward images][3 transposed images][6 vectors][pos][gpos][lane terms][lane g_nm][reduction]
+    f4* const w_img = reinterpret_cast<f4*>(smem);
+    float* const vecs = smem + 6 * IMG4 * 4;
+    float* const s_pos = vecs + EDGE_CONST_VECS * FP;
+    float* const s_gpos = s_pos + ((3 * n + 3) & ~3);
+    f4* const s_lane = reinterpret_cast<f4*>(s_gpos + ((3 * n + 3) & ~3));
+    f4* const s_gnm = s_lane + NT * 64;
+    float* const s_red = reinterpret_cast<float*>(s_gnm + NT * 64);
+    const int64_t pq_b = (int64_t)b * a.pq_bstride;
+    {
+        const f4* src = reinterpret_cast<const f4*>(a.packed + (SPLIT ? L.s_w1c : L.w1c));
+        for (int i = tid; i < 3 * IMG4; i += EDGE_WAVES * 64) w_img[i] = src[i];
+        const f4* srcT = reinterpret_cast<const f4*>(a.packed + (SPLIT ? L.s_w1cT : L.w1cT));
+        for (int i = tid; i < 3 * IMG4; i += EDGE_WAVES * 64) w_img[3 * IMG4 + i] = srcT[i];
+        const f4* vsrc = reinterpret_cast<const f4*>(a.packed + L.b2);
+        for (int i = tid; i < EDGE_CONST_VECS * FP / 4; i += EDGE_WAVES * 64) w_img[6 * IMG4 + i] = vsrc[i];
+        const float* px = a.pos + (int64_t)b * 3 * n;
+        const float* pg = a.g_pos_out + (int64_t)b * 3 * n;
+        for (int i = tid; i < 3 * n; i += EDGE_WAVES * 64) { s_pos[i] = px[i]; s_gpos[i] = pg[i]; }
+        // lane-owned node terms: Q of the destinations (dest-owned) or P of the sources (source-owned); and, dest-owned,
+        // the cotangent of the aggregated messages of the lane's destination
+        const float* lane_src = SRC_OWNED ? a.P : a.Q;
+        for (int e = tid; e < NT * 64 * 2; e += EDGE_WAVES * 64) {
+            const bool second = e >= NT * 64;
+            const int ee = second ? e - NT * 64 : e;
+            const int cc = ee & 15, tq = ee >> 4;
+            const int node = ab * 16 + cc;
+            f4 v = f4{0.f, 0.f, 0.f, 0.f};
+            if (node < n) {
+                if (!second) v = reinterpret_cast<const f4*>(lane_src + (pq_b + node) * FP)[tq];
+                else if (!SRC_OWNED && a.g_nm != nullptr) v = reinterpret_cast<const f4*>(a.g_nm + ((int64_t)b * n + node) * FP)[tq];
+            }
+            (second ? s_gnm : s_lane)[ee] = v;
+        }
+    }
+    const float att_b = a.packed[L.scal];
+    const float inv1 = SPLIT ? 1.0f / (a.packed[L.scal + 1] * SPLIT_X_SCALE) : 1.0f;
+    const float inv2 = SPLIT ? 1.0f / (a.packed[L.scal + 2] * SPLIT_X_SCALE) : 1.0f;
+    const float inv3 = SPLIT ? 1.0f / (a.packed[L.scal + 3] * SPLIT_X_SCALE) : 1.0f;
+    __syncthreads();
+    const f4* const img_w1c = w_img;
+    const f4* const img_w2 = w_img + IMG4;
+    const f4* const img_x1 = w_img + 2 * IMG4;
+    const f4* const img_w1cT = w_img + 3 * IMG4;
+    const f4* const img_w2T = w_img + 4 * IMG4;
+    const f4* const img_x1T = w_img + 5 * IMG4;
+    const f4* const v_b2 = reinterpret_cast<const f4*>(vecs);
+    const f4* const v_d1 = v_b2 + FP / 4;
+    const f4* const v_wa = v_d1 + FP / 4;
+    const f4* const v_x2 = v_wa + FP / 4;
+    const f4* const v_mu = v_x2 + FP / 4;
+    const f4* const v_ga = v_mu + FP / 4;
+    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+    // out = init + W x
+    auto product = [&](const f4* img, const f4 (&x)[NT], f4 (&out)[NT], float inv, auto init) {
+        f4 dummy[NT];
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) out[t] = zero4;
+            chain_gemm_split<NT, false>(reinterpret_cast<const h8*>(img), x, x, out, dummy, lane);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) out[t] = out[t] * inv + init(t);
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) out[t] = init(t);
+            chain_gemm<NT, false>(img, x, x, out, dummy, lane);
+        }
+    };
+    auto zero_init = [&](int) { return zero4; };
+
+    const int an = ab * 16 + c;                          // the lane's own node
+    const bool a_ok = an < n;
+    const int ac = a_ok ? an : 0;
+    const float xa0 = s_pos[3 * ac], xa1 = s_pos[3 * ac + 1], xa2 = s_pos[3 * ac + 2];
+    const float gpa0 = s_gpos[3 * ac], gpa1 = s_gpos[3 * ac + 1], gpa2 = s_gpos[3 * ac + 2];
+    f4 gacc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) gacc[t] = zero4;
+    float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f;
+    const float rc = a.r_cutoff, pi_rc = 3.14159265358979323846f / rc;
+    // loop-node terms, fetched one iteration ahead: P of the source (dest-owned) or Q of the destination (source-owned),
+    // and, source-owned, the cotangent of the destination's aggregated messages
+    const float* const loop_base = (SRC_OWNED ? a.Q : a.P) + pq_b * FP;
+    const float* const gnm_base = (SRC_OWNED && a.g_nm != nullptr) ? a.g_nm + (int64_t)b * n * FP : nullptr;
+    f4 Ln[NT], Gn[NT];
+    auto fetch_loop = [&](int i) {
+        const int ic = i < n ? i : 0;
+        const f4* p = reinterpret_cast<const f4*>(loop_base + (int64_t)ic * FP);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) Ln[t] = p[4 * t + q];
+        if (SRC_OWNED) {
+            if (gnm_base != nullptr) {
+                const f4* g = reinterpret_cast<const f4*>(gnm_base + (int64_t)ic * FP);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) Gn[t] = g[4 * t + q];
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) Gn[t] = zero4;
+            }
+        }
+    };
+    fetch_loop(wave);
+    for (int i = wave; i < n; i += EDGE_WAVES) {
+        // v = x_dest - x_src (graph.py:254): the lane's node is the destination (dest-owned) or the source
+        const float sg = SRC_OWNED ? -1.0f : 1.0f;
+        const float v0 = sg * (xa0 - s_pos[3 * i]), v1 = sg * (xa1 - s_pos[3 * i + 1]), v2 = sg * (xa2 - s_pos[3 * i + 2]);
+        const float d = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+        const bool keep = a_ok && (an != i) && (d <= rc);
+        if (__ballot(keep) == 0ull) {
+            fetch_loop(i + EDGE_WAVES);
+            continue;
+        }
+        const float inv_d = keep ? 1.0f / d : 0.0f;
+        const float u0 = v0 * inv_d, u1 = v1 * inv_d, u2 = v2 * inv_d;
+        // cotangent of the DESTINATION's output position
+        const float gp0 = SRC_OWNED ? s_gpos[3 * i] : gpa0, gp1 = SRC_OWNED ? s_gpos[3 * i + 1] : gpa1,
+                    gp2 = SRC_OWNED ? s_gpos[3 * i + 2] : gpa2;
+        float sn, cs;
+        sincosf(pi_rc * d, &sn, &cs);
+        const float sw = 0.5f * cs + 0.5f;
+        const float dsw = -0.5f * pi_rc * sn;
+        // ---- forward chain, keeping the activation derivatives (registers are the scarce resource of this kernel: the
+        // radial derivatives are recomputed at the end rather than kept, the message cotangent is read where it is used)
+        f4 z[NT], ds1[NT], ds2[NT], ds3[NT], a2[NT];
+        {
+            f4 rbf[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f4 mu = v_mu[4 * t + q], ga = v_ga[4 * t + q];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dm = d - mu[r];
+                    rbf[t][r] = fast_exp(-ga[r] * dm * dm) * sw;
+                }
+            }
+            product(img_w1c, rbf, z, inv1, [&](int t) { return Ln[t] + s_lane[(4 * t + q) * 16 + c]; });
+        }
+        silu_keep<NT>(z, ds1);
+        product(img_w2, z, a2, inv2, [&](int t) { return v_b2[4 * t + q]; });
+        silu_keep<NT>(a2, ds2);
+        float e = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f4 wa = v_wa[4 * t + q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e += wa[r] * a2[t][r];
+        }
+        e = sum_over_q(e) + att_b;
+        const float sig_e = 1.0f / (1.0f + expf(-e));
+        const float att = keep ? sig_e : 0.0f;
+        f4 m[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) m[t] = a2[t] * att;
+        product(img_x1, m, z, inv3, [&](int t) { return v_d1[4 * t + q]; });
+        silu_keep<NT>(z, ds3);
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f4 x2 = v_x2[4 * t + q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s += x2[r] * z[t][r];
+        }
+        const float mag = tanhf(sum_over_q(s));
+        // ---- reverse chain
+        const float cs_k = keep ? a.speed_factor : 0.0f;
+        const float g_mag = cs_k * (u0 * gp0 + u1 * gp1 + u2 * gp2);
+        const float gu0 = cs_k * mag * gp0, gu1 = cs_k * mag * gp1, gu2 = cs_k * mag * gp2;
+        const float g_s = (1.0f - mag * mag) * g_mag;
+        f4 gz[NT], gm[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f4 x2 = v_x2[4 * t + q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gz[t][r] = ds3[t][r] * x2[r] * g_s;
+        }
+        // g_m = X1^T g_z3 + g_nm_dest
+        product(img_x1T, gz, gm, inv3, [&](int t) { return SRC_OWNED ? Gn[t] : s_gnm[(4 * t + q) * 16 + c]; });
+        fetch_loop(i + EDGE_WAVES);                 // the loop node's terms of the next iteration land under the rest
+        float g_att = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) g_att += gm[t][r] * a2[t][r];
+        const float ce = sum_over_q(g_att) * att * (1.0f - sig_e);             // d att / d e = att (1 - sigma(e))
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f4 wa = v_wa[4 * t + q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gz[t][r] = ds2[t][r] * (att * gm[t][r] + wa[r] * ce);
+        }
+        product(img_w2T, gz, gm, inv2, zero_init);                               // g_a1 = W2^T g_z2
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            gz[t] = ds1[t] * gm[t];                                              // g_z1
+            gacc[t] += gz[t];                                                    // g_Q_dest / g_P_src
+        }
+        product(img_w1cT, gz, gm, inv1, zero_init);                              // g_rbf = W1c^T g_z1
+        float g_d = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f4 mu = v_mu[4 * t + q], ga = v_ga[4 * t + q];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                                      // d rbf_k / d distance
+                const float dm = d - mu[r];
+                g_d += gm[t][r] * fast_exp(-ga[r] * dm * dm) * (dsw - 2.0f * ga[r] * dm * sw);
+            }
+        }
+        g_d = sum_over_q(g_d);
+        const float ug = u0 * gu0 + u1 * gu1 + u2 * gu2;
+        const float gv0 = g_d * u0 + (gu0 - u0 * ug) * inv_d, gv1 = g_d * u1 + (gu1 - u1 * ug) * inv_d,
+                    gv2 = g_d * u2 + (gu2 - u2 * ug) * inv_d;
+        const float k = keep ? sg : 0.0f;                                        // + for the destination, - for the source
+        gx0 += k * gv0; gx1 += k * gv1; gx2 += k * gv2;
+    }
+
+    // ---- cross-wave reduction in a fixed order, then the outputs of the lane-owned nodes
+    constexpr int NM4 = NT * 64;
+    f4* const r_acc = reinterpret_cast<f4*>(s_red);
+    float* const r_gx = reinterpret_cast<float*>(r_acc + EDGE_WAVES * NM4);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) r_acc[wave * NM4 + t * 64 + lane] = gacc[t];
+    if (q == 0) {
+        float* p = r_gx + (wave * 16 + c) * 4;
+        p[0] = gx0; p[1] = gx1; p[2] = gx2;
+    }
+    __syncthreads();
+    for (int e = tid; e < NM4; e += EDGE_WAVES * 64) {
+        f4 sum = r_acc[e];
+#pragma unroll
+        for (int w = 1; w < EDGE_WAVES; ++w) sum += r_acc[w * NM4 + e];
+        const int t = e >> 6, l = e & 63;
+        const int node = ab * 16 + (l & 15);
+        if (node < n) reinterpret_cast<f4*>(a.g_lane + ((int64_t)b * n + node) * FP)[4 * t + (l >> 4)] = sum;
+    }
+    if (tid < 16 * 3) {
+        const int comp = tid % 3, cc = tid / 3;
+        const int node = ab * 16 + cc;
+        if (node < n) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < EDGE_WAVES; ++w) sum += r_gx[(w * 16 + cc) * 4 + comp];
+            float* dst = a.g_pos + ((int64_t)b * n + node) * 3 + comp;
+            // dest-owned: the identity path pos' = pos + ... plus the destination-side terms; source-owned: adds its terms
+            *dst = SRC_OWNED ? *dst + sum : s_gpos[3 * node + comp] + sum;
+        }
+    }
+}
+
+template <int NT, bool SPLIT>
+size_t edge_bwd_lds_bytes(int n) {
+    const size_t fp = 16 * NT, img4 = SPLIT ? (size_t)NT * ((NT + 1) / 2) * 64 * 2 : (size_t)NT * NT * 64;
+    size_t fl = 6 * img4 * 4 + EDGE_CONST_VECS * fp + 2 * (size_t)((3 * n + 3) & ~3) + 2 * (size_t)NT * 64 * 4;
+    fl += (size_t)EDGE_WAVES * NT * 64 * 4 + EDGE_WAVES * 16 * 4;
+    return fl * sizeof(float);
+}
+
+// Reverse pass of the node update between layer l and l + 1 (egnn_node_kernel):
+//   G = g_h' + W1a^T g_P' + W1b^T g_Q',   q = silu'(U1a h + U1b nm + c1) (U2^T G),   g_h = G + U1a^T q,   g_nm = U1b^T q
+template <int NT>
+__global__ __launch_bounds__(NODE_WAVES * 64) void egnn_node_bwd_kernel(tfep_egnn_node_bwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int FP = 16 * NT;
+    constexpr int IMG4 = NT * NT * 64;
+    const PackedLayout L = packed_layout(NT);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane >> 4, c = lane & 15;
+    // LDS: [U1a, U1b][c1][U2^T, U1a^T, U1b^T] of this layer, [W1a^T, W1b^T] of the next
+    f4* const fwd = reinterpret_cast<f4*>(smem);
+    f4* const vc1 = fwd + 2 * IMG4;
+    f4* const rev = vc1 + FP / 4;
+    f4* const nxt = rev + 3 * IMG4;
+    {
+        const f4* s0 = reinterpret_cast<const f4*>(a.packed + L.u1a);
+        for (int i = tid; i < 2 * IMG4; i += NODE_WAVES * 64) fwd[i] = s0[i];
+        const f4* s1 = reinterpret_cast<const f4*>(a.packed + L.c1);
+        for (int i = tid; i < FP / 4; i += NODE_WAVES * 64) vc1[i] = s1[i];
+        const f4* s2 = reinterpret_cast<const f4*>(a.packed + L.u2T);
+        for (int i = tid; i < 3 * IMG4; i += NODE_WAVES * 64) rev[i] = s2[i];
+        const f4* s3 = reinterpret_cast<const f4*>(a.packed_next + L.w1aT);
+        for (int i = tid; i < 2 * IMG4; i += NODE_WAVES * 64) nxt[i] = s3[i];
+    }
+    __syncthreads();
+    const f4 *img_u1a = fwd, *img_u1b = fwd + IMG4;
+    const f4 *img_u2T = rev, *img_u1aT = rev + IMG4, *img_u1bT = rev + 2 * IMG4;
+    const f4 *img_w1aT = nxt, *img_w1bT = nxt + IMG4;
+    const int64_t n_total = (int64_t)a.B * a.n_nodes;
+    const int64_t n_groups = (n_total + 15) / 16;
+    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
+    for (int64_t g = (int64_t)blockIdx.x * NODE_WAVES + wave; g < n_groups; g += (int64_t)gridDim.x * NODE_WAVES) {
+        const int64_t node = g * 16 + c;
+        const bool ok = node < n_total;
+        const int64_t nd = ok ? node : 0;
+        const int64_t hb = (nd / a.n_nodes) * a.h_bstride + (nd % a.n_nodes);
+        f4 h[NT], m[NT], gP[NT], gQ[NT], G[NT], dummy[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            h[t] = reinterpret_cast<const f4*>(a.h + hb * FP)[4 * t + q];
+            m[t] = reinterpret_cast<const f4*>(a.nm + nd * FP)[4 * t + q];
+            gP[t] = reinterpret_cast<const f4*>(a.g_P + nd * FP)[4 * t + q];
+            gQ[t] = reinterpret_cast<const f4*>(a.g_Q + nd * FP)[4 * t + q];
+            G[t] = a.g_h_next != nullptr ? reinterpret_cast<const f4*>(a.g_h_next + nd * FP)[4 * t + q] : zero4;
+        }
+        chain_gemm<NT, false>(img_w1aT, gP, gP, G, dummy, lane);
+        chain_gemm<NT, false>(img_w1bT, gQ, gQ, G, dummy, lane);
+        f4 z[NT], ds[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) z[t] = vc1[4 * t + q];
+        chain_gemm<NT, false>(img_u1a, h, h, z, dummy, lane);
+        chain_gemm<NT, false>(img_u1b, m, m, z, dummy, lane);
+        silu_keep<NT>(z, ds);
+        f4 tt[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) tt[t] = zero4;
+        chain_gemm<NT, false>(img_u2T, G, G, tt, dummy, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) tt[t] = tt[t] * ds[t];
+        f4 gnm[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gnm[t] = zero4;
+        chain_gemm<NT, false>(img_u1aT, tt, tt, G, dummy, lane);             // g_h = G + U1a^T q
+        chain_gemm<NT, false>(img_u1bT, tt, tt, gnm, dummy, lane);           // g_nm = U1b^T q
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                reinterpret_cast<f4*>(a.g_h + node * FP)[4 * t + q] = G[t];
+                reinterpret_cast<f4*>(a.g_nm + node * FP)[4 * t + q] = gnm[t];
+            }
+        }
+    }
+}
+
+// out = in - mean over the nodes (per sample and component): the centring of the velocity (egnn.py:187-191) is a symmetric
+// projector, so this is also its reverse pass.
+__global__ void egnn_center_kernel(const float* __restrict__ in, int n_nodes, float sign, float* __restrict__ out) {
+    __shared__ double red[4][4];
+    __shared__ double mean[3];
+    const int b = blockIdx.x, D = 3 * n_nodes;
+    const float* p = in + (int64_t)b * D;
+    double s[3] = {0, 0, 0};
+    for (int i = threadIdx.x; i < n_nodes; i += blockDim.x)
+        for (int k = 0; k < 3; ++k) s[k] += (double)p[3 * i + k];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    for (int k = 0; k < 3; ++k) {
+        const double v = wave_sum(s[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double tot = 0;
+        for (int w = 0; w < n_waves; ++w) tot += red[w][threadIdx.x];
+        mean[threadIdx.x] = tot / n_nodes;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += blockDim.x) out[(int64_t)b * D + i] = sign * (float)((double)p[i] - mean[i % 3]);
+}
+
+// per row: dot += scale a . b, sumsq += scale |a|^2  (the quadratic forms of continuous.py:307-361 from e^T J)
+__global__ void egnn_rowdots_kernel(const float* __restrict__ x, const float* __restrict__ y, int D, float scale,
+                                    float* __restrict__ dot, float* __restrict__ sumsq) {
+    __shared__ double red[4][2];
+    const int b = blockIdx.x;
+    double s0 = 0, s1 = 0;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        const double a = x[(int64_t)b * D + i];
+        s0 += a * (double)y[(int64_t)b * D + i];
+        s1 += a * a;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+    if (lane == 0) { red[wave][0] = s0; red[wave][1] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t0 = 0, t1 = 0;
+        for (int w = 0; w < n_waves; ++w) { t0 += red[w][0]; t1 += red[w][1]; }
+        if (dot != nullptr) dot[b] += scale * (float)t0;
+        if (sumsq != nullptr) sumsq[b] += scale * (float)t1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // velocity (egnn.py:178-193): vel = (pos_L - x) - mean over nodes; with a tangent also d vel = (dpos_L - e) - mean and
 // the quadratic forms the trace estimators need: e . (J e) and |J e|^2 (continuous.py:307-324, :285-304).
 // One workgroup per sample.
@@ -816,6 +1263,34 @@ int launch_node(const tfep_egnn_node_args& a, hipStream_t st) {
     return check_launch("tfep_egnn_node");
 }
 
+template <int NT, bool SRC_OWNED, bool SPLIT>
+int launch_edge_bwd_impl(const tfep_egnn_edge_bwd_args& a, hipStream_t st) {
+    const size_t lds = edge_bwd_lds_bytes<NT, SPLIT>(a.n_nodes);
+    int rc = allow_lds(egnn_edge_bwd_kernel<NT, SRC_OWNED, SPLIT>, lds, "tfep_egnn_edge_backward");
+    if (rc != TFEP_OK) return rc;
+    const int64_t blocks = (int64_t)a.B * ((a.n_nodes + 15) / 16);
+    TFEP_REQUIRE(blocks < (1ll << 31), "tfep_egnn_edge_backward: too many workgroups");
+    hipLaunchKernelGGL((egnn_edge_bwd_kernel<NT, SRC_OWNED, SPLIT>), dim3((unsigned)blocks), dim3(EDGE_WAVES * 64), lds, st, a);
+    return check_launch("tfep_egnn_edge_backward");
+}
+
+template <int NT>
+int launch_edge_bwd(const tfep_egnn_edge_bwd_args& a, hipStream_t st) {
+    if (a.src_owned) return a.split ? launch_edge_bwd_impl<NT, true, true>(a, st) : launch_edge_bwd_impl<NT, true, false>(a, st);
+    return a.split ? launch_edge_bwd_impl<NT, false, true>(a, st) : launch_edge_bwd_impl<NT, false, false>(a, st);
+}
+
+template <int NT>
+int launch_node_bwd(const tfep_egnn_node_bwd_args& a, hipStream_t st) {
+    const size_t lds = ((size_t)7 * NT * NT * 64 * 4 + 16 * NT) * sizeof(float);
+    int rc = allow_lds(egnn_node_bwd_kernel<NT>, lds, "tfep_egnn_node_backward");
+    if (rc != TFEP_OK) return rc;
+    const int64_t groups = ((int64_t)a.B * a.n_nodes + 15) / 16;
+    const int blocks = (int)std::min<int64_t>((groups + NODE_WAVES - 1) / NODE_WAVES, 256 * 8);
+    hipLaunchKernelGGL((egnn_node_bwd_kernel<NT>), dim3(blocks), dim3(NODE_WAVES * 64), lds, st, a);
+    return check_launch("tfep_egnn_node_backward");
+}
+
 }  // namespace
 }  // namespace tfep
 
@@ -847,7 +1322,7 @@ int tfep_egnn_pack_layer(const tfep_egnn_layer_params* p, int nt, float* packed,
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(egnn_scale_kernel, dim3(3), dim3(256), 0, st, *p, nt, packed);
     hipLaunchKernelGGL(egnn_pack_kernel, dim3(grid_for(L.s_w1c, 256)), dim3(256), 0, st, *p, nt, packed);
-    hipLaunchKernelGGL(egnn_pack_split_kernel, dim3(grid_for(3 * split_img_floats(nt), 256)), dim3(256), 0, st, *p, nt, packed);
+    hipLaunchKernelGGL(egnn_pack_split_kernel, dim3(grid_for(6 * split_img_floats(nt), 256)), dim3(256), 0, st, *p, nt, packed);
     return check_launch("tfep_egnn_pack_layer");
 }
 
@@ -919,6 +1394,52 @@ int tfep_egnn_finish(const float* pos, const float* x, const float* dpos, const 
     hipLaunchKernelGGL(egnn_finish_kernel, dim3(B), dim3(block), 0, (hipStream_t)stream, pos, x, dpos, eps, n_nodes, vel,
                        jvp, scale, trace, frob, vel_sq);
     return check_launch("tfep_egnn_finish");
+}
+
+int tfep_egnn_edge_backward(const tfep_egnn_edge_bwd_args* a, void* stream) {
+    TFEP_REQUIRE(a != nullptr, "tfep_egnn_edge_backward: null argument");
+    TFEP_REQUIRE(a->B >= 1 && a->n_nodes >= 1 && a->n_nodes <= 4096, "tfep_egnn_edge_backward: bad sizes (B=%d, n_nodes=%d)",
+                 a->B, a->n_nodes);
+    TFEP_REQUIRE(a->packed && a->pos && a->P && a->Q && a->g_pos_out && a->g_lane && a->g_pos,
+                 "tfep_egnn_edge_backward: null tensor");
+    TFEP_REQUIRE(a->r_cutoff > 0.0f, "tfep_egnn_edge_backward: r_cutoff must be positive");
+    TFEP_REQUIRE(a->pq_bstride == 0 || a->pq_bstride == a->n_nodes, "tfep_egnn_edge_backward: pq_bstride must be 0 or n_nodes");
+    hipStream_t st = (hipStream_t)stream;
+    switch (a->nt) {
+        case 1: return launch_edge_bwd<1>(*a, st);
+        case 2: return launch_edge_bwd<2>(*a, st);
+        case 4: return launch_edge_bwd<4>(*a, st);
+    }
+    return fail(TFEP_ERR_INVALID_ARGUMENT, "tfep_egnn_edge_backward: nt must be 1, 2 or 4 (got %d)", a->nt);
+}
+
+int tfep_egnn_node_backward(const tfep_egnn_node_bwd_args* a, void* stream) {
+    TFEP_REQUIRE(a != nullptr, "tfep_egnn_node_backward: null argument");
+    TFEP_REQUIRE(a->B >= 1 && a->n_nodes >= 1, "tfep_egnn_node_backward: bad sizes");
+    TFEP_REQUIRE(a->packed && a->packed_next && a->h && a->nm && a->g_P && a->g_Q && a->g_h && a->g_nm,
+                 "tfep_egnn_node_backward: null tensor");
+    TFEP_REQUIRE(a->h_bstride == 0 || a->h_bstride == a->n_nodes, "tfep_egnn_node_backward: h_bstride must be 0 or n_nodes");
+    hipStream_t st = (hipStream_t)stream;
+    switch (a->nt) {
+        case 1: return launch_node_bwd<1>(*a, st);
+        case 2: return launch_node_bwd<2>(*a, st);
+        case 4: return launch_node_bwd<4>(*a, st);
+    }
+    return fail(TFEP_ERR_INVALID_ARGUMENT, "tfep_egnn_node_backward: nt must be 1, 2 or 4 (got %d)", a->nt);
+}
+
+int tfep_egnn_center(const float* in, int B, int n_nodes, float sign, float* out, void* stream) {
+    TFEP_REQUIRE(in && out && B >= 1 && n_nodes >= 1, "tfep_egnn_center: bad arguments");
+    hipLaunchKernelGGL(egnn_center_kernel, dim3(B), dim3(n_nodes >= 256 ? 256 : 64), 0, (hipStream_t)stream, in, n_nodes,
+                       sign, out);
+    return check_launch("tfep_egnn_center");
+}
+
+int tfep_row_dots(const float* x, const float* y, int B, int D, float scale, float* dot, float* sumsq, void* stream) {
+    TFEP_REQUIRE(x && y && B >= 1 && D >= 1, "tfep_row_dots: bad arguments");
+    hipLaunchKernelGGL(egnn_rowdots_kernel, dim3(B), dim3(D >= 256 ? 256 : 64), 0, (hipStream_t)stream, x, y, D, scale, dot,
+                       sumsq);
+    return check_launch("tfep_row_dots");
 }
 
 int tfep_radial_expansion(const float* r, int64_t n, const float* means, const float* log_gammas, int n_basis,

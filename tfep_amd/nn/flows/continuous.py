@@ -4,12 +4,12 @@
 inverse negated, :176-180), the ``ode_func`` submodule (``ode_func.dynamics.*`` in the ``state_dict``) and
 ``before_odeint``'s fresh Hutchinson noise per integration (:223-229).  Two execution paths:
 
-* dynamics with a Jacobian-vector-product kernel (``tfep_amd.nn.dynamics.EGNNDynamics``): the integrands come from the
-  HIP kernels -- velocity, ``e . (J e)`` (Hutchinson, :307-324; equal to the reference's ``(e^T J) . e``) or
-  ``sum_k e_k . (J e_k)`` (exact, :285-304), and the regulariser ``|v|^2 + |J|_F^2`` (:262-268).  The exact Frobenius norm
-  is ``sum_k |J e_k|^2``; the Hutchinson Frobenius estimate is formed from ``|J e|^2`` -- the same expectation as the
-  reference's ``|e^T J|^2`` but not the same number for a given ``e`` (a reverse pass through the kernels does not exist
-  yet).  Not differentiable: backward raises.
+* dynamics with product kernels (``tfep_amd.nn.dynamics.EGNNDynamics``): the integrands come from the HIP kernels --
+  velocity; Hutchinson trace ``(e^T J) . e`` and Frobenius estimate ``|e^T J|^2`` (:307-361) from the reverse pass
+  (``dynamics.vjp``) when the regulariser is requested, the trace alone from the cheaper forward-mode pass
+  (``dynamics.jvp``: ``e . (J e)``, the same number); exact trace ``sum_k e_k . (J e_k)`` and Frobenius norm
+  ``sum_k |J e_k|^2`` (:285-304) from one forward-mode pass per coordinate; regulariser ``|v|^2 + |J|_F^2`` (:262-268).
+  Not differentiable with respect to the parameters: backward raises.
 * any other ``dynamics(t, x)`` torch module: velocity and vector-Jacobian products by autograd on the device, as the
   reference does; differentiable with ``adjoint=False`` semantics (plain backpropagation through the steps).
 
@@ -99,6 +99,10 @@ class _ODEFunc(torch.nn.Module):
         #: Set to a ``(n_hutchinson_samples, batch, features)`` tensor to use THAT noise instead of fresh normal
         #: samples in the next integrations (reproducible traces; the reference redraws on every call).
         self.fixed_noise = None
+        #: Hutchinson products of kernel dynamics: True = reverse pass (e^T J, the reference's numbers for trace AND
+        #: Frobenius estimate), False = forward mode (J e: the same trace, the Frobenius estimate from |J e|^2 -- same
+        #: expectation, another number), None = reverse exactly when the regulariser is requested.
+        self.reverse_mode = None
 
     @property
     def trace_estimator(self):
@@ -143,9 +147,17 @@ class _ODEFunc(torch.nn.Module):
         vel = None
         if self._trace_estimator == self.TraceEstimators.hutchinson:
             S = len(self._eps)
+            # With the regulariser the reference needs e^T J itself (|e^T J|^2, continuous.py:344-361): the reverse pass.
+            # The trace alone is the same number forward or reverse, e . (J e) = (e^T J) . e: the forward-mode kernel
+            # (one pass, ~2.5 x cheaper) unless ``reverse_mode`` says otherwise.
+            reverse = regularization if self.reverse_mode is None else bool(self.reverse_mode)
             for s in range(S):
-                v, _ = dyn.jvp(t, x, self._eps[s], trace=trace, frobenius=frob, scale=1.0 / S,
-                               velocity_squared_norm=vsq if s == 0 else None, need_jvp=False)
+                if reverse and hasattr(dyn, 'vjp'):
+                    v, _ = dyn.vjp(t, x, self._eps[s], trace=trace, frobenius=frob, scale=1.0 / S,
+                                   velocity_squared_norm=vsq if s == 0 else None)
+                else:
+                    v, _ = dyn.jvp(t, x, self._eps[s], trace=trace, frobenius=frob, scale=1.0 / S,
+                                   velocity_squared_norm=vsq if s == 0 else None, need_jvp=False)
                 vel = v if vel is None else vel
         else:
             for k in range(D):                   # one unit tangent per coordinate (the reference: D reverse passes)

@@ -5,7 +5,8 @@ fixed grid of 10 steps = 40 dynamics evaluations), Hutchinson trace.  Prints one
     python tools/measure_cfg5.py [--batch 16384] [--atoms 256] [--steps 10] [--solver rk4] [--evals-only N]
 
 Algorithmic work: per live edge and layer three F x F products for the value and three for the tangent
-= 6 * 2 * F^2 flop (F = 64: 49 152); the node-level products are < 1 % and not counted.  ``--evals-only N`` times N single
+= 6 * 2 * F^2 flop (F = 64: 49 152); with ``--regularization`` the reverse pass runs instead (15 products: the
+Hutchinson-Frobenius estimate needs e^T J itself); the node-level products are < 1 % and not counted.  ``--evals-only N`` times N single
 dynamics + JVP evaluations instead of the whole flow (a quick look at the edge kernel).
 """
 import argparse
@@ -55,7 +56,10 @@ def main():
     d = (pos[:, :, None] - pos[:, None]).norm(dim=-1)
     live = float(((d <= r_cutoff) & (d > 0)).float().sum(dim=(1, 2)).mean())       # live directed edges per sample
     F, L = 64, 4
-    flop_eval = live * L * 6 * 2 * F * F * B                                        # value + tangent, one evaluation
+    # per live edge and layer: forward-mode evaluation = 3 products for the value + 3 for the tangent; with the regulariser
+    # the reverse pass runs instead: 3 (forward, kept) + 2 passes x (3 recomputed + 3 reverse) = 15 products
+    units = 15 if (args.regularization and not args.evals_only) else 6
+    flop_eval = live * L * units * 2 * F * F * B
     res = dict(config=dict(workload=f'cfg5: continuous flow, EGNN dynamics (4 layers, 64 features, 64 radial basis '
                                     f'functions), 3x{n} atoms, batch {B}, {args.solver} with {args.steps} steps, Hutchinson trace',
                            r_cutoff=r_cutoff, live_edges_per_sample=live, all_pairs=n * (n - 1)),
@@ -87,7 +91,11 @@ def main():
                        displacement_rms=float((out[0] - x).pow(2).mean().sqrt()),
                        roofline=dict(bound='mfma', achieved=flop_eval * n_eval / dt / 1e12, peak=PEAK_FP32_MFMA,
                                      unit='TFLOP/s', frac=flop_eval * n_eval / dt / 1e12 / PEAK_FP32_MFMA,
-                                     flops_per_evaluation=flop_eval, kernel='egnn_edge_kernel<4,true> (v_mfma_f32_16x16x4_f32)'))
+                                     flops_per_evaluation=flop_eval, products_per_edge_and_layer=units,
+                                     kernel=('egnn_edge_kernel<4,false,S> + 2 x egnn_edge_bwd_kernel<4,*,S> (reverse pass: e^T J)'
+                                             if units == 15 else 'egnn_edge_kernel<4,true,S> (value + forward-mode tangent)'),
+                                     arithmetic='split-f16 (3 x v_mfma_f32_16x16x32_f16 per fp32 product)'
+                                     if os.environ.get('TFEP_EGNN_SPLIT', '1') != '0' else 'v_mfma_f32_16x16x4_f32'))
     print(json.dumps(res), flush=True)
 
 
