@@ -410,3 +410,21 @@ def test_vjp_matches_reference_reverse_mode(name, split):
         assert torch.equal(dyn.vjp(t, x, eps[0])[1], ej1)
         if B > 2:
             assert torch.equal(dyn.vjp(t, x[1:3].clone(), eps[0, 1:3].clone())[1], ej1[1:3])
+
+
+@pytest.mark.parametrize('solver,options,tol', [('bosh3', None, 5e-3), ('adaptive_heun', None, 5e-3), ('fehlberg2', None, 5e-2),
+                                                ('heun3', {'step_size': 1 / 16}, 1e-4), ('midpoint', {'step_size': 1 / 64}, 1e-4)])
+def test_other_solvers_agree_with_a_fine_rk4_grid(solver, options, tol):
+    from tfep_amd.nn.flows import ContinuousFlow
+    g = gu.load('continuous.npz')
+    dyn, cfg = build_dynamics('tiny', g)
+    x = dev(g['tiny/x'])
+    eps = dev(g['tiny/eps'][:1])
+    ref = ContinuousFlow(dyn, solver='rk4', solver_options={'step_size': 1 / 64}, regularization=False)
+    flow = ContinuousFlow(dyn, solver=solver, solver_options=options, regularization=False)
+    ref.ode_func.fixed_noise = flow.ode_func.fixed_noise = eps
+    with torch.no_grad():
+        y0, t0 = ref(x)
+        y1, t1 = flow(x)
+    assert float((y1 - y0).abs().max()) < tol and float((t1 - t0).abs().max()) < 10 * tol
+    assert flow.last_solver_stats['n_steps'] >= 1

@@ -3,10 +3,12 @@
 
 torchdiffeq is an un-vendored optional dependency of the reference (absent in the build container), so
 nothing here can be compared with reference outputs -- "ODE-solve parity unpinned".  What is implemented are the
-published schemes behind torchdiffeq's method names: the fixed-grid ``euler``, ``midpoint`` and ``rk4`` (torchdiffeq's
-``rk4`` is the 3/8-rule variant) with its ``step_size`` option (equal steps, a shorter last one; ``None`` = one step
-over the interval), and the adaptive Dormand-Prince 5(4) ``dopri5`` with an RMS mixed absolute / relative error norm
-over the whole state, the 0.9 safety factor and growth limits [0.2, 10], Hairer's initial-step heuristic and FSAL.
+published schemes behind torchdiffeq's method names: the fixed-grid ``euler``, ``midpoint``, ``heun3`` and ``rk4``
+(torchdiffeq's ``rk4`` is the 3/8-rule variant) with its ``step_size`` option (equal steps, a shorter last one; ``None`` =
+one step over the interval), and the adaptive embedded pairs ``dopri5`` (Dormand-Prince 5(4)), ``bosh3``
+(Bogacki-Shampine 3(2)), ``fehlberg2`` and ``adaptive_heun`` with an RMS mixed absolute / relative error norm over the
+whole state, the 0.9 safety factor and growth limits [0.2, 10], Hairer's initial-step heuristic and FSAL where the pair
+has it.  (Not implemented: ``dopri8``, the Adams multistep methods, ``scipy_solver``.)
 They are verified by convergence order, step-size control tests and forward / inverse round trips.
 
 The state is a tuple of tensors; ``axpy(x, terms)`` forms ``x + sum a_k v_k`` (``tfep_ode_axpy`` on the HIP path).
@@ -14,22 +16,36 @@ The state is a tuple of tensors; ``axpy(x, terms)`` forms ``x + sum a_k v_k`` (`
 import math
 
 
-FIXED_GRID = ('euler', 'midpoint', 'rk4')
-ADAPTIVE = ('dopri5',)
+FIXED_GRID = ('euler', 'midpoint', 'heun3', 'rk4')
+ADAPTIVE = ('dopri5', 'bosh3', 'fehlberg2', 'adaptive_heun')
 
-# Dormand-Prince 5(4): nodes, stage coefficients, 5th-order weights (= last row: FSAL) and the error weights b5 - b4
-_DP_C = (0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0)
-_DP_A = (
-    (),
-    (1 / 5,),
-    (3 / 40, 9 / 40),
-    (44 / 45, -56 / 15, 32 / 9),
-    (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
-    (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656),
-    (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84),
-)
-_DP_E = (71 / 57600, 0.0, -71 / 16695, 71 / 1920, -17253 / 339200, 22 / 525, -1 / 40)
-
+# Embedded explicit Runge-Kutta pairs as published: (order of the propagated solution, nodes c, stage coefficients a,
+# weights b of the propagated solution, error weights e = b - b_embedded, first-same-as-last).
+_TABLEAUS = {
+    # Dormand & Prince 1980, 5(4), 7 stages, FSAL
+    'dopri5': (5, (0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0),
+               ((), (1 / 5,), (3 / 40, 9 / 40), (44 / 45, -56 / 15, 32 / 9),
+                (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
+                (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656),
+                (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84)),
+               (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0.0),
+               (71 / 57600, 0.0, -71 / 16695, 71 / 1920, -17253 / 339200, 22 / 525, -1 / 40), True),
+    # Bogacki & Shampine 1989, 3(2), 4 stages, FSAL
+    'bosh3': (3, (0.0, 1 / 2, 3 / 4, 1.0),
+              ((), (1 / 2,), (0.0, 3 / 4), (2 / 9, 1 / 3, 4 / 9)),
+              (2 / 9, 1 / 3, 4 / 9, 0.0),
+              (2 / 9 - 7 / 24, 1 / 3 - 1 / 4, 4 / 9 - 1 / 3, -1 / 8), True),
+    # Fehlberg 2(1), 3 stages (the pair torchdiffeq calls fehlberg2)
+    'fehlberg2': (2, (0.0, 1 / 2, 1.0),
+                  ((), (1 / 2,), (1 / 256, 255 / 256)),
+                  (1 / 512, 255 / 256, 1 / 512),
+                  (-1 / 512, 0.0, 1 / 512), False),
+    # Heun's method with the Euler step embedded, 2(1)
+    'adaptive_heun': (2, (0.0, 1.0),
+                      ((), (1.0,)),
+                      (1 / 2, 1 / 2),
+                      (1 / 2 - 1.0, 1 / 2), False),
+}
 
 def _combine(axpy, y, ks, coeffs, dt):
     """``y + dt * sum_j coeffs[j] ks[j]`` for every component of the state."""
@@ -43,6 +59,11 @@ def _fixed_step(f, method, t0, dt, y, axpy):
         k1 = f(t0, y)
         k2 = f(t0 + 0.5 * dt, _combine(axpy, y, [k1], (0.5,), dt))
         return _combine(axpy, y, [k2], (1.0,), dt)
+    if method == 'heun3':                                           # Heun's third-order method
+        k1 = f(t0, y)
+        k2 = f(t0 + dt / 3.0, _combine(axpy, y, [k1], (1 / 3,), dt))
+        k3 = f(t0 + dt * 2.0 / 3.0, _combine(axpy, y, [k2], (2 / 3,), dt))
+        return _combine(axpy, y, [k1, k3], (0.25, 0.75), dt)
     k1 = f(t0, y)                                                   # rk4, 3/8 rule
     k2 = f(t0 + dt / 3.0, _combine(axpy, y, [k1], (1 / 3,), dt))
     k3 = f(t0 + dt * 2.0 / 3.0, _combine(axpy, y, [k1, k2], (-1 / 3, 1.0), dt))
@@ -92,39 +113,43 @@ def odeint(f, y0, t0, t1, method='dopri5', options=None, rtol=1e-4, atol=1e-4, a
             y = _fixed_step(fe, method, a, b - a, y, axpy)
             n_steps += 1
     elif method in ADAPTIVE:
+        order, C, A, Bw, E, fsal = _TABLEAUS[method]
+        n_stages = len(C)
         max_steps = int(options.pop('max_num_steps', 2 ** 31 - 1))
         t = t0
         k1 = fe(t, y)
         h = options.pop('first_step', None)
-        if h is None:                                               # Hairer, Norsett & Wanner II.4, order 4 error estimate
+        if h is None:                                               # Hairer, Norsett & Wanner II.4
             d0, d1 = _rms(_scaled(y, y, None, rtol, atol)), _rms(_scaled(k1, y, None, rtol, atol))
             h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
             y_try = _combine(axpy, y, [k1], (1.0,), sign * h0)
             k_try = fe(t + sign * h0, y_try)
             d2 = _rms(_scaled([b - a for a, b in zip(k1, k_try)], y, None, rtol, atol)) / h0
-            h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / 5.0)
+            h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / order)
             h = min(100.0 * h0, h1)
         h = abs(float(h))
         while (t1 - t) * sign > 1e-12 * max(1.0, abs(t1)):
             if n_steps + n_rej >= max_steps:
-                raise RuntimeError('dopri5: max_num_steps exceeded')
+                raise RuntimeError(f'{method}: max_num_steps exceeded')
             h = min(h, abs(t1 - t))
             dt = sign * h
             ks = [k1]
-            for s in range(1, 7):
-                ks.append(fe(t + _DP_C[s] * dt, _combine(axpy, y, ks, _DP_A[s], dt)))
-            y_new = _combine(axpy, y, ks[:6], _DP_A[6], dt)        # the argument of stage 7 IS the 5th-order solution
-            err = [sum(dt * e * k[c] for e, k in zip(_DP_E, ks) if e != 0.0) for c in range(len(y))]
+            for s_ in range(1, n_stages):
+                ks.append(fe(t + C[s_] * dt, _combine(axpy, y, ks, A[s_], dt)))
+            # (FSAL pairs: the argument of the last stage IS the propagated solution)
+            y_new = _combine(axpy, y, ks, Bw, dt)
+            err = [sum(dt * e * k[c] for e, k in zip(E, ks) if e != 0.0) for c in range(len(y))]
             ratio = _rms(_scaled(err, y, y_new, rtol, atol))
             if ratio <= 1.0:
-                t, y, k1 = t + dt, y_new, ks[6]                     # FSAL
+                t, y = t + dt, y_new
+                k1 = ks[-1] if fsal else fe(t, y)
                 n_steps += 1
             else:
                 n_rej += 1
             if ratio == 0.0:
                 factor = 10.0
             else:
-                factor = min(10.0, max(0.9 * ratio ** -0.2, 1.0 if ratio < 1.0 else 0.2))
+                factor = min(10.0, max(0.9 * ratio ** (-1.0 / order), 1.0 if ratio < 1.0 else 0.2))
             h *= factor
     else:
         raise ValueError(f"solver must be one of {FIXED_GRID + ADAPTIVE} (torchdiffeq's other methods are not implemented)")

@@ -26,8 +26,9 @@ from . import _odeint
 
 class ContinuousFlow(torch.nn.Module):
     """Continuous normalizing flow (Chen et al. 2018; Hutchinson trace as in FFJORD; regularisation as in Finlay et
-    al. 2020).  Arguments as reference continuous.py:29-112; ``solver`` is one of ``euler``, ``midpoint``, ``rk4``
-    (with ``solver_options={'step_size': h}``) or ``dopri5`` (``rtol = atol = 1e-4`` as in the reference)."""
+    al. 2020).  Arguments as reference continuous.py:29-112; ``solver`` is one of the fixed-grid ``euler``, ``midpoint``,
+    ``heun3``, ``rk4`` (with ``solver_options={'step_size': h}``) or the adaptive ``dopri5`` (default), ``bosh3``,
+    ``fehlberg2``, ``adaptive_heun`` (``rtol = atol = 1e-4`` as in the reference)."""
 
     def __init__(
             self,
