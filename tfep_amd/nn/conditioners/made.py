@@ -151,6 +151,8 @@ class MADE(Conditioner):
         #: has been updated in place (``Tensor._version``); default off: re-pack on every forward like the reference's
         #: pre-hook (masked.py:397-398).  SURVEY.md section 8(b) sanctions caches invalidated by parameter version.
         self.cache_packed_weights = False
+        #: Let the choice between split-f16 and exact-fp32 GEMMs also depend on the batch size (see ``split_worthwhile``).
+        self.split_by_batch = os.environ.get('TFEP_SPLIT_BY_BATCH', '0') != '0'
         self._packed_ahead = None      # split weights packed on a side stream for the next forward (prepack_split_async)
 
     # ------------------------------------------------------------------ reference API
@@ -535,13 +537,18 @@ class MADE(Conditioner):
                                              tile_order=plan['tile_order'][li])
         return h, plan
 
-    def split_worthwhile(self):
-        """True when the layers are large enough (>= 4 M weights) for the split-f16 GEMMs to pay for their operand
-        conversions; tiny conditioners are launch bound either way."""
+    def split_worthwhile(self, batch=None):
+        """True when the GEMMs are large enough for the split-f16 kernels to pay for their operand conversions: at
+        least 4 M weights; with ``split_by_batch`` also at least 2^35 weight x row products (a 3 M-weight conditioner at
+        batch 131 072, BASELINE cfg4-ii, is GEMM-bound all the same: 20.2 -> 12.7 ms).  That second rule is opt-in because
+        it makes the ARITHMETIC depend on the batch size: a row pushed through in a small batch would no longer equal, bit
+        for bit, the same row in a large one.  Tiny problems are launch bound either way and keep the exact-fp32 kernel,
+        which needs no conversions."""
         n = self.__dict__.get('_n_weights')
         if n is None:
             n = self.__dict__['_n_weights'] = sum(lin.mask.numel() for lin in self._linears())
-        return n >= (1 << 22)
+        by_batch = self.split_by_batch and batch is not None and n * int(batch) >= (1 << 35)
+        return n >= (1 << 22) or by_batch
 
     def forward_hidden_split(self, x):
         """``forward_hidden`` for the split-f16 GEMMs without fp32 intermediates: every hidden layer writes its
@@ -565,9 +572,9 @@ class MADE(Conditioner):
     def forward(self, x, split=None):
         """Transformer parameters ``(..., n_out)`` (reference made.py:355).  ``split``: run the GEMMs on split-f16
         operands (fp32-equivalent, ``csrc/split_gemm.hip``); None = the ``TFEP_SPLIT_GEMM`` default."""
-        split = (ops.split_gemm_enabled() and self.split_worthwhile()) if split is None else bool(split)
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
+        split = (ops.split_gemm_enabled() and self.split_worthwhile(x2.shape[0])) if split is None else bool(split)
         if split:
             hs, h_inv, plan = self.forward_hidden_split(x2)
         else:

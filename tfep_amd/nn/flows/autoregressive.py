@@ -156,11 +156,11 @@ class AutoregressiveFlow(torch.nn.Module):
                 return _FUSED_SPLINE
         return None
 
-    def prepack_async(self, device, stream):
+    def prepack_async(self, device, stream, batch=None):
         """Start packing this layer's weights on ``stream`` for its next forward pass (called by SequentialFlow while
         the previous layer computes).  Only for the fused split-f16 path; a no-op otherwise."""
         kind = self._fused_kind()
-        if kind is None or not self._use_split_gemm() or not isinstance(self._conditioner, MADE):
+        if kind is None or not self._use_split_gemm(batch) or not isinstance(self._conditioner, MADE):
             return
         # only worth the stream fork / join when the re-pack moves real data (cfg1-sized layers are launch bound)
         if not self._conditioner.split_worthwhile():
@@ -168,14 +168,15 @@ class AutoregressiveFlow(torch.nn.Module):
         fp = self._fused_plan(device, kind, self._tables(device))
         self._conditioner.prepack_split_async(device, stream, last=(fp['row_of_out'], fp['n_rows']))
 
-    def _use_split_gemm(self):
-        """Split-f16 GEMMs for the forward pass: ``self.split_gemm`` if set; else ``TFEP_SPLIT_GEMM`` (default on) for
-        conditioners with at least 4 M weights -- smaller layers are launch bound and the exact-fp32 kernel needs no
-        operand conversions."""
+    def _use_split_gemm(self, batch=None):
+        """Split-f16 GEMMs for the forward pass: ``self.split_gemm`` if set; else ``TFEP_SPLIT_GEMM`` (default on) when
+        the conditioner is large enough for the operand conversions to pay (``MADE.split_worthwhile``: >= 4 M weights, or
+        enough weight x row products at the given batch) -- smaller problems are launch bound and stay on the exact-fp32
+        kernel."""
         if self.split_gemm is not None:
             return bool(self.split_gemm)
         made = self._conditioner
-        return ops.split_gemm_enabled() and isinstance(made, MADE) and made.split_worthwhile()
+        return ops.split_gemm_enabled() and isinstance(made, MADE) and made.split_worthwhile(batch)
 
     def _fused_plan(self, device, kind, tables):
         key = ('fused', str(device), kind)
@@ -225,7 +226,7 @@ class AutoregressiveFlow(torch.nn.Module):
         tables = self._tables(x.device)
         fp = self._fused_plan(x.device, kind, tables)
         made = self._conditioner
-        split = self._use_split_gemm()
+        split = self._use_split_gemm(B)
         if split:
             h, h_inv, mplan = made.forward_hidden_split(x)
             w, w_inv, b, _ = made._pack_layer_split(mplan, fp['li'], made.layers[-1], row_of_out=fp['row_of_out'],
@@ -839,7 +840,7 @@ class AutoregressiveFlow(torch.nn.Module):
         if len(self._conditioner_indices) > 0:
             x = ops.gather_columns(x, self._tables(x.device)['cond'])
         if isinstance(self._conditioner, MADE):
-            return self._conditioner(x, split=self._use_split_gemm())
+            return self._conditioner(x, split=self._use_split_gemm(x.shape[0]))
         return self._conditioner(x)
 
 

@@ -26,7 +26,7 @@ def _run_chain(layers, method, x):
                and os.environ.get('TFEP_OVERLAP_PACK', '1') != '0')
     for i, layer in enumerate(layers):
         if overlap and i + 1 < len(layers) and hasattr(layers[i + 1], 'prepack_async'):
-            layers[i + 1].prepack_async(x.device, _side_stream(x.device))
+            layers[i + 1].prepack_async(x.device, _side_stream(x.device), x.shape[0])
         x, log_det_J = getattr(layer, method)(x)
         total = log_det_J if total is None else total + log_det_J
     if total is None:                                   # no layers: the identity map

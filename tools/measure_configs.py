@@ -41,7 +41,7 @@ def mfma_roofline(flow, B, dt, passes=1.0, note=None):
     ``passes`` (1 = one forward's worth: forward, or the blocked inverse; a training step = forward + recompute +
     grad_input + grad_weight = 4) over the measured time, against the bound of the arithmetic the layers run on."""
     nnz = sum(float(torch.count_nonzero(lin.mask)) for layer in flow for lin in layer._conditioner.layers[::2])
-    split = all(layer._use_split_gemm() for layer in flow)
+    split = all(layer._use_split_gemm(B) for layer in flow)
     peak = PEAK_SPLIT if split else PEAK_F32
     tf = 2.0 * nnz * B * passes / dt / 1e12
     out = dict(bound='mfma', achieved=round(tf, 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(tf / peak, 4),
@@ -184,7 +184,8 @@ if 'cfg4' in which:
                                     embedding=PeriodicEmbedding(D, limits=[0.0, 1.0]), initialize_identity=False)
                                 for i in range(4)])
     x = torch.rand(B, D, device=dev)
-    dt, (y, _) = timeit(lambda: flow(x), 1, 3)
+    with torch.no_grad():
+        dt, (y, _) = timeit(lambda: flow(x), 1, 3)
     report('cfg4-i forward: 4-layer MAF + circular RQ-8 + periodic embedding, 512 torsions', B, dt,
            y_in_domain=bool(((y >= 0) & (y <= 1)).all()), roofline=mfma_roofline(flow, B, dt))
     Bi = 16384
@@ -199,7 +200,8 @@ if 'cfg4' in which:
                                     initialize_identity=False) for i in range(4)])
     ang = torch.rand(B, D, device=dev) * 2 * math.pi
     x = torch.stack([torch.cos(ang), torch.sin(ang)], dim=2).reshape(B, 2 * D)
-    dt, (y, _) = timeit(lambda: flow(x), 1, 3)
+    with torch.no_grad():
+        dt, (y, _) = timeit(lambda: flow(x), 1, 3)
     # generic path: per layer x (4 KB) in, 3 activations / parameter rows of 1024 floats written and re-read, y out
     hbm = B * 4 * 1024 * 4 * (2 + 2 * 3) / dt / 1e9
     report('cfg4-ii forward: 4-layer MAF + Moebius(d=2, unit sphere), 512 torsions as 1024 features', B, dt,
@@ -207,6 +209,14 @@ if 'cfg4' in which:
            roofline=dict(bound='hbm', achieved=round(hbm, 1), peak=8000.0, unit='GB/s', frac=round(hbm / 8000.0, 4),
                          note='unfused path: activations and the (B, P D) parameters round-trip HBM; 3.1 M weights'),
            mfma=mfma_roofline(flow, B, dt))
+    for l in flow:                                   # opt-in: split-f16 GEMMs chosen by weights x batch (MADE.split_by_batch)
+        l._conditioner.split_by_batch = True
+    with torch.no_grad():
+        dt2, _ = timeit(lambda: flow(x), 1, 3)
+    report('cfg4-ii forward with split_by_batch (split-f16 GEMMs for this 3 M-weight conditioner at batch 131072)', B, dt2,
+           mfma=mfma_roofline(flow, B, dt2))
+    for l in flow:
+        l._conditioner.split_by_batch = False
     with torch.no_grad():
         dti, (xi, _) = timeit(lambda: flow.inverse(y[:Bi]), 1, 2)
     report('cfg4-ii inverse (blocked; 4 layers x 512 degrees)', Bi, dti,
