@@ -338,3 +338,55 @@ def test_inverse_under_autograd_fails_loudly_at_backward():
     with torch.no_grad():
         x2, _ = maf.inverse(y)
     assert not x2.requires_grad and torch.equal(x2, x.detach())
+
+
+@pytest.mark.parametrize('order', ['ascending', 'descending', 'random'])
+@pytest.mark.parametrize('periodic', [False, True])
+def test_lookahead_inverse_equals_the_in_order_inverse(order, periodic):
+    """The blocked inverse overlaps the wide GEMMs of block k + 1 (over the hidden units that were complete before block
+    k) with block k's kernel on a side stream; what block k adds follows as one more split-K slab.  Same products, one
+    more term in the association: results within a few ulp of the in-order schedule, for every degree order (a random
+    order keeps its layer-0 GEMM whole: its new input columns are not one range), stable from call to call (no race
+    between the side-stream GEMMs and the block kernel's writes), and a round trip."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.embeddings import PeriodicEmbedding
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    torch.manual_seed(11)
+    D, B = 600, 517
+    deg = generate_degrees(D, order) if order != 'random' else torch.randperm(D)
+    lim = (-4.0, 4.0)
+    emb = PeriodicEmbedding(n_features_in=D, limits=list(lim), periodic_indices=list(range(0, D, 3))) if periodic else None
+    maf = MAF(degrees_in=deg, transformer=NeuralSplineTransformer(torch.full((D,), lim[0]), torch.full((D,), lim[1]), 8),
+              hidden_layers=[1300, 1500], embedding=emb, initialize_identity=False).cuda()
+    x = (torch.rand(B, D, device='cuda') * 2 - 1) * 3.9
+    with torch.no_grad():
+        y, lf = maf(x)
+        plan = maf._blocked_plan(y.device)
+        assert plan['fused'] is not None and len(plan['blocks']) > 2
+        looks = [b['fused']['wide0']['look'] for b in plan['blocks'][1:] if b['fused']['wide0'] is not None]
+        # (the first blocks know too few columns for a split to pay; the embedding keeps periodic and plain columns apart)
+        assert any(looks) or order == 'random' or periodic
+        assert maf.inverse_lookahead
+        x1, l1 = maf.inverse(y)
+        x2, l2 = maf.inverse(y)
+        maf.inverse_lookahead = False
+        x0, l0 = maf.inverse(y)
+    assert torch.equal(x1, x2) and torch.equal(l1, l2)
+    assert float((x1 - x0).abs().max()) < 2e-5 and float((l1 - l0).abs().max()) < 2e-4
+    # (600 sequential degrees of a random-init network amplify rounding in a few rows: the typical row, not the worst)
+    assert float((x1 - x).abs().max(dim=1).values.median()) < 1e-3 and float((l1 + lf).abs().median()) < 1e-2
+
+
+def test_a_tensor_of_another_width_never_reaches_the_kernels():
+    """The kernels index x by the layer's feature tables; the reference fails in its first F.linear (RuntimeError)."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    maf = MAF(degrees_in=generate_degrees(12, 'ascending'), initialize_identity=False).cuda()
+    for bad in (torch.zeros(5, 11, device='cuda'), torch.zeros(5, 16, device='cuda')):
+        with pytest.raises(RuntimeError, match='features'):
+            maf(bad)
+        with pytest.raises(RuntimeError, match='features'):
+            maf.inverse(bad)
+    y, ldj = maf(torch.zeros(5, 12, device='cuda'))
+    assert y.shape == (5, 12) and ldj.shape == (5,)

@@ -23,6 +23,7 @@ from ..embeddings.mafembed import PeriodicEmbedding
 from ..transformers.affine import AffineTransformer
 from ..transformers.moebius import MoebiusTransformer
 from ..transformers.spline import NeuralSplineTransformer
+from .sequential import _side_stream
 
 _FUSED_AFFINE, _FUSED_SPLINE = 0, 1
 
@@ -264,6 +265,7 @@ class AutoregressiveFlow(torch.nn.Module):
         (``flows/_backward.py``); otherwise it is the plain forward.
         """
         ops.check_device_tensor(x, 'x')
+        self._check_features(x, 'x')
         self._sync_conditioner()
         if torch.is_grad_enabled():
             from . import _backward
@@ -276,6 +278,14 @@ class AutoregressiveFlow(torch.nn.Module):
                     return _backward.generic_forward(self, x)          # conditioner by autograd, transformer VJP kernel
                 return _backward.UnsupportedBackward.apply(self, x, *params)
         return self._forward_impl(x)
+
+    def _check_features(self, x, name):
+        """The kernels index ``x`` by the layer's own feature tables: a tensor of another width must never reach them
+        (the reference fails in its first ``F.linear`` with a shape RuntimeError)."""
+        n = self._inverse_masks.shape[1]
+        if x.dim() < 1 or x.shape[-1] != n:
+            raise RuntimeError(f'{type(self).__name__}: {name} has {x.shape[-1] if x.dim() else 0} features, the layer was '
+                               f'built for {n} (degrees_in / dimension_in are those of the flow input, before any embedding)')
 
     def _forward_impl(self, x: torch.Tensor):
         kind = self._fused_kind()
@@ -302,6 +312,7 @@ class AutoregressiveFlow(torch.nn.Module):
         reference; the last pass' log-det is the total.
         """
         ops.check_device_tensor(y, 'y')
+        self._check_features(y, 'y')
         self._sync_conditioner()
         if torch.is_grad_enabled():
             params = [p for p in self.parameters() if p.requires_grad]
@@ -479,17 +490,27 @@ class AutoregressiveFlow(torch.nn.Module):
 
         i32 = dict(device=device, dtype=torch.int32)
         blocks = []
+        kA_prev = None
         for d0 in range(0, max_deg + 1, G):
             d1 = min(d0 + G, max_deg + 1)
             blk = dict(wide=[], steps=[])
             # split point between "old" and "block" inputs of layer l >= 1 / the output layer:
             # old units of layer l-1 have degree <= d0 - 2
             kA = [0] + [(r_hi(l - 1, d0 - 2) // tk) * tk for l in range(1, L + 1)]
+            # look-ahead split of the old range (see _inverse_blocked): [0, kP) was already complete before the PREVIOUS
+            # block ran ('kr_old': its GEMM can overlap that block's kernel), [kP, kA) is what the previous block added
+            # ('kr_new': a short GEMM afterwards)
+            kP = kA if kA_prev is None else kA_prev
+
+            def wide_desc(l, r0, r1):
+                return dict(layer=l, row0=r0, n_rows=r1 - r0, kr=rng(0, kA[l]), kr_old=rng(0, kP[l]),
+                            kr_new=rng(kP[l], kA[l]), has_new=kA[l] > kP[l])
             for l in range(1, L):      # hidden layers fed by hidden layers
                 r0, r1 = r_lo(l, d0 - 1), r_hi(l, d1 - 2)
                 if r1 > r0:
-                    blk['wide'].append(dict(layer=l, row0=r0, n_rows=r1 - r0, kr=rng(0, kA[l])))
-            blk['out_wide'] = dict(row0=base[d0], n_rows=base[d1] - base[d0], kr=rng(0, kA[L]))
+                    blk['wide'].append(wide_desc(l, r0, r1))
+            blk['out_wide'] = wide_desc(L, base[d0], base[d1])
+            kA_prev = kA
             for d in range(d0, d1):
                 e = d - 1
                 hidden = []
@@ -511,7 +532,7 @@ class AutoregressiveFlow(torch.nn.Module):
                 blk['steps'].append(dict(hidden=hidden, out=dict(row0=base[d], n_rows=P * len(sel), kr=rng(kA[L], ke)),
                                          n_d=len(sel), sel_host=sel, cols_host=tr_idx[sel]))
             blk['fused'] = self._fused_block_tables(d0, d1, blk, kA, r_lo, r_hi, base, sels, tr_idx, deg_in, mplan, L, P,
-                                                    rng, up, i32)
+                                                    rng, up, i32, d0_prev=d0 - G if d0 > 0 else None)
             blocks.append(blk)
         narrow = lib.tfep_masked_linear_narrow_tile_n()
         max_rows = max([w['n_rows'] for b_ in blocks for w in b_['wide']] + [b_['out_wide']['n_rows'] for b_ in blocks] +
@@ -542,6 +563,10 @@ class AutoregressiveFlow(torch.nn.Module):
 
     #: Run the per-degree chain of each block in ONE kernel (``tfep_inverse_block``) when the layer qualifies.
     fused_inverse = True
+
+    #: Overlap the wide GEMMs of the next block with the block kernel of the current one (side stream; results are the
+    #: same sums in a different association: one more split-K slab).
+    inverse_lookahead = True
 
     #: The wide output-layer GEMM of every block (40 % of a cfg2 inverse) on split-f16 operands: None = when the forward
     #: uses them (``_use_split_gemm``) and a bound on |x| is known beforehand (see ``_split_inverse_bound``).
@@ -586,7 +611,8 @@ class AutoregressiveFlow(torch.nn.Module):
             return 1 <= tr.dimension <= 8
         return type(tr) is NeuralSplineTransformer and tr.host()['n_bins'] <= 8
 
-    def _fused_block_tables(self, d0, d1, blk, kA, r_lo, r_hi, base, sels, tr_idx, deg_in, mplan, L, P, rng, up, i32):
+    def _fused_block_tables(self, d0, d1, blk, kA, r_lo, r_hi, base, sels, tr_idx, deg_in, mplan, L, P, rng, up, i32,
+                            d0_prev=None):
         """Device tables of ``tfep_inverse_block`` for the block of degrees [d0, d1) (see include/tfep_hip.h)."""
         if not self._fused_inverse_supported(L):
             return None
@@ -601,7 +627,18 @@ class AutoregressiveFlow(torch.nn.Module):
         else:
             kb0, ke0 = 0, 0
         r0, r1 = r_lo(0, d0 - 1), r_hi(0, d1 - 2)
-        wide0 = dict(layer=0, row0=r0, n_rows=r1 - r0, kr=rng(kb0, ke0)) if r1 > r0 else None
+        wide0 = dict(layer=0, row0=r0, n_rows=r1 - r0, kr=rng(kb0, ke0), look=False) if r1 > r0 else None
+        if wide0 is not None and d0_prev is not None:
+            # look-ahead halves of the column range (see _inverse_blocked): 'kr_old' must not touch a column the PREVIOUS
+            # block writes (its GEMM runs while that block does) and what is left must be one short range -- the case
+            # for monotone degree orders; otherwise this block's layer-0 GEMM stays whole, after the previous block
+            prev = torch.nonzero((deg_in >= d0_prev) & (deg_in <= d0 - 1)).flatten()
+            if len(prev) and len(known) > len(prev):
+                lo_p, hi_p = (int(prev.min()) // tk) * tk, min(up(int(prev.max()) + 1), ke0)
+                cands = [(kb0, lo_p, lo_p, ke0), (hi_p, ke0, kb0, hi_p)]        # (old range, new range): prefix / suffix
+                a0, a1, b0, b1 = max(cands, key=lambda c: c[1] - c[0])
+                if a1 - a0 >= 4 * tk and b1 - b0 <= max(8 * tk, (ke0 - kb0) // 4):
+                    wide0.update(look=True, kr_old=rng(a0, a1), kr_new=rng(b0, b1), has_new=b1 > b0)
         c0 = [kA[l + 1] for l in range(L)]
         n_old = [max(0, r_hi(l, d0 - 2) - c0[l]) for l in range(L)]
         cache_need = max([r_hi(l, d1 - 2) - c0[l] for l in range(L)] + [1])
@@ -744,8 +781,15 @@ class AutoregressiveFlow(torch.nn.Module):
                     for wd in b_['wide'] + ([b_['fused']['wide0']] if b_['fused']['wide0'] is not None else []):
                         wz[wd['layer']] = max(wz[wd['layer']], wd['n_rows'])
                     wzout = max(wzout, b_['out_wide']['n_rows'])
-                z = [torch.empty(S, B, ops.round_up(wz[l], 4), **f32) for l in range(L)]
-                zout = torch.empty(S, B, ops.round_up(wzout, 4), **f32)
+                # look-ahead: the long "old" part of block k + 1's wide GEMMs runs on a side stream WHILE block k's kernel
+                # (one wave per 64 samples: half the CUs at batch 8192) runs; what block k added follows as one short
+                # GEMM into an extra slab.  Two sets of slabs, alternating between blocks.
+                look = self.inverse_lookahead and len(bp['blocks']) > 1 and \
+                    os.environ.get('TFEP_INV_LOOKAHEAD', '1') != '0'
+                n_par = 2 if look else 1
+                zs = [[torch.empty(S + 1, B, ops.round_up(wz[l], 4), **f32) for l in range(L)] for _ in range(n_par)]
+                z = zs[0]
+                S_out = S
                 tr = self._transformer
                 kind = {NeuralSplineTransformer: 1, MoebiusTransformer: 2}.get(type(tr), 0)
                 spl = tr.config(dev).desc if kind == 1 else None
@@ -759,10 +803,9 @@ class AutoregressiveFlow(torch.nn.Module):
                 for l in range(L):
                     d.h[l], d.ldh[l] = h[l].data_ptr(), h[l].shape[1]
                     d.z[l], d.ldz[l] = z[l].data_ptr(), z[l].shape[-1]
-                    d.z_slabs[l], d.z_slab_stride[l] = S, B * z[l].shape[-1]
+                    d.z_slab_stride[l] = B * z[l].shape[-1]
                     d.w[l], d.ldw[l] = packs[l][0].data_ptr(), packs[l][0].shape[1]
-                d.zout, d.ldzout, d.log_det_J = zout.data_ptr(), zout.shape[-1], ldj.data_ptr()
-                d.zout_slabs, d.zout_slab_stride = S, B * zout.shape[-1]
+                d.log_det_J = ldj.data_ptr()
                 d.wout, d.ldwout = w_out.data_ptr(), w_out.shape[1]
                 d.cache_len, d.max_feats = fused['cache_len'], fused['max_feats']
                 d.spline = ctypes.cast(ctypes.pointer(spl), ctypes.c_void_p) if spl is not None else None
@@ -773,23 +816,62 @@ class AutoregressiveFlow(torch.nn.Module):
                 sp = self._split_inverse_state(y, bp, mplan, lins, packs, h[L - 1], wzout, y_tr=y_tr)
                 if sp is not None:
                     hs, hs_inv, ws_out, winv_out, S_out = sp
-                    zout = torch.empty(S_out, B, ops.round_up(wzout, 4), **f32)
-                    d.ldzout, d.zout_slabs, d.zout_slab_stride = zout.shape[-1], S_out, B * zout.shape[-1]
-            for blk in bp['blocks']:
+                zouts = [torch.empty(S_out + 1, B, ops.round_up(wzout, 4), **f32) for _ in range(n_par)]
+                d.ldzout, d.zout_slab_stride = zouts[0].shape[-1], B * zouts[0].shape[-1]
+
+                def wide_gemms(blk, par, part):
+                    """The wide GEMMs of a block over the old hidden units into the slabs of parity ``par``:
+                    ``part`` 'kr' = the whole old range, 'kr_old' / 'kr_new' = its look-ahead halves."""
+                    new_part = part == 'kr_new'
+                    w0 = blk['fused']['wide0']
+                    for wd in blk['wide'] + ([w0] if w0 is not None and (part == 'kr' or w0['look']) else []) + \
+                            [blk['out_wide']]:
+                        if new_part and not wd['has_new']:
+                            continue
+                        l = wd['layer']
+                        desc = dict(wd, kr=wd[part])
+                        if l < L:
+                            out, ks = (zs[par][l][S], 1) if new_part else (zs[par][l], S)
+                            launch(h[l - 1] if l > 0 else xpad, packs[l][0], None if new_part else packs[l][1], desc, out, 0,
+                                   act=0, k_split=ks)
+                        elif hs is not None and not new_part:
+                            out, ks = (zouts[par][S_out], 1) if new_part else (zouts[par], S_out)
+                            launch(hs, ws_out, None if new_part else b_out, desc, out, 0, act=0, k_split=ks,
+                                   split=(hs_inv, winv_out))
+                        else:
+                            out, ks = (zouts[par][S_out], 1) if new_part else (zouts[par], S_out)
+                            launch(h[L - 1], w_out, None if new_part else b_out, desc, out, 0, act=0,
+                                   wide=wd['n_rows'] > 4 * narrow, k_split=ks)
+
+                if look:
+                    main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+                    wide_gemms(bp['blocks'][0], 0, 'kr_old')
+                    old_done = None
+            for i_blk, blk in enumerate(bp['blocks']):
                 # ---- contribution of all earlier degrees to the whole block, once
                 ow = blk['out_wide']
                 if fused is not None:
                     # ---- the block's own degrees: wide GEMMs into compact slabs, then one kernel, one thread per sample
                     fb = blk['fused']
-                    for wd in blk['wide'] + ([fb['wide0']] if fb['wide0'] is not None else []):
-                        l = wd['layer']
-                        launch(h[l - 1] if l > 0 else xpad, packs[l][0], packs[l][1], wd, z[l], 0, act=0, k_split=S)
-                        d.z[l] = z[l].data_ptr() - 4 * wd['row0']       # the kernel indexes by packed row
-                    if hs is not None:
-                        launch(hs, ws_out, b_out, ow, zout, 0, act=0, k_split=S_out, split=(hs_inv, winv_out))
+                    par = i_blk & 1 if look else 0
+                    z, zout = zs[par], zouts[par]
+                    if look:
+                        if old_done is not None:
+                            main.wait_event(old_done)
+                        wide_gemms(blk, par, 'kr_new')
                     else:
-                        launch(h[L - 1], w_out, b_out, ow, zout, 0, act=0, wide=ow['n_rows'] > 4 * narrow, k_split=S)
-                    d.zout = zout.data_ptr() - 4 * ow['row0']
+                        wide_gemms(blk, par, 'kr')
+                    w0 = fb['wide0']                           # layer 0: every feature of an earlier block
+                    if w0 is not None and look and (i_blk == 0 or not w0['look']):
+                        launch(xpad, packs[0][0], packs[0][1], w0, z[0], 0, act=0, k_split=S)      # whole, no look-ahead
+                    extra = {wd['layer']: int(look and wd['has_new']) for wd in blk['wide'] + [ow]}
+                    if w0 is not None:
+                        extra[0] = int(look and i_blk > 0 and w0['look'] and w0['has_new'])
+                    for wd in blk['wide'] + ([w0] if w0 is not None else []):
+                        d.z[wd['layer']] = z[wd['layer']].data_ptr() - 4 * wd['row0']   # the kernel indexes by packed row
+                    for l in range(L):
+                        d.z_slabs[l] = S + extra.get(l, 0)
+                    d.zout, d.zout_slabs = zout.data_ptr() - 4 * ow['row0'], S_out + extra[L]
                 else:
                     for wd in blk['wide']:
                         l = wd['layer']
@@ -801,7 +883,21 @@ class AutoregressiveFlow(torch.nn.Module):
                     d.feat_in, d.feat_periodic, d.in_cols = fb['feat_in'].data_ptr(), fb['feat_per'].data_ptr(), fb['in_cols'].data_ptr()
                     for l in range(L):
                         d.cache_col0[l], d.cache_n_old[l] = fb['c0'][l], fb['n_old'][l]
+                    if look:
+                        # everything up to block i_blk - 1 is complete here.  The event is recorded right before the block
+                        # kernel so that the kernel (all of a CU's LDS per workgroup) is dispatched first and the
+                        # look-ahead GEMMs fill the CUs it leaves free, not the other way round.
+                        ready = torch.cuda.Event()
+                        ready.record(main)
                     _lib.call('tfep_inverse_block', ctypes.byref(d), stream)
+                    if look:
+                        old_done = None
+                        if i_blk + 1 < len(bp['blocks']):
+                            with torch.cuda.stream(side):
+                                side.wait_event(ready)
+                                wide_gemms(bp['blocks'][i_blk + 1], 1 - par, 'kr_old')
+                                old_done = torch.cuda.Event()
+                                old_done.record(side)
                     if hs is not None:                      # the block's new units of the last hidden layer, as split rows
                         lo, hi = fb['unit_range'][L - 1]
                         if hi > lo:
