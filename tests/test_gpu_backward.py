@@ -386,3 +386,67 @@ def test_backward_in_several_batch_chunks_equals_one_chunk(monkeypatch, split, e
         scale = float(a.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, n
         assert torch.equal(b, b2), n
+
+
+@pytest.mark.parametrize('split', [False, True])
+@pytest.mark.parametrize('kind', ['spline', 'affine', 'fixed+periodic'])
+def test_activation_saving_forward_equals_the_recomputing_one(monkeypatch, split, kind):
+    """A training forward keeps the hidden activations and transformer parameters for its backward when they fit
+    ``_SAVE_BYTES`` (un-fused kernels on the backward's weight packing); otherwise the backward recomputes them.  Same
+    kernels on the same operands either way: y / log|det J| agree with the fused forward to rounding and so does
+    every gradient; the packed weights are shared between the two passes and re-made after an optimiser step."""
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.embeddings import PeriodicEmbedding
+    from tfep_amd.nn.flows import MAF, _backward as bw
+    from tfep_amd.nn.transformers import AffineTransformer, NeuralSplineTransformer
+    torch.manual_seed(5)
+    D, B = 66, 700
+    if kind == 'affine':
+        deg, emb, tr = generate_degrees(D, 'descending'), None, AffineTransformer()
+    elif kind == 'spline':
+        deg, emb = generate_degrees(D, 'ascending'), None
+        tr = NeuralSplineTransformer(torch.full((D,), -4.0), torch.full((D,), 4.0), 8)
+    else:
+        fixed = [3, 17, 40]
+        deg = generate_degrees(D, 'ascending', conditioning_indices=fixed)
+        emb = PeriodicEmbedding(D, limits=[-4.0, 4.0], periodic_indices=list(range(1, D, 4)))
+        tr = NeuralSplineTransformer(torch.full((D - 3,), -4.0), torch.full((D - 3,), 4.0), 6)
+    maf = MAF(deg, transformer=tr, embedding=emb, hidden_layers=[140, 170], initialize_identity=False).cuda()
+    maf.split_gemm = split
+    x0 = (torch.randn(B, D) * 1.3).clamp(-3.9, 3.9).cuda()
+    c = torch.linspace(0.1, 0.4, D, device='cuda')
+
+    def step():
+        for p in maf.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        y, l = maf(x)
+        BoltzmannKLDivLoss()((c * y ** 2).sum(dim=1), l).backward()
+        return y.detach(), l.detach(), [x.grad.clone()] + [p.grad.clone() for p in maf.parameters()]
+
+    assert bw.saves_activations(maf, x0)
+    ys, ls, gs = step()
+    assert ('bwd_weights', str(x0.device)) in maf._dev
+    monkeypatch.setattr(bw, '_SAVE_BYTES', 0)
+    assert not bw.saves_activations(maf, x0)
+    yr, lr, gr = step()
+    monkeypatch.undo()
+    names = ['x'] + [n for n, _ in maf.named_parameters()]
+    assert float((ys - yr).abs().max()) < 2e-5 and float((ls - lr).abs().max()) < 2e-4
+    for n, a, b in zip(names, gs, gr):
+        # (the loss gradient starts from y: the fused and un-fused forwards agree to rounding, bit for bit on the
+        # exact-fp32 kernels)
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-8, n
+        assert torch.equal(a, b) or split, n
+    # an in-place parameter update invalidates the shared weight packing
+    with torch.no_grad():
+        for p in maf.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    y2, l2, g2 = step()
+    monkeypatch.setattr(bw, '_SAVE_BYTES', 0)
+    maf._dev.pop(('bwd_weights', str(x0.device)), None)
+    y3, l3, g3 = step()
+    for n, a, b in zip(names, g2, g3):
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-8, n
+    assert float((g2[1] - gs[1]).abs().max()) > 1e-3 * float(gs[1].abs().max())

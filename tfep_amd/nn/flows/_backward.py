@@ -35,6 +35,13 @@ from ..transformers.spline import NeuralSplineTransformer
 # output-layer weight and longer k in the grad_weight GEMMs; 2 -> 8 GiB: 348 -> 315 ms per cfg2 layer at B=16384)
 _CHUNK_BYTES = int(float(os.environ.get('TFEP_BACKWARD_CHUNK_GIB', 8)) * (1 << 30))
 
+# A training forward KEEPS the hidden activations and the transformer parameters of the layer for its backward when the
+# parameters take at most this many bytes (TFEP_SAVE_ACTIVATIONS_GIB, default 24; 0 = always recompute).  4.9 GB per cfg2
+# layer at B = 16 384 against 288 GB of HBM: storing them costs ~1 ms of writes, recomputing them costs the two largest
+# GEMMs of the layer a second time (52 of 303 ms).  The forward then runs the un-fused kernels (GEMM -> parameters in HBM
+# -> transformer kernel) on the backward's weight packing, which is shared between the two passes.
+_SAVE_BYTES = int(float(os.environ.get('TFEP_SAVE_ACTIVATIONS_GIB', 24)) * (1 << 30))
+
 
 def supported(layer):
     made = layer._conditioner
@@ -87,17 +94,7 @@ def transformer_vjp(tr, x, theta, th_off, ld_theta, gy, gl, gtheta, gx, stream, 
     # `order`: the features are given in this permutation (slot order), so per-feature constants follow it.
     lay = _lib.ParamLayout(*layout) if layout is not None else _lib.ParamLayout(ld_theta, D, 1)
     if type(tr) is NeuralSplineTransformer:
-        cfg = tr.config(dev)
-        if order is not None:
-            key = ('slot_cfg', str(dev))
-            if tr.__dict__.get('_slot_cfg_key') != (key, id(order)):
-                h = tr.host()
-                o = order.long()
-                tr.__dict__['_slot_cfg'] = ops.SplineConfig(cfg.x0[o], cfg.xf[o], cfg.y0[o], cfg.yf[o], h['n_bins'],
-                                                            h['circular'], h['identity'], h['learn_lower'],
-                                                            h['learn_upper'], h['min_bin'], h['min_slope'])
-                tr.__dict__['_slot_cfg_key'] = (key, id(order))
-            cfg = tr.__dict__['_slot_cfg']
+        cfg = _slot_config(tr, dev, order)
         _lib.call('tfep_spline_backward', _lib.ptr(x), D, th, lay, ctypes.byref(cfg.desc), _lib.ptr(gy), D,
                   _lib.ptr(gl), gth, lay, _lib.ptr(gx), D, B, D, stream)
     elif type(tr) is AffineTransformer:
@@ -110,6 +107,38 @@ def transformer_vjp(tr, x, theta, th_off, ld_theta, gy, gl, gtheta, gx, stream, 
     else:   # volume-preserving shift: y = x + b (wrap is piecewise identity), log-det = 0
         _lib.call('tfep_copy_2d', _lib.ptr(gy), D, gth, ld_theta, B, D, stream)
         _lib.call('tfep_copy_2d', _lib.ptr(gy), D, _lib.ptr(gx), D, B, D, stream)
+
+
+def _slot_config(tr, dev, order):
+    """Spline constants of ``tr`` in the feature permutation ``order`` (cached on the transformer)."""
+    cfg = tr.config(dev)
+    if order is None:
+        return cfg
+    key = ('slot_cfg', str(dev))
+    if tr.__dict__.get('_slot_cfg_key') != (key, id(order)):
+        h = tr.host()
+        o = order.long()
+        tr.__dict__['_slot_cfg'] = ops.SplineConfig(cfg.x0[o], cfg.xf[o], cfg.y0[o], cfg.yf[o], h['n_bins'],
+                                                    h['circular'], h['identity'], h['learn_lower'],
+                                                    h['learn_upper'], h['min_bin'], h['min_slope'])
+        tr.__dict__['_slot_cfg_key'] = (key, id(order))
+    return tr.__dict__['_slot_cfg']
+
+
+def transformer_forward(tr, x, theta, layout, order, stream):
+    """``(y, log_det_J)`` of an affine / spline transformer on parameters stored as ``layout`` says, features of ``x``
+    in the permutation ``order`` (the counterpart of ``transformer_vjp`` for the activation-saving forward)."""
+    B, D = x.shape
+    y = torch.empty(B, D, dtype=torch.float32, device=x.device)
+    ldj = torch.empty(B, dtype=torch.float32, device=x.device)
+    lay = _lib.ParamLayout(*layout)
+    if type(tr) is NeuralSplineTransformer:
+        cfg = _slot_config(tr, x.device, order)
+        _lib.call('tfep_spline_forward', _lib.ptr(x), D, _lib.ptr(theta), lay, ctypes.byref(cfg.desc), _lib.ptr(y), D,
+                  _lib.ptr(ldj), 0, B, D, stream)
+    else:
+        _lib.call('tfep_affine_forward', _lib.ptr(x), D, _lib.ptr(theta), lay, _lib.ptr(y), D, _lib.ptr(ldj), 0, B, D, stream)
+    return y, ldj
 
 
 def trainable_tensors(layer):
@@ -127,8 +156,12 @@ def trainable_tensors(layer):
 class MAFLayerFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, layer, x, *params):
+        ctx.saved_activations = None
         with torch.no_grad():
-            y, ldj = layer._forward_impl(x)
+            if saves_activations(layer, x):
+                y, ldj, ctx.saved_activations = forward_saving(layer, x)
+            else:
+                y, ldj = layer._forward_impl(x)
         ctx.layer = layer
         ctx.save_for_backward(x)
         return y, ldj
@@ -138,7 +171,7 @@ class MAFLayerFunction(torch.autograd.Function):
         layer = ctx.layer
         (x,) = ctx.saved_tensors
         with torch.no_grad():
-            gx, gparams = layer_backward(layer, x, gy, gldj)
+            gx, gparams = layer_backward(layer, x, gy, gldj, saved=ctx.saved_activations)
         return (None, gx, *gparams)
 
 
@@ -315,8 +348,121 @@ def _backward_plan(layer, device):
     return bp
 
 
-def layer_backward(layer, x, gy, gldj):
-    """Returns (gx, [grads in trainable_tensors() order])."""
+def _dims(layer, dev):
+    made = layer._conditioner
+    mplan = made.plan(dev)
+    lins = made._linears()
+    L = len(lins) - 1
+    tm, tn, tk = ops.tile_sizes()
+    n_out = lins[-1].out_features
+    n_out_pad = ops.round_up(n_out, tk)
+    n_pad = [mplan['n_pad'][l] for l in range(L)] + [n_out_pad]
+    return mplan, lins, L, n_out, n_out_pad, n_pad, list(mplan['k_pad'])
+
+
+def _weights(layer, dev):
+    """Packed (degree sorted, padded) weights of every layer, their transposes, and the split-f16 versions of both, in
+    the backward's row order.  Kept on the layer until a parameter or mask changes (``Tensor._version``): the
+    activation-saving forward and the backward of the same step share one preparation."""
+    made = layer._conditioner
+    mplan, lins, L, n_out, n_out_pad, n_pad, k_pad = _dims(layer, dev)
+    bplan = _backward_plan(layer, dev)
+    split = layer._use_split_gemm()
+    key = ('bwd_weights', str(dev))
+    versions = (made._param_versions(), split)
+    capturing = torch.cuda.is_current_stream_capturing()
+    cached = layer._dev.get(key)
+    if cached is not None and cached['versions'] == versions and not capturing:
+        return cached
+    f32 = dict(dtype=torch.float32, device=dev)
+    W, WT, bias = [], [], []
+    for l, lin in enumerate(lins):
+        if l == L and bplan['sorted_out']:
+            w, b = made._pack_layer(mplan, l, lin, row_of_out=bplan['row_of_out'], n_rows=n_pad[l])
+        else:
+            w, b = made._pack_layer(mplan, l, lin, n_rows=n_pad[l])
+        W.append(w)
+        bias.append(b)
+        wt = torch.zeros(k_pad[l], n_pad[l], **f32)
+        WT.append(_transpose(w, n_pad[l], k_pad[l], wt))
+    # Split-f16 operands for every GEMM of the step (the same fp32-equivalent kernel as the forward pass): the packed
+    # weights and their transposes are converted once, activations / gradients per use.
+    Ws = [ops.split_rows(w, w.shape[1], per_tensor=True) for w in W] if split else [None] * (L + 1)
+    WTs = [ops.split_rows(w, w.shape[1], per_tensor=True) for w in WT] if split else [None] * (L + 1)
+    if split:
+        WT = [None] * (L + 1)        # (W itself lives in the conditioner's pack buffers either way)
+    wts = dict(versions=versions, split=split, W=W, WT=WT, bias=bias, Ws=Ws, WTs=WTs)
+    if _SAVE_BYTES > 0 and not capturing:
+        layer._dev[key] = wts
+    return wts
+
+
+def _conditioner_forward(layer, wts, cin, Bc):
+    """Hidden activations (``h[0]`` = the zero-padded conditioner input) and transformer parameters, backward row order."""
+    dev = cin.device
+    mplan, lins, L, n_out, n_out_pad, n_pad, k_pad = _dims(layer, dev)
+    bplan = _backward_plan(layer, dev)
+    f32 = dict(dtype=torch.float32, device=dev)
+    split = wts['split']
+    h = [ops.pad_columns(cin, k_pad[0])]
+    for l in range(L):
+        h.append(_gemm(h[-1], wts['W'][l], torch.empty(Bc, n_pad[l], **f32), Bc, n_pad[l], n_pad[l], bias=wts['bias'][l],
+                       k_ranges=mplan['k_ranges'][l], act=1, split=split, w_split=wts['Ws'][l]))
+    theta = torch.empty(Bc, n_out_pad, **f32)
+    _gemm(h[-1], wts['W'][L], theta, Bc, n_out_pad, n_pad[L], bias=wts['bias'][L], k_ranges=bplan['k_ranges'][L],
+          split=split, w_split=wts['Ws'][L])
+    return h, theta
+
+
+def saves_activations(layer, x):
+    """Whether the training forward of ``layer`` keeps its activations for the backward (see ``_SAVE_BYTES``)."""
+    return x.dim() == 2 and saves_activations_at(layer, x.shape[0])
+
+
+def saves_activations_at(layer, batch):
+    if _SAVE_BYTES <= 0 or not supported(layer) or torch.cuda.is_current_stream_capturing():
+        return False
+    if type(layer._transformer) not in (AffineTransformer, NeuralSplineTransformer):
+        return False
+    emb = getattr(layer._conditioner, 'embedding', None)
+    if emb is not None and type(emb) is not PeriodicEmbedding:
+        return False
+    n_out = layer._conditioner._linears()[-1].out_features
+    return 0 < int(batch) * n_out * 4 <= _SAVE_BYTES
+
+
+def forward_saving(layer, x):
+    """``(y, log_det_J, saved)`` of the layer by the un-fused kernels on the backward's weight packing; ``saved`` holds
+    the hidden activations and the transformer parameters for ``layer_backward``."""
+    x, _ = _lib.rows(x, 'x')
+    dev = x.device
+    B, D = x.shape
+    made = layer._conditioner
+    emb = getattr(made, 'embedding', None)
+    tables = layer._tables(dev)
+    bplan = _backward_plan(layer, dev)
+    mplan, lins, L, n_out, n_out_pad, n_pad, k_pad = _dims(layer, dev)
+    n_tr = tables['n_tr']
+    P = n_out // n_tr
+    wts = _weights(layer, dev)
+    cin = emb(x) if emb is not None else x
+    h, theta = _conditioner_forward(layer, wts, cin, B)
+    x_tr = ops.gather_columns(x, tables['tr']) if layer.has_fixed_indices else x
+    xs = ops.gather_columns(x_tr, bplan['order'])
+    ys, ldj = transformer_forward(layer._transformer, xs, theta, (n_out_pad, 1, P), bplan['order'], _lib.stream_of(x))
+    if layer.has_fixed_indices:
+        y_tr = torch.empty(B, n_tr, dtype=torch.float32, device=dev)
+        ops.scatter_columns(ys, bplan['order'], y_tr)
+        y = x.clone()
+        ops.scatter_columns(y_tr, tables['tr'], y)
+    else:
+        y = torch.empty(B, D, dtype=torch.float32, device=dev)
+        ops.scatter_columns(ys, bplan['order'], y)
+    return y, ldj, dict(h=h, theta=theta)
+
+
+def layer_backward(layer, x, gy, gldj, saved=None):
+    """Returns (gx, [grads in trainable_tensors() order]).  ``saved``: activations kept by ``forward_saving``."""
     if not supported(layer):
         raise NotImplementedError(
             'tfep_amd: backward needs a transformer with a VJP kernel (affine / neural-spline / Moebius / '
@@ -331,37 +477,18 @@ def layer_backward(layer, x, gy, gldj):
     emb = getattr(made, 'embedding', None)
     tr = layer._transformer
     tables = layer._tables(dev)
-    mplan = made.plan(dev)
     bplan = _backward_plan(layer, dev)
-    lins = made._linears()
-    L = len(lins) - 1
+    mplan, lins, L, n_out, n_out_pad, n_pad, k_pad = _dims(layer, dev)
     tm, tn, tk = ops.tile_sizes()
     f32 = dict(dtype=torch.float32, device=dev)
     n_tr = tables['n_tr']
-    n_out = lins[-1].out_features
-    n_out_pad = ops.round_up(n_out, tk)
     P = n_out // n_tr
     stream = _lib.stream_of(x)
 
-    # ---- weights: packed (degree sorted, padded) and their transposes, once per backward
-    n_pad = [mplan['n_pad'][l] for l in range(L)] + [n_out_pad]
-    k_pad = list(mplan['k_pad'])
-    W, WT, bias = [], [], []
+    # ---- weights: packed (degree sorted, padded) and their transposes (shared with forward_saving of the same step)
+    wts = _weights(layer, dev)
+    W, WT, bias, Ws, WTs, split = wts['W'], wts['WT'], wts['bias'], wts['Ws'], wts['WTs'], wts['split']
     sorted_out = bplan['sorted_out']
-    for l, lin in enumerate(lins):
-        if l == L and sorted_out:
-            w, b = made._pack_layer(mplan, l, lin, row_of_out=bplan['row_of_out'], n_rows=n_pad[l])
-        else:
-            w, b = made._pack_layer(mplan, l, lin, n_rows=n_pad[l])
-        W.append(w)
-        bias.append(b)
-        wt = torch.zeros(k_pad[l], n_pad[l], **f32)
-        WT.append(_transpose(w, n_pad[l], k_pad[l], wt))
-    # Split-f16 operands for every GEMM of the step (the same fp32-equivalent kernel as the forward pass): the packed
-    # weights and their transposes are converted once per backward, activations / gradients per use.
-    split = layer._use_split_gemm()
-    Ws = [ops.split_rows(w, w.shape[1], per_tensor=True) for w in W] if split else [None] * (L + 1)
-    WTs = [ops.split_rows(w, w.shape[1], per_tensor=True) for w in WT] if split else [None] * (L + 1)
     gW = [torch.zeros(n_pad[l], k_pad[l], **f32) for l in range(L + 1)]
     gb = [torch.zeros(n_pad[l], **f32) for l in range(L + 1)]
     gx = torch.empty(B, D, **f32)
@@ -385,14 +512,11 @@ def layer_backward(layer, x, gy, gldj):
                 cin_graph = emb(x_emb)
             cin = cin_graph.detach()
         else:
-            cin = emb(xc) if emb is not None else xc
-        h = [ops.pad_columns(cin, k_pad[0])]
-        for l in range(L):
-            h.append(_gemm(h[-1], W[l], torch.empty(Bc, n_pad[l], **f32), Bc, n_pad[l], n_pad[l], bias=bias[l],
-                           k_ranges=mplan['k_ranges'][l], act=1, split=split, w_split=Ws[l]))
-        theta = torch.empty(Bc, n_out_pad, **f32)
-        _gemm(h[-1], W[L], theta, Bc, n_out_pad, n_pad[L], bias=bias[L], k_ranges=bplan['k_ranges'][L],
-              split=split, w_split=Ws[L])
+            cin = emb(xc) if emb is not None and saved is None else xc
+        if saved is not None:                                  # kept by the forward of this step
+            h, theta = [t[b0:b1] for t in saved['h']], saved['theta'][b0:b1]
+        else:
+            h, theta = _conditioner_forward(layer, wts, cin, Bc)
 
         # ---- transformer VJP: gtheta (reference parameter layout, zero padded columns), direct gx
         if layer.has_fixed_indices:

@@ -166,6 +166,10 @@ class AutoregressiveFlow(torch.nn.Module):
         # only worth the stream fork / join when the re-pack moves real data (cfg1-sized layers are launch bound)
         if not self._conditioner.split_worthwhile():
             return
+        if torch.is_grad_enabled() and batch is not None and any(p.requires_grad for p in self._conditioner.parameters()):
+            from . import _backward
+            if _backward.saves_activations_at(self, batch):
+                return                              # a training forward that keeps its activations packs the backward's way
         fp = self._fused_plan(device, kind, self._tables(device))
         self._conditioner.prepack_split_async(device, stream, last=(fp['row_of_out'], fp['n_rows']))
 

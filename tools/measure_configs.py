@@ -174,7 +174,8 @@ if 'train' in which:
     report('cfg2 ONE layer forward (no grad)', B, dtf, roofline=mfma_roofline(flow, B, dtf))
     report('cfg2 ONE layer training step (forward + backward of all parameters)', B, dt, loss=float(loss),
            peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
-           roofline=mfma_roofline(flow, B, dt, passes=4.0, note='forward + recompute + grad_input + grad_weight'))
+           roofline=mfma_roofline(flow, B, dt, passes=3.0, note='forward + grad_input + grad_weight (the forward keeps its '
+                                                                'activations: no recompute; TFEP_SAVE_ACTIVATIONS_GIB)'))
 
 if 'cfg4' in which:
     D, B = 512, 131072
