@@ -501,7 +501,7 @@ class MADE(Conditioner):
 
     def _param_versions(self):
         """In-place update counters of every tensor the packed weights depend on."""
-        return tuple(t._version for lin in self._linears() for t in (*lin.parameters(), lin.mask))
+        return tuple((t._version, t.data_ptr()) for lin in self._linears() for t in (*lin.parameters(), lin.mask))
 
     def drop_packed_ahead(self):
         self._packed_ahead = None
