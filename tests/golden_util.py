@@ -313,6 +313,26 @@ def build_wrapped(cfg, inner, flows_module):
 
 
 # ---------------------------------------------------------------------------
+# golden PCA-whitened flows (tools/gen_golden.py:gen_pca)
+# ---------------------------------------------------------------------------
+
+def pca_configs():
+    return {
+        'pca_affine': dict(D=9, n_data=400, batch=64, spline=False, order='ascending', blacken=True, seed=7100),
+        'pca_spline_white': dict(D=12, n_data=600, batch=80, spline=True, order='descending', blacken=False, seed=7101),
+    }
+
+
+def pca_data(cfg):
+    """The (n_data, D) float32 samples the whitening is estimated from: correlated Gaussian, means of order 1."""
+    import torch
+    g = torch.Generator().manual_seed(cfg['seed'])
+    D = cfg['D']
+    a = torch.randn(D, D, generator=g) / D ** 0.5 + 0.6 * torch.eye(D)
+    return torch.randn(cfg['n_data'], D, generator=g) @ a.t() + 2.0 * torch.rand(D, generator=g)
+
+
+# ---------------------------------------------------------------------------
 # golden embeddings (tools/gen_golden.py:gen_embeddings)
 # ---------------------------------------------------------------------------
 

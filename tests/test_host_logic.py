@@ -211,3 +211,29 @@ def test_custom_torch_ops_are_registered():
         assert 'Tensor' in str(op.default._schema), name
     s = str(torch.ops.tfep.spline_forward.default._schema)
     assert 'n_bins' in s and 'circular' in s and '-> (Tensor, Tensor)' in s
+
+
+def test_pca_whitened_flow_statistics_on_the_host():
+    """PCAWhitenedFlow estimates its matrices at construction with torch (reference pca.py:52-76): W^T cov W = 1,
+    B = W^-1, log-det = -sum(log singular values); a CPU tensor fails loudly instead of taking a CPU path."""
+    import golden_util as gu
+    from tfep_amd.nn.flows import PCAWhitenedFlow
+
+    class Inner(torch.nn.Module):
+        def forward(self, x):
+            return x, torch.zeros(len(x))
+
+        def n_parameters(self):
+            return 3
+    data = gu.pca_data(dict(D=7, n_data=300, seed=2)).double()
+    flow = PCAWhitenedFlow(Inner(), data, blacken=False)
+    assert list(flow.state_dict()) == ['mean', 'whitening_matrix', 'blackening_matrix', 'whitening_log_det_J']
+    xc = data - data.mean(0)
+    cov = xc.t() @ xc / (len(data) - 1)
+    w, b = flow.whitening_matrix, flow.blackening_matrix
+    assert torch.allclose(w.t() @ cov @ w, torch.eye(7, dtype=torch.float64), atol=1e-9)
+    assert torch.allclose(w @ b, torch.eye(7, dtype=torch.float64), atol=1e-9)
+    assert abs(float(flow.whitening_log_det_J) + 0.5 * float(torch.logdet(cov))) < 1e-9
+    assert flow.n_parameters() == 3
+    with pytest.raises(Exception):
+        flow(data.float())

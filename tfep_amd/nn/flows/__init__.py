@@ -5,3 +5,4 @@ from .partial import PartialFlow  # noqa: F401
 from .centroid import CenteredCentroidFlow  # noqa: F401
 from .oriented import OrientedFlow  # noqa: F401
 from .continuous import ContinuousFlow  # noqa: F401
+from .pca import PCAWhitenedFlow  # noqa: F401

@@ -1095,6 +1095,42 @@ def gen_continuous():
     np.savez_compressed(os.path.join(OUT, 'continuous.npz'), **out)
 
 
+# -----------------------------------------------------------------------------
+# 13. PCAWhitenedFlow around a MAF (reference flows/pca.py): forward / inverse, blackened or not, gradients
+# -----------------------------------------------------------------------------
+
+def gen_pca():
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT)))
+    import golden_util as gu
+    from tfep.nn.flows.pca import PCAWhitenedFlow
+    out = {}
+    for i, (name, cfg) in enumerate(gu.pca_configs().items()):
+        D = cfg['D']
+        data = gu.pca_data(cfg)                                   # correlated, off-centre samples the PCA is estimated from
+        x = data[:cfg['batch']].clone()
+
+        def make(dt, cfg=cfg, D=D):
+            if cfg['spline']:
+                tr = NeuralSplineTransformer(x0=torch.full((D,), -9.0), xf=torch.full((D,), 9.0), n_bins=5)
+            else:
+                tr = AffineTransformer()
+            inner = MAF(degrees_in=generate_degrees(D, order=cfg['order']), transformer=tr, initialize_identity=False)
+            return PCAWhitenedFlow(inner, data.to(dt), blacken=cfg['blacken'])
+        run_flow(make, x, 900 + i, out, name, inverse=True)
+        with f64():
+            m = make(torch.float64)
+            m.load_state_dict(to_double_sd({k[len(name) + 4:]: torch.from_numpy(v) for k, v in out.items()
+                                            if k.startswith(name + '/sd/')}), strict=False)
+            xg = x.double().requires_grad_(True)
+            y, ldj = m(xg)
+            c = torch.cos(torch.arange(y.shape[0]).unsqueeze(1) + 2.0 * torch.arange(y.shape[1]).unsqueeze(0))
+            ((y * c).sum() + ldj.sum()).backward()
+            out[f'{name}/gx_f64'] = npy(xg.grad)
+            for k, prm in m.named_parameters():
+                out[f'{name}/gp/{k}'] = npy(prm.grad)
+    np.savez_compressed(os.path.join(OUT, 'pca.npz'), **out)
+
+
 if __name__ == '__main__':
     torch.set_num_threads(4)
     if len(sys.argv) > 1:
@@ -1113,5 +1149,6 @@ if __name__ == '__main__':
     gen_bootstrap()
     gen_logger()
     gen_continuous()
+    gen_pca()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
