@@ -367,7 +367,8 @@ def test_lookahead_inverse_equals_the_in_order_inverse(order, periodic):
         looks = [b['fused']['wide0']['look'] for b in plan['blocks'][1:] if b['fused']['wide0'] is not None]
         # (the first blocks know too few columns for a split to pay; the embedding keeps periodic and plain columns apart)
         assert any(looks) or order == 'random' or periodic
-        assert maf.inverse_lookahead
+        assert maf.inverse_lookahead is None                     # default: by batch and layer size; forced here
+        maf.inverse_lookahead = True
         x1, l1 = maf.inverse(y)
         x2, l2 = maf.inverse(y)
         maf.inverse_lookahead = False

@@ -569,8 +569,8 @@ class AutoregressiveFlow(torch.nn.Module):
     fused_inverse = True
 
     #: Overlap the wide GEMMs of the next block with the block kernel of the current one (side stream; results are the
-    #: same sums in a different association: one more split-K slab).
-    inverse_lookahead = True
+    #: same sums in a different association: one more split-K slab).  None: when it pays (see ``_inverse_blocked``).
+    inverse_lookahead = None
 
     #: The wide output-layer GEMM of every block (40 % of a cfg2 inverse) on split-f16 operands: None = when the forward
     #: uses them (``_use_split_gemm``) and a bound on |x| is known beforehand (see ``_split_inverse_bound``).
@@ -788,8 +788,16 @@ class AutoregressiveFlow(torch.nn.Module):
                 # look-ahead: the long "old" part of block k + 1's wide GEMMs runs on a side stream WHILE block k's kernel
                 # (one wave per 64 samples: half the CUs at batch 8192) runs; what block k added follows as one short
                 # GEMM into an extra slab.  Two sets of slabs, alternating between blocks.
-                look = self.inverse_lookahead and len(bp['blocks']) > 1 and \
-                    os.environ.get('TFEP_INV_LOOKAHEAD', '1') != '0'
+                look = self.inverse_lookahead
+                if os.environ.get('TFEP_INV_LOOKAHEAD') is not None:
+                    look = os.environ['TFEP_INV_LOOKAHEAD'] != '0'
+                if look is None:
+                    # pays when the block kernel leaves CUs free (one wave per 64 samples, one workgroup per CU) and the
+                    # GEMMs are long enough to be worth two event round trips per block: cfg2 layer at B = 8192
+                    # 150 -> 138 ms, neutral at B = 16 384 (all 256 CUs taken); cfg1 (launch bound) +7 %, cfg4-i at
+                    # B = 16 384 +11 % with it -- those stay in order
+                    look = (B + 63) // 64 <= 160 and max(mplan['k_pad']) >= 4096
+                look = bool(look) and len(bp['blocks']) > 1
                 n_par = 2 if look else 1
                 zs = [[torch.empty(S + 1, B, ops.round_up(wz[l], 4), **f32) for l in range(L)] for _ in range(n_par)]
                 z = zs[0]
