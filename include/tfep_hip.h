@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFEP_HIP_ABI_VERSION 5
+#define TFEP_HIP_ABI_VERSION 6
 
 typedef enum tfep_status {
     TFEP_OK = 0,
@@ -378,11 +378,14 @@ typedef struct tfep_inverse_block_desc {
     const tfep_spline_desc* spline;
     int32_t moebius_dim, moebius_unit_sphere;
     float moebius_max_radius;
+    int32_t rows_per_wave;      /* 64 (or 0): one sample row per lane; 16: four lanes per row, 4x the waves (for batches
+                                   that leave SIMDs idle: the chain is bound by one wave's instruction issue rate) */
 } tfep_inverse_block_desc;
 int tfep_inverse_block_step_ints(void);
 /* LDS bytes a launch with these sizes needs (activation cache + input entries + the weight stage); a block fits iff
- * this is <= 160 KiB.  -1 for invalid arguments. */
+ * this is <= 160 KiB.  -1 for invalid arguments.  (_rows: for the given rows_per_wave; the plain form is 64.) */
 int64_t tfep_inverse_block_lds_bytes(int n_layers, int cache_len, int max_feats);
+int64_t tfep_inverse_block_lds_bytes_rows(int n_layers, int cache_len, int max_feats, int rows_per_wave);
 int tfep_inverse_block(const tfep_inverse_block_desc* desc, void* stream);
 
 /* ------------------------------------------------------------------------- */

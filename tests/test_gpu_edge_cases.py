@@ -391,3 +391,49 @@ def test_a_tensor_of_another_width_never_reaches_the_kernels():
             maf.inverse(bad)
     y, ldj = maf(torch.zeros(5, 12, device='cuda'))
     assert y.shape == (5, 12) and ldj.shape == (5,)
+
+
+@pytest.mark.parametrize('kind', ['spline', 'affine', 'moebius', 'spline+periodic+fixed'])
+def test_block_kernel_row_layouts_agree(kind):
+    """``tfep_inverse_block`` with one sample row per lane (rows_per_wave 64) and with 16 rows per wave (every dot on
+    16 x 16 MFMA tiles, four lanes per row in the transformer inverse): the same inverse to rounding, for a batch that is
+    not a multiple of 16 (dead rows store nothing), each reproducible from call to call."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.embeddings import PeriodicEmbedding
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import AffineTransformer, MoebiusTransformer, NeuralSplineTransformer
+    torch.manual_seed(21)
+    D, B = 96, 203
+    emb, deg = None, generate_degrees(D, 'ascending')
+    if kind == 'affine':
+        tr = AffineTransformer()
+    elif kind == 'moebius':
+        deg = generate_degrees(D, 'descending', repeats=3)
+        tr = MoebiusTransformer(dimension=3)
+    elif kind == 'spline':
+        tr = NeuralSplineTransformer(torch.full((D,), -4.0), torch.full((D,), 4.0), 8)
+    else:
+        deg = generate_degrees(D, 'ascending', conditioning_indices=[5, 50])
+        emb = PeriodicEmbedding(D, limits=[-4.0, 4.0], periodic_indices=list(range(2, D, 5)))
+        tr = NeuralSplineTransformer(torch.full((D - 2,), -4.0), torch.full((D - 2,), 4.0), 5, circular=False,
+                                     identity_boundary_slopes=True)
+    maf = MAF(deg, transformer=tr, embedding=emb, hidden_layers=[260, 300], initialize_identity=False).cuda()
+    x = (torch.rand(B, D, device='cuda') * 2 - 1) * 3.5
+    out = {}
+    with torch.no_grad():
+        y, lf = maf(x)
+        assert maf._blocked_plan(y.device)['fused'] is not None
+        for rows in (16, 64):
+            maf.inverse_rows_per_wave = rows
+            out[rows] = maf.inverse(y)
+            again = maf.inverse(y)
+            assert torch.equal(out[rows][0], again[0]) and torch.equal(out[rows][1], again[1])
+    assert float((out[16][0] - out[64][0]).abs().max()) < 5e-5 and float((out[16][1] - out[64][1]).abs().max()) < 5e-4
+    assert float((out[16][0] - x).abs().max(dim=1).values.median()) < 1e-3
+    # the entry point rejects any other layout
+    from tfep_amd import _lib
+    d = _lib.InverseBlockDesc()
+    d.B, d.n_steps, d.n_layers, d.rows_per_wave = 4, 1, 1, 32
+    assert _lib.load().tfep_inverse_block(ctypes.byref(d), None) != 0
+    assert _lib.load().tfep_inverse_block_lds_bytes_rows(2, 100, 16, 32) == -1
+    assert 0 < _lib.load().tfep_inverse_block_lds_bytes_rows(2, 100, 16, 16) < _lib.load().tfep_inverse_block_lds_bytes_rows(2, 100, 16, 64)

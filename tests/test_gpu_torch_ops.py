@@ -149,3 +149,16 @@ def test_modules_dispatch_through_torch_ops_and_trace_under_fake_tensors():
     # CPU tensors never reach a kernel: no CPU implementation is registered
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.tfep.affine_forward(torch.zeros(2, 2), torch.zeros(2, 4))
+
+
+def test_masked_linear_op_rejects_mismatched_shapes():
+    """F.linear raises on these; without the checks a narrower input would be zero padded up to the tile size."""
+    import tfep_amd.torch_ops  # noqa: F401
+    w = torch.randn(5, 6, device='cuda')
+    x = torch.randn(3, 6, device='cuda')
+    ok = torch.ops.tfep.masked_linear(x, w, None, None, None)
+    assert torch.allclose(ok, x @ w.t(), atol=1e-5)
+    for args in ((x[:, :5].contiguous(), w, None, None, None), (x, w, torch.zeros(4, device='cuda'), None, None),
+                 (x, w, None, torch.ones(5, 5, device='cuda'), None), (x, w, None, None, torch.ones(4, 1, device='cuda'))):
+        with pytest.raises(RuntimeError, match='masked_linear'):
+            torch.ops.tfep.masked_linear(*args)

@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TFEP_HIP_LIB') or os.path.join(_HERE, 'lib', 'libtfep_hip.so')
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 
@@ -49,7 +49,8 @@ class InverseBlockDesc(Structure):
                 ('emb_lower', c_float), ('emb_upper', c_float),
                 ('cache_col0', c_int32 * 4), ('cache_n_old', c_int32 * 4),
                 ('cache_len', c_int32), ('max_feats', c_int32), ('spline', c_void_p),
-                ('moebius_dim', c_int32), ('moebius_unit_sphere', c_int32), ('moebius_max_radius', c_float)]
+                ('moebius_dim', c_int32), ('moebius_unit_sphere', c_int32), ('moebius_max_radius', c_float),
+                ('rows_per_wave', c_int32)]
 
 
 class SplineDesc(Structure):
@@ -140,6 +141,7 @@ _SIGNATURES = {
     'tfep_diag_split_cycles': (c_int, [_P]),
     'tfep_inverse_block_step_ints': (c_int, []),
     'tfep_inverse_block_lds_bytes': (c_int64, [c_int, c_int, c_int]),
+    'tfep_inverse_block_lds_bytes_rows': (c_int64, [c_int, c_int, c_int, c_int]),
     'tfep_inverse_block': (c_int, [POINTER(InverseBlockDesc), _P]),
     'tfep_diag_mfma_peak': (c_int, [_P, c_int, c_int, _P]),
     'tfep_masked_linear_gemm': (c_int, [POINTER(GemmDesc), _P]),

@@ -474,6 +474,312 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
     if (live) a.ldj[row] = (float)((double)a.ldj[row] + ldj_acc);
 }
 
+
+// =====================================================================================================================
+// Sixteen sample rows per wave ("q4": four lanes per row in the per-row phases).
+//
+// The one-row-per-lane kernel above is bound by the instruction issue rate of its single wave per workgroup, and at the
+// batch sizes the inverse usually runs at (B / 64 workgroups <= 256 CUs) three SIMDs of every CU it touches -- and at
+// B = 8192 half the CUs -- sit idle.  Here the same chain runs on 4x as many waves of 16 rows each:
+//   every dot product runs on the matrix cores as 16 x 16 tiles of v_mfma_f32_16x16x4_f32 (exact fp32), D^T[unit or
+//     parameter][row] with A = the staged weights, B = the [unit][16 rows] activation cache, C = the staged
+//     pre-activations: hidden units are finished (ELU, stores) straight from the accumulator layout (hidden_mfma16),
+//     the <= 32 parameters of a feature / Moebius vector are handed to the rows' lanes through LDS (out_dot_mfma16);
+//   the pre-activation stage loads 16 rows instead of 64 per wave; the weight stage is the same cooperative fetch;
+//   the transformer inverse of a row is evaluated by its four lanes (lane = 4 row + part) redundantly -- identical
+//     instructions and results; lane part 0 stores.
+// Per wave the dot products and the pre-activation loads shrink, weight staging and the transformer inverse do not: the
+// total instruction count over all waves is higher than the one-row-per-lane kernel's, so this layout is for batches
+// that leave SIMDs idle (host: rows_per_wave = 16 up to 16 384 rows).  Sums associate differently from the kernel above
+// (MFMA accumulation order), i.e. the last bits of an inverse depend on which layout the batch size selects.
+// =====================================================================================================================
+constexpr int Q4_ROWS = 16;
+constexpr int Q4_Z_PITCH = 24;       // floats per value of the pre-activation stage: 8 values x 8 rows per store instruction, conflict free
+constexpr int Q4_P_PITCH = 20;       // floats per parameter of the MFMA hand-over [IB_MAX_P parameters][16 rows + 4]
+
+// columns per 8-row group of the weight stage: + 4 puts consecutive groups 32 banks apart -- a 16 x 4 operand fragment (two
+// groups x four columns x eight rows) then touches every bank once
+__host__ __device__ inline int ib_stage_cols_q4(int cache_len, int max_feats) {
+    return ib_round8(cache_len > max_feats ? cache_len : max_feats) + 4;
+}
+__host__ __device__ inline size_t ib_lds_floats_q4(int L, int cache_len, int max_feats) {
+    return ((size_t)L * ib_round4(cache_len) + ib_round4(max_feats)) * Q4_ROWS + (size_t)IB_STAGE_ROWS * ib_stage_cols_q4(cache_len, max_feats) +
+           IB_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH + (size_t)IB_MAX_P * Q4_P_PITCH;
+}
+
+// zs[v * Q4_Z_PITCH + i] = sum_s z[s * slab_stride + (wave_row0 + i) * ldz + base + v * vstride],  v < nv <= 32, i < 16
+__device__ __forceinline__ void stage_z16(float* __restrict__ zs, const float* __restrict__ z, int64_t ldz, int wave_row0, int n_rows_total,
+                                          int base, int vstride, int nv, int slabs, int64_t slab_stride, int lane) {
+    const int vq = lane & 7, rq = lane >> 3;
+    float val[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { val[q][0] = 0.f; val[q][1] = 0.f; }
+    for (int sl = 0; sl < slabs; ++sl) {
+        float t[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q * 8 < nv) {
+                const int v = min(q * 8 + vq, nv - 1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = min(wave_row0 + rq + 8 * i, n_rows_total - 1);      // dead rows shadow the last one
+                    t[q][i] = z[sl * slab_stride + (int64_t)row * ldz + base + v * vstride];
+                }
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q * 8 < nv) { val[q][0] += t[q][0]; val[q][1] += t[q][1]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int v = q * 8 + vq;
+        if (v < nv) {
+            zs[v * Q4_Z_PITCH + rq] = val[q][0];                     // bank = 24 vq + rq (+8): conflict free
+            zs[v * Q4_Z_PITCH + rq + 8] = val[q][1];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// nu <= 16 hidden units (stage rows ug .. ug + nu) for the wave's 16 sample rows on the matrix cores:
+//   D[unit][row] = z[unit][row] + sum_k W[unit][k] act[k][row]   as one 16 x 16 tile of v_mfma_f32_16x16x4_f32 per 4 columns
+// (A: lane l = stage row ug + l % 16, column k + l / 16;  B: activation k + l / 16 of sample row l % 16;  D: register r of
+// lane l = unit 4 (l / 16) + r, sample row l % 16), then ELU and the stores straight from the accumulator layout.  Against
+// packed FMAs on quarter dots: 2 LDS dwords per lane and 4 columns instead of 36 bytes, a third of the instructions --
+// with four of these waves per CU the LDS pipe, not the issue rate, was the limit of the FMA form.
+__device__ __forceinline__ void hidden_mfma16(const float* __restrict__ stg, int gstride, int ug, const float* __restrict__ zs,
+                                              const float* __restrict__ act, int len, int nu, float* __restrict__ cl_u0,
+                                              float* __restrict__ h_u0, bool live16, int lane) {
+    const int col = lane & 15, kq = lane >> 4;
+    ib_f4 d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = 4 * kq + r < nu ? zs[(ug + 4 * kq + r) * Q4_Z_PITCH + col] : 0.f;
+    const int srow = ug + col;
+    const float* wp = stg + (srow >> 3) * gstride + kq * 8 + (srow & 7);         // element (stage row ug + col, column k + kq)
+    const float* ap = act + kq * Q4_ROWS + col;
+    const bool on = col < nu;                                                    // rows past nu: not staged (stale LDS)
+    float w[2], b[2];
+    auto load = [&](int k) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            w[q] = on ? wp[(k + 4 * q) * 8] : 0.f;
+            b[q] = ap[(k + 4 * q) * Q4_ROWS];
+        }
+    };
+    load(0);
+    for (int k = 0; k < len; k += 8) {                                   // len is a multiple of 8
+        float wc[2], bc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { wc[q] = w[q]; bc[q] = b[q]; }
+        load(k + 8);                                    // (one slice past the end on the last pass: inside the LDS slack)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[q], bc[q], d, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int u = 4 * kq + r;
+        if (u < nu) {
+            const float hv = elu_ib(d[r]);
+            cl_u0[u * Q4_ROWS + col] = hv;
+            if (live16) h_u0[u] = hv;
+        }
+    }
+}
+
+// prm[m] (m < P <= 32) of this lane's row:  z[m][row] + sum_k W[m][k] act[k][row]  as two 16 x 16 tiles of
+// v_mfma_f32_16x16x4_f32 (A: lane l = row l % 16 of the tile, column k + l / 16;  B: activation k + l / 16 of sample row
+// l % 16;  D: register r of lane l = parameter 4 (l / 16) + r, sample row l % 16), then through LDS to the rows' lanes.
+__device__ __forceinline__ void out_dot_mfma16(float (&prm)[IB_MAX_P], const float* __restrict__ stg, int gstride,
+                                               const float* __restrict__ zso, const float* __restrict__ act, float* __restrict__ pb,
+                                               int len, int P, int lane) {
+    const int col = lane & 15, kq = lane >> 4;
+    ib_f4 d0, d1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = 4 * kq + r;
+        d0[r] = m < P ? zso[m * Q4_Z_PITCH + col] : 0.f;                  // rows past P: never staged (stale LDS), keep them zero
+        d1[r] = 16 + m < P ? zso[(16 + m) * Q4_Z_PITCH + col] : 0.f;
+    }
+    const float* w0 = stg + (col >> 3) * gstride + kq * 8 + (col & 7);           // element (row col, column k + kq)
+    const float* w1 = stg + ((16 + col) >> 3) * gstride + kq * 8 + (col & 7);    // element (row 16 + col, column k + kq)
+    const float* ap = act + kq * Q4_ROWS + col;
+    const bool on0 = col < P, on1 = 16 + col < P;
+    const bool two = P > 16;                                            // wave-uniform
+    float a0[2], a1[2], b[2];
+    auto load = [&](int k) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            a0[q] = on0 ? w0[(k + 4 * q) * 8] : 0.f;
+            a1[q] = on1 ? w1[(k + 4 * q) * 8] : 0.f;
+            b[q] = ap[(k + 4 * q) * Q4_ROWS];
+        }
+    };
+    load(0);
+    for (int k = 0; k < len; k += 8) {                                   // len is a multiple of 8: two k-groups of 4 per pass
+        float a0c[2], a1c[2], bc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { a0c[q] = a0[q]; a1c[q] = a1[q]; bc[q] = b[q]; }
+        load(k + 8);                                    // (one slice past the end on the last pass: inside the LDS slack)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0c[q], bc[q], d0, 0, 0, 0);
+            if (two) d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1c[q], bc[q], d1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        pb[(4 * kq + r) * Q4_P_PITCH + col] = d0[r];                     // bank = 16 kq + 20 r + col: conflict free
+        pb[(16 + 4 * kq + r) * Q4_P_PITCH + col] = d1[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int s = lane >> 2;
+#pragma unroll
+    for (int m = 0; m < IB_MAX_P; ++m) prm[m] = m < P ? pb[m * Q4_P_PITCH + s] : 0.f;
+    __builtin_amdgcn_wave_barrier();                                     // (the next feature overwrites pb)
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(64) inverse_block_q4_kernel(InverseBlockArgs a) {
+    extern __shared__ float cache[];              // [L][cache_len][16] hidden activations, then [max_feats][16] x values
+    const int lane = threadIdx.x;
+    const int s = lane >> 2, part = lane & 3;
+    const int wave_row0 = blockIdx.x * Q4_ROWS;
+    const int row = wave_row0 + s;
+    const bool live = row < a.B;
+    const bool writer = live && part == 0;
+    const int64_t r = live ? row : 0;             // dead lanes shadow row 0 and store nothing
+    const bool live16 = wave_row0 + (lane & 15) < a.B;
+    const int64_t r16 = live16 ? wave_row0 + (lane & 15) : 0;
+    float* xc = cache + (size_t)a.L * a.cache_len * Q4_ROWS;
+    float* stg = xc + (size_t)a.max_feats * Q4_ROWS;
+    const int gstride = a.stage_gstride;
+    float* zs = stg + (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* pb = zs + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
+
+    for (int j = lane * 4; j < a.lds_floats; j += 256) *(ib_f4_alias*)(cache + j) = ib_f4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_wave_barrier();
+    for (int l = 0; l < a.L; ++l) {
+        const float* hr = a.h[l] + r * a.ldh[l] + a.c0[l];
+        float* cl = cache + (size_t)l * a.cache_len * Q4_ROWS;
+        for (int j = part; j < a.n_old[l]; j += 4) cl[j * Q4_ROWS + s] = hr[j];
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    double ldj_acc = 0.0;
+    for (int st_i = 0; st_i < a.n_steps; ++st_i) {
+        const int32_t* st = a.steps + st_i * IB_STEP_INTS;
+        // ---- hidden units of this degree, layer by layer
+        for (int l = 0; l < a.L; ++l) {
+            const int row0 = st[4 * l], n = st[4 * l + 1], kb = st[4 * l + 2], ke = st[4 * l + 3];
+            float* cl = cache + (size_t)l * a.cache_len * Q4_ROWS;
+            float* h16 = a.h[l] + r16 * a.ldh[l];                    // the matrix-core phases: lane = sample row lane % 16
+            const float* act = l == 0 ? xc : cache + ((size_t)(l - 1) * a.cache_len + (kb - a.c0[l - 1])) * Q4_ROWS;
+            const int len = ib_round8(l == 0 ? ke : ke - kb);
+            for (int ub = row0; ub < row0 + n; ub += IB_STAGE_ROWS) {
+                const int nb = min(IB_STAGE_ROWS, row0 + n - ub);
+                if (l == 0) stage_gather(stg, gstride, a.w[0], a.ldw[0], ub, nb, a.in_cols, ke, lane);
+                else stage_rows(stg, gstride, a.w[l], a.ldw[l], ub, 1, nb, kb, ke, lane);
+                stage_z16(zs, a.z[l], a.ldz[l], wave_row0, a.B, ub, 1, nb, a.z_slabs[l], a.z_slab_stride[l], lane);
+                for (int u0 = ub; u0 < ub + nb; u0 += 16)
+                    hidden_mfma16(stg, gstride, u0 - ub, zs, act, len, min(16, ub + nb - u0), cl + (size_t)(u0 - a.c0[l]) * Q4_ROWS,
+                                  h16 + u0, live16, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        // ---- parameters and transformer inverse of this degree's features
+        const int out_row0 = st[4 * IB_MAX_LAYERS], n_d = st[4 * IB_MAX_LAYERS + 1];
+        const int okb = st[4 * IB_MAX_LAYERS + 2], oke = st[4 * IB_MAX_LAYERS + 3], foff = st[4 * IB_MAX_LAYERS + 4];
+        const float* cp = cache + ((size_t)(a.L - 1) * a.cache_len + (okb - a.c0[a.L - 1])) * Q4_ROWS;
+        const int olen = ib_round8(oke - okb);
+        auto emit = [&](int fi, float xv) {
+            const int col = a.feat_cols[fi], e0 = a.feat_in[fi], icol = a.in_cols[e0];
+            float in0 = xv, in1 = 0.f;
+            const bool per = a.feat_per[fi] != 0;
+            if (per) sincosf((xv - a.emb_lower) * a.emb_scale, &in1, &in0);
+            xc[e0 * Q4_ROWS + s] = in0;                                          // (the same value from the four lanes of the row)
+            if (per) xc[(e0 + 1) * Q4_ROWS + s] = in1;
+            if (writer) {
+                a.x[r * a.ldx + col] = xv;
+                a.xpad[r * a.ldxpad + icol] = in0;
+                if (per) a.xpad[r * a.ldxpad + icol + 1] = in1;
+            }
+        };
+        if constexpr (KIND == 2) {
+            const int dim = a.mb_dim;
+            for (int f = 0; f < n_d; f += dim) {
+                stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, 1, dim, okb, oke, lane);
+                stage_z16(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, 1, dim, a.zout_slabs, a.zout_slab_stride, lane);
+                float acc[IB_MAX_P];
+                out_dot_mfma16(acc, stg, gstride, zs, cp, pb, olen, dim, lane);
+                double yv[MOEBIUS_MAX_DIM], wv[MOEBIUS_MAX_DIM], xv[MOEBIUS_MAX_DIM];
+#pragma unroll
+                for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+                    if (i < dim) {
+                        yv[i] = (double)a.y[r * a.ldy + a.feat_sel[foff + f + i]];
+                        wv[i] = (double)(-acc[i]);
+                    }
+                ldj_acc += moebius_vector(yv, wv, dim, a.mb_max_radius, a.mb_unit_sphere, xv);
+#pragma unroll
+                for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+                    if (i < dim) emit(foff + f + i, (float)xv[i]);
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+        for (int f = 0; f < n_d; ++f) {
+            float prm[IB_MAX_P];
+            stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, n_d, a.P, okb, oke, lane);   // the feature's P rows at once
+            stage_z16(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, n_d, a.P, a.zout_slabs, a.zout_slab_stride, lane);
+            out_dot_mfma16(prm, stg, gstride, zs, cp, pb, olen, a.P, lane);
+            const int sel = a.feat_sel[foff + f];
+            const float yv = a.y[r * a.ldy + sel];
+            float xv;
+            if constexpr (KIND == 0) {                                  // affine.py:361-363
+                xv = (yv - prm[0]) * expf(-prm[1]);
+                ldj_acc -= (double)prm[1];
+            } else {
+                const SplineFlags& fl = a.sp.f;
+                const int K = fl.K;
+                float w[8], hh[8], sraw[9];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    w[k] = k < K ? prm[k] : 0.f;
+                    hh[k] = k < K ? prm[K + k] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j <= 8; ++j) {
+                    sraw[j] = 0.f;
+                    if (j <= K) {
+                        const int pi = spline_slope_param(j, K, fl.circular, fl.identity);
+                        if (pi >= 0) sraw[j] = prm[pi];
+                    }
+                }
+                float last = 0.f, last2 = 0.f;
+                if (fl.circular || fl.learn_lower || fl.learn_upper) last = prm[a.P - 1];
+                if (fl.learn_lower && fl.learn_upper) last2 = prm[a.P - 2];
+                double ld;
+                xv = (float)rq_spline_element<8, true>(w, hh, sraw, last, last2, fl, a.sp.x0[sel], a.sp.xf[sel],
+                                                       a.sp.y0[sel], a.sp.yf[sel], yv, &ld);
+                ldj_acc -= ld;
+            }
+            const int col = a.feat_cols[foff + f];
+            const int e0 = a.feat_in[foff + f], icol = a.in_cols[e0];
+            float in0 = xv, in1 = 0.f;
+            const bool per = a.feat_per[foff + f] != 0;
+            if (per) sincosf((xv - a.emb_lower) * a.emb_scale, &in1, &in0);
+            xc[e0 * Q4_ROWS + s] = in0;
+            if (per) xc[(e0 + 1) * Q4_ROWS + s] = in1;
+            if (writer) {
+                a.x[r * a.ldx + col] = xv;
+                a.xpad[r * a.ldxpad + icol] = in0;
+                if (per) a.xpad[r * a.ldxpad + icol + 1] = in1;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        }
+    }
+    if (writer) a.ldj[row] = (float)((double)a.ldj[row] + ldj_acc);
+}
+
 }  // namespace tfep
 
 using namespace tfep;
@@ -485,6 +791,12 @@ int tfep_inverse_block_step_ints(void) { return IB_STEP_INTS; }
 int64_t tfep_inverse_block_lds_bytes(int n_layers, int cache_len, int max_feats) {
     if (n_layers < 1 || cache_len < 0 || max_feats < 0) return -1;
     return (int64_t)(ib_lds_floats(n_layers, cache_len, max_feats) * sizeof(float));
+}
+
+int64_t tfep_inverse_block_lds_bytes_rows(int n_layers, int cache_len, int max_feats, int rows_per_wave) {
+    if (n_layers < 1 || cache_len < 0 || max_feats < 0 || (rows_per_wave != 16 && rows_per_wave != 64)) return -1;
+    return (int64_t)((rows_per_wave == 16 ? ib_lds_floats_q4(n_layers, cache_len, max_feats)
+                                          : ib_lds_floats(n_layers, cache_len, max_feats)) * sizeof(float));
 }
 
 int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
@@ -533,19 +845,26 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
         a.P = 2;
     }
     TFEP_REQUIRE(a.P <= IB_MAX_P, "inverse_block: too many parameters per feature");
-    const size_t lds = ib_lds_floats(d->n_layers, d->cache_len, d->max_feats) * sizeof(float);
+    TFEP_REQUIRE(d->rows_per_wave == 0 || d->rows_per_wave == 16 || d->rows_per_wave == 64,
+                 "inverse_block: rows_per_wave must be 64 (or 0: one sample row per lane) or 16 (four lanes per row)");
+    const bool q4 = d->rows_per_wave == 16;
+    const size_t lds = (q4 ? ib_lds_floats_q4(d->n_layers, d->cache_len, d->max_feats)
+                           : ib_lds_floats(d->n_layers, d->cache_len, d->max_feats)) * sizeof(float);
     a.lds_floats = (int)(lds / sizeof(float));
     TFEP_REQUIRE(lds <= 160 * 1024, "inverse_block: block needs %zu bytes of LDS (> 160 KiB)", lds);
-    static size_t lds_attr_on[3][TFEP_MAX_DEVICES] = {};       // per kernel and device: a process may drive several GPUs
-    size_t& lds_attr = lds_attr_on[d->kind][current_device_slot()];
-    void (*kernel)(InverseBlockArgs) = d->kind == 0 ? inverse_block_kernel<0> : d->kind == 1 ? inverse_block_kernel<1>
-                                                                                             : inverse_block_kernel<2>;
+    static size_t lds_attr_on[6][TFEP_MAX_DEVICES] = {};       // per kernel and device: a process may drive several GPUs
+    size_t& lds_attr = lds_attr_on[d->kind + (q4 ? 3 : 0)][current_device_slot()];
+    void (*kernel)(InverseBlockArgs) =
+        q4 ? (d->kind == 0 ? inverse_block_q4_kernel<0> : d->kind == 1 ? inverse_block_q4_kernel<1> : inverse_block_q4_kernel<2>)
+           : (d->kind == 0 ? inverse_block_kernel<0> : d->kind == 1 ? inverse_block_kernel<1> : inverse_block_kernel<2>);
+    const int rows = q4 ? Q4_ROWS : 64;
+    if (q4) a.stage_gstride = 8 * ib_stage_cols_q4(d->cache_len, d->max_feats);
     if (lds > lds_attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));
         lds_attr = lds;
     }
-    kernel<<<(unsigned)((d->B + 63) / 64), 64, lds, (hipStream_t)stream>>>(a);
+    kernel<<<(unsigned)((d->B + rows - 1) / rows), 64, lds, (hipStream_t)stream>>>(a);
     return check_launch("inverse_block_kernel");
 }
 

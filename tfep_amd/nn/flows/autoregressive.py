@@ -568,6 +568,9 @@ class AutoregressiveFlow(torch.nn.Module):
     #: Run the per-degree chain of each block in ONE kernel (``tfep_inverse_block``) when the layer qualifies.
     fused_inverse = True
 
+    #: Sample rows per wave of the block kernel: 64 (one per lane) or 16 (four lanes per row); None: by batch size.
+    inverse_rows_per_wave = None
+
     #: Overlap the wide GEMMs of the next block with the block kernel of the current one (side stream; results are the
     #: same sums in a different association: one more split-K slab).  None: when it pays (see ``_inverse_blocked``).
     inverse_lookahead = None
@@ -820,6 +823,18 @@ class AutoregressiveFlow(torch.nn.Module):
                 d.log_det_J = ldj.data_ptr()
                 d.wout, d.ldwout = w_out.data_ptr(), w_out.shape[1]
                 d.cache_len, d.max_feats = fused['cache_len'], fused['max_feats']
+                # four lanes per sample row (4x the waves) while the batch leaves SIMDs idle: B / 64 one-row-per-lane
+                # waves fill at most a quarter of the 1024 SIMDs up to 16 384 rows (see csrc/inverse_block.hip)
+                rows = self.inverse_rows_per_wave
+                if os.environ.get('TFEP_INV_ROWS_PER_WAVE'):
+                    rows = int(os.environ['TFEP_INV_ROWS_PER_WAVE'])
+                if not rows:
+                    # ... and only while every 16-row workgroup is resident at once (LDS per workgroup: the weight stage
+                    # does not shrink with the rows): cfg4-i at B = 16 384 would need 4 per CU at 85 KB each
+                    lds16 = _lib.load().tfep_inverse_block_lds_bytes_rows(L, fused['cache_len'], fused['max_feats'], 16)
+                    fit = (160 * 1024) // max(int(lds16), 1)
+                    rows = 16 if B <= 16384 and 0 < lds16 and (B + 15) // 16 <= 256 * fit else 64
+                d.rows_per_wave = int(rows)
                 d.spline = ctypes.cast(ctypes.pointer(spl), ctypes.c_void_p) if spl is not None else None
                 d.emb_lower, d.emb_upper = self._input_columns()[2]
                 stream = _lib.stream_of(y)

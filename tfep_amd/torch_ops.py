@@ -201,6 +201,15 @@ def masked_linear(input: Tensor, weight: Tensor, bias: Optional[Tensor], mask: O
                   weight_g: Optional[Tensor]) -> Tensor:
     x2 = input.reshape(-1, input.shape[-1])
     n_out, k = weight.shape
+    # (F.linear's shape errors: a narrower input would otherwise be zero padded up to the tile size without a word)
+    if input.shape[-1] != k:
+        raise RuntimeError(f'masked_linear: input has {input.shape[-1]} features, weight is {n_out} x {k}')
+    if mask is not None and tuple(mask.shape) != (n_out, k):
+        raise RuntimeError(f'masked_linear: mask is {tuple(mask.shape)}, weight is {n_out} x {k}')
+    if bias is not None and bias.numel() != n_out:
+        raise RuntimeError(f'masked_linear: bias has {bias.numel()} entries for {n_out} output features')
+    if weight_g is not None and weight_g.numel() != n_out:
+        raise RuntimeError(f'masked_linear: weight_g has {weight_g.numel()} entries for {n_out} output features')
     tm, tn, tk = ops.tile_sizes()
     k_pad, n_pad = ops.round_up(k, tk), ops.round_up(n_out, tk)
     w = ops.masked_weight_prepare(weight, weight_g, mask, n_rows_padded=n_pad, k_padded=k_pad)
