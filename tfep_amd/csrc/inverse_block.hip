@@ -514,21 +514,35 @@ __device__ __forceinline__ void stage_z16(float* __restrict__ zs, const float* _
     float val[4][2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { val[q][0] = 0.f; val[q][1] = 0.f; }
-    for (int sl = 0; sl < slabs; ++sl) {
-        float t[4][2];
+    // four slabs per pass with every load of the pass in flight before the first add (a slab per pass made each slab a
+    // dependent round trip on the chain: the trip count is not known to the compiler); no predicates on the loads -- a
+    // pass past the last slab re-reads it and adds zero.  The sum still runs in slab order.
+    for (int sl0 = 0; sl0 < slabs; sl0 += 4) {
+        float t[4][4][2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q * 8 < nv) {
-                const int v = min(q * 8 + vq, nv - 1);
+        for (int u = 0; u < 4; ++u) {
+            const int sl = min(sl0 + u, slabs - 1);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int row = min(wave_row0 + rq + 8 * i, n_rows_total - 1);      // dead rows shadow the last one
-                    t[q][i] = z[sl * slab_stride + (int64_t)row * ldz + base + v * vstride];
+            for (int q = 0; q < 4; ++q)
+                if (q * 8 < nv) {
+                    const int v = min(q * 8 + vq, nv - 1);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int row = min(wave_row0 + rq + 8 * i, n_rows_total - 1);      // dead rows shadow the last one
+                        t[u][q][i] = z[sl * slab_stride + (int64_t)row * ldz + base + v * vstride];
+                    }
                 }
-            }
+        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q * 8 < nv) { val[q][0] += t[q][0]; val[q][1] += t[q][1]; }
+        for (int u = 0; u < 4; ++u) {
+            const bool on = sl0 + u < slabs;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (q * 8 < nv) {
+                    val[q][0] += on ? t[u][q][0] : 0.f;
+                    val[q][1] += on ? t[u][q][1] : 0.f;
+                }
+        }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

@@ -804,6 +804,11 @@ int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s)
         return launch_split<NREP, EPI_ELU_SPLIT, 1, 1>(g, n_rows_w, n_tiles, s);
     }
     if (act == 1) return launch_split<NREP, EPI_ELU, 1, 1>(g, n_rows_w, n_tiles, s);
+    // the hidden-layer block GEMMs of the inverse are ~100 outputs wide: a 128-column tile instead of a 256-column one
+    // that would be 60 % padding
+    constexpr int NARROW = 8;
+    if (g.N <= STile<NARROW>::BN && env_int("TFEP_SPLIT_NARROW", 1))
+        return launch_split<NARROW, EPI_LINEAR, 1, 1>(g, n_rows_w, 1, s);
     return launch_split<NREP, EPI_LINEAR, 1, 1>(g, n_rows_w, n_tiles, s);
 }
 

@@ -683,7 +683,10 @@ class AutoregressiveFlow(torch.nn.Module):
                     cols=dev_i32(cols), sel=dev_i32(selv), feat_in=dev_i32(feat_in), feat_per=dev_i32(feat_per),
                     in_cols=dev_i32(in_cols))
 
-    def _split_inverse_state(self, y, bp, mplan, lins, packs, h_last, n_out_max, y_tr=None):
+    #: The hidden-layer block GEMMs on split-f16 operands too (with ``split_inverse``): split copies of every hidden panel.
+    split_inverse_hidden = True
+
+    def _split_inverse_state(self, y, bp, mplan, lins, packs, h_last, n_out_max, y_tr=None, h_all=None):
         """Operands of the split-f16 output-layer block GEMM, or None when the layer does not qualify:
         ``(hs, hs_inv, w_split, w_inv, k_split)`` -- the (zeroed) split copy of the last hidden panel ``h_last`` with its
         bound-based per-row inverse scales, the split output weights in the inverse's row order, the number of slabs."""
@@ -703,15 +706,21 @@ class AutoregressiveFlow(torch.nn.Module):
         x_bound = torch.maximum(ops.abs_reduce(y, 'row_max'), info['dom']) + \
             ops.abs_reduce(outside, 'row_max') * (1.0 / info['tail_slope'])
         bound = torch.clamp(x_bound, min=1.0)
+        hidden = {}                 # layer l >= 1 fed by the hidden panel h[l - 1]: (split panel, its row scales, split W, W scale)
         for l in range(L):
             bound = torch.clamp(bound * ops.abs_reduce(packs[l][0], 'max_row_sum') +
                                 ops.abs_reduce(packs[l][1].reshape(1, -1), 'row_max'), min=1.0)
+            if l + 1 < L and self.split_inverse_hidden and h_all is not None:
+                wsl, winvl = made._pack_layer_split(mplan, l + 1, lins[l + 1])[:2]
+                hidden[l + 1] = (ops.zeros(*h_all[l].shape, dtype=torch.float32, device=dev), ops.pow2_inv_scale(bound), wsl, winvl)
         hs = ops.zeros(*h_last.shape, dtype=torch.float32, device=dev)          # filled block by block
         lib = _lib.load()
         tm, tn = lib.tfep_masked_linear_tile_m(), lib.tfep_masked_linear_tile_n()
-        positions = max(1, ((y.shape[0] + tm - 1) // tm) * ((n_out_max + tn - 1) // tn))
+        # split-K slabs: enough workgroups for 256 CUs (the split kernel's tile is 256 rows x 256 columns; the block kernel
+        # fetches all slabs of a value in one round trip), >= 512 k per slice
+        positions = max(1, ((y.shape[0] + 255) // 256) * ((n_out_max + 255) // 256))
         k_split = int(min(8, max(1, 256 // positions), max(1, mplan['k_pad'][L] // 512)))
-        return hs, ops.pow2_inv_scale(bound), w_split, w_inv, k_split
+        return hs, ops.pow2_inv_scale(bound), w_split, w_inv, k_split, hidden
 
     def _inverse_blocked(self, y):
         y, _ = _lib.rows(y, 'y')
@@ -780,7 +789,10 @@ class AutoregressiveFlow(torch.nn.Module):
                 tm = ops.tile_sizes()[0]
                 m_tiles = (B + tm - 1) // tm
                 S = int(min(8, max(1, 256 // max(1, 2 * m_tiles)), max(1, max(mplan['k_pad']) // 512)))   # >= 512 k per slice
-                S = int(os.environ.get('TFEP_INV_SLABS', S))
+                if self.split_inverse_hidden and self._split_inverse_bound(dev) is not None and L > 1:
+                    S = int(min(8, max(1, 256 // max(1, (B + 255) // 256)), max(1, max(mplan['k_pad']) // 512)))   # 256-row tiles
+                if os.environ.get('TFEP_INV_SLABS'):
+                    S = int(os.environ['TFEP_INV_SLABS'])
                 # slabs hold only the block's own rows: column c of a slab is packed row (first row of the block + c)
                 wz = [1] * L
                 wzout = 1
@@ -788,6 +800,18 @@ class AutoregressiveFlow(torch.nn.Module):
                     for wd in b_['wide'] + ([b_['fused']['wide0']] if b_['fused']['wide0'] is not None else []):
                         wz[wd['layer']] = max(wz[wd['layer']], wd['n_rows'])
                     wzout = max(wzout, b_['out_wide']['n_rows'])
+                # 16 sample rows per wave (4x the waves) while the batch leaves SIMDs idle: B / 64 one-row-per-lane
+                # waves fill at most a quarter of the 1024 SIMDs up to 16 384 rows (see csrc/inverse_block.hip)
+                rows = self.inverse_rows_per_wave
+                if os.environ.get('TFEP_INV_ROWS_PER_WAVE'):
+                    rows = int(os.environ['TFEP_INV_ROWS_PER_WAVE'])
+                if not rows:
+                    # ... and only while every 16-row workgroup is resident at once (LDS per workgroup: the weight stage
+                    # does not shrink with the rows): cfg4-i at B = 16 384 would need 4 per CU at 85 KB each
+                    lds16 = _lib.load().tfep_inverse_block_lds_bytes_rows(L, fused['cache_len'], fused['max_feats'], 16)
+                    fit = (160 * 1024) // max(int(lds16), 1)
+                    rows = 16 if B <= 16384 and 0 < lds16 and (B + 15) // 16 <= 256 * fit else 64
+                rows_per_wave = int(rows)
                 # look-ahead: the long "old" part of block k + 1's wide GEMMs runs on a side stream WHILE block k's kernel
                 # (one wave per 64 samples: half the CUs at batch 8192) runs; what block k added follows as one short
                 # GEMM into an extra slab.  Two sets of slabs, alternating between blocks.
@@ -799,7 +823,9 @@ class AutoregressiveFlow(torch.nn.Module):
                     # GEMMs are long enough to be worth two event round trips per block: cfg2 layer at B = 8192
                     # 150 -> 138 ms, neutral at B = 16 384 (all 256 CUs taken); cfg1 (launch bound) +7 %, cfg4-i at
                     # B = 16 384 +11 % with it -- those stay in order
-                    look = (B + 63) // 64 <= 160 and max(mplan['k_pad']) >= 4096
+                    # 16-row waves sit on every CU: the GEMMs (a whole SIMD's registers per wave) find no room beside them
+                    # (cfg2 layer at B = 8192, hidden GEMMs on split operands: 125.5 ms in order, 140 ms with look-ahead)
+                    look = rows_per_wave == 64 and (B + 63) // 64 <= 160 and max(mplan['k_pad']) >= 4096
                 look = bool(look) and len(bp['blocks']) > 1
                 n_par = 2 if look else 1
                 zs = [[torch.empty(S + 1, B, ops.round_up(wz[l], 4), **f32) for l in range(L)] for _ in range(n_par)]
@@ -823,26 +849,15 @@ class AutoregressiveFlow(torch.nn.Module):
                 d.log_det_J = ldj.data_ptr()
                 d.wout, d.ldwout = w_out.data_ptr(), w_out.shape[1]
                 d.cache_len, d.max_feats = fused['cache_len'], fused['max_feats']
-                # four lanes per sample row (4x the waves) while the batch leaves SIMDs idle: B / 64 one-row-per-lane
-                # waves fill at most a quarter of the 1024 SIMDs up to 16 384 rows (see csrc/inverse_block.hip)
-                rows = self.inverse_rows_per_wave
-                if os.environ.get('TFEP_INV_ROWS_PER_WAVE'):
-                    rows = int(os.environ['TFEP_INV_ROWS_PER_WAVE'])
-                if not rows:
-                    # ... and only while every 16-row workgroup is resident at once (LDS per workgroup: the weight stage
-                    # does not shrink with the rows): cfg4-i at B = 16 384 would need 4 per CU at 85 KB each
-                    lds16 = _lib.load().tfep_inverse_block_lds_bytes_rows(L, fused['cache_len'], fused['max_feats'], 16)
-                    fit = (160 * 1024) // max(int(lds16), 1)
-                    rows = 16 if B <= 16384 and 0 < lds16 and (B + 15) // 16 <= 256 * fit else 64
-                d.rows_per_wave = int(rows)
+                d.rows_per_wave = rows_per_wave
                 d.spline = ctypes.cast(ctypes.pointer(spl), ctypes.c_void_p) if spl is not None else None
                 d.emb_lower, d.emb_upper = self._input_columns()[2]
                 stream = _lib.stream_of(y)
                 # ---- the output-layer block GEMM on split-f16 operands (see _split_inverse_bound)
-                hs = None
-                sp = self._split_inverse_state(y, bp, mplan, lins, packs, h[L - 1], wzout, y_tr=y_tr)
+                hs, hs_hidden = None, {}
+                sp = self._split_inverse_state(y, bp, mplan, lins, packs, h[L - 1], wzout, y_tr=y_tr, h_all=h)
                 if sp is not None:
-                    hs, hs_inv, ws_out, winv_out, S_out = sp
+                    hs, hs_inv, ws_out, winv_out, S_out, hs_hidden = sp
                 zouts = [torch.empty(S_out + 1, B, ops.round_up(wzout, 4), **f32) for _ in range(n_par)]
                 d.ldzout, d.zout_slab_stride = zouts[0].shape[-1], B * zouts[0].shape[-1]
 
@@ -857,7 +872,10 @@ class AutoregressiveFlow(torch.nn.Module):
                             continue
                         l = wd['layer']
                         desc = dict(wd, kr=wd[part])
-                        if l < L:
+                        if l < L and l in hs_hidden and not new_part:
+                            hsl, hsl_inv, wsl, winvl = hs_hidden[l]
+                            launch(hsl, wsl, packs[l][1], desc, zs[par][l], 0, act=0, k_split=S, split=(hsl_inv, winvl))
+                        elif l < L:
                             out, ks = (zs[par][l][S], 1) if new_part else (zs[par][l], S)
                             launch(h[l - 1] if l > 0 else xpad, packs[l][0], None if new_part else packs[l][1], desc, out, 0,
                                    act=0, k_split=ks)
@@ -930,6 +948,11 @@ class AutoregressiveFlow(torch.nn.Module):
                         if hi > lo:
                             g0 = lo // 8 * 8
                             ops.split_columns_scaled(h[L - 1], g0, hi - g0, hs, hs_inv)
+                        for l_next, (hsl, hsl_inv, _, _) in hs_hidden.items():      # ... and of the panels below it
+                            lo, hi = fb['unit_range'][l_next - 1]
+                            if hi > lo:
+                                g0 = lo // 8 * 8
+                                ops.split_columns_scaled(h[l_next - 1], g0, hi - g0, hsl, hsl_inv)
                     continue
                 # ---- the block's own degrees, one after the other
                 for st in blk['steps']:
