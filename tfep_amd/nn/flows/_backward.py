@@ -427,8 +427,17 @@ def saves_activations_at(layer, batch):
     emb = getattr(layer._conditioner, 'embedding', None)
     if emb is not None and type(emb) is not PeriodicEmbedding:
         return False
-    n_out = layer._conditioner._linears()[-1].out_features
-    return 0 < int(batch) * n_out * 4 <= _SAVE_BYTES
+    lins = layer._conditioner._linears()
+    need = int(batch) * 4 * (lins[-1].out_features + sum(lin.out_features for lin in lins[:-1]))
+    if not 0 < int(batch) * lins[-1].out_features * 4 <= _SAVE_BYTES:
+        return False
+    # ... and only a modest share of what the device still has (a deep flow keeps this for every layer until its backward
+    # has run; the weight packings and gradient buffers of the backward need room too): otherwise recompute
+    dev = lins[-1].bias.device
+    if dev.type != 'cuda':
+        return False
+    free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    return need <= 0.15 * free
 
 
 def forward_saving(layer, x):
