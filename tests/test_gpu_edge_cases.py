@@ -342,7 +342,8 @@ def test_inverse_under_autograd_fails_loudly_at_backward():
 
 @pytest.mark.parametrize('order', ['ascending', 'descending', 'random'])
 @pytest.mark.parametrize('periodic', [False, True])
-def test_lookahead_inverse_equals_the_in_order_inverse(order, periodic):
+@pytest.mark.parametrize('rows', [64, 16])
+def test_lookahead_inverse_equals_the_in_order_inverse(order, periodic, rows):
     """The blocked inverse overlaps the wide GEMMs of block k + 1 (over the hidden units that were complete before block
     k) with block k's kernel on a side stream; what block k adds follows as one more split-K slab.  Same products, one
     more term in the association: results within a few ulp of the in-order schedule, for every degree order (a random
@@ -367,8 +368,9 @@ def test_lookahead_inverse_equals_the_in_order_inverse(order, periodic):
         looks = [b['fused']['wide0']['look'] for b in plan['blocks'][1:] if b['fused']['wide0'] is not None]
         # (the first blocks know too few columns for a split to pay; the embedding keeps periodic and plain columns apart)
         assert any(looks) or order == 'random' or periodic
-        assert maf.inverse_lookahead is None                     # default: by batch and layer size; forced here
+        assert maf.inverse_lookahead is None                     # default: by batch, layer size and row layout; forced here
         maf.inverse_lookahead = True
+        maf.inverse_rows_per_wave = rows                          # (the default pairs look-ahead with 64-row waves)
         x1, l1 = maf.inverse(y)
         x2, l2 = maf.inverse(y)
         maf.inverse_lookahead = False
