@@ -16,8 +16,9 @@ N > 1 is BASELINE config 3: the SAME 65536-sample batch sharded by rows over the
 ``tfep_amd.distributed.shard_rows``), a full weight replica per rank, no collective on the data path: STRONG scaling
 (``--scaling weak`` gives every rank its own 65536 rows instead).  Rank 0 prints ONE JSON line.  After the timed
 headline region the same process also times (a) the step with the packed weights cached across forwards
-(``cached_repack``; the headline re-packs every step), (b) the step on the exact-fp32 MFMA GEMMs (``exact_fp32``) and
-(c), on rank 0 at N = 1, the CPU restatement of the path on the host cores (``cpu_baseline``).
+(``cached_repack``; the headline re-packs every step), (b) the step on the exact-fp32 MFMA GEMMs (``exact_fp32``),
+(c) at N = 1 one layer's blocked inverse (8192 rows) and training step (16 384 rows) with their rooflines
+(``other_paths``) and (d), on rank 0 at N = 1, the CPU restatement of the path on the host cores (``cpu_baseline``).
 """
 import argparse
 import json
@@ -99,7 +100,8 @@ def main():
     ap.add_argument('--bins', type=int, default=8)
     ap.add_argument('--cpu-chunk', type=int, default=1024)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extra-arms', action='store_true', help='skip the cached-repack and exact-fp32 arms')
+    ap.add_argument('--no-extra-arms', action='store_true',
+                    help='skip the cached-repack and exact-fp32 arms and the one-layer inverse / training-step lines')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -197,6 +199,55 @@ def main():
             'kernel': 'gemm_kernel<2,25,EPI_SPLINE> (v_mfma_f32_16x16x4_f32: exact fp32 products, fp32 accumulate)'}
         for l in flow:
             l.split_gemm = None
+
+    # ---------------------------------------------------------------- the rows either side of the headline
+    # one layer of the same flow: blocked inverse on 8192 rows and a training step (forward + backward of every
+    # parameter) on 16 384 rows, each with the mask-aware MFMA roofline of the arithmetic it runs on
+    if not args.no_extra_arms and world == 1 and B >= 16384:
+        try:
+            from tfep_amd.loss import BoltzmannKLDivLoss
+            layer, other = flow[0], {}
+            flops_layer = 2.0 * nnz_all[0]
+            peak_other = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
+
+            def clock(fn, n):
+                fn()
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize(device)
+                return (time.perf_counter() - t0) / n
+            with torch.no_grad():
+                y8, _ = layer(x[:8192])
+                t_i = clock(lambda: layer.inverse(y8), 2)
+                xi, _ = layer.inverse(y8)
+            other['inverse_one_layer'] = {
+                'rows': 8192, 'ms': 1e3 * t_i, 'samples_per_s': 8192 / t_i,
+                'roundtrip_max_abs': float((xi - x[:8192]).abs().max()),
+                'roofline': {'bound': 'mfma', 'achieved': flops_layer * 8192 / t_i / 1e12, 'peak': peak_other, 'unit': 'TFLOP/s',
+                             'frac': flops_layer * 8192 / t_i / 1e12 / peak_other,
+                             'note': 'one forward of flops; 3000 sequential degree steps (blocked forward substitution)'}}
+            del y8, xi
+            c = torch.rand(D, device=device, generator=gen) * 0.3
+            x16 = x[:16384]
+
+            def train_step():
+                for prm in layer.parameters():
+                    prm.grad = None
+                yt, lt = layer(x16)
+                BoltzmannKLDivLoss()((c * yt ** 2).sum(dim=1), lt).backward()
+            t_t = clock(train_step, 2)
+            other['training_step_one_layer'] = {
+                'rows': 16384, 'ms': 1e3 * t_t, 'samples_per_s': 16384 / t_t,
+                'roofline': {'bound': 'mfma', 'achieved': 3.0 * flops_layer * 16384 / t_t / 1e12, 'peak': peak_other,
+                             'unit': 'TFLOP/s', 'frac': 3.0 * flops_layer * 16384 / t_t / 1e12 / peak_other,
+                             'note': 'forward + grad_input + grad_weight of every masked linear (activations kept, no recompute)'}}
+            for prm in layer.parameters():
+                prm.grad = None
+            extra['other_paths'] = other
+        except Exception as e:                                  # the headline number must still print
+            extra['other_paths'] = {'failed': f'{type(e).__name__}: {e}'}
 
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the
     # figure comes from the committed rocprofv3 --pmc passes of this same command (profiles/README.md).
