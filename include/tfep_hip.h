@@ -78,6 +78,15 @@ int tfep_masked_weight_prepare(const float* weight_v, const float* weight_g, con
                                int out_features, int in_features,
                                const int32_t* row_of_out, const int32_t* col_of_in, const int32_t* col_cut, int clear,
                                float* w_out, int n_rows_padded, int64_t ldw, void* stream);
+/* The same packing for a layer whose mask rows are prefixes of its packed columns (col_cut, see
+ * tfep_masked_weight_prepare_split): the mask is not read, a row of weight_v goes through LDS once (in_features * 4 <=
+ * 64 KiB), and only the live prefix of each packed row is written, in whole 32-byte groups -- w_out must have been
+ * zeroed when it was allocated and always hold this layer (ldw >= in_features rounded up to 8, 16-byte aligned rows).
+ * in_of_col: packed column -> input feature (the inverse of col_of_in), or NULL.  Bit-identical to
+ * tfep_masked_weight_prepare on the entries it writes.  (masked.py:369-371, :433-439) */
+int tfep_masked_weight_prepare_prefix(const float* weight_v, const float* weight_g, int out_features, int in_features,
+                                      const int32_t* row_of_out, const int32_t* in_of_col, const int32_t* col_cut,
+                                      float* w_out, int n_rows_padded, int64_t ldw, void* stream);
 
 /*
  * Per column-tile bounding range of the mask non-zeros, in PACKED coordinates:

@@ -384,3 +384,42 @@ def test_elu_of_the_gemm_epilogues_is_fp32_accurate():
         assert float(rel.max()) < 2.5e-7
         assert bool((y[(ref == 0) & rows_ok[:, None]] == 0).all())
     assert torch.isnan(y32[~rows_ok]).any()                              # NaN in -> NaN out (not -1)
+
+
+@pytest.mark.parametrize('weight_norm', [True, False])
+@pytest.mark.parametrize('K', [8192, 9001, 14998])
+def test_fp32_prefix_pack_writes_the_bits_of_the_masked_pack(K, weight_norm):
+    """``tfep_masked_weight_prepare_prefix`` (row staged in LDS, mask not read, only the live prefix written) against
+    ``tfep_masked_weight_prepare`` reading the mask: identical bits everywhere, for permuted rows and columns, a fully
+    masked row, rows whose prefix ends inside a group of 8 and a full row; the masked suffix stays the zeros of the
+    allocation; misuse is rejected."""
+    import ctypes
+    from tfep_amd import _lib, ops
+    torch.manual_seed(K)
+    N = 77
+    g_ = torch.Generator(device='cuda').manual_seed(K + 1)
+    v = torch.randn(N, K, device='cuda', generator=g_)
+    wg = (torch.rand(N, 1, device='cuda', generator=g_) + 0.5) if weight_norm else None
+    in_of_col = torch.randperm(K, device='cuda', generator=g_).to(torch.int32)          # packed column -> input feature
+    col_of_in = torch.empty(K, dtype=torch.int32, device='cuda')
+    col_of_in[in_of_col.long()] = torch.arange(K, dtype=torch.int32, device='cuda')
+    row_of_out = torch.randperm(N + 3, device='cuda', generator=g_)[:N].to(torch.int32)
+    cut = torch.randint(0, K + 1, (N,), device='cuda', generator=g_).to(torch.int32)
+    cut[0], cut[1], cut[2], cut[3] = 0, K, 13, K - 5
+    mask = (col_of_in[None, :].long() < cut[:, None].long()).float()                    # mask[o, i] = packed column of i < cut[o]
+    k_pad = ops.round_up(K, ops.tile_sizes()[2])
+    ref = ops.masked_weight_prepare(v, wg, mask, row_of_out, col_of_in, N + 3, k_pad)
+    out = torch.zeros(N + 3, k_pad, device='cuda')
+    got = ops.masked_weight_prepare(v, wg, None, row_of_out, col_of_in, N + 3, k_pad, out=out, col_cut=cut, clear=False,
+                                    in_of_col=in_of_col)
+    assert got is out and torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    again = ops.masked_weight_prepare(v, wg, None, row_of_out, col_of_in, N + 3, k_pad, out=out, col_cut=cut, clear=False,
+                                      in_of_col=in_of_col)
+    assert torch.equal(again.view(torch.int32), ref.view(torch.int32))
+    lib = _lib.load()
+    args = (_lib.ptr(v), _lib.ptr(wg), N, K, _lib.ptr(row_of_out), _lib.ptr(in_of_col), _lib.ptr(cut))
+    assert lib.tfep_masked_weight_prepare_prefix(*args, _lib.ptr(out), N + 3, k_pad, None) == 0
+    assert lib.tfep_masked_weight_prepare_prefix(*args[:6], None, _lib.ptr(out), N + 3, k_pad, None) != 0       # no col_cut
+    assert lib.tfep_masked_weight_prepare_prefix(*args, _lib.ptr(out), N - 1, k_pad, None) != 0                 # too few rows
+    assert lib.tfep_masked_weight_prepare_prefix(*args, _lib.ptr(out), N + 3, K - 8, None) != 0                 # rows too short
+    torch.cuda.synchronize()

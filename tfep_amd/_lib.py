@@ -99,6 +99,7 @@ _SIGNATURES = {
     'tfep_hip_abi_version': (c_int, []),
     'tfep_last_error': (c_char_p, []),
     'tfep_masked_weight_prepare': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int, _P, c_int, c_int64, _P]),
+    'tfep_masked_weight_prepare_prefix': (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, c_int, c_int64, _P]),
     'tfep_mask_k_ranges': (c_int, [_P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, _P, _P]),
     'tfep_masked_linear_forward': (c_int, [_P, c_int64, _P, c_int64, _P, _P, _P, _P, _P, c_int64,
                                            c_int, c_int, c_int, c_int, c_int, c_int, _P]),

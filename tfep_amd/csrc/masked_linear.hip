@@ -60,6 +60,72 @@ __global__ void __launch_bounds__(256) weight_prepare_kernel(const float* __rest
     }
 }
 
+// The fp32 pack of a layer whose mask rows are prefixes of its packed columns (tfep_masked_weight_prepare_split's col_cut):
+// one workgroup per output row, the row of v staged in LDS with coalesced 16-byte loads, the permuted gather out of LDS,
+// only the live prefix [0, cut) written, in whole 32-byte groups -- the masked suffix was zeroed when the buffer was
+// allocated and nothing writes it.  Same values, bit for bit, as weight_prepare_kernel (same norm summation order), which
+// gathers 4-byte elements through L2 and writes the zeros of the suffix too.
+constexpr int PFX32_THREADS = 512;
+__global__ void __launch_bounds__(PFX32_THREADS) weight_prepare_prefix_kernel(const float* __restrict__ v, const float* __restrict__ g,
+                                                                              int N, int K, const int32_t* __restrict__ row_of_out,
+                                                                              const int32_t* __restrict__ in_of_col,
+                                                                              const int32_t* __restrict__ col_cut,
+                                                                              float* __restrict__ w_out, int64_t ldw) {
+    extern __shared__ float srow[];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const float* vr = v + (int64_t)o * K;
+    {
+        // rows start 8-byte aligned at best: scalar head up to the first 16-byte boundary, float4 body with eight loads in
+        // flight per lane, scalar tail
+        const int head = min(K, (int)(((16u - (uint32_t)((uintptr_t)vr & 15u)) & 15u) >> 2));
+        const int n4 = (K - head) >> 2;
+        const float4* v4 = reinterpret_cast<const float4*>(vr + head);
+        if (tid < head) srow[tid] = vr[tid];
+        for (int i0 = tid; i0 < n4; i0 += 8 * PFX32_THREADS) {
+            float4 q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * PFX32_THREADS;
+                q[u] = i < n4 ? v4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * PFX32_THREADS;
+                if (i < n4) {
+                    float* d = srow + head + 4 * i;
+                    d[0] = q[u].x; d[1] = q[u].y; d[2] = q[u].z; d[3] = q[u].w;
+                }
+            }
+        }
+        for (int i = head + 4 * n4 + tid; i < K; i += PFX32_THREADS) srow[i] = vr[i];
+    }
+    __syncthreads();
+    float wn = 1.0f;
+    if (g) {
+        // the row norm in weight_prepare_kernel's summation order (lane l: l, l + 64, ...; then the butterfly), every wave
+        // for itself from LDS
+        float ss = 0.f;
+        for (int i = tid & 63; i < K; i += 64) ss += srow[i] * srow[i];
+        ss = wave_sum(ss);
+        wn = g[o] / sqrtf(ss);             // may be inf/NaN for a fully-masked row: never used below
+    }
+    const int cut = min(col_cut[o], K);
+    const int64_t orow = row_of_out ? row_of_out[o] : o;
+    float4* dr = reinterpret_cast<float4*>(w_out + orow * ldw);
+    const int n_groups = (cut + 7) >> 3;
+    for (int g8 = tid; g8 < n_groups; g8 += PFX32_THREADS) {
+        float val[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = g8 * 8 + j;
+            const int idx = (in_of_col && c < K) ? in_of_col[c] : min(c, K - 1);
+            val[j] = c < cut ? (g ? srow[idx] * wn : srow[idx]) : 0.f;
+        }
+        dr[g8 * 2] = make_float4(val[0], val[1], val[2], val[3]);
+        dr[g8 * 2 + 1] = make_float4(val[4], val[5], val[6], val[7]);
+    }
+}
+
 // Bounding k-range of the mask non-zeros per tile of `tile_n` packed rows.
 __global__ void __launch_bounds__(256) mask_k_ranges_kernel(const float* __restrict__ mask, int N, int K,
                                                             const int32_t* __restrict__ row_of_out,
@@ -412,6 +478,21 @@ int tfep_masked_weight_prepare(const float* weight_v, const float* weight_g, con
     weight_prepare_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, s>>>(weight_v, weight_g, mask, out_features,
                                                                               in_features, row_of_out, col_of_in, col_cut, w_out, ldw);
     return check_launch("weight_prepare_kernel");
+}
+
+int tfep_masked_weight_prepare_prefix(const float* weight_v, const float* weight_g, int out_features, int in_features,
+                                      const int32_t* row_of_out, const int32_t* in_of_col, const int32_t* col_cut,
+                                      float* w_out, int n_rows_padded, int64_t ldw, void* stream) {
+    TFEP_REQUIRE(weight_v && w_out && col_cut, "masked_weight_prepare_prefix: NULL pointer");
+    TFEP_REQUIRE(out_features >= 0 && in_features >= 0, "masked_weight_prepare_prefix: negative size");
+    TFEP_REQUIRE(n_rows_padded >= out_features && ldw >= ((in_features + 7) & ~7) && ldw % 4 == 0 && ((uintptr_t)w_out & 15) == 0,
+                 "masked_weight_prepare_prefix: output too small or not aligned to 16 bytes");
+    TFEP_REQUIRE((size_t)in_features * 4 <= 64 * 1024, "masked_weight_prepare_prefix: a row of %d weights does not fit the LDS stage",
+                 in_features);
+    if (out_features == 0 || in_features == 0) return TFEP_OK;
+    weight_prepare_prefix_kernel<<<(unsigned)out_features, PFX32_THREADS, (size_t)in_features * 4, (hipStream_t)stream>>>(
+        weight_v, weight_g, out_features, in_features, row_of_out, in_of_col, col_cut, w_out, ldw);
+    return check_launch("weight_prepare_prefix_kernel");
 }
 
 int tfep_mask_k_ranges(const float* mask, int out_features, int in_features, const int32_t* row_of_out,

@@ -373,7 +373,7 @@ class MADE(Conditioner):
             entry = plan[key] = (ops.zeros(n_rows, plan['k_pad'][li], dtype=torch.float32, device=v.device), row_of_out)
         buf = entry[0]
         ops.masked_weight_prepare(v, g, lin.mask, row_of_out, plan['col_of_in'][li], n_rows, plan['k_pad'][li], out=buf,
-                                  col_cut=self._mask_prefix_cuts(plan, li, lin), clear=False)
+                                  col_cut=self._mask_prefix_cuts(plan, li, lin), clear=False, in_of_col=plan['in_of_col'][li])
         bias = ops.zeros(1, n_rows, dtype=torch.float32, device=v.device)
         if row_of_out is None:
             bias[0, :lin.out_features] = lin.bias.detach()

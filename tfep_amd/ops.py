@@ -165,10 +165,11 @@ def pad_columns(x, k_padded):
 
 
 def masked_weight_prepare(weight_v, weight_g=None, mask=None, row_of_out=None, col_of_in=None,
-                          n_rows_padded=None, k_padded=None, out=None, col_cut=None, clear=True):
+                          n_rows_padded=None, k_padded=None, out=None, col_cut=None, clear=True, in_of_col=None):
     """Effective masked weight, permuted + zero padded (reference masked.py:369-371, :433-439, :270).  ``col_cut``:
     prefix mask rows (see ``masked_weight_prepare_split``); ``clear=False``: ``out`` was zeroed once and always holds the
-    same layer, so its padding needs no clearing."""
+    same layer, so its padding needs no clearing.  With ``col_cut``, ``clear=False`` and ``in_of_col`` (the inverse of
+    ``col_of_in``) long rows take the LDS-staged prefix kernel, which writes only the live prefix of each packed row."""
     check_device_tensor(weight_v, 'weight')
     N, K = weight_v.shape
     tk = tile_sizes()[2]
@@ -181,6 +182,11 @@ def masked_weight_prepare(weight_v, weight_g=None, mask=None, row_of_out=None, c
     v_c = weight_v.contiguous()
     g_c = None if weight_g is None else weight_g.contiguous()
     m_c = None if mask is None else mask.contiguous()
+    if col_cut is not None and not clear and (in_of_col is not None or col_of_in is None) and 8192 <= K <= 16384 and \
+            out.shape[1] % 4 == 0 and out.shape[1] >= round_up(K, 8) and os.environ.get('TFEP_PACK_LDS', '1') != '0':
+        call('tfep_masked_weight_prepare_prefix', ptr(v_c), ptr(g_c), N, K, ptr(row_of_out), ptr(in_of_col), ptr(col_cut),
+             ptr(out), n_rows_padded, out.shape[1], stream_of(weight_v))
+        return out
     call('tfep_masked_weight_prepare', ptr(v_c), ptr(g_c), ptr(m_c), N, K, ptr(row_of_out), ptr(col_of_in), ptr(col_cut),
          int(bool(clear)), ptr(out), n_rows_padded, k_padded, stream_of(weight_v))
     return out
