@@ -73,7 +73,17 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ s
     const int lane = threadIdx.x & 63;
     const float* sr = src + row * ld;
     float m = 0.f;
-    for (int64_t i = lane; i < cols; i += 64) m = fmaxf(m, fabsf(sr[i]));
+    if (((uintptr_t)sr & 15u) == 0) {                  // 16-byte loads (a maximum: the order of the comparisons does not matter)
+        const float4* s4 = reinterpret_cast<const float4*>(sr);
+        const int64_t n4 = cols >> 2;
+        for (int64_t i = lane; i < n4; i += 64) {
+            const float4 q = s4[i];
+            m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+        }
+        for (int64_t i = 4 * n4 + lane; i < cols; i += 64) m = fmaxf(m, fabsf(sr[i]));
+    } else {
+        for (int64_t i = lane; i < cols; i += 64) m = fmaxf(m, fabsf(sr[i]));
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     // non-negative floats order like their bits; look before the atomic (same-address atomics serialise in L2)
@@ -90,12 +100,23 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const float* sr = src + row * ld_src;
+    const bool vec = ((uintptr_t)sr & 15u) == 0;       // wave-uniform: 16-byte loads when the row starts on a 16-byte boundary
     float amax;
     if (tensor_max_bits) {
         amax = __uint_as_float(*tensor_max_bits);
     } else {
         amax = 0.f;
-        for (int64_t i = lane; i < cols; i += 64) amax = fmaxf(amax, fabsf(sr[i]));
+        if (vec) {                                // (a maximum: the order of the comparisons does not matter)
+            const float4* s4 = reinterpret_cast<const float4*>(sr);
+            const int64_t n4 = cols >> 2;
+            for (int64_t i = lane; i < n4; i += 64) {
+                const float4 q = s4[i];
+                amax = fmaxf(fmaxf(amax, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+            }
+            for (int64_t i = 4 * n4 + lane; i < cols; i += 64) amax = fmaxf(amax, fabsf(sr[i]));
+        } else {
+            for (int64_t i = lane; i < cols; i += 64) amax = fmaxf(amax, fabsf(sr[i]));
+        }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
     }
@@ -104,10 +125,20 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
     uint4* dr = dst + row * (ld_dst / 4);        // 16 bytes = 4 elements of pitch
     for (int64_t g8 = lane; g8 * 8 < cols_padded; g8 += 64) {
         f16x8 hi, lo;
+        float e[8];
+        if (vec && g8 * 8 + 8 <= cols) {          // two 16-byte loads per group (element loads: 8 instructions at a 32-byte lane stride)
+            const float4 a = reinterpret_cast<const float4*>(sr)[g8 * 2], b = reinterpret_cast<const float4*>(sr)[g8 * 2 + 1];
+            e[0] = a.x; e[1] = a.y; e[2] = a.z; e[3] = a.w; e[4] = b.x; e[5] = b.y; e[6] = b.z; e[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int64_t c = g8 * 8 + j;
+                e[j] = c < cols ? sr[c] : 0.f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int64_t c = g8 * 8 + j;
-            const float v = c < cols ? sr[c] * s : 0.f;
+            const float v = e[j] * s;
             const _Float16 h = (_Float16)v;
             hi[j] = h;
             lo[j] = (_Float16)(v - (float)h);
