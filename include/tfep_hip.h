@@ -442,6 +442,13 @@ int tfep_weight_norm_backward(const float* gw_packed, int64_t ldw, const float* 
                               const float* weight_g, const float* mask, int out_features, int in_features,
                               const int32_t* row_of_out, const int32_t* col_of_in,
                               float* grad_v, float* grad_g, void* stream);
+/* The same for a layer whose mask rows are prefixes of its packed columns (col_cut / in_of_col as in
+ * tfep_masked_weight_prepare_prefix): the mask is not read, a row of weight_v goes through LDS once (in_features * 4 <=
+ * 64 KiB) and the packed gradient is read over the live prefix only.  Same formulas; the double-precision sums run in
+ * another (fixed) order. */
+int tfep_weight_norm_backward_prefix(const float* gw_packed, int64_t ldw, const float* weight_v, const float* weight_g,
+                                     int out_features, int in_features, const int32_t* row_of_out, const int32_t* in_of_col,
+                                     const int32_t* col_cut, float* grad_v, float* grad_g, void* stream);
 
 /* Backward of tfep_periodic_embedding: gx[:, f] for every input feature (periodic and not). */
 int tfep_periodic_embedding_backward(const float* x, int64_t ldx, const int32_t* periodic_indices,

@@ -450,3 +450,43 @@ def test_activation_saving_forward_equals_the_recomputing_one(monkeypatch, split
     for n, a, b in zip(names, g2, g3):
         assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-8, n
     assert float((g2[1] - gs[1]).abs().max()) > 1e-3 * float(gs[1].abs().max())
+
+
+@pytest.mark.parametrize('weight_norm', [True, False])
+def test_weight_norm_backward_prefix_kernel_matches_the_masked_one(weight_norm):
+    """``tfep_weight_norm_backward_prefix`` (row of v staged in LDS, mask not read, packed gradient read over the live
+    prefix) against ``tfep_weight_norm_backward`` reading the mask: same gradients to the rounding of the float64 sums
+    (they run in another order), exact zeros on masked entries and fully masked rows, for permuted rows and columns."""
+    from tfep_amd import _lib
+    torch.manual_seed(9)
+    N, K, ldw = 53, 9001, 9024
+    dev = 'cuda'
+    v = torch.randn(N, K, device=dev)
+    wg = torch.rand(N, 1, device=dev) + 0.5 if weight_norm else None
+    gW = torch.randn(N + 2, ldw, device=dev)
+    in_of_col = torch.randperm(K, device=dev).to(torch.int32)
+    col_of_in = torch.empty(K, dtype=torch.int32, device=dev)
+    col_of_in[in_of_col.long()] = torch.arange(K, dtype=torch.int32, device=dev)
+    row_of_out = torch.randperm(N + 2, device=dev)[:N].to(torch.int32)
+    cut = torch.randint(0, K + 1, (N,), device=dev).to(torch.int32)
+    cut[0], cut[1], cut[2] = 0, K, 5
+    mask = (col_of_in[None, :].long() < cut[:, None].long()).float()
+    lib = _lib.load()
+    gv0, gg0 = torch.empty(N, K, device=dev), torch.empty(N, 1, device=dev)
+    gv1, gg1 = torch.full((N, K), 7.0, device=dev), torch.full((N, 1), 7.0, device=dev)
+    assert lib.tfep_weight_norm_backward(_lib.ptr(gW), ldw, _lib.ptr(v), _lib.ptr(wg), _lib.ptr(mask), N, K, _lib.ptr(row_of_out),
+                                         _lib.ptr(col_of_in), _lib.ptr(gv0), _lib.ptr(gg0) if weight_norm else None, None) == 0
+    assert lib.tfep_weight_norm_backward_prefix(_lib.ptr(gW), ldw, _lib.ptr(v), _lib.ptr(wg), N, K, _lib.ptr(row_of_out),
+                                                _lib.ptr(in_of_col), _lib.ptr(cut), _lib.ptr(gv1),
+                                                _lib.ptr(gg1) if weight_norm else None, None) == 0
+    torch.cuda.synchronize()
+    scale = float(gv0.abs().max())
+    assert float((gv1 - gv0).abs().max()) <= 2e-6 * scale
+    assert bool((gv1[mask == 0] == 0).all()) and bool((gv1[0] == 0).all())
+    if weight_norm:
+        assert torch.allclose(gg1, gg0, rtol=1e-6, atol=1e-7 * float(gg0.abs().max())) and float(gg1[0]) == 0.0
+    # misuse
+    assert lib.tfep_weight_norm_backward_prefix(_lib.ptr(gW), ldw, _lib.ptr(v), _lib.ptr(wg), N, K, None, _lib.ptr(in_of_col), None,
+                                                _lib.ptr(gv1), _lib.ptr(gg1), None) != 0
+    assert lib.tfep_weight_norm_backward_prefix(_lib.ptr(gW), K - 1, _lib.ptr(v), _lib.ptr(wg), N, K, None, _lib.ptr(in_of_col),
+                                                _lib.ptr(cut), _lib.ptr(gv1), _lib.ptr(gg1), None) != 0

@@ -157,6 +157,7 @@ _SIGNATURES = {
                                       _P, c_int64, _P, c_int64, c_int, c_int, _P]),
     'tfep_copy_2d': (c_int, [_P, c_int64, _P, c_int64, c_int, c_int, _P]),
     'tfep_weight_norm_backward': (c_int, [_P, c_int64, _P, _P, _P, c_int, c_int, _P, _P, _P, _P, _P]),
+    'tfep_weight_norm_backward_prefix': (c_int, [_P, c_int64, _P, _P, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     'tfep_periodic_embedding_backward': (c_int, [_P, c_int64, _P, c_int, _P, c_int, c_float, c_float, _P, c_int64,
                                                  _P, c_int64, c_int, _P]),
     'tfep_tfep_reduce': (c_int, [_P, _P, _P, _P, _P, c_float, c_int, c_int, _P, _P, _P]),

@@ -590,18 +590,33 @@ def layer_backward(layer, x, gy, gldj, saved=None):
     for l, lin in enumerate(lins):
         row_of_out = bplan['row_of_out'] if (l == L and sorted_out) else mplan['row_of_out'][l]
         col_of_in = mplan['col_of_in'][l]
+        # long rows under a prefix mask: the LDS-staged kernel (mask not read, packed gradient read over the live prefix)
+        cut = made._mask_prefix_cuts(mplan, l, lin) if 8192 <= lin.in_features <= 16384 and \
+            os.environ.get('TFEP_PACK_LDS', '1') != '0' else None
+        in_of_col = mplan['in_of_col'][l]
+        prefix = cut is not None and (in_of_col is not None or col_of_in is None)
         if lin.has_weight_norm:
             gv = torch.empty_like(lin.weight_v)
             gg = torch.empty(lin.out_features, 1, **f32)
-            _lib.call('tfep_weight_norm_backward', _lib.ptr(gW[l]), k_pad[l], _lib.ptr(lin.weight_v.detach()),
-                      _lib.ptr(lin.weight_g.detach()), _lib.ptr(lin.mask), lin.out_features, lin.in_features,
-                      _lib.ptr(row_of_out), _lib.ptr(col_of_in), _lib.ptr(gv), _lib.ptr(gg), stream)
+            if prefix:
+                _lib.call('tfep_weight_norm_backward_prefix', _lib.ptr(gW[l]), k_pad[l], _lib.ptr(lin.weight_v.detach()),
+                          _lib.ptr(lin.weight_g.detach()), lin.out_features, lin.in_features, _lib.ptr(row_of_out),
+                          _lib.ptr(in_of_col), _lib.ptr(cut), _lib.ptr(gv), _lib.ptr(gg), stream)
+            else:
+                _lib.call('tfep_weight_norm_backward', _lib.ptr(gW[l]), k_pad[l], _lib.ptr(lin.weight_v.detach()),
+                          _lib.ptr(lin.weight_g.detach()), _lib.ptr(lin.mask), lin.out_features, lin.in_features,
+                          _lib.ptr(row_of_out), _lib.ptr(col_of_in), _lib.ptr(gv), _lib.ptr(gg), stream)
             grads += [gg, gv]
         else:
             gw = torch.empty_like(lin._parameters['weight'])
-            _lib.call('tfep_weight_norm_backward', _lib.ptr(gW[l]), k_pad[l], _lib.ptr(lin._parameters['weight'].detach()),
-                      None, _lib.ptr(lin.mask), lin.out_features, lin.in_features, _lib.ptr(row_of_out),
-                      _lib.ptr(col_of_in), _lib.ptr(gw), None, stream)
+            if prefix:
+                _lib.call('tfep_weight_norm_backward_prefix', _lib.ptr(gW[l]), k_pad[l], _lib.ptr(lin._parameters['weight'].detach()),
+                          None, lin.out_features, lin.in_features, _lib.ptr(row_of_out), _lib.ptr(in_of_col), _lib.ptr(cut),
+                          _lib.ptr(gw), None, stream)
+            else:
+                _lib.call('tfep_weight_norm_backward', _lib.ptr(gW[l]), k_pad[l], _lib.ptr(lin._parameters['weight'].detach()),
+                          None, _lib.ptr(lin.mask), lin.out_features, lin.in_features, _lib.ptr(row_of_out),
+                          _lib.ptr(col_of_in), _lib.ptr(gw), None, stream)
             grads.append(gw)
         if row_of_out is None:
             grads.append(gb[l][:lin.out_features].clone())
