@@ -207,6 +207,9 @@ def main():
         try:
             from tfep_amd.loss import BoltzmannKLDivLoss
             layer, other = flow[0], {}
+            for l in flow:
+                l._conditioner.invalidate_plan()                # packs of the arms above: this arm times one layer on its own
+            torch.cuda.empty_cache()
             flops_layer = 2.0 * nnz_all[0]
             peak_other = PEAK_F16_MFMA_TFLOPS / 3.0 if split else PEAK_FP32_MFMA_TFLOPS
 
