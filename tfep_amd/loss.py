@@ -73,7 +73,7 @@ class _LossFunction(torch.autograd.Function):
         loss, stats = module._value(uB, ldj, lw, uA)
         ctx.module = module
         ctx.stats = stats
-        ctx.loss = loss
+        ctx.loss = loss.detach()          # (not the output tensor itself: output -> grad_fn -> ctx -> output is a reference cycle)
         ctx.save_for_backward(uB, ldj, lw, uA)
         return loss
 
