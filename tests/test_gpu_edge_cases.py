@@ -255,8 +255,8 @@ def test_weight_prepack_on_side_stream_is_transparent_and_never_stale():
         assert torch.equal(got2[0], ref[0]) and torch.equal(got2[1], ref[1])
 
 
-@pytest.mark.parametrize('split', [False, True])
-def test_graph_replay_of_the_blocked_inverse_equals_the_eager_inverse(split):
+@pytest.mark.parametrize('split,lookahead', [(False, False), (True, False), (True, True)])
+def test_graph_replay_of_the_blocked_inverse_equals_the_eager_inverse(split, lookahead):
     """HIP-graph replay of the blocked inverse (block kernel, split-K block GEMMs, and -- ``split`` -- the split-f16
     output-layer GEMM with its bound-based row scales) gives the bits of the eager call, replay after replay, also for a
     second graph captured later.  (Memset nodes broke exactly this once: ``ops.zeros`` / ``fill_zero_kernel``.)"""
@@ -270,6 +270,8 @@ def test_graph_replay_of_the_blocked_inverse_equals_the_eager_inverse(split):
                                 hidden_layers=[1100, 1300], initialize_identity=False) for o in ('ascending', 'descending')]).cuda()
     for layer in flow:
         layer.split_inverse = split
+        if lookahead:                      # side-stream GEMMs of the next block inside the capture (fork / join by events)
+            layer.inverse_lookahead, layer.inverse_rows_per_wave = True, 64
     x = torch.randn(B, D, device='cuda') * 1.3
     y, _ = flow(x)                                   # (grad mode on: like a training script that then samples)
     xe, le = flow.inverse(y)
