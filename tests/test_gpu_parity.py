@@ -501,6 +501,15 @@ def test_cfg4_moebius_size_properties():
         assert float((r - 1).abs().max()) < 1e-4                                  # unit circle preserved through 4 layers
         y2, l2 = flow(x)
         assert torch.equal(y, y2) and torch.equal(l, l2)
+        # at this batch the 3 M-weight conditioners run on split-f16 operands (MADE.split_by_batch), small batches on the
+        # exact-fp32 kernels: equal to the split format's rounding; bit for bit once the arithmetic is pinned
+        assert all(layer._use_split_gemm(B) and not layer._use_split_gemm(200) for layer in flow)
+        for lo, hi in ((0, 200), (77777, 77777 + 131), (B - 64, B)):
+            ys, ls = flow(x[lo:hi].clone())
+            assert float((ys - y[lo:hi]).abs().max()) < 2e-5 and float((ls - l[lo:hi]).abs().max()) < 2e-4, (lo, hi)
+        for layer in flow:
+            layer._conditioner.split_by_batch = False
+        y, l = flow(x)
         for lo, hi in ((0, 200), (77777, 77777 + 131), (B - 64, B)):
             ys, ls = flow(x[lo:hi].clone())
             assert torch.equal(ys, y[lo:hi]) and torch.equal(ls, l[lo:hi]), (lo, hi)

@@ -151,8 +151,9 @@ class MADE(Conditioner):
         #: has been updated in place (``Tensor._version``); default off: re-pack on every forward like the reference's
         #: pre-hook (masked.py:397-398).  SURVEY.md section 8(b) sanctions caches invalidated by parameter version.
         self.cache_packed_weights = False
-        #: Let the choice between split-f16 and exact-fp32 GEMMs also depend on the batch size (see ``split_worthwhile``).
-        self.split_by_batch = os.environ.get('TFEP_SPLIT_BY_BATCH', '0') != '0'
+        #: Let the choice between split-f16 and exact-fp32 GEMMs also depend on the batch size (see ``split_worthwhile``);
+        #: ``TFEP_SPLIT_BY_BATCH=0`` (or False) pins small conditioners to the exact-fp32 kernels at every batch size.
+        self.split_by_batch = os.environ.get('TFEP_SPLIT_BY_BATCH', '1') != '0'
         self._packed_ahead = None      # split weights packed on a side stream for the next forward (prepack_split_async)
 
     # ------------------------------------------------------------------ reference API
@@ -539,11 +540,13 @@ class MADE(Conditioner):
 
     def split_worthwhile(self, batch=None):
         """True when the GEMMs are large enough for the split-f16 kernels to pay for their operand conversions: at
-        least 4 M weights; with ``split_by_batch`` also at least 2^35 weight x row products (a 3 M-weight conditioner at
-        batch 131 072, BASELINE cfg4-ii, is GEMM-bound all the same: 20.2 -> 12.7 ms).  That second rule is opt-in because
-        it makes the ARITHMETIC depend on the batch size: a row pushed through in a small batch would no longer equal, bit
-        for bit, the same row in a large one.  Tiny problems are launch bound either way and keep the exact-fp32 kernel,
-        which needs no conversions."""
+        least 4 M weights; with ``split_by_batch`` (the default) also at least 2^35 weight x row products (a 3 M-weight
+        conditioner at batch 131 072, BASELINE cfg4-ii, is GEMM-bound all the same: 20.2 -> 12.7 ms).  That second rule
+        makes the ARITHMETIC depend on the batch size: a row pushed through in a small batch equals the same row in a
+        large one to the split format's 2^-22, not bit for bit (like the blocked inverse, whose schedule follows the batch
+        size too; the reference's BLAS does not promise batch-independent bits either).  ``split_by_batch = False`` /
+        ``TFEP_SPLIT_BY_BATCH=0`` restores one arithmetic per conditioner.  Tiny problems are launch bound either way and
+        keep the exact-fp32 kernel, which needs no conversions."""
         n = self.__dict__.get('_n_weights')
         if n is None:
             n = self.__dict__['_n_weights'] = sum(lin.mask.numel() for lin in self._linears())

@@ -205,19 +205,19 @@ if 'cfg4' in which:
         dt, (y, _) = timeit(lambda: flow(x), 1, 3)
     # generic path: per layer x (4 KB) in, 3 activations / parameter rows of 1024 floats written and re-read, y out
     hbm = B * 4 * 1024 * 4 * (2 + 2 * 3) / dt / 1e9
-    report('cfg4-ii forward: 4-layer MAF + Moebius(d=2, unit sphere), 512 torsions as 1024 features', B, dt,
+    report('cfg4-ii forward: 4-layer MAF + Moebius(d=2, unit sphere), 512 torsions as 1024 features (split-f16 GEMMs by batch size)', B, dt,
            max_norm_error=float((y.reshape(B, D, 2).norm(dim=2) - 1).abs().max()),
            roofline=dict(bound='hbm', achieved=round(hbm, 1), peak=8000.0, unit='GB/s', frac=round(hbm / 8000.0, 4),
                          note='unfused path: activations and the (B, P D) parameters round-trip HBM; 3.1 M weights'),
            mfma=mfma_roofline(flow, B, dt))
-    for l in flow:                                   # opt-in: split-f16 GEMMs chosen by weights x batch (MADE.split_by_batch)
-        l._conditioner.split_by_batch = True
+    for l in flow:                                   # one arithmetic per conditioner: exact-fp32 kernels at every batch size
+        l._conditioner.split_by_batch = False
     with torch.no_grad():
         dt2, _ = timeit(lambda: flow(x), 1, 3)
-    report('cfg4-ii forward with split_by_batch (split-f16 GEMMs for this 3 M-weight conditioner at batch 131072)', B, dt2,
+    report('cfg4-ii forward with split_by_batch = False (exact-fp32 GEMMs for this 3 M-weight conditioner)', B, dt2,
            mfma=mfma_roofline(flow, B, dt2))
     for l in flow:
-        l._conditioner.split_by_batch = False
+        l._conditioner.split_by_batch = True
     with torch.no_grad():
         dti, (xi, _) = timeit(lambda: flow.inverse(y[:Bi]), 1, 2)
     report('cfg4-ii inverse (blocked; 4 layers x 512 degrees)', Bi, dti,
