@@ -169,24 +169,34 @@ __device__ __forceinline__ void stage_z(float* __restrict__ zs, const float* __r
     // No per-lane predicate on the loads (a predicated `val += load` makes the compiler wait for each load inside its
     // own exec region): lanes past nv re-read value nv - 1 and are dropped at the LDS write; the q blocks are skipped
     // wave-uniformly.
-    for (int sl = 0; sl < slabs; ++sl) {
-        float t[4][8];
+    // two slabs per pass, both fetches in flight before the first add (a slab per pass is a dependent round trip of its own:
+    // the trip count is not known to the compiler); a pass past the last slab re-reads it and adds zero
+    for (int sl0 = 0; sl0 < slabs; sl0 += 2) {
+        float t[2][4][8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q * 8 < nv) {
-                const int v = min(q * 8 + vq, nv - 1);
+        for (int u = 0; u < 2; ++u) {
+            const int sl = min(sl0 + u, slabs - 1);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int row = min(wave_row0 + rq + 8 * i, n_rows_total - 1);      // dead rows shadow the last one
-                    t[q][i] = z[sl * slab_stride + (int64_t)row * ldz + base + v * vstride];
+            for (int q = 0; q < 4; ++q)
+                if (q * 8 < nv) {
+                    const int v = min(q * 8 + vq, nv - 1);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int row = min(wave_row0 + rq + 8 * i, n_rows_total - 1);      // dead rows shadow the last one
+                        t[u][q][i] = z[sl * slab_stride + (int64_t)row * ldz + base + v * vstride];
+                    }
                 }
-            }
+        }
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q * 8 < nv) {
+        for (int u = 0; u < 2; ++u) {
+            const bool on = sl0 + u < slabs;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) val[q][i] += t[q][i];
-            }
+            for (int q = 0; q < 4; ++q)
+                if (q * 8 < nv) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) val[q][i] += on ? t[u][q][i] : 0.f;
+                }
+        }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
