@@ -235,17 +235,21 @@ def main():
             c = torch.rand(D, device=device, generator=gen) * 0.3
             x16 = x[:16384]
 
+            opt = torch.optim.SGD(layer.parameters(), lr=1e-7)
+
             def train_step():
                 for prm in layer.parameters():
                     prm.grad = None
                 yt, lt = layer(x16)
                 BoltzmannKLDivLoss()((c * yt ** 2).sum(dim=1), lt).backward()
+                opt.step()          # parameters change: every step packs its weights again, as a real loop does
             t_t = clock(train_step, 2)
             other['training_step_one_layer'] = {
                 'rows': 16384, 'ms': 1e3 * t_t, 'samples_per_s': 16384 / t_t,
                 'roofline': {'bound': 'mfma', 'achieved': 3.0 * flops_layer * 16384 / t_t / 1e12, 'peak': peak_other,
                              'unit': 'TFLOP/s', 'frac': 3.0 * flops_layer * 16384 / t_t / 1e12 / peak_other,
-                             'note': 'forward + grad_input + grad_weight of every masked linear (activations kept, no recompute)'}}
+                             'note': 'forward + grad_input + grad_weight of every masked linear (activations kept, no recompute) + SGD '
+                                     'update: the weights are packed again on every step'}}
             for prm in layer.parameters():
                 prm.grad = None
             extra['other_paths'] = other

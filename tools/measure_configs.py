@@ -161,21 +161,28 @@ if 'train' in which:
     x = torch.randn(B, D, device=dev).clamp_(-4.9, 4.9)
     c = torch.rand(D, device=dev) * 0.3
 
-    def train_step():
+    opt = torch.optim.SGD(flow.parameters(), lr=1e-7)
+
+    def train_step(update=False):
         for p in flow.parameters():
             p.grad = None
         y, ldj = flow(x)
         loss = BoltzmannKLDivLoss()((c * y ** 2).sum(dim=1), ldj)
         loss.backward()
+        if update:
+            opt.step()                 # parameters change: the next step packs its weights again, as a real loop does
         return loss.detach()
     with torch.no_grad():
         dtf, _ = timeit(lambda: flow(x), 1, 2)
     dt, loss = timeit(train_step, 1, 2)
+    dtu, _ = timeit(lambda: train_step(True), 1, 3)
     report('cfg2 ONE layer forward (no grad)', B, dtf, roofline=mfma_roofline(flow, B, dtf))
     report('cfg2 ONE layer training step (forward + backward of all parameters)', B, dt, loss=float(loss),
            peak_mem_gb=round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
            roofline=mfma_roofline(flow, B, dt, passes=3.0, note='forward + grad_input + grad_weight (the forward keeps its '
                                                                 'activations: no recompute; TFEP_SAVE_ACTIVATIONS_GIB)'))
+    report('cfg2 ONE layer training step + SGD update (weights re-packed every step)', B, dtu,
+           roofline=mfma_roofline(flow, B, dtu, passes=3.0, note='as above, parameters updated between the steps'))
 
 if 'cfg4' in which:
     D, B = 512, 131072
