@@ -423,3 +423,26 @@ def test_fp32_prefix_pack_writes_the_bits_of_the_masked_pack(K, weight_norm):
     assert lib.tfep_masked_weight_prepare_prefix(*args, _lib.ptr(out), N - 1, k_pad, None) != 0                 # too few rows
     assert lib.tfep_masked_weight_prepare_prefix(*args, _lib.ptr(out), N + 3, K - 8, None) != 0                 # rows too short
     torch.cuda.synchronize()
+
+
+def test_transpose_split_equals_split_of_the_transpose():
+    """``tfep_transpose_split`` (one pass, the per-tensor scale taken from the split of the matrix itself) writes the bits
+    of ``tfep_transpose`` followed by ``tfep_split_rows(per_tensor)``; ragged tiles, a padded row stride; misuse rejected."""
+    from tfep_amd import _lib, ops
+    from tfep_amd.nn.flows._backward import _transpose
+    torch.manual_seed(4)
+    R, C, ld = 224, 333, 352                      # R a multiple of 32 (split rows); C and the strides not multiples of the 64 x 64 tile
+    src = torch.zeros(R, ld, device='cuda')
+    src[:, :C] = torch.randn(R, C, device='cuda') * torch.logspace(-3, 2, C, device='cuda')
+    ws, w_inv = ops.split_rows(src[:, :C], ld, per_tensor=True)
+    wt = _transpose(src, R, C, torch.zeros(C, R, device='cuda'))
+    ref, ref_inv = ops.split_rows(wt, R, per_tensor=True)
+    assert float(ref_inv[0]) == float(w_inv[0])
+    out = torch.full((C, R), 7.0, device='cuda')
+    lib = _lib.load()
+    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R, _lib.ptr(w_inv), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R - 4, C, _lib.ptr(out), R, _lib.ptr(w_inv), None) != 0      # R % 8
+    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R - 8, _lib.ptr(w_inv), None) != 0      # rows too short
+    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R, None, None) != 0

@@ -388,14 +388,21 @@ def _weights(layer, dev):
             w, b = made._pack_layer(mplan, l, lin, n_rows=n_pad[l])
         W.append(w)
         bias.append(b)
-        wt = torch.zeros(k_pad[l], n_pad[l], **f32)
-        WT.append(_transpose(w, n_pad[l], k_pad[l], wt))
+        WT.append(None if split else _transpose(w, n_pad[l], k_pad[l], torch.zeros(k_pad[l], n_pad[l], **f32)))
     # Split-f16 operands for every GEMM of the step (the same fp32-equivalent kernel as the forward pass): the packed
     # weights and their transposes are converted once, activations / gradients per use.
     Ws = [ops.split_rows(w, w.shape[1], per_tensor=True) for w in W] if split else [None] * (L + 1)
-    WTs = [ops.split_rows(w, w.shape[1], per_tensor=True) for w in WT] if split else [None] * (L + 1)
     if split:
+        # the transposes as split rows in one pass each (a matrix and its transpose share the per-tensor scale)
+        WTs = []
+        for l in range(L + 1):
+            wts_l = torch.empty(k_pad[l], n_pad[l], **f32)
+            _lib.call('tfep_transpose_split', _lib.ptr(W[l]), W[l].shape[1], n_pad[l], k_pad[l], _lib.ptr(wts_l), n_pad[l],
+                      _lib.ptr(Ws[l][1]), _lib.stream_of(W[l]))
+            WTs.append((wts_l, Ws[l][1]))
         WT = [None] * (L + 1)        # (W itself lives in the conditioner's pack buffers either way)
+    else:
+        WTs = [None] * (L + 1)
     wts = dict(versions=versions, split=split, W=W, WT=WT, bias=bias, Ws=Ws, WTs=WTs)
     if _SAVE_BYTES > 0 and not capturing:
         layer._dev[key] = wts
