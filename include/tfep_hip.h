@@ -404,12 +404,17 @@ int tfep_inverse_block(const tfep_inverse_block_desc* desc, void* stream);
 /* out (C x R, row stride ld_out >= R) = in^T for in (R x C, row stride ld_in).  Layout helper of the
  * backward GEMMs: grad_input = g W needs W^T K-contiguous, grad_weight = g^T x needs g^T and x^T. */
 int tfep_transpose(const float* in, int64_t ld_in, int R, int C, float* out, int64_t ld_out, void* stream);
-/* out (C rows of split-f16 groups, row stride ld_out floats >= R) = tfep_split_rows(in^T) with the per-tensor scale that
- * tfep_split_rows(in, per_tensor) already found (inv_scale[0] = 1 / scale: a matrix and its transpose share their
- * maximum): one pass instead of tfep_transpose + tfep_split_rows.  R a multiple of 8; columns of `out` past R are not
- * written (allocate it zeroed when ld_out > R).  Same bits as the two-step form. */
-int tfep_transpose_split(const float* in, int64_t ld_in, int R, int C, void* out_split, int64_t ld_out,
-                         const float* inv_scale, void* stream);
+/* out (C rows of split-f16 groups, row stride ld_out floats >= R_pad) = tfep_split_rows(in^T) in one pass (instead of
+ * tfep_transpose + tfep_split_rows); rows r >= R of `in` read as zero, groups up to R_pad (a multiple of 8) written.
+ *   mode 0: the per-tensor scale is known, scale_src[0] = 1 / scale (a matrix and its transpose share their maximum);
+ *   mode 1: per-tensor scale computed here: inv_scale_out[0] = 1 / scale (inv_scale_out: 2 floats, [1] scratch);
+ *   mode 2: one scale per output row from scale_src[c] = max_r |in[r, c]| (tfep_column_sums_absmax):
+ *           inv_scale_out[c] = 1 / scale_c.
+ * Same bits as the two-step form. */
+int tfep_transpose_split(const float* in, int64_t ld_in, int R, int C, void* out_split, int64_t ld_out, int R_pad, int mode,
+                         const float* scale_src, float* inv_scale_out, void* stream);
+/* tfep_column_sums that also returns absmax[c] = max_r |in[r, c]| from the same pass. */
+int tfep_column_sums_absmax(const float* in, int64_t ld, int R, int C, float* out, int accumulate, float* absmax, void* stream);
 /* out[c] (+)= sum_r in[r, c]      grad_bias = grad_output.sum(0)  (masked.py:299-300) */
 int tfep_column_sums(const float* in, int64_t ld, int R, int C, float* out, int accumulate, void* stream);
 /* out[b, c] += in[b, c] */

@@ -440,9 +440,28 @@ def test_transpose_split_equals_split_of_the_transpose():
     assert float(ref_inv[0]) == float(w_inv[0])
     out = torch.full((C, R), 7.0, device='cuda')
     lib = _lib.load()
-    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R, _lib.ptr(w_inv), None) == 0
+    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R, R, 0, _lib.ptr(w_inv), None, None) == 0
     torch.cuda.synchronize()
     assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
-    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R - 4, C, _lib.ptr(out), R, _lib.ptr(w_inv), None) != 0      # R % 8
-    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R - 8, _lib.ptr(w_inv), None) != 0      # rows too short
-    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R, None, None) != 0
+    # mode 1: the per-tensor scale computed on the way
+    out1, inv1 = torch.full((C, R), 7.0, device='cuda'), torch.zeros(2, device='cuda')
+    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out1), R, R, 1, None, _lib.ptr(inv1), None) == 0
+    assert torch.equal(out1.view(torch.int32), ref.view(torch.int32)) and float(inv1[0]) == float(ref_inv[0])
+    # mode 2: one scale per output row from the column maxima of the same pass as the column sums; fewer valid rows than the
+    # padded width (rows past R read as zero)
+    Rv, Rp = 203, 224
+    sums, cmax = torch.zeros(C, device='cuda'), torch.empty(C, device='cuda')
+    assert lib.tfep_column_sums_absmax(_lib.ptr(src), ld, Rv, C, _lib.ptr(sums), 1, _lib.ptr(cmax), None) == 0
+    assert torch.equal(cmax, src[:Rv, :C].abs().amax(dim=0))
+    assert torch.allclose(sums, src[:Rv, :C].double().sum(dim=0).float(), rtol=1e-6, atol=1e-6)
+    wt2 = _transpose(src, Rv, C, torch.zeros(C, Rp, device='cuda'))
+    ref2, ref2_inv = ops.split_rows(wt2, Rp)
+    out2, inv2 = torch.full((C, Rp), 7.0, device='cuda'), torch.zeros(C, device='cuda')
+    assert lib.tfep_transpose_split(_lib.ptr(src), ld, Rv, C, _lib.ptr(out2), Rp, Rp, 2, _lib.ptr(cmax), _lib.ptr(inv2), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out2.view(torch.int32), ref2.view(torch.int32)) and torch.equal(inv2, ref2_inv)
+    # misuse
+    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R, R - 4, 0, _lib.ptr(w_inv), None, None) != 0   # R_pad < R
+    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R - 8, R, 0, _lib.ptr(w_inv), None, None) != 0   # rows too short
+    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R, R, 0, None, None, None) != 0
+    assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R, R, 3, _lib.ptr(w_inv), None, None) != 0

@@ -33,43 +33,6 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict_
 }
 
 // out[c] (+)= sum_r in[r, c]   (bias gradient, masked.py:299-300)
-// out (C x R_pad split rows: per 8 consecutive r  [8 x fp16 hi][8 x fp16 lo]) = split(in^T) for in (R x C fp32), with a
-// scale that is already known (*inv_scale_in = 1 / s: the transposed matrix has the maximum of the matrix itself).  One
-// pass instead of transpose + absmax + split_rows over a 4.5 GB weight.  64 x 64 tiles; R a multiple of 8.
-typedef _Float16 tsp_f16x8 __attribute__((ext_vector_type(8)));
-__global__ void __launch_bounds__(256) transpose_split_kernel(const float* __restrict__ in, int64_t ld_in, int R, int C,
-                                                              uint4* __restrict__ out, int64_t ld_out,
-                                                              const float* __restrict__ inv_scale_in) {
-    __shared__ float tile[64][65];
-    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
-#pragma unroll
-    for (int i = 0; i < 64; i += 4) {
-        const int r = r0 + ty + i, c = c0 + tx;
-        tile[ty + i][tx] = (r < R && c < C) ? in[(int64_t)r * ld_in + c] : 0.f;
-    }
-    __syncthreads();
-    const float s = 1.0f / inv_scale_in[0];                      // a power of two: exact
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int item = threadIdx.x + 256 * p;                  // 64 output rows x 8 groups of 8
-        const int cc = item & 63, g = item >> 6;
-        const int c = c0 + cc, rg = r0 + 8 * g;
-        if (c < C && rg < R) {
-            tsp_f16x8 hi, lo;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float v = tile[8 * g + k][cc] * s;
-                const _Float16 h = (_Float16)v;
-                hi[k] = h;
-                lo[k] = (_Float16)(v - (float)h);
-            }
-            uint4* dr = out + (int64_t)c * (ld_out / 4) + (rg >> 3) * 2;
-            dr[0] = *reinterpret_cast<uint4*>(&hi);
-            dr[1] = *reinterpret_cast<uint4*>(&lo);
-        }
-    }
-}
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ in, int64_t ld, int R, int C,
                                                      float* __restrict__ out, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -84,6 +47,32 @@ __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ i
     for (; r < R; ++r) p[0] += (double)in[(int64_t)r * ld + c];
     const double s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     out[c] = accumulate ? (float)((double)out[c] + s) : (float)s;
+}
+
+// The same pass also returning max_r |in[r, c]| (the row scale of the transposed split operand of grad_weight).
+__global__ void __launch_bounds__(256) colsum_absmax_kernel(const float* __restrict__ in, int64_t ld, int R, int C,
+                                                            float* __restrict__ out, int accumulate, float* __restrict__ amax) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double p[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    float m[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int r = 0;
+    for (; r + 8 <= R; r += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = in[(int64_t)(r + j) * ld + c];
+            p[j] += (double)v;
+            m[j] = fmaxf(m[j], fabsf(v));
+        }
+    }
+    for (; r < R; ++r) {
+        const float v = in[(int64_t)r * ld + c];
+        p[0] += (double)v;
+        m[0] = fmaxf(m[0], fabsf(v));
+    }
+    const double s = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));       // colsum_kernel's order
+    out[c] = accumulate ? (float)((double)out[c] + s) : (float)s;
+    amax[c] = fmaxf(fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])), fmaxf(fmaxf(m[4], m[5]), fmaxf(m[6], m[7])));
 }
 
 // ---------------------------------------------------------------- affine backward (affine.py:321-323)
@@ -659,16 +648,12 @@ int tfep_transpose(const float* in, int64_t ld_in, int R, int C, float* out, int
     return check_launch("transpose_kernel");
 }
 
-int tfep_transpose_split(const float* in, int64_t ld_in, int R, int C, void* out_split, int64_t ld_out,
-                         const float* inv_scale, void* stream) {
-    TFEP_REQUIRE(R >= 0 && C >= 0 && ld_in >= C, "transpose_split: bad sizes");
-    if (R == 0 || C == 0) return TFEP_OK;
-    TFEP_REQUIRE(in && out_split && inv_scale, "transpose_split: NULL pointer");
-    TFEP_REQUIRE(R % 8 == 0 && ld_out >= R && ld_out % 4 == 0 && ((uintptr_t)out_split & 15) == 0,
-                 "transpose_split: R must be a multiple of 8, output rows 16-byte aligned and at least R wide");
-    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
-    transpose_split_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(in, ld_in, R, C, (uint4*)out_split, ld_out, inv_scale);
-    return check_launch("transpose_split_kernel");
+int tfep_column_sums_absmax(const float* in, int64_t ld, int R, int C, float* out, int accumulate, float* absmax, void* stream) {
+    TFEP_REQUIRE(R >= 0 && C >= 0, "column_sums_absmax: bad sizes");
+    if (C == 0) return TFEP_OK;
+    TFEP_REQUIRE(out && absmax && (in || R == 0), "column_sums_absmax: NULL pointer");
+    colsum_absmax_kernel<<<(unsigned)((C + 255) / 256), 256, 0, (hipStream_t)stream>>>(in, ld, R, C, out, accumulate, absmax);
+    return check_launch("colsum_absmax_kernel");
 }
 
 int tfep_column_sums(const float* in, int64_t ld, int R, int C, float* out, int accumulate, void* stream) {

@@ -148,6 +148,58 @@ __global__ void __launch_bounds__(256) split_rows_kernel(const float* __restrict
     }
 }
 
+// out (C rows of split groups: per 8 consecutive r  [8 x fp16 hi][8 x fp16 lo], groups up to R_pad) = split(in^T) for
+// in (R x C fp32), rows r >= R read as zero.  One pass instead of transpose + absmax + split_rows.  The scale:
+//   mode 0: *scale_src = 1 / s is known (a matrix and its transpose share the per-tensor maximum: the weights);
+//   mode 1: per tensor from *max_bits (absmax_kernel ran on `in`): inv_scale_out[0] = 1 / s;
+//   mode 2: per output row from scale_src[c] = max_r |in[r, c]| (colsum_absmax_kernel): inv_scale_out[c] = 1 / s_c.
+// 64 x 64 tiles; R_pad a multiple of 8.
+__global__ void __launch_bounds__(256) transpose_split_kernel(const float* __restrict__ in, int64_t ld_in, int R, int C,
+                                                              uint4* __restrict__ out, int64_t ld_out, int R_pad, int mode,
+                                                              const float* __restrict__ scale_src,
+                                                              const uint32_t* __restrict__ max_bits,
+                                                              float* __restrict__ inv_scale_out) {
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;      // 64 x 4
+#pragma unroll
+    for (int i = 0; i < 64; i += 4) {
+        const int r = r0 + ty + i, c = c0 + tx;
+        tile[ty + i][tx] = (r < R && c < C) ? in[(int64_t)r * ld_in + c] : 0.f;
+    }
+    __syncthreads();
+    float s_all = 1.0f;
+    if (mode == 0) s_all = 1.0f / scale_src[0];                  // a power of two: exact
+    if (mode == 1) {
+        s_all = pow2_scale_for(__uint_as_float(*max_bits));
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) inv_scale_out[0] = 1.0f / s_all;
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int item = threadIdx.x + 256 * p;                  // 64 output rows x 8 groups of 8
+        const int cc = item & 63, g = item >> 6;
+        const int c = c0 + cc, rg = r0 + 8 * g;
+        if (c < C && rg < R_pad) {
+            float s = s_all;
+            if (mode == 2) {
+                s = pow2_scale_for(scale_src[c]);
+                if (blockIdx.y == 0 && g == 0) inv_scale_out[c] = 1.0f / s;
+            }
+            f16x8 hi, lo;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = tile[8 * g + k][cc] * s;
+                const _Float16 h = (_Float16)v;
+                hi[k] = h;
+                lo[k] = (_Float16)(v - (float)h);
+            }
+            uint4* dr = out + (int64_t)c * (ld_out / 4) + (rg >> 3) * 2;
+            dr[0] = *reinterpret_cast<uint4*>(&hi);
+            dr[1] = *reinterpret_cast<uint4*>(&lo);
+        }
+    }
+}
+
 // |.| reductions for row-scale bounds, one wave per row.  mode 0: out[row] = max_k |src[row, k]|;  mode 1: out[0] =
 // max_row sum_k |src[row, k]| (the infinity norm; out[0] cleared by zero_u32_kernel first; non-negative floats order
 // like their bit patterns, so the maximum is an integer atomicMax -- exact and order-independent).
@@ -857,6 +909,30 @@ using namespace tfep;
 extern "C" {
 
 int tfep_split_tile_k(void) { return SBK; }
+
+int tfep_transpose_split(const float* in, int64_t ld_in, int R, int C, void* out_split, int64_t ld_out, int R_pad, int mode,
+                         const float* scale_src, float* inv_scale_out, void* stream) {
+    TFEP_REQUIRE(R >= 0 && C >= 0 && ld_in >= C && R_pad >= R, "transpose_split: bad sizes");
+    if (R_pad == 0 || C == 0) return TFEP_OK;
+    TFEP_REQUIRE(in && out_split, "transpose_split: NULL pointer");
+    TFEP_REQUIRE(mode >= 0 && mode <= 2, "transpose_split: mode must be 0 (known scale), 1 (per tensor) or 2 (per output row)");
+    TFEP_REQUIRE((mode == 1 || scale_src) && (mode == 0 || inv_scale_out), "transpose_split: NULL scale pointer");
+    TFEP_REQUIRE(R_pad % 8 == 0 && ld_out >= R_pad && ld_out % 4 == 0 && ((uintptr_t)out_split & 15) == 0,
+                 "transpose_split: R_pad must be a multiple of 8, output rows 16-byte aligned and at least R_pad wide");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* max_bits = nullptr;
+    if (mode == 1) {                                   // inv_scale_out[1] is scratch for the tensor maximum (as bits)
+        max_bits = reinterpret_cast<uint32_t*>(inv_scale_out + 1);
+        zero_u32_kernel<<<1, 1, 0, s>>>(max_bits);
+        if (R > 0) absmax_kernel<<<(unsigned)((R + 3) / 4), 256, 0, s>>>(in, ld_in, R, C, max_bits);
+    }
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R_pad + 63) / 64));
+    transpose_split_kernel<<<grid, 256, 0, s>>>(in, ld_in, R, C, (uint4*)out_split, ld_out, R_pad, mode, scale_src, max_bits,
+                                                inv_scale_out);
+    return check_launch("transpose_split_kernel");
+}
+
+
 
 int tfep_split_rows(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int64_t ld_dst,
                     int64_t cols_padded, float* inv_scale, int per_tensor, void* stream) {

@@ -265,12 +265,12 @@ class UnsupportedBackward(torch.autograd.Function):
 
 
 def _gemm(x, w, y, B, N, n_rows_w, bias=None, k_ranges=None, act=0, accumulate=0, elu_grad_of=None, tile_live=None,
-          split=False, w_split=None):
-    """``split``: run on split-f16 operands (x converted here with one scale per row; ``w_split`` = already converted
-    ``(rows, inv_scale)`` of w, else w is converted here with one scale for the matrix)."""
+          split=False, w_split=None, x_split=None):
+    """``split``: run on split-f16 operands (x converted here with one scale per row; ``w_split`` / ``x_split`` = already
+    converted ``(rows, inv_scale)`` of w / x, else w is converted here with one scale for the matrix)."""
     d = _lib.GemmDesc()
     if split:
-        xs, x_inv = ops.split_rows(x, x.shape[1])
+        xs, x_inv = x_split if x_split is not None else ops.split_rows(x, x.shape[1])
         ws, w_inv = w_split if w_split is not None else ops.split_rows(w, w.shape[1], per_tensor=True)
         d.split, d.x_inv_scale, d.w_inv_scale = 1, x_inv.data_ptr(), w_inv.data_ptr()
         x, w = xs, ws
@@ -398,7 +398,7 @@ def _weights(layer, dev):
         for l in range(L + 1):
             wts_l = torch.empty(k_pad[l], n_pad[l], **f32)
             _lib.call('tfep_transpose_split', _lib.ptr(W[l]), W[l].shape[1], n_pad[l], k_pad[l], _lib.ptr(wts_l), n_pad[l],
-                      _lib.ptr(Ws[l][1]), _lib.stream_of(W[l]))
+                      n_pad[l], 0, _lib.ptr(Ws[l][1]), None, _lib.stream_of(W[l]))
             WTs.append((wts_l, Ws[l][1]))
         WT = [None] * (L + 1)        # (W itself lives in the conditioner's pack buffers either way)
     else:
@@ -561,12 +561,27 @@ def layer_backward(layer, x, gy, gldj, saved=None):
         # ---- masked linears, last to first.  g = gradient w.r.t. the layer's pre-activation output.
         g = gtheta
         for l in range(L, -1, -1):
-            _lib.call('tfep_column_sums', _lib.ptr(g), g.shape[1], Bc, n_pad[l], _lib.ptr(gb[l]), 1, stream)
-            gT = _transpose(g, Bc, n_pad[l], torch.zeros(n_pad[l], Bc_pad, **f32))
-            hT = _transpose(h[l], Bc, k_pad[l], torch.zeros(k_pad[l], Bc_pad, **f32))
-            # grad_weight (packed) += g^T h   [rows n, cols k], masked tiles skipped
-            _gemm(gT, hT, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=1, tile_live=bplan['live'][l], split=split)
-            del gT, hT
+            if split:
+                # bias gradient and the row scales of g^T from one pass over g; g^T and h^T straight to split rows (no fp32
+                # transposes: the 4.9 GB gradient of the transformer parameters went through HBM nine times before)
+                cmax = torch.empty(n_pad[l], **f32)
+                _lib.call('tfep_column_sums_absmax', _lib.ptr(g), g.shape[1], Bc, n_pad[l], _lib.ptr(gb[l]), 1, _lib.ptr(cmax), stream)
+                gTs, gT_inv = torch.empty(n_pad[l], Bc_pad, **f32), torch.empty(n_pad[l], **f32)
+                _lib.call('tfep_transpose_split', _lib.ptr(g), g.shape[1], Bc, n_pad[l], _lib.ptr(gTs), Bc_pad, Bc_pad, 2,
+                          _lib.ptr(cmax), _lib.ptr(gT_inv), stream)
+                hTs, hT_inv = torch.empty(k_pad[l], Bc_pad, **f32), torch.empty(2, **f32)
+                _lib.call('tfep_transpose_split', _lib.ptr(h[l]), h[l].shape[1], Bc, k_pad[l], _lib.ptr(hTs), Bc_pad, Bc_pad, 1,
+                          None, _lib.ptr(hT_inv), stream)
+                # grad_weight (packed) += g^T h   [rows n, cols k], masked tiles skipped
+                _gemm(gTs, hTs, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=1, tile_live=bplan['live'][l], split=True,
+                      x_split=(gTs, gT_inv), w_split=(hTs, hT_inv))
+                del gTs, hTs, cmax
+            else:
+                _lib.call('tfep_column_sums', _lib.ptr(g), g.shape[1], Bc, n_pad[l], _lib.ptr(gb[l]), 1, stream)
+                gT = _transpose(g, Bc, n_pad[l], torch.zeros(n_pad[l], Bc_pad, **f32))
+                hT = _transpose(h[l], Bc, k_pad[l], torch.zeros(k_pad[l], Bc_pad, **f32))
+                _gemm(gT, hT, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=1, tile_live=bplan['live'][l])
+                del gT, hT
             # grad_input = g W  (x ELU'(h) for hidden inputs)
             gin = torch.empty(Bc, k_pad[l], **f32)
             _gemm(g, WT[l], gin, Bc, k_pad[l], k_pad[l], k_ranges=bplan['dx_ranges'][l],
