@@ -401,7 +401,7 @@ def test_activation_saving_forward_equals_the_recomputing_one(monkeypatch, split
     from tfep_amd.nn.flows import MAF, _backward as bw
     from tfep_amd.nn.transformers import AffineTransformer, NeuralSplineTransformer
     torch.manual_seed(5)
-    D, B = 66, 700
+    D, B = 66, 2200                    # (above the 1 MiB of transformer parameters from which activations are kept)
     if kind == 'affine':
         deg, emb, tr = generate_degrees(D, 'descending'), None, AffineTransformer()
     elif kind == 'spline':

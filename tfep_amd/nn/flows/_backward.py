@@ -441,8 +441,8 @@ def saves_activations_at(layer, batch):
         return False
     lins = layer._conditioner._linears()
     need = int(batch) * 4 * (lins[-1].out_features + sum(lin.out_features for lin in lins[:-1]))
-    if not 0 < int(batch) * lins[-1].out_features * 4 <= _SAVE_BYTES:
-        return False
+    if not (1 << 20) <= int(batch) * lins[-1].out_features * 4 <= _SAVE_BYTES:
+        return False                 # (below a MiB of parameters the step is launch bound: the fused forward + recompute wins)
     # ... and only a modest share of what the device still has (a deep flow keeps this for every layer until its backward
     # has run; the weight packings and gradient buffers of the backward need room too): otherwise recompute
     dev = lins[-1].bias.device
