@@ -441,3 +441,65 @@ def test_block_kernel_row_layouts_agree(kind):
     assert _lib.load().tfep_inverse_block(ctypes.byref(d), None) != 0
     assert _lib.load().tfep_inverse_block_lds_bytes_rows(2, 100, 16, 32) == -1
     assert 0 < _lib.load().tfep_inverse_block_lds_bytes_rows(2, 100, 16, 16) < _lib.load().tfep_inverse_block_lds_bytes_rows(2, 100, 16, 64)
+
+
+@pytest.mark.parametrize('kind', ['affine', 'spline+periodic'])
+def test_graphed_training_step_equals_eager_steps(kind):
+    """``GraphedTrainingStep``: forward, loss, backward and the optimiser update of a small flow captured into one HIP
+    graph.  Replays on a sequence of batches give the losses and the parameters of the same steps run eagerly, bit for
+    bit (the eager arm recomputes its activations like the captured one), and keep doing so after the parameters were
+    changed from outside (the graph reads the current values)."""
+    import copy
+    from tfep_amd.graphs import GraphedTrainingStep
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.embeddings import PeriodicEmbedding
+    from tfep_amd.nn.flows import MAF, SequentialFlow, _backward as bw
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    torch.manual_seed(17)
+    D, B = 30, 260
+    layers = []
+    for o in ('ascending', 'descending'):
+        if kind == 'affine':
+            layers.append(MAF(generate_degrees(D, o), initialize_identity=False))
+        else:
+            layers.append(MAF(generate_degrees(D, o), transformer=NeuralSplineTransformer(torch.full((D,), -4.0), torch.full((D,), 4.0), 6),
+                              embedding=PeriodicEmbedding(D, limits=[-4.0, 4.0], periodic_indices=[1, 7, 20]),
+                              initialize_identity=False))
+    flow = SequentialFlow(*layers).cuda()
+    twin = copy.deepcopy(flow)
+    xs = [(torch.rand(B, D, device='cuda') * 2 - 1) * 3.5 for _ in range(6)]
+    loss_mod = BoltzmannKLDivLoss()
+    c = torch.linspace(0.1, 0.5, D, device='cuda')
+
+    def loss_fn(y, ldj):
+        return loss_mod((c * y ** 2).sum(dim=1), ldj)
+    opt, opt_twin = torch.optim.SGD(flow.parameters(), lr=1e-3, momentum=0.9), torch.optim.SGD(twin.parameters(), lr=1e-3, momentum=0.9)
+    step = GraphedTrainingStep(twin, loss_fn, opt_twin, B, D)
+    # the capture's warm-up took optimiser steps: bring both arms to the same parameters and momentum buffers
+    twin.load_state_dict(flow.state_dict())
+    for st in opt_twin.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+    save = bw._SAVE_BYTES
+    bw._SAVE_BYTES = 0                                  # (inside a capture the layers recompute their activations)
+    try:
+        for i, x in enumerate(xs):
+            opt.zero_grad(set_to_none=True)
+            loss = loss_fn(*flow(x))
+            loss.backward()
+            opt.step()
+            got = step(x)
+            assert float(got) == float(loss.detach()), i
+            if i == 2:                                  # parameters changed from outside, both arms alike
+                with torch.no_grad():
+                    for p, q in zip(flow.parameters(), twin.parameters()):
+                        p.mul_(1.01)
+                        q.mul_(1.01)
+    finally:
+        bw._SAVE_BYTES = save
+    for (n, p), q in zip(flow.named_parameters(), twin.parameters()):
+        assert torch.equal(p, q), n
+    with pytest.raises(ValueError):
+        step(xs[0][:10])

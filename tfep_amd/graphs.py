@@ -37,3 +37,52 @@ class GraphedFlow:
         self.static_in.copy_(x)
         self.graph.replay()
         return self.static_out.clone(), self.static_ldj.clone()
+
+
+class GraphedTrainingStep:
+    """One training step -- ``flow(x)``, ``loss_fn(y, log_det_J)``, ``backward()``, ``optimizer.step()`` -- captured into
+    a HIP graph for a fixed input shape and replayed with one host call.
+
+    A cfg1-sized step (2 MAF layers on 66 features, batch 1024) is ~100 kernel launches whose host side costs 4 ms while
+    the kernels themselves take a fraction of that; replayed as a graph the step runs at kernel speed.  Everything inside
+    is launched on the capturing stream through the C ABI or by torch ops, reads the CURRENT parameters (the optimiser
+    updates them in place) and writes the gradients into the same ``.grad`` tensors at every replay.
+
+    ``step(x)`` returns the loss of that step (a tensor that the next call overwrites).  ``loss_fn`` must be built from
+    capturable ops (no ``.item()`` / host round trips); the optimiser must be capturable (SGD; Adam with
+    ``capturable=True``).  Activations are not kept across the forward inside a capture (the layer recomputes them), the
+    weights are packed on every replay."""
+
+    def __init__(self, flow, loss_fn, optimizer, batch_size, n_features, device=None, warmup=3):
+        self.flow, self.loss_fn, self.optimizer = flow, loss_fn, optimizer
+        device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.static_in = torch.zeros(batch_size, n_features, dtype=torch.float32, device=device)
+        # Warm-up off the default stream (plans, kernel attributes, optimiser state), as torch's whole-network capture asks
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._eager(self.static_in)
+        torch.cuda.current_stream(device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)          # the capture allocates the gradients in the graph's own pool
+        with torch.cuda.graph(self.graph):
+            y, ldj = flow(self.static_in)
+            self.static_loss = loss_fn(y, ldj)
+            self.static_loss.backward()
+            optimizer.step()
+
+    def _eager(self, x):
+        self.optimizer.zero_grad(set_to_none=True)
+        y, ldj = self.flow(x)
+        loss = self.loss_fn(y, ldj)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, x):
+        if x.shape != self.static_in.shape:
+            raise ValueError(f'GraphedTrainingStep was captured for shape {tuple(self.static_in.shape)}, got {tuple(x.shape)}')
+        self.static_in.copy_(x)
+        self.graph.replay()
+        return self.static_loss.detach()

@@ -284,6 +284,11 @@ def _gemm(x, w, y, B, N, n_rows_w, bias=None, k_ranges=None, act=0, accumulate=0
     if elu_grad_of is not None:
         d.elu_grad_of, d.ld_elu_grad_of = elu_grad_of.data_ptr(), elu_grad_of.shape[1]
     d.tile_live = tile_live.data_ptr() if tile_live is not None else None
+    if not split and ops.few_wide_tiles(B, N):
+        # a cfg1-sized product is one or two 256 x 256 tiles: one workgroup walks the whole k range while 255 CUs idle
+        # (130 us for a 224 x 224 x 1024 grad_weight).  The 32-column tile spreads it over the columns; the mask tables are
+        # per 256-column tile and only save work (masked weights are zeros, masked gradients are dropped later): dense.
+        d.tile_n, d.k_ranges, d.tile_live = ops.narrow_tile_n(), None, None
     _lib.call('tfep_masked_linear_gemm', ctypes.byref(d), _lib.stream_of(x))
     return y
 
@@ -388,7 +393,7 @@ def _weights(layer, dev):
             w, b = made._pack_layer(mplan, l, lin, n_rows=n_pad[l])
         W.append(w)
         bias.append(b)
-        WT.append(None if split else _transpose(w, n_pad[l], k_pad[l], torch.zeros(k_pad[l], n_pad[l], **f32)))
+        WT.append(None if split else _transpose(w, n_pad[l], k_pad[l], ops.zeros(k_pad[l], n_pad[l], **f32)))
     # Split-f16 operands for every GEMM of the step (the same fp32-equivalent kernel as the forward pass): the packed
     # weights and their transposes are converted once, activations / gradients per use.
     Ws = [ops.split_rows(w, w.shape[1], per_tensor=True) for w in W] if split else [None] * (L + 1)
@@ -510,8 +515,9 @@ def layer_backward(layer, x, gy, gldj, saved=None):
     wts = _weights(layer, dev)
     W, WT, bias, Ws, WTs, split = wts['W'], wts['WT'], wts['bias'], wts['Ws'], wts['WTs'], wts['split']
     sorted_out = bplan['sorted_out']
-    gW = [torch.zeros(n_pad[l], k_pad[l], **f32) for l in range(L + 1)]
-    gb = [torch.zeros(n_pad[l], **f32) for l in range(L + 1)]
+    # (ops.zeros: fill kernels, not memsets -- a captured training step replays them; see ops.zeros)
+    gW = [ops.zeros(n_pad[l], k_pad[l], **f32) for l in range(L + 1)]
+    gb = [ops.zeros(n_pad[l], **f32) for l in range(L + 1)]
     gx = torch.empty(B, D, **f32)
     emb_generic = emb is not None and type(emb) is not PeriodicEmbedding
     emb_params = _embedding_params(layer)
@@ -544,7 +550,7 @@ def layer_backward(layer, x, gy, gldj, saved=None):
             x_tr, gy_tr = ops.gather_columns(xc, tables['tr']), ops.gather_columns(gyc, tables['tr'])
         else:
             x_tr, gy_tr = xc, gyc
-        gtheta = torch.zeros(Bc, n_out_pad, **f32)
+        gtheta = ops.zeros(Bc, n_out_pad, **f32)
         gx_dir = torch.empty(Bc, n_tr, **f32)
         x_tr, gy_tr = x_tr.contiguous(), gy_tr.contiguous()
         if sorted_out:
@@ -578,8 +584,8 @@ def layer_backward(layer, x, gy, gldj, saved=None):
                 del gTs, hTs, cmax
             else:
                 _lib.call('tfep_column_sums', _lib.ptr(g), g.shape[1], Bc, n_pad[l], _lib.ptr(gb[l]), 1, stream)
-                gT = _transpose(g, Bc, n_pad[l], torch.zeros(n_pad[l], Bc_pad, **f32))
-                hT = _transpose(h[l], Bc, k_pad[l], torch.zeros(k_pad[l], Bc_pad, **f32))
+                gT = _transpose(g, Bc, n_pad[l], ops.zeros(n_pad[l], Bc_pad, **f32))
+                hT = _transpose(h[l], Bc, k_pad[l], ops.zeros(k_pad[l], Bc_pad, **f32))
                 _gemm(gT, hT, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=1, tile_live=bplan['live'][l])
                 del gT, hT
             # grad_input = g W  (x ELU'(h) for hidden inputs)
@@ -598,7 +604,7 @@ def layer_backward(layer, x, gy, gldj, saved=None):
             del cin_graph, x_emb
         elif emb is not None:
             per, non = emb.device_indices(dev)
-            gxc = torch.zeros(Bc, D, **f32)
+            gxc = ops.zeros(Bc, D, **f32)
             _lib.call('tfep_periodic_embedding_backward', _lib.ptr(xc), xc.shape[1] if Bc > 1 else D, _lib.ptr(per),
                       per.numel(), _lib.ptr(non), non.numel(), *emb.host_limits(),
                       _lib.ptr(g), g.shape[1], _lib.ptr(gxc), D, Bc, stream)

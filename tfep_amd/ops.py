@@ -209,16 +209,31 @@ def heavy_first_order(k_ranges):
     return order.to(device=k_ranges.device, dtype=torch.int32)
 
 
+def narrow_tile_n():
+    return _lib.load().tfep_masked_linear_narrow_tile_n()
+
+
+def few_wide_tiles(B, N):
+    """True when a (B x N) product is at most 8 of the 256 x 256 tiles but more than one 32-column tile wide: small enough
+    that one workgroup per wide tile leaves the chip idle, see ``masked_linear_packed``."""
+    tm, tn, _ = tile_sizes()
+    return ((B + tm - 1) // tm) * ((N + tn - 1) // tn) <= 8 and N > narrow_tile_n()
+
+
 def masked_linear_packed(x_padded, w_packed, bias, n_out, k_ranges=None, col_map=None, act=0, out=None,
                          out_cols=None, tile_order=None):
-    """y = act(x W^T + b) on packed operands (reference masked.py:265-277 + made.py:320)."""
+    """y = act(x W^T + b) on packed operands (reference masked.py:265-277 + made.py:320).  Small products (cfg1-sized
+    layers: a handful of 256 x 256 tiles) run on the 32-column tile instead, dense: more workgroups, shorter chains."""
     B = x_padded.shape[0]
     n_rows_w, k_padded = w_packed.shape
     if out is None:
         out = torch.empty(B, n_out if out_cols is None else out_cols, dtype=torch.float32, device=x_padded.device)
+    tile_n = 0
+    if col_map is None and few_wide_tiles(B, n_out):
+        tile_n, k_ranges, tile_order = narrow_tile_n(), None, None      # (the mask tables are per 256-column tile)
     call('tfep_masked_linear_forward', ptr(x_padded), x_padded.shape[1], ptr(w_packed), k_padded,
          ptr(bias), ptr(k_ranges), ptr(tile_order), ptr(col_map), ptr(out), out.shape[1], B, n_out, n_rows_w,
-         k_padded, int(act), 0,
+         k_padded, int(act), tile_n,
          stream_of(x_padded))
     return out
 

@@ -80,6 +80,24 @@ if 'cfg1' in which:
         l.blocked_inverse = False
     dt, _ = timeit(lambda: flow.inverse(y), 1, 3)
     report('cfg1 inverse (one full pass per degree, reference algorithm)', B, dt)
+    for l in flow:
+        l.blocked_inverse = True
+    # training step (forward, TFEP loss, backward, SGD update): eager, and captured into one HIP graph
+    from tfep_amd.graphs import GraphedTrainingStep
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    loss_mod = BoltzmannKLDivLoss()
+    loss_fn = lambda yy, ll: loss_mod((yy ** 2).sum(dim=1), ll)
+    opt = torch.optim.SGD(flow.parameters(), lr=1e-6)
+
+    def eager_step():
+        opt.zero_grad(set_to_none=True)
+        loss_fn(*flow(x)).backward()
+        opt.step()
+    dt, _ = timeit(eager_step, 5, 50)
+    report('cfg1 training step (forward + loss + backward + SGD), eager', B, dt)
+    gstep = GraphedTrainingStep(flow, loss_fn, opt, B, D)
+    dt, _ = timeit(lambda: gstep(x), 5, 50)
+    report('cfg1 training step, HIP-graph replay (GraphedTrainingStep)', B, dt)
 
 if 'cfg2inv' in which:
     D = 3000
