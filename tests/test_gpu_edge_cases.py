@@ -503,3 +503,13 @@ def test_graphed_training_step_equals_eager_steps(kind):
         assert torch.equal(p, q), n
     with pytest.raises(ValueError):
         step(xs[0][:10])
+    # an autograd graph over the parameters that is still alive (its gradient accumulators belong to the stream it was built
+    # on; a capture that meets them dies inside the HIP runtime): refused up front
+    del loss                                                          # (the last eager loss is such a tensor too)
+    held = flow(xs[0])
+    assert held[0].grad_fn is not None
+    with pytest.raises(RuntimeError, match='autograd graph'):
+        GraphedTrainingStep(flow, loss_fn, opt, B, D)
+    del held
+    again = GraphedTrainingStep(flow, loss_fn, opt, B, D)              # gone: captures
+    assert bool(torch.isfinite(again(xs[1])))

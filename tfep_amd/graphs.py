@@ -39,6 +39,26 @@ class GraphedFlow:
         return self.static_out.clone(), self.static_ldj.clone()
 
 
+def _held_by_a_live_graph(params):
+    """True when the gradient accumulator node of one of ``params`` is owned by somebody else -- a live autograd graph.
+    The node exists only while a graph refers to it: mark the one we are handed, drop it, ask again."""
+    import gc
+    import uuid
+    token = uuid.uuid4().hex
+    for p in params:
+        node = torch.autograd.graph.get_gradient_edge(p).node
+        node.metadata['tfep_probe'] = token
+        del node
+    gc.collect()
+    held = False
+    for p in params:
+        node = torch.autograd.graph.get_gradient_edge(p).node
+        if node.metadata.pop('tfep_probe', None) == token:
+            held = True
+        del node
+    return held
+
+
 class GraphedTrainingStep:
     """One training step -- ``flow(x)``, ``loss_fn(y, log_det_J)``, ``backward()``, ``optimizer.step()`` -- captured into
     a HIP graph for a fixed input shape and replayed with one host call.
@@ -50,11 +70,20 @@ class GraphedTrainingStep:
 
     ``step(x)`` returns the loss of that step (a tensor that the next call overwrites).  ``loss_fn`` must be built from
     capturable ops (no ``.item()`` / host round trips); the optimiser must be capturable (SGD; Adam with
-    ``capturable=True``).  Activations are not kept across the forward inside a capture (the layer recomputes them), the
+    ``capturable=True``).  No tensor computed from the parameters under grad mode may be alive when the step is constructed
+    (checked: RuntimeError).  Activations are not kept across the forward inside a capture (the layer recomputes them), the
     weights are packed on every replay."""
 
     def __init__(self, flow, loss_fn, optimizer, batch_size, n_features, device=None, warmup=3):
         self.flow, self.loss_fn, self.optimizer = flow, loss_fn, optimizer
+        self.params = [p for group in optimizer.param_groups for p in group['params'] if p.requires_grad]
+        if _held_by_a_live_graph(self.params):
+            # The gradient accumulator of a parameter belongs to the stream on which the first live graph over it was built.
+            # With such a graph still alive (the output of an earlier flow(x) / flow.inverse(y) under grad mode, kept by the
+            # caller) the backward inside the capture synchronises with that stream, and ending such a capture takes the
+            # process down inside the HIP runtime.
+            raise RuntimeError('GraphedTrainingStep: an autograd graph over the parameters is still alive (a tensor computed '
+                               'from the flow outside torch.no_grad()?): delete it before capturing the step')
         device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.static_in = torch.zeros(batch_size, n_features, dtype=torch.float32, device=device)
         # Warm-up off the default stream (plans, kernel attributes, optimiser state), as torch's whole-network capture asks
@@ -62,21 +91,23 @@ class GraphedTrainingStep:
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
-                self._eager(self.static_in)
+                self._step(self.static_in)
         torch.cuda.current_stream(device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)          # the capture allocates the gradients in the graph's own pool
         with torch.cuda.graph(self.graph):
-            y, ldj = flow(self.static_in)
-            self.static_loss = loss_fn(y, ldj)
-            self.static_loss.backward()
-            optimizer.step()
+            self.static_loss = self._step(self.static_in)
 
-    def _eager(self, x):
-        self.optimizer.zero_grad(set_to_none=True)
+    def _step(self, x):
         y, ldj = self.flow(x)
         loss = self.loss_fn(y, ldj)
-        loss.backward()
+        # torch.autograd.grad, not loss.backward(): the parameters' gradient accumulators are then never executed.  They
+        # belong to whichever stream first built a graph over the parameters; if such a graph is still alive (the output of
+        # an earlier flow(x) under grad mode, kept by the caller), backward() would synchronise the capture with that
+        # stream -- and ending such a capture takes the process down inside the HIP runtime.
+        grads = torch.autograd.grad(loss, self.params, allow_unused=True)
+        for p, g in zip(self.params, grads):
+            p.grad = g
         self.optimizer.step()
         return loss.detach()
 
@@ -85,4 +116,4 @@ class GraphedTrainingStep:
             raise ValueError(f'GraphedTrainingStep was captured for shape {tuple(self.static_in.shape)}, got {tuple(x.shape)}')
         self.static_in.copy_(x)
         self.graph.replay()
-        return self.static_loss.detach()
+        return self.static_loss

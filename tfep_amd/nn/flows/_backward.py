@@ -24,6 +24,7 @@ import torch
 
 from ... import _lib, ops
 from ..conditioners.made import MADE
+from ..masked import GRAD_IS_MASKED
 from ..embeddings.mafembed import MAFEmbedding, PeriodicEmbedding
 from ..transformers.affine import AffineTransformer, VolumePreservingShiftTransformer
 from ..transformers.mixed import MixedTransformer
@@ -640,6 +641,10 @@ def layer_backward(layer, x, gy, gldj, saved=None):
                           _lib.ptr(lin.weight_g.detach()), _lib.ptr(lin.mask), lin.out_features, lin.in_features,
                           _lib.ptr(row_of_out), _lib.ptr(col_of_in), _lib.ptr(gv), _lib.ptr(gg), stream)
             grads += [gg, gv]
+            # (already masked by the kernel: the parameters' gradient hooks of masked_weight_norm need not do it again)
+            for prm in (lin.weight_g, lin.weight_v):
+                if prm.requires_grad:
+                    prm.__dict__[GRAD_IS_MASKED] = True
         else:
             gw = torch.empty_like(lin._parameters['weight'])
             if prefix:

@@ -178,6 +178,10 @@ class MaskedLinear(torch.nn.Linear):
 # WEIGHT NORMALIZATION
 # =============================================================================
 
+#: attribute set on a parameter by a backward that returns its gradient already masked (consumed by the hooks below)
+GRAD_IS_MASKED = '_tfep_grad_is_masked'
+
+
 def masked_weight_norm(module, name='weight', dim=0):
     """NaN-free weight normalisation of a (masked) linear module (reference masked.py:312-404).
 
@@ -197,18 +201,25 @@ def masked_weight_norm(module, name='weight', dim=0):
     module.register_parameter(name + '_g', g)
     module.register_parameter(name + '_v', v)
     if mask is not None:
-        zero_rows = (torch.linalg.vector_norm(mask, ord=2, dim=1) == 0.0)
-        zero_entries = mask == 0.0
+        # The hooks read the module's mask buffer when they run (it follows the module across devices; nothing is copied
+        # per step and nothing but torch ops on the gradient's device runs, so they can be captured in a HIP graph).  The
+        # MAF layer's own backward already returns masked gradients (tfep_weight_norm_backward applies these very rules)
+        # and says so on the parameter (GRAD_IS_MASKED): the hook then passes the gradient through instead of re-masking
+        # 4.5 GB per cfg2 output layer and step.
+        def _g_hook(grad, module=module, g=g):
+            if g.__dict__.pop(GRAD_IS_MASKED, False):
+                return grad
+            m = module.mask
+            key = (m._version, m.data_ptr())
+            cached = module.__dict__.get('_tfep_live_rows')
+            if cached is None or cached[0] != key:
+                cached = module.__dict__['_tfep_live_rows'] = (key, (m != 0).any(dim=1, keepdim=True))
+            return grad * cached[1].to(dtype=grad.dtype, device=grad.device)
 
-        def _g_hook(grad, zero_rows=zero_rows):
-            grad = grad.clone()
-            grad[zero_rows.to(grad.device)] = 0.0
-            return grad
-
-        def _v_hook(grad, zero_entries=zero_entries):
-            grad = grad.clone()
-            grad[zero_entries.to(grad.device)] = 0.0
-            return grad
+        def _v_hook(grad, module=module, v=v):
+            if v.__dict__.pop(GRAD_IS_MASKED, False):
+                return grad
+            return grad.masked_fill(module.mask.to(grad.device) == 0, 0.0)
 
         module._tfep_wn_hooks = (g.register_hook(_g_hook), v.register_hook(_v_hook))
     return module

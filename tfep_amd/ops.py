@@ -144,9 +144,14 @@ def scatter_columns(src, idx, dst):
 
 # ----------------------------------------------------------------------------- masked linear
 
+_TILES = {}
+
+
 def tile_sizes():
-    lib = _lib.load()
-    return lib.tfep_masked_linear_tile_m(), lib.tfep_masked_linear_tile_n(), lib.tfep_masked_linear_tile_k()
+    if 'wide' not in _TILES:                    # (constants of the library: asked once, not on every launch)
+        lib = _lib.load()
+        _TILES['wide'] = (lib.tfep_masked_linear_tile_m(), lib.tfep_masked_linear_tile_n(), lib.tfep_masked_linear_tile_k())
+    return _TILES['wide']
 
 
 def round_up(n, m):
@@ -210,7 +215,9 @@ def heavy_first_order(k_ranges):
 
 
 def narrow_tile_n():
-    return _lib.load().tfep_masked_linear_narrow_tile_n()
+    if 'narrow' not in _TILES:
+        _TILES['narrow'] = _lib.load().tfep_masked_linear_narrow_tile_n()
+    return _TILES['narrow']
 
 
 def few_wide_tiles(B, N):

@@ -67,7 +67,8 @@ if 'cfg1' in which:
         dt, (y, _) = timeit(lambda: flow(x), 3, 20)
     report('cfg1 forward: 2-layer MAF + affine, D=66', B, dt,
            roofline=mfma_roofline(flow, B, dt, note='27 k weights: launch / latency bound, absolute number only'))
-    dt, (xi, _) = timeit(lambda: flow.inverse(y), 1, 5)
+    with torch.no_grad():
+        dt, (xi, _) = timeit(lambda: flow.inverse(y), 1, 5)
     report('cfg1 inverse (blocked)', B, dt, roundtrip_max_abs=float((xi - x).detach().abs().max()))
     from tfep_amd.graphs import GraphedFlow
     with torch.no_grad():
@@ -78,7 +79,8 @@ if 'cfg1' in which:
         report('cfg1 inverse (blocked), HIP-graph replay', B, dt)
     for l in flow:
         l.blocked_inverse = False
-    dt, _ = timeit(lambda: flow.inverse(y), 1, 3)
+    with torch.no_grad():
+        dt, _ = timeit(lambda: flow.inverse(y), 1, 3)
     report('cfg1 inverse (one full pass per degree, reference algorithm)', B, dt)
     for l in flow:
         l.blocked_inverse = True
