@@ -443,7 +443,7 @@ def test_block_kernel_row_layouts_agree(kind):
     assert 0 < _lib.load().tfep_inverse_block_lds_bytes_rows(2, 100, 16, 16) < _lib.load().tfep_inverse_block_lds_bytes_rows(2, 100, 16, 64)
 
 
-@pytest.mark.parametrize('kind', ['affine', 'spline+periodic'])
+@pytest.mark.parametrize('kind', ['affine', 'spline+periodic', 'spline, activations kept when eager'])
 def test_graphed_training_step_equals_eager_steps(kind):
     """``GraphedTrainingStep``: forward, loss, backward and the optimiser update of a small flow captured into one HIP
     graph.  Replays on a sequence of batches give the losses and the parameters of the same steps run eagerly, bit for
@@ -457,11 +457,14 @@ def test_graphed_training_step_equals_eager_steps(kind):
     from tfep_amd.nn.flows import MAF, SequentialFlow, _backward as bw
     from tfep_amd.nn.transformers import NeuralSplineTransformer
     torch.manual_seed(17)
-    D, B = 30, 260
+    D, B = (66, 1024) if kind.startswith('spline,') else (30, 260)     # (6.7 MB of spline parameters: the eager forward keeps them)
     layers = []
     for o in ('ascending', 'descending'):
         if kind == 'affine':
             layers.append(MAF(generate_degrees(D, o), initialize_identity=False))
+        elif kind.startswith('spline,'):
+            layers.append(MAF(generate_degrees(D, o), transformer=NeuralSplineTransformer(torch.full((D,), -4.0), torch.full((D,), 4.0), 8),
+                              initialize_identity=False))
         else:
             layers.append(MAF(generate_degrees(D, o), transformer=NeuralSplineTransformer(torch.full((D,), -4.0), torch.full((D,), 4.0), 6),
                               embedding=PeriodicEmbedding(D, limits=[-4.0, 4.0], periodic_indices=[1, 7, 20]),

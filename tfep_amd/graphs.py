@@ -87,16 +87,22 @@ class GraphedTrainingStep:
         device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.static_in = torch.zeros(batch_size, n_features, dtype=torch.float32, device=device)
         # Warm-up off the default stream (plans, kernel attributes, optimiser state), as torch's whole-network capture asks
+        from .nn.flows import _backward
         side = torch.cuda.Stream(device)
         side.wait_stream(torch.cuda.current_stream(device))
-        with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):
-                self._step(self.static_in)
-        torch.cuda.current_stream(device).wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        optimizer.zero_grad(set_to_none=True)          # the capture allocates the gradients in the graph's own pool
-        with torch.cuda.graph(self.graph):
-            self.static_loss = self._step(self.static_in)
+        was = _backward.FORCE_RECOMPUTE
+        _backward.FORCE_RECOMPUTE = True               # warm up the path the capture takes (no activations kept inside one)
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup)):
+                    self._step(self.static_in)
+            torch.cuda.current_stream(device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            optimizer.zero_grad(set_to_none=True)      # the capture allocates the gradients in the graph's own pool
+            with torch.cuda.graph(self.graph):
+                self.static_loss = self._step(self.static_in)
+        finally:
+            _backward.FORCE_RECOMPUTE = was
 
     def _step(self, x):
         y, ldj = self.flow(x)

@@ -437,8 +437,13 @@ def saves_activations(layer, x):
     return x.dim() == 2 and saves_activations_at(layer, x.shape[0])
 
 
+#: set by ``tfep_amd.graphs.GraphedTrainingStep`` around its warm-up and capture: inside a capture the layers recompute their
+#: activations, and the warm-up has to build the plans of exactly that path
+FORCE_RECOMPUTE = False
+
+
 def saves_activations_at(layer, batch):
-    if _SAVE_BYTES <= 0 or not supported(layer) or torch.cuda.is_current_stream_capturing():
+    if _SAVE_BYTES <= 0 or FORCE_RECOMPUTE or not supported(layer) or torch.cuda.is_current_stream_capturing():
         return False
     if type(layer._transformer) not in (AffineTransformer, NeuralSplineTransformer):
         return False
