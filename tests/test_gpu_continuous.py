@@ -428,3 +428,23 @@ def test_other_solvers_agree_with_a_fine_rk4_grid(solver, options, tol):
         y1, t1 = flow(x)
     assert float((y1 - y0).abs().max()) < tol and float((t1 - t0).abs().max()) < 10 * tol
     assert flow.last_solver_stats['n_steps'] >= 1
+
+
+def test_empty_batch_through_the_dynamics_and_the_flow():
+    """B = 0: empty velocity / tangent / cotangent and an empty flow output, no launch on an empty grid."""
+    from tfep_amd.nn.dynamics import EGNNDynamics
+    from tfep_amd.nn.flows import ContinuousFlow
+    dyn = EGNNDynamics(node_types=[0, 1, 1, 0], r_cutoff=2.0, time_feat_dim=4, node_feat_dim=16, distance_feat_dim=8, n_layers=2,
+                       initialize_identity=False).cuda()
+    x = torch.empty(0, 12, device='cuda')
+    with torch.no_grad():
+        assert dyn(0.3, x).shape == (0, 12)
+        vel, jv = dyn.jvp(0.3, x, x.clone(), trace=torch.empty(0, device='cuda'))
+        assert vel.shape == (0, 12) and jv.shape == (0, 12)
+        vel, gj = dyn.vjp(0.3, x, x.clone())
+        assert vel.shape == (0, 12) and gj.shape == (0, 12)
+        for reg in (False, True):
+            flow = ContinuousFlow(dyn, solver='rk4', solver_options={'step_size': 0.5}, regularization=reg)
+            out = flow(x)
+            assert len(out) == (3 if reg else 2) and out[0].shape == (0, 12) and all(o.shape == (0,) for o in out[1:])
+            assert flow.inverse(out[0])[0].shape == (0, 12)

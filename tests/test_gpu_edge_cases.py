@@ -516,3 +516,35 @@ def test_graphed_training_step_equals_eager_steps(kind):
     del held
     again = GraphedTrainingStep(flow, loss_fn, opt, B, D)              # gone: captures
     assert bool(torch.isfinite(again(xs[1])))
+
+
+@pytest.mark.parametrize('kind', ['affine', 'spline', 'moebius'])
+def test_empty_batch_through_every_path(kind):
+    """B = 0 (the reference returns empty tensors: torch ops on empty batches): forward (fused and generic), blocked
+    inverse, the training step with its gradients (zeros), the estimator-side reductions -- nothing launches on an empty
+    grid, nothing faults."""
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF, SequentialFlow
+    from tfep_amd.nn.transformers import MoebiusTransformer, NeuralSplineTransformer
+    D = 12
+    tr = {'affine': lambda: None, 'spline': lambda: NeuralSplineTransformer(torch.full((D,), -3.0), torch.full((D,), 3.0), 4),
+          'moebius': lambda: MoebiusTransformer(dimension=3)}[kind]
+    deg = (lambda o: generate_degrees(D, o, repeats=3)) if kind == 'moebius' else (lambda o: generate_degrees(D, o))
+    flow = SequentialFlow(*[MAF(deg(o), transformer=tr(), initialize_identity=False) for o in ('ascending', 'descending')]).cuda()
+    x = torch.empty(0, D, device='cuda')
+    with torch.no_grad():
+        for fused in (True, False):
+            for layer in flow:
+                layer.fused = fused
+            y, l = flow(x)
+            assert y.shape == (0, D) and l.shape == (0,)
+        xi, li = flow.inverse(y)
+        assert xi.shape == (0, D) and li.shape == (0,)
+    y, l = flow(x)                                        # under autograd
+    (y.sum() + l.sum()).backward()
+    for n, p in flow.named_parameters():
+        assert p.grad is not None and p.grad.shape == p.shape and float(p.grad.abs().sum()) == 0.0, n
+    loss = BoltzmannKLDivLoss()
+    with pytest.raises(Exception):
+        float(loss(l.detach(), l.detach()))              # the mean over no samples is not a number the reference returns either

@@ -515,12 +515,12 @@ int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int6
                                const int32_t* k_ranges, const int32_t* tile_order, const int32_t* col_map, float* y,
                                int64_t ldy, int B, int N, int n_rows_w, int k_padded, int act, int tile_n,
                                void* stream) {
+    TFEP_REQUIRE(B >= 0 && N >= 0 && n_rows_w >= N, "masked_linear: bad sizes B=%d N=%d rows=%d", B, N, n_rows_w);
+    TFEP_REQUIRE(act == 0 || act == 1, "masked_linear: act must be 0 (identity) or 1 (ELU)");
+    if (B == 0 || N == 0) return TFEP_OK;                  // (an empty batch has no storage: its pointers are NULL)
     int rc = check_gemm_operands(x, ldx, w, ldw, k_padded);
     if (rc) return rc;
     TFEP_REQUIRE(y, "masked_linear: y is NULL");
-    TFEP_REQUIRE(B >= 0 && N >= 0 && n_rows_w >= N, "masked_linear: bad sizes B=%d N=%d rows=%d", B, N, n_rows_w);
-    TFEP_REQUIRE(act == 0 || act == 1, "masked_linear: act must be 0 (identity) or 1 (ELU)");
-    if (B == 0 || N == 0) return TFEP_OK;
     GemmArgs g = {};
     g.a = x; g.lda = ldx; g.w = w; g.ldw = ldw; g.bias = bias; g.k_ranges = k_ranges; g.col_map = col_map;
     g.y = y; g.ldy = ldy; g.B = B; g.N = N; g.k_padded = k_padded; g.tile_order = tile_order;
@@ -540,12 +540,12 @@ int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int6
 
 int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
     TFEP_REQUIRE(d != nullptr, "masked_linear_gemm: NULL descriptor");
+    TFEP_REQUIRE(d->B >= 0 && d->N >= 0 && d->n_rows_w >= 1, "masked_linear_gemm: bad sizes");
+    TFEP_REQUIRE(d->act == 0 || d->act == 1, "masked_linear_gemm: act must be 0 or 1");
+    if (d->B == 0 || d->N == 0) return TFEP_OK;            // (an empty batch has no storage: its pointers are NULL)
     int rc = check_gemm_operands(d->x, d->ldx, d->w, d->ldw, d->k_padded);
     if (rc) return rc;
     TFEP_REQUIRE(d->y, "masked_linear_gemm: y is NULL");
-    TFEP_REQUIRE(d->B >= 0 && d->N >= 0 && d->n_rows_w >= 1, "masked_linear_gemm: bad sizes");
-    TFEP_REQUIRE(d->act == 0 || d->act == 1, "masked_linear_gemm: act must be 0 or 1");
-    if (d->B == 0 || d->N == 0) return TFEP_OK;
     GemmArgs g = {};
     g.a = d->x; g.lda = d->ldx; g.w = d->w; g.ldw = d->ldw; g.bias = d->bias; g.k_ranges = d->k_ranges;
     g.col_map = d->col_map; g.y = d->y; g.ldy = d->ldy; g.B = d->B; g.N = d->N; g.k_padded = d->k_padded;
@@ -605,13 +605,14 @@ static int fused_forward(const float* h, int64_t ldh, const float* w, int64_t ld
                          const int32_t* feat_tr, int n_feature_slots, double* ldj_partial, float* log_det_J,
                          int accumulate, int B, int n_rows_w, int k_padded, bool split, const float* h_inv_scale,
                          const float* w_inv_scale, void* stream) {
-    int rc = check_gemm_operands(h, ldh, w, ldw, k_padded);
-    if (rc) return rc;
-    TFEP_REQUIRE(x && y && feat_index && ldj_partial && log_det_J, "fused: NULL pointer");
     TFEP_REQUIRE(n_feature_slots > 0 && n_feature_slots % FUSED_TILE_FEATURES == 0,
                  "fused: n_feature_slots=%d must be a positive multiple of %d", n_feature_slots, FUSED_TILE_FEATURES);
     if (!tfep_fused_supported(kind, desc)) return fail(TFEP_ERR_UNSUPPORTED, "fused: unsupported transformer configuration");
-    if (B == 0) return TFEP_OK;
+    TFEP_REQUIRE(B >= 0, "fused: negative batch");
+    if (B == 0) return TFEP_OK;                            // (an empty batch has no storage: its pointers are NULL)
+    int rc = check_gemm_operands(h, ldh, w, ldw, k_padded);
+    if (rc) return rc;
+    TFEP_REQUIRE(x && y && feat_index && ldj_partial && log_det_J, "fused: NULL pointer");
     hipStream_t s = (hipStream_t)stream;
     GemmArgs g = {};
     g.a = h; g.lda = ldh; g.w = w; g.ldw = ldw; g.bias = bias_packed; g.k_ranges = k_ranges;

@@ -137,6 +137,8 @@ class EGNNDynamics(FixedGraph):
         n = self.n_nodes
         if D != 3 * n:
             raise ValueError(f'x must have shape (batch_size, {3 * n}), got {tuple(x.shape)}')
+        if B == 0:                             # an empty batch: empty velocity (and tangent); the accumulators stay as they are
+            return torch.empty_like(x), (torch.empty_like(x) if v is not None and need_jvp else None)
         tan = v is not None
         if tan:
             _lib.check_device_tensor(v, 'v')
@@ -234,6 +236,8 @@ def _run_vjp(self, t, x, g, trace=None, frob=None, scale=1.0, vel_sq=None):
     n = self.n_nodes
     if D != 3 * n or g.shape != x.shape:
         raise ValueError(f'x and g must have shape (batch_size, {3 * n})')
+    if B == 0:
+        return torch.empty_like(x), torch.empty_like(x)
     for name, acc in (('trace', trace), ('frobenius', frob), ('velocity_squared_norm', vel_sq)):
         if acc is not None:
             _lib.check_device_tensor(acc, name)

@@ -71,6 +71,9 @@ class ContinuousFlow(torch.nn.Module):
     def _integrate(self, x, t0, t1, hip):
         f = self.ode_func
         trace = torch.full((x.shape[0],), 0.0, dtype=x.dtype, device=x.device)
+        if hip and x.shape[0] == 0:            # an empty batch: nothing to integrate (the kernels take no empty grids)
+            self.last_solver_stats = {}
+            return [x.clone(), trace, trace.clone()] if self.regularization else [x.clone(), trace]
         f.before_odeint(x)
         state = (x, trace, trace.clone()) if self.regularization else (x, trace)
         stats = {}
