@@ -529,3 +529,67 @@ def test_training_steps_release_their_activations_without_the_garbage_collector(
         if was_enabled:
             gc.enable()
     assert after_six - after_one < 0.5 * kept, (after_one, after_six, kept)
+
+
+def test_cfg2_width_gradients_by_directional_derivative():
+    """One cfg2 layer at full width (3000 features, 15 000 hidden units, 75 000 spline parameters) through the training
+    path proper -- activations kept, split-f16 GEMMs, LDS-staged prefix packs and weight-norm backward, transposed operands
+    as split rows: the gradient of the TFEP loss along a random direction in parameter space against the central
+    difference of the loss itself, and the input gradient along a random direction in x."""
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF, _backward as bw
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    torch.manual_seed(3)
+    D, B = 3000, 384
+    with torch.device('cuda'):
+        maf = MAF(generate_degrees(D, 'ascending'), transformer=NeuralSplineTransformer(torch.full((D,), -5.0), torch.full((D,), 5.0), 8),
+                  initialize_identity=False)
+    assert maf._use_split_gemm()
+    x = torch.randn(B, D, device='cuda').clamp_(-4.5, 4.5).requires_grad_(True)
+    c = torch.rand(D, device='cuda') * 0.3
+    loss_mod = BoltzmannKLDivLoss()
+
+    def loss_of(xx):
+        y, l = maf(xx)
+        return loss_mod((c * y ** 2).sum(dim=1), l)
+    assert bw.saves_activations(maf, x)
+    loss = loss_of(x)
+    loss.backward()
+    params = [p for p in maf.parameters() if p.requires_grad]
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in params)
+    gen = torch.Generator(device='cuda').manual_seed(8)
+    # input gradient: along a direction in the first 300 features (they feed every later output through the conditioner);
+    # over all 3000 features at once the loss of a random-init layer this wide is too rough for a central difference (its
+    # value moves 10 % between steps of 1e-2 and 1e-3), which says nothing about the gradient
+    dx = torch.zeros(B, D, device='cuda')
+    dx[:, :300] = torch.randn(B, 300, device='cuda', generator=gen) * 3.0
+    analytic_x = float((x.grad.double() * dx.double()).sum())
+
+    def loss64(xx):                       # the same loss (mean of u_B - log|det J|) accumulated in float64: a float32 loss of
+        y, l = maf(xx)                    # ~450 resolves 3e-5 of itself, which is the size of the differences taken here
+        return float(((c * y ** 2).sum(dim=1).double() - l.double()).mean())
+    assert abs(loss64(x.detach()) - float(loss)) < 1e-3 * abs(float(loss))
+    # one direction per parameter tensor (a sum over all nine cancels to a tenth of its terms: their 0.5 % errors would read
+    # as 4 %), errors measured against the largest of the nine derivatives
+    got = []
+    for p in params:
+        d = torch.randn(p.shape, device='cuda', generator=gen) * p.detach().abs().mean()
+        analytic = float((p.grad.double() * d.double()).sum())
+        eps = 0.005
+        with torch.no_grad():
+            p.add_(d, alpha=eps)
+            lp = loss64(x.detach())
+            p.add_(d, alpha=-2 * eps)
+            lm = loss64(x.detach())
+            p.add_(d, alpha=eps)
+        got.append((analytic, (lp - lm) / (2 * eps)))
+    scale = max(abs(a) for a, _ in got)
+    for (a, fd), (name, _) in zip(got, maf.named_parameters()):
+        assert abs(fd - a) <= 0.015 * scale, (name, a, fd)
+    with torch.no_grad():
+        eps_x = 3e-3
+        lp = loss64((x.detach() + eps_x * dx).clamp(-4.99, 4.99))
+        lm = loss64((x.detach() - eps_x * dx).clamp(-4.99, 4.99))
+    fd_x = (lp - lm) / (2 * eps_x)
+    assert abs(fd_x - analytic_x) <= 0.03 * abs(analytic_x) + 1e-3, (fd_x, analytic_x)
