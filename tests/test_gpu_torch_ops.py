@@ -162,3 +162,43 @@ def test_masked_linear_op_rejects_mismatched_shapes():
                  (x, w, None, torch.ones(5, 5, device='cuda'), None), (x, w, None, None, torch.ones(4, 1, device='cuda'))):
         with pytest.raises(RuntimeError, match='masked_linear'):
             torch.ops.tfep.masked_linear(*args)
+
+
+@pytest.mark.parametrize('K,circular', [(4, False), (5, False), (5, True), (8, True)])
+def test_splines_of_4_5_and_8_bins_take_the_fused_epilogue(K, circular):
+    """The fused output-GEMM + spline kernel is instantiated for 8, 5 and 4 bins (plain and circular): such layers dispatch
+    through tfep::fused_output_transformer (fp32 and split kernels) and agree with the un-fused path; identity boundary
+    slopes / learnable bounds keep the generic path."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+
+    class Spy(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            self.seen.append(str(func))
+            return func(*args, **(kwargs or {}))
+    torch.manual_seed(K)
+    D, B = 37, 301
+    lo, hi = (0.0, 2.0) if circular else (-3.0, 3.0)
+    maf = MAF(generate_degrees(D, 'ascending'), transformer=NeuralSplineTransformer(torch.full((D,), lo), torch.full((D,), hi), K, circular=circular),
+              hidden_layers=[90, 110], initialize_identity=False).cuda()
+    x = torch.rand(B, D, device='cuda') * (hi - lo) + lo
+    with torch.no_grad():
+        for split in (False, True):
+            maf.split_gemm = split
+            maf.fused = True
+            with Spy() as spy:
+                y, l = maf(x)
+            assert any('tfep.fused_output_transformer' in s for s in spy.seen)
+            maf.fused = False
+            yg, lg = maf(x)
+            assert float((y - yg).abs().max()) < 2e-5 and float((l - lg).abs().max()) < 2e-4
+    other = MAF(generate_degrees(D, 'ascending'), transformer=NeuralSplineTransformer(torch.full((D,), -3.0), torch.full((D,), 3.0), 5,
+                                                                                      identity_boundary_slopes=True),
+                initialize_identity=False).cuda()
+    assert other._fused_kind() is None

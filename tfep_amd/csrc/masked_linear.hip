@@ -589,13 +589,14 @@ int tfep_diag_mfma_peak(float* scratch, int blocks, int iters, void* stream) {
 int tfep_fused_supported(int kind, const tfep_spline_desc* d) {
     if (kind == TFEP_FUSED_AFFINE) return 1;
     if (kind == TFEP_FUSED_SPLINE && d)
-        return d->n_bins == 8 && !d->identity_boundary_slopes && !d->learn_lower_bound && !d->learn_upper_bound;
+        return (d->n_bins == 8 || d->n_bins == 5 || d->n_bins == 4) && !d->identity_boundary_slopes && !d->learn_lower_bound &&
+               !d->learn_upper_bound;
     return 0;
 }
 
 int tfep_fused_tile_columns(int kind, const tfep_spline_desc* d) {
     if (kind == TFEP_FUSED_AFFINE) return 16 * 16;      // P = 2, FT = 8
-    if (kind == TFEP_FUSED_SPLINE && tfep_fused_supported(kind, d)) return 16 * 25;   // P = 25, FT = 1
+    if (kind == TFEP_FUSED_SPLINE && tfep_fused_supported(kind, d)) return 16 * (3 * d->n_bins + 1);   // P = 3 K + 1, FT = 1
     return fail(TFEP_ERR_UNSUPPORTED, "fused: unsupported transformer configuration");
 }
 
@@ -629,7 +630,7 @@ static int fused_forward(const float* h, int64_t ldh, const float* w, int64_t ld
         rc = split ? launch_split_fused(g, n_rows_w, kind, n_groups / FT, s)
                    : launch_gemm<2, P * FT, EPI_AFFINE, P, 1>(g, n_rows_w, n_groups / FT, s);
     } else {
-        constexpr int P = 25, KS = 8;
+        const int KS = desc->n_bins, P = 3 * KS + 1;
         TFEP_REQUIRE(feat_tr && desc->x0 && desc->xf && desc->y0 && desc->yf, "fused spline: NULL descriptor arrays");
         TFEP_REQUIRE(n_rows_w >= n_feature_slots * P, "fused: weight has too few rows");
         g.N = n_feature_slots * P;
@@ -638,8 +639,10 @@ static int fused_forward(const float* h, int64_t ldh, const float* w, int64_t ld
         g.fu.sf.learn_lower = false; g.fu.sf.learn_upper = false;
         g.fu.sf.min_bin = desc->min_bin_size; g.fu.sf.min_slope = desc->min_slope;
         g.fu.sf.slope_offset = (float)log(exp(1.0 - (double)desc->min_slope) - 1.0);
-        rc = split ? launch_split_fused(g, n_rows_w, kind, n_groups, s)
-                   : launch_gemm<2, P, EPI_SPLINE, P, KS>(g, n_rows_w, n_groups, s);
+        if (split) rc = launch_split_fused(g, n_rows_w, kind, n_groups, s);
+        else if (KS == 5) rc = launch_gemm<2, 16, EPI_SPLINE, 16, 5>(g, n_rows_w, n_groups, s);
+        else if (KS == 4) rc = launch_gemm<2, 13, EPI_SPLINE, 13, 4>(g, n_rows_w, n_groups, s);
+        else rc = launch_gemm<2, 25, EPI_SPLINE, 25, 8>(g, n_rows_w, n_groups, s);
     }
     if (rc) return rc;
     ldj_reduce_kernel<<<(unsigned)((B + 255) / 256), 256, 0, s>>>(ldj_partial, n_groups, B, log_det_J, accumulate);

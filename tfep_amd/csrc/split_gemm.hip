@@ -468,14 +468,17 @@ __device__ inline void split_dma(const SplitCtx& sc, char* a_wave, char* b_stage
 // Same arithmetic as gemm_epilogue<EPI_SPLINE> (spline.h), same outputs.
 // the records are written float by float and read back 16 bytes at a time: the vector type must be allowed to alias
 typedef float f32x4_alias __attribute__((ext_vector_type(4), may_alias));
-constexpr int SPL_REC = 28;                                   // floats per record: 16-byte aligned, conflict-free
-constexpr int SPL_WAVE_BYTES = 16 * 16 * SPL_REC * 4;         // one 16-row block of one wave
+// floats per record: 16-byte aligned, > P, and a stride that spreads the 16 features of a block over 16 banks (28 for the
+// 25 parameters of 8 bins; 20 for the 16 / 13 of 5 / 4 bins -- 16 would put them on 4)
+template <int KSPL> constexpr int spl_rec() { return 3 * KSPL + 2 <= 20 ? 20 : 28; }
+template <int KSPL> constexpr int spl_wave_bytes() { return 16 * 16 * spl_rec<KSPL>() * 4; }     // one 16-row block of one wave
 
 template <int KSPL>
 __device__ __forceinline__ void split_spline_epilogue(const GemmArgs& g, f32x4 (&acc)[3 * KSPL + 1][SMREP],
                                                       const f32x4 (&rs)[SMREP], int nt, int n0, int wrow0, int lane,
                                                       float* rec_base) {
     constexpr int P = 3 * KSPL + 1;
+    constexpr int SPL_REC = spl_rec<KSPL>();
     static_assert(P + 1 <= SPL_REC, "record too small");
     const FusedArgs& fu = g.fu;
     const int cj = lane & 15, gq = lane >> 4;
@@ -719,9 +722,9 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
         });
     }
     if constexpr (EPI == EPI_SPLINE) {
-        static_assert(SWAVES * SPL_WAVE_BYTES <= T::LDS_BYTES, "epilogue records do not fit in LDS");
+        static_assert(SWAVES * spl_wave_bytes<KSPL>() <= T::LDS_BYTES, "epilogue records do not fit in LDS");
         __syncthreads();                        // every wave is done with the operand stages: LDS is reused below
-        split_spline_epilogue<KSPL>(g, acc, rs, nt, n0, wrow0, lane, (float*)(slds + wave * SPL_WAVE_BYTES));
+        split_spline_epilogue<KSPL>(g, acc, rs, nt, n0, wrow0, lane, (float*)(slds + wave * spl_wave_bytes<KSPL>()));
     } else if constexpr (EPI == EPI_ELU_SPLIT) {
         // y = ELU(x W^T + b) written straight as split rows for the next GEMM.  The row scale cannot wait for the row
         // maximum (other workgroups hold the other columns), so it comes from a bound every workgroup can compute:
@@ -899,6 +902,9 @@ int launch_split_fused(const GemmArgs& g, int n_rows_w, int kind, int n_col_tile
     int rc = check_split_operands(g);
     if (rc) return rc;
     if (kind == TFEP_FUSED_AFFINE) return launch_split<16, EPI_AFFINE, 2, 1>(g, n_rows_w, n_col_tiles, s);
+    // one feature group (16 features x P = 3 K + 1 parameters) per column tile: 8, 5 or 4 bins
+    if (g.fu.sf.K == 5) return launch_split<16, EPI_SPLINE, 16, 5>(g, n_rows_w, n_col_tiles, s);
+    if (g.fu.sf.K == 4) return launch_split<13, EPI_SPLINE, 13, 4>(g, n_rows_w, n_col_tiles, s);
     return launch_split<25, EPI_SPLINE, 25, 8>(g, n_rows_w, n_col_tiles, s);
 }
 

@@ -153,7 +153,7 @@ class AutoregressiveFlow(torch.nn.Module):
             return _FUSED_AFFINE
         if type(tr) is NeuralSplineTransformer:
             h = tr.host()
-            if h['n_bins'] == 8 and not h['identity'] and not h['learn_lower'] and not h['learn_upper']:
+            if h['n_bins'] in (4, 5, 8) and not h['identity'] and not h['learn_lower'] and not h['learn_upper']:
                 return _FUSED_SPLINE
         return None
 
@@ -193,7 +193,7 @@ class AutoregressiveFlow(torch.nn.Module):
         mplan = made.plan(device)
         last = made.layers[-1]
         n_tr = tables['n_tr']
-        P = 2 if kind == _FUSED_AFFINE else 25
+        P = 2 if kind == _FUSED_AFFINE else 3 * self._transformer.host()['n_bins'] + 1
         if last.out_features != P * n_tr:
             raise ValueError('conditioner output does not match the transformer parameters')
         desc = self._transformer.config(device).desc if kind == _FUSED_SPLINE else None

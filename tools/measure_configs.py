@@ -153,6 +153,10 @@ if 'variants' in which:
     x = torch.randn(B, D, device=dev).clamp_(-4.9, 4.9)
     for name, kw in (('K=8 plain (fused epilogue)', dict(n_bins=8)),
                      ('K=8 plain, fused=False (generic path)', dict(n_bins=8)),
+                     ('K=5 plain (fused epilogue)', dict(n_bins=5)),
+                     ('K=5 plain, fused=False (generic path)', dict(n_bins=5)),
+                     ('K=5 circular (fused epilogue)', dict(n_bins=5, circular=True)),
+                     ('K=4 plain (fused epilogue)', dict(n_bins=4)),
                      ('K=5 identity slopes (generic path)', dict(n_bins=5, identity_boundary_slopes=True)),
                      ('K=5 identity slopes + learnable bounds (generic path)',
                       dict(n_bins=5, identity_boundary_slopes=True, learn_lower_bound=True, learn_upper_bound=True))):
