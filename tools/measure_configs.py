@@ -109,9 +109,10 @@ if 'cfg2inv' in which:
                                   transformer=NeuralSplineTransformer(torch.full((D,), -5.0), torch.full((D,), 5.0), 8),
                                   initialize_identity=False))
     x = torch.randn(B, D, device=dev).clamp_(-4.9, 4.9)
-    dt, (y, lf) = timeit(lambda: flow(x), 1, 2)
-    report('cfg2 ONE layer forward', B, dt, roofline=mfma_roofline(flow, B, dt))
-    dt, (xi, li) = timeit(lambda: flow.inverse(y), 1, 1)
+    with torch.no_grad():
+        dt, (y, lf) = timeit(lambda: flow(x), 1, 2)
+        report('cfg2 ONE layer forward', B, dt, roofline=mfma_roofline(flow, B, dt))
+        dt, (xi, li) = timeit(lambda: flow.inverse(y), 1, 1)
     report('cfg2 ONE layer inverse (blocked, 3000 degrees)', B, dt,
            roundtrip_rel_l2=float((xi - x).detach().norm() / x.norm()), ldj_cancel_max_abs=float((lf + li).detach().abs().max()),
            roofline=mfma_roofline(flow, B, dt, note='one forward of flops; the chain of 3000 degree steps is sequential: '
