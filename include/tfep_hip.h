@@ -244,15 +244,18 @@ int tfep_scatter_columns(const float* src, int64_t lds, const int32_t* idx, int 
 
 typedef enum tfep_fused_kind {
     TFEP_FUSED_AFFINE = 0,   /* P = 2                                         */
-    TFEP_FUSED_SPLINE = 1    /* plain or circular RQ spline, no learnable bounds */
+    TFEP_FUSED_SPLINE = 1    /* RQ spline of 8, 5 or 4 bins: see tfep_fused_supported */
 } tfep_fused_kind;
 
 /* Feature slots per 16-wide MFMA column group (16). */
 int tfep_fused_tile_features(void);
-/* 1 if (kind, desc) is supported by the fused kernel. */
+/* 1 if (kind, desc) is supported by the fused kernel: the affine transformer; RQ splines of 8, 5 or 4 bins, plain or
+ * circular, with or without identity boundary slopes and learnable bounds, of at most 25 parameters per feature (all
+ * layouts but the 8-bin ones with a learnable bound and free boundary slopes: 26 / 27). */
 int tfep_fused_supported(int kind, const tfep_spline_desc* desc);
 /* Packed weight rows per column tile of the fused kernel (= tile_n for tfep_mask_k_ranges):
- * P * FT * 16 where FT feature groups of 16 slots share a tile (spline K=8: 25*1*16, affine: 2*8*16).
+ * P * FT * 16 where FT feature groups of 16 slots share a tile (spline: P = parameters per feature, FT = 1;
+ * affine: 2*8*16).
  * Packed row of (slot s, parameter p):  tile = s / (16*FT), ft = (s / 16) % FT, j = s % 16,
  *   row = tile * (P*FT*16) + (ft * P + p) * 16 + j. */
 int tfep_fused_tile_columns(int kind, const tfep_spline_desc* desc);

@@ -221,7 +221,7 @@ def test_fused_path_is_taken_where_expected():
     assert gu.build_flow('rq4', g)[0]._fused_kind() == 1
     assert gu.build_flow('circ', g)[0]._fused_kind() == 1
     assert gu.build_flow('cond', g)[0]._fused_kind() == 0
-    assert gu.build_flow('cond', g)[1]._fused_kind() is None      # identity slopes, K=5: generic path
+    assert gu.build_flow('cond', g)[1]._fused_kind() == 1         # identity slopes, K=5: the 14-parameter layout
     assert gu.build_flow('moeb', g)[0]._fused_kind() is None
 
 

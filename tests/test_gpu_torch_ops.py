@@ -164,11 +164,35 @@ def test_masked_linear_op_rejects_mismatched_shapes():
             torch.ops.tfep.masked_linear(*args)
 
 
-@pytest.mark.parametrize('K,circular', [(4, False), (5, False), (5, True), (8, True)])
-def test_splines_of_4_5_and_8_bins_take_the_fused_epilogue(K, circular):
-    """The fused output-GEMM + spline kernel is instantiated for 8, 5 and 4 bins (plain and circular): such layers dispatch
-    through tfep::fused_output_transformer (fp32 and split kernels) and agree with the un-fused path; identity boundary
-    slopes / learnable bounds keep the generic path."""
+# (bins, circular, identity boundary slopes, learnable lower bound, learnable upper bound) -> parameters per feature
+_FUSED_LAYOUTS = [
+    (4, False, False, False, False), (5, False, False, False, False), (5, True, False, False, False),
+    (8, True, False, False, False),
+    (8, False, True, False, False),      # 23
+    (8, True, True, False, False),       # 24
+    (8, False, True, True, False),       # 24
+    (5, False, True, False, False),      # 14
+    (5, True, True, False, False),       # 15
+    (5, False, True, False, True),       # 15
+    (5, False, False, True, False),      # 17
+    (5, False, False, False, True),      # 17
+    (5, False, False, True, True),       # 18
+    (4, False, True, False, False),      # 11
+    (4, False, True, True, False),       # 12
+    (4, False, False, False, True),      # 14
+    (4, False, False, True, True),       # 15
+    (8, False, True, True, True),        # 25, like the plain layout: a kernel of its own
+    (5, False, True, True, True),        # 16
+    (4, False, True, True, True),        # 13
+]
+
+
+@pytest.mark.parametrize('K,circular,identity,learn_lower,learn_upper', _FUSED_LAYOUTS)
+def test_spline_layouts_take_the_fused_epilogue(K, circular, identity, learn_lower, learn_upper):
+    """The fused output-GEMM + spline kernel is instantiated for 8, 5 and 4 bins and every parameter layout of at most 25
+    parameters per feature (plain / circular, identity boundary slopes, learnable bounds): such layers dispatch through
+    tfep::fused_output_transformer (fp32 and split kernels) and agree with the un-fused path, inside the domain and in
+    both tails."""
     from torch.utils._python_dispatch import TorchDispatchMode
     from tfep_amd.nn.conditioners import generate_degrees
     from tfep_amd.nn.flows import MAF
@@ -185,9 +209,14 @@ def test_splines_of_4_5_and_8_bins_take_the_fused_epilogue(K, circular):
     torch.manual_seed(K)
     D, B = 37, 301
     lo, hi = (0.0, 2.0) if circular else (-3.0, 3.0)
-    maf = MAF(generate_degrees(D, 'ascending'), transformer=NeuralSplineTransformer(torch.full((D,), lo), torch.full((D,), hi), K, circular=circular),
-              hidden_layers=[90, 110], initialize_identity=False).cuda()
-    x = torch.rand(B, D, device='cuda') * (hi - lo) + lo
+    tr = NeuralSplineTransformer(torch.full((D,), lo), torch.full((D,), hi), K, circular=circular,
+                                 identity_boundary_slopes=identity, learn_lower_bound=learn_lower,
+                                 learn_upper_bound=learn_upper)
+    maf = MAF(generate_degrees(D, 'ascending'), transformer=tr, hidden_layers=[90, 110], initialize_identity=False).cuda()
+    assert maf._conditioner.layers[-1].out_features == tr.n_parameters_per_feature * D
+    # a learnable domain shrinks or grows with the parameters, and the plain spline has linear tails: sample beyond [lo, hi]
+    wide = 1.0 if circular else 1.4
+    x = (torch.rand(B, D, device='cuda') - 0.5) * (hi - lo) * wide + 0.5 * (hi + lo)
     with torch.no_grad():
         for split in (False, True):
             maf.split_gemm = split
@@ -198,7 +227,26 @@ def test_splines_of_4_5_and_8_bins_take_the_fused_epilogue(K, circular):
             maf.fused = False
             yg, lg = maf(x)
             assert float((y - yg).abs().max()) < 2e-5 and float((l - lg).abs().max()) < 2e-4
-    other = MAF(generate_degrees(D, 'ascending'), transformer=NeuralSplineTransformer(torch.full((D,), -3.0), torch.full((D,), 3.0), 5,
-                                                                                      identity_boundary_slopes=True),
-                initialize_identity=False).cuda()
-    assert other._fused_kind() is None
+            assert float((y - x).abs().max()) > 1e-2                    # (not the identity map)
+
+
+@pytest.mark.parametrize('K,identity,learn_lower,learn_upper', [(8, False, True, False), (8, False, True, True),
+                                                                (6, False, False, False), (6, True, True, True)])
+def test_spline_layouts_outside_the_fused_kernels(K, identity, learn_lower, learn_upper):
+    """More than 25 parameters per feature (8 bins with learnable bounds and free boundary slopes) and other bin numbers
+    keep the un-fused kernels -- and the library says the same."""
+    import ctypes
+    from tfep_amd import _lib
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    D = 9
+    tr = NeuralSplineTransformer(torch.full((D,), -3.0), torch.full((D,), 3.0), K, identity_boundary_slopes=identity,
+                                 learn_lower_bound=learn_lower, learn_upper_bound=learn_upper)
+    maf = MAF(generate_degrees(D, 'ascending'), transformer=tr, initialize_identity=False).cuda()
+    assert maf._fused_kind() is None
+    desc = maf._transformer.config(torch.device('cuda', torch.cuda.current_device())).desc
+    assert _lib.load().tfep_fused_supported(1, ctypes.byref(desc)) == 0
+    with torch.no_grad():
+        y, l = maf(torch.randn(20, D, device='cuda'))
+    assert torch.isfinite(y).all() and torch.isfinite(l).all()

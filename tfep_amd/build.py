@@ -13,8 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libtfep_hip.so')
-SOURCES = ['transformers.hip', 'masked_linear.hip', 'split_gemm.hip', 'inverse_block.hip', 'reduce.hip', 'backward.hip',
-           'egnn.hip']
+SOURCES = ['transformers.hip', 'masked_linear.hip', 'split_gemm.hip', 'split_gemm_layouts.hip', 'inverse_block.hip',
+           'reduce.hip', 'backward.hip', 'egnn.hip']
 
 
 def _hipcc():

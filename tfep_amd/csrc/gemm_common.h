@@ -11,7 +11,10 @@ namespace tfep {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum Epilogue { EPI_LINEAR = 0, EPI_ELU = 1, EPI_AFFINE = 2, EPI_SPLINE = 3, EPI_ELU_SPLIT = 4 };
+// EPI_SPLINE_IDB: the RQ-spline epilogue for identity boundary slopes with BOTH bounds learnable -- the one layout whose
+// parameter count (3 K + 1) does not tell it apart from the plain one
+enum Epilogue { EPI_LINEAR = 0, EPI_ELU = 1, EPI_AFFINE = 2, EPI_SPLINE = 3, EPI_ELU_SPLIT = 4, EPI_SPLINE_IDB = 5 };
+constexpr bool epi_is_spline(int epi) { return epi == EPI_SPLINE || epi == EPI_SPLINE_IDB; }
 
 struct FusedArgs {
     const float* x;            // transformer input  (B, ldx)
@@ -131,7 +134,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
 #pragma unroll
             for (int p = 0; p < P; ++p) bias_p[p] = g.bias ? g.bias[n0 + (ft * P + p) * 16 + cj] : 0.f;
             float x0 = 0.f, xf = 1.f, y0 = 0.f, yf = 1.f;
-            if (EPI == EPI_SPLINE && live) {
+            if (epi_is_spline(EPI) && live) {
                 const int ftr = fu.feat_tr[slot];
                 x0 = fu.x0[ftr];
                 xf = fu.xf[ftr];
@@ -154,18 +157,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[NR
                             out = xv * expf(ls) + shift;           // affine.py:321-323
                             ld = (double)ls;
                         } else {
-                            float w[KSPL], h[KSPL], sraw[KSPL + 1];
-#pragma unroll
-                            for (int k = 0; k < KSPL; ++k) {
-                                w[k] = acc[ft * P + k][m][i] + bias_p[k];
-                                h[k] = acc[ft * P + KSPL + k][m][i] + bias_p[KSPL + k];
-                            }
-                            // plain: K+1 slopes; circular: K slopes, slope_K := slope_0, last = shift
-#pragma unroll
-                            for (int k = 0; k < KSPL; ++k) sraw[k] = acc[ft * P + 2 * KSPL + k][m][i] + bias_p[2 * KSPL + k];
-                            const float lastp = acc[ft * P + 3 * KSPL][m][i] + bias_p[3 * KSPL];
-                            sraw[KSPL] = fu.sf.circular ? sraw[0] : lastp;
-                            out = (float)rq_spline_element<KSPL, false>(w, h, sraw, lastp, 0.f, fu.sf, x0, xf, y0, yf, xv, &ld);
+                            float w[KSPL], h[KSPL], sraw[KSPL + 1], lastp, last2;
+                            const SplineFlags sf = spline_flags_of_layout<KSPL, P, EPI == EPI_SPLINE_IDB>(fu.sf);
+                            spline_expand<KSPL, P>(sf, [&](auto pc) __attribute__((always_inline)) {
+                                return acc[ft * P + pc.value][m][i] + bias_p[pc.value];
+                            }, w, h, sraw, lastp, last2);
+                            out = (float)rq_spline_element<KSPL, false>(w, h, sraw, lastp, last2, sf, x0, xf, y0, yf, xv, &ld);
                         }
                         fu.y[(int64_t)row * fu.ldy + fcol] = out;
                     }
@@ -202,5 +199,7 @@ constexpr int FUSED_TILE_FEATURES = 16;
 // split_gemm.hip: the same GEMMs on split-f16 operands (g.a / g.w point to split rows, g.a_inv_scale / g.w_inv_scale set)
 int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s);
 int launch_split_fused(const GemmArgs& g, int n_rows_w, int kind, int n_col_tiles, hipStream_t s);
+// (split_gemm_layouts.hip) the spline layouts with identity boundary slopes / learnable bounds: P != 3 K + 1
+int launch_split_fused_layouts(const GemmArgs& g, int n_rows_w, int K, int P, int n_col_tiles, hipStream_t s);
 
 }  // namespace tfep

@@ -586,17 +586,26 @@ int tfep_diag_mfma_peak(float* scratch, int blocks, int iters, void* stream) {
     return check_launch("mfma_peak_kernel");
 }
 
+// parameters per feature of a spline descriptor (spline_n_params)
+static int desc_n_params(const tfep_spline_desc* d) {
+    return spline_n_params(d->n_bins, d->circular != 0, d->identity_boundary_slopes != 0, d->learn_lower_bound != 0,
+                           d->learn_upper_bound != 0);
+}
+
 int tfep_fused_supported(int kind, const tfep_spline_desc* d) {
     if (kind == TFEP_FUSED_AFFINE) return 1;
-    if (kind == TFEP_FUSED_SPLINE && d)
-        return (d->n_bins == 8 || d->n_bins == 5 || d->n_bins == 4) && !d->identity_boundary_slopes && !d->learn_lower_bound &&
-               !d->learn_upper_bound;
+    if (kind == TFEP_FUSED_SPLINE && d) {
+        if (d->n_bins != 8 && d->n_bins != 5 && d->n_bins != 4) return 0;
+        if (d->circular && (d->learn_lower_bound || d->learn_upper_bound)) return 0;       // (not a valid spline)
+        // 8 bins: 26 / 27 accumulator tiles per wave do not fit the register file of the split kernel
+        return desc_n_params(d) <= 25;
+    }
     return 0;
 }
 
 int tfep_fused_tile_columns(int kind, const tfep_spline_desc* d) {
     if (kind == TFEP_FUSED_AFFINE) return 16 * 16;      // P = 2, FT = 8
-    if (kind == TFEP_FUSED_SPLINE && tfep_fused_supported(kind, d)) return 16 * (3 * d->n_bins + 1);   // P = 3 K + 1, FT = 1
+    if (kind == TFEP_FUSED_SPLINE && tfep_fused_supported(kind, d)) return 16 * desc_n_params(d);   // FT = 1
     return fail(TFEP_ERR_UNSUPPORTED, "fused: unsupported transformer configuration");
 }
 
@@ -630,19 +639,34 @@ static int fused_forward(const float* h, int64_t ldh, const float* w, int64_t ld
         rc = split ? launch_split_fused(g, n_rows_w, kind, n_groups / FT, s)
                    : launch_gemm<2, P * FT, EPI_AFFINE, P, 1>(g, n_rows_w, n_groups / FT, s);
     } else {
-        const int KS = desc->n_bins, P = 3 * KS + 1;
+        const int KS = desc->n_bins, P = desc_n_params(desc);
         TFEP_REQUIRE(feat_tr && desc->x0 && desc->xf && desc->y0 && desc->yf, "fused spline: NULL descriptor arrays");
         TFEP_REQUIRE(n_rows_w >= n_feature_slots * P, "fused: weight has too few rows");
         g.N = n_feature_slots * P;
         g.fu.x0 = desc->x0; g.fu.xf = desc->xf; g.fu.y0 = desc->y0; g.fu.yf = desc->yf;
-        g.fu.sf.K = KS; g.fu.sf.circular = desc->circular != 0; g.fu.sf.identity = false;
-        g.fu.sf.learn_lower = false; g.fu.sf.learn_upper = false;
+        g.fu.sf.K = KS; g.fu.sf.circular = desc->circular != 0; g.fu.sf.identity = desc->identity_boundary_slopes != 0;
+        g.fu.sf.learn_lower = desc->learn_lower_bound != 0; g.fu.sf.learn_upper = desc->learn_upper_bound != 0;
         g.fu.sf.min_bin = desc->min_bin_size; g.fu.sf.min_slope = desc->min_slope;
         g.fu.sf.slope_offset = (float)log(exp(1.0 - (double)desc->min_slope) - 1.0);
-        if (split) rc = launch_split_fused(g, n_rows_w, kind, n_groups, s);
-        else if (KS == 5) rc = launch_gemm<2, 16, EPI_SPLINE, 16, 5>(g, n_rows_w, n_groups, s);
-        else if (KS == 4) rc = launch_gemm<2, 13, EPI_SPLINE, 13, 4>(g, n_rows_w, n_groups, s);
-        else rc = launch_gemm<2, 25, EPI_SPLINE, 25, 8>(g, n_rows_w, n_groups, s);
+        if (split) {
+            rc = launch_split_fused(g, n_rows_w, kind, n_groups, s);
+        } else {
+            rc = fail(TFEP_ERR_UNSUPPORTED, "fused: no kernel for this spline layout");
+#define TFEP_FUSED_SPLINE(KK, PP) \
+    if (KS == KK && P == PP) rc = launch_gemm<2, PP, EPI_SPLINE, PP, KK>(g, n_rows_w, n_groups, s);
+            // (identity slopes + both bounds learnable count 3 K + 1 parameters like the plain layout: EPI_SPLINE_IDB)
+            const bool idb = g.fu.sf.identity && P == 3 * KS + 1;
+#define TFEP_FUSED_SPLINE_IDB(KK) \
+    if (KS == KK && idb) rc = launch_gemm<2, 3 * KK + 1, EPI_SPLINE_IDB, 3 * KK + 1, KK>(g, n_rows_w, n_groups, s);
+            TFEP_FUSED_SPLINE_IDB(8) TFEP_FUSED_SPLINE_IDB(5) TFEP_FUSED_SPLINE_IDB(4)
+#undef TFEP_FUSED_SPLINE_IDB
+            if (!idb) {
+            TFEP_FUSED_SPLINE(8, 25) TFEP_FUSED_SPLINE(8, 23) TFEP_FUSED_SPLINE(8, 24)
+            TFEP_FUSED_SPLINE(5, 16) TFEP_FUSED_SPLINE(5, 14) TFEP_FUSED_SPLINE(5, 15) TFEP_FUSED_SPLINE(5, 17) TFEP_FUSED_SPLINE(5, 18)
+            TFEP_FUSED_SPLINE(4, 13) TFEP_FUSED_SPLINE(4, 11) TFEP_FUSED_SPLINE(4, 12) TFEP_FUSED_SPLINE(4, 14) TFEP_FUSED_SPLINE(4, 15)
+            }
+#undef TFEP_FUSED_SPLINE
+        }
     }
     if (rc) return rc;
     ldj_reduce_kernel<<<(unsigned)((B + 255) / 256), 256, 0, s>>>(ldj_partial, n_groups, B, log_det_J, accumulate);

@@ -13,6 +13,8 @@
 // reference are algebraically a linear map with the boundary slope; it is evaluated directly.
 #pragma once
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace tfep {
@@ -29,6 +31,25 @@ struct SplineFlags {
 // library exp(): the 16 softmax exponentials dominate the fused epilogue.
 __device__ inline double exp_nonpos(double x) {
     x = fmax(x, -700.0);
+    const double n = rint(x * 1.4426950408889634);
+    const double r = fma(n, -0.69314718055994530942, x);
+    double p = 1.0 / 362880.0;
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// exp(x) for |x| <= 700 by the same reduction and polynomial (relative error < 1e-11): the scale of a learnable domain
+// in the fused epilogue, where the library exp() costs registers the 512-register GEMM wave does not have.
+__device__ inline double exp_poly(double x) {
+    x = fmin(fmax(x, -700.0), 700.0);
     const double n = rint(x * 1.4426950408889634);
     const double r = fma(n, -0.69314718055994530942, x);
     double p = 1.0 / 362880.0;
@@ -203,20 +224,92 @@ __device__ inline double rq_spline_element(const float (&w)[KMAX], const float (
     return out;
 }
 
-// Branch-free forward evaluation for the fused epilogue of the split-f16 GEMM: exactly K bins, K + 1 slopes,
-// no learnable bounds, no identity slopes.  The same arithmetic in the same order as
-// rq_spline_element<K, false> (bit-identical results), written as straight-line code with selects: a lone wave
-// on a SIMD has no partner to hide the latency of a dependent fp64 chain behind, so the caller evaluates
-// several elements in one basic block and lets the scheduler interleave their chains.
+// The parameters of one element, expanded from the P values the conditioner produced for it (spline.py:359-380;
+// the same positions as spline_slope_param): K widths, K heights, the K + 1 knot slopes (identity boundary slopes:
+// raw slope 0 at knots 0 and K and K - 1 parameters in between; circular: knot K shares the parameter of knot 0),
+// then `last` / `last2` = parameters P - 1 / P - 2 (circular shift; log-scale and shift of a learnable domain).
+// Every position is a compile-time constant (`get` takes a std::integral_constant), so that the values can stay
+// in registers; the flags are wave uniform and become selects.
+template <int I, int N, class F>
+__device__ __forceinline__ void spline_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        spline_static_for<I + 1, N>(f);
+    }
+}
+
+// The flags a parameter count pins down, as compile-time constants: the epilogue of the plain layout then carries no
+// code for the other ones.  P = 3 K + 1 is the plain / circular layout -- and identity slopes with both bounds learnable
+// (IDB), which is an instantiation of its own.
+template <int K, int P, bool IDB>
+__device__ __forceinline__ SplineFlags spline_flags_of_layout(SplineFlags f) {
+    static_assert(!IDB || P == 3 * K + 1, "identity slopes + both bounds learnable: 3 K + 1 parameters");
+    if constexpr (IDB) {
+        f.identity = true; f.circular = false; f.learn_lower = true; f.learn_upper = true;
+        return f;
+    }
+    if constexpr (P == 3 * K + 1) {
+        f.identity = false; f.learn_lower = false; f.learn_upper = false;
+    } else if constexpr (P == 3 * K - 1) {
+        f.identity = true; f.circular = false; f.learn_lower = false; f.learn_upper = false;
+    } else if constexpr (P == 3 * K) {
+        f.identity = true;                              // circular, or one learnable bound
+    } else if constexpr (P == 3 * K + 2) {
+        f.identity = false; f.circular = false;         // one learnable bound
+    } else {
+        f.identity = false; f.circular = false; f.learn_lower = true; f.learn_upper = true;
+    }
+    return f;
+}
+
+template <int K, int P, class Get>
+__device__ __forceinline__ void spline_expand(const SplineFlags& f, Get&& get, float (&w)[K], float (&h)[K],
+                                              float (&sraw)[K + 1], float& last, float& last2) {
+    static_assert(P >= 3 * K - 1 && P <= 3 * K + 3, "not a parameter count of a K-bin spline");
+    spline_static_for<0, K>([&](auto kc) __attribute__((always_inline)) {
+        constexpr int k = kc.value;
+        w[k] = get(std::integral_constant<int, k>{});
+        h[k] = get(std::integral_constant<int, K + k>{});
+    });
+    spline_static_for<0, K + 1>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = jc.value;
+        constexpr int p_plain = 2 * K + j < P ? 2 * K + j : P - 1;         // (clamped: read but not selected)
+        constexpr int p_ident = (j == 0 || j == K) ? 0 : 2 * K + j - 1;
+        float plain = get(std::integral_constant<int, p_plain>{});
+        if (j == K) plain = f.circular ? get(std::integral_constant<int, 2 * K>{}) : plain;
+        const float ident = (j == 0 || j == K) ? 0.f : get(std::integral_constant<int, p_ident>{});
+        sraw[j] = f.identity ? ident : plain;
+    });
+    last = get(std::integral_constant<int, P - 1>{});
+    last2 = get(std::integral_constant<int, P - 2>{});
+}
+
+// Branch-free forward evaluation for the fused epilogue of the split-f16 GEMM: exactly K bins, the K + 1 slopes
+// already expanded (spline_expand).  The same arithmetic in the same order as rq_spline_element<K, false>
+// (bit-identical results), written as straight-line code with selects: a lone wave on a SIMD has no partner to
+// hide the latency of a dependent fp64 chain behind, so the caller evaluates several elements in one basic
+// block and lets the scheduler interleave their chains.
 template <int K>
 __device__ __forceinline__ double rq_spline_forward_full(const float (&w)[K], const float (&h)[K],
-                                                        const float (&sraw)[K + 1], float last,
+                                                        const float (&sraw)[K + 1], float last, float last2,
                                                         const SplineFlags& f, float x0f, float xff, float y0f,
                                                         float yff, float vin, double* logd) {
     const double mb = (double)f.min_bin;
-    const double x0 = x0f, y0 = y0f;
-    const double W = (double)xff - (double)x0f - K * mb;
-    const double H = (double)yff - (double)y0f - K * mb;
+    double x0 = x0f, y0 = y0f;
+    double W = (double)xff - (double)x0f - K * mb;
+    double H = (double)yff - (double)y0f - K * mb;
+    if (f.learn_lower || f.learn_upper) {                                         // wave-uniform branch
+        const double scale = exp_poly((double)last);
+        W *= scale;
+        H *= scale;
+        if (f.learn_lower && f.learn_upper) {
+            x0 += (double)last2;
+            y0 += (double)last2;
+        } else if (f.learn_lower) {
+            x0 = (double)xff - W - K * mb;
+            y0 = (double)yff - H - K * mb;
+        }
+    }
     double v = vin;
     if (f.circular) v = py_mod(v - x0 + (double)last, (double)xff - x0) + x0;     // wave-uniform branch
 

@@ -152,8 +152,8 @@ class AutoregressiveFlow(torch.nn.Module):
         if type(tr) is AffineTransformer:
             return _FUSED_AFFINE
         if type(tr) is NeuralSplineTransformer:
-            h = tr.host()
-            if h['n_bins'] in (4, 5, 8) and not h['identity'] and not h['learn_lower'] and not h['learn_upper']:
+            # the rule of tfep_fused_supported: 8, 5 or 4 bins, every layout of at most 25 parameters per feature
+            if tr.host()['n_bins'] in (4, 5, 8) and tr.n_parameters_per_feature <= 25:
                 return _FUSED_SPLINE
         return None
 
@@ -193,7 +193,7 @@ class AutoregressiveFlow(torch.nn.Module):
         mplan = made.plan(device)
         last = made.layers[-1]
         n_tr = tables['n_tr']
-        P = 2 if kind == _FUSED_AFFINE else 3 * self._transformer.host()['n_bins'] + 1
+        P = 2 if kind == _FUSED_AFFINE else self._transformer.n_parameters_per_feature
         if last.out_features != P * n_tr:
             raise ValueError('conditioner output does not match the transformer parameters')
         desc = self._transformer.config(device).desc if kind == _FUSED_SPLINE else None

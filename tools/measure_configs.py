@@ -146,21 +146,27 @@ if 'cfg3shard' in which:
     del flow
 
 if 'variants' in which:
-    # what the unfused path costs for the spline variants the fused epilogue does not cover.  One
-    # cfg2-sized layer (D = 3000, H = 14998) at B = 32768: fused K = 8 plain spline against the K = 5 identity-slope /
-    # learnable-bound splines of MixedMAFMap (app/mixedmaf.py:770-811) on the generic path (split GEMMs, the (B, P D)
-    # parameters through HBM, stand-alone spline kernel).
+    # the spline layouts on the fused epilogue against the generic path (split GEMMs, the (B, P D)
+    # parameters through HBM, stand-alone spline kernel).  One cfg2-sized layer (D = 3000, H = 14998) at B = 32768: K = 8 /
+    # 5 / 4 plain splines and the identity-slope / learnable-bound splines of MixedMAFMap (app/mixedmaf.py:770-811).
     D, B = 3000, 32768
     x = torch.randn(B, D, device=dev).clamp_(-4.9, 4.9)
-    for name, kw in (('K=8 plain (fused epilogue)', dict(n_bins=8)),
-                     ('K=8 plain, fused=False (generic path)', dict(n_bins=8)),
-                     ('K=5 plain (fused epilogue)', dict(n_bins=5)),
-                     ('K=5 plain, fused=False (generic path)', dict(n_bins=5)),
-                     ('K=5 circular (fused epilogue)', dict(n_bins=5, circular=True)),
-                     ('K=4 plain (fused epilogue)', dict(n_bins=4)),
-                     ('K=5 identity slopes (generic path)', dict(n_bins=5, identity_boundary_slopes=True)),
-                     ('K=5 identity slopes + learnable bounds (generic path)',
-                      dict(n_bins=5, identity_boundary_slopes=True, learn_lower_bound=True, learn_upper_bound=True))):
+    ident = dict(identity_boundary_slopes=True)
+    both = dict(learn_lower_bound=True, learn_upper_bound=True)
+    for name, kw in (('K=8 plain', dict(n_bins=8)),
+                     ('K=8 plain, fused=False', dict(n_bins=8)),
+                     ('K=5 plain', dict(n_bins=5)),
+                     ('K=5 plain, fused=False', dict(n_bins=5)),
+                     ('K=5 circular', dict(n_bins=5, circular=True)),
+                     ('K=4 plain', dict(n_bins=4)),
+                     ('K=8 identity slopes', dict(n_bins=8, **ident)),
+                     ('K=8 identity slopes, fused=False', dict(n_bins=8, **ident)),
+                     ('K=5 identity slopes', dict(n_bins=5, **ident)),
+                     ('K=5 identity slopes, fused=False', dict(n_bins=5, **ident)),
+                     ('K=5 learnable bounds', dict(n_bins=5, **both)),
+                     ('K=5 learnable bounds, fused=False', dict(n_bins=5, **both)),
+                     ('K=5 identity slopes + learnable bounds (same count as plain: generic path)',
+                      dict(n_bins=5, **ident, **both))):
         torch.manual_seed(0)
         with torch.device(dev):
             flow = SequentialFlow(MAF(generate_degrees(D, 'ascending'),
