@@ -60,7 +60,7 @@ def test_every_op_is_registered_with_a_fake_and_passes_opcheck():
     samples = _samples()
     for name in to.OPS:
         op = getattr(torch.ops.tfep, name).default
-        if name == 'fused_output_transformer':
+        if name.startswith('fused_output_transformer'):
             continue                                                  # exercised through the Module API below
         assert name in samples, name
         for args in samples[name]:
@@ -250,3 +250,60 @@ def test_spline_layouts_outside_the_fused_kernels(K, identity, learn_lower, lear
     with torch.no_grad():
         y, l = maf(torch.randn(20, D, device='cuda'))
     assert torch.isfinite(y).all() and torch.isfinite(l).all()
+
+
+@pytest.mark.parametrize('with_affine', [False, True])
+def test_mixed_transformer_runs_one_fused_launch_per_group(with_affine):
+    """A MixedTransformer whose members all have a fused epilogue (the four 5-bin spline layouts of the reference's
+    MixedMAFMap, app/mixedmaf.py:770-811; optionally an affine group) packs the output layer once, every group on its own
+    column tiles, and launches the fused kernel once per group; same results as the generic path."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import AffineTransformer, MixedTransformer, NeuralSplineTransformer
+
+    class Spy(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            self.seen.append(str(func))
+            return func(*args, **(kwargs or {}))
+    torch.manual_seed(11)
+    D, B = 83, 300
+    perm = torch.randperm(D)
+    sizes = [21, 17, 30, 15] if not with_affine else [21, 17, 20, 15, 10]
+    idx = [perm[sum(sizes[:i]):sum(sizes[:i + 1])].sort().values for i in range(len(sizes))]
+    members = [
+        NeuralSplineTransformer(torch.full((sizes[0],), 0.5), torch.full((sizes[0],), 3.0), 5, identity_boundary_slopes=True,
+                                learn_upper_bound=True),
+        NeuralSplineTransformer(torch.zeros(sizes[1]), torch.ones(sizes[1]), 5),
+        NeuralSplineTransformer(torch.zeros(sizes[2]), torch.ones(sizes[2]), 5, circular=True),
+        NeuralSplineTransformer(torch.full((sizes[3],), -2.0), torch.full((sizes[3],), 2.0), 5, identity_boundary_slopes=True,
+                                learn_lower_bound=True, learn_upper_bound=True),
+    ]
+    if with_affine:
+        members.append(AffineTransformer())
+    maf = MAF(generate_degrees(D, 'descending'), transformer=MixedTransformer(members, idx), hidden_layers=[150, 170],
+              initialize_identity=False).cuda()
+    assert maf._fused_kind() == 2
+    x = torch.rand(B, D, device='cuda')
+    x[:, idx[0]] = x[:, idx[0]] * 3.5 + 0.25
+    x[:, idx[3]] = (x[:, idx[3]] - 0.5) * 5.0
+    with torch.no_grad():
+        for split in (False, True):
+            maf.split_gemm = split
+            maf.fused = True
+            with Spy() as spy:
+                y, l = maf(x)
+            assert sum('tfep.fused_output_transformer' in s for s in spy.seen) == len(members)
+            maf.fused = False
+            yg, lg = maf(x)
+            assert float((y - yg).abs().max()) < 2e-5 and float((l - lg).abs().max()) < 3e-4
+            assert float((y - x).abs().max()) > 1e-2
+    # a member without a fused epilogue keeps the whole layer on the generic path
+    other = MAF(generate_degrees(6, 'ascending'),
+                transformer=MixedTransformer([NeuralSplineTransformer(torch.zeros(3), torch.ones(3), 6), AffineTransformer()],
+                                             [[0, 1, 2], [3, 4, 5]]), initialize_identity=False).cuda()
+    assert other._fused_kind() is None

@@ -21,11 +21,12 @@ from ...utils.misc import ensure_tensor_sequence
 from ..conditioners.made import MADE
 from ..embeddings.mafembed import PeriodicEmbedding
 from ..transformers.affine import AffineTransformer
+from ..transformers.mixed import MixedTransformer
 from ..transformers.moebius import MoebiusTransformer
 from ..transformers.spline import NeuralSplineTransformer
 from .sequential import _side_stream
 
-_FUSED_AFFINE, _FUSED_SPLINE = 0, 1
+_FUSED_AFFINE, _FUSED_SPLINE, _FUSED_MIXED = 0, 1, 2      # (0 / 1: tfep_fused_kind; 2: one launch per group)
 
 
 class AutoregressiveFlow(torch.nn.Module):
@@ -145,17 +146,26 @@ class AutoregressiveFlow(torch.nn.Module):
         return t['inverse_steps']
 
     # ------------------------------------------------------------------ fused path
+    @staticmethod
+    def _transformer_fused_kind(tr):
+        """Fused epilogue of one transformer (the rule of tfep_fused_supported): affine; RQ splines of 8, 5 or 4 bins in
+        every layout of at most 25 parameters per feature."""
+        if type(tr) is AffineTransformer:
+            return _FUSED_AFFINE
+        if type(tr) is NeuralSplineTransformer and tr.host()['n_bins'] in (4, 5, 8) and tr.n_parameters_per_feature <= 25:
+            return _FUSED_SPLINE
+        return None
+
     def _fused_kind(self):
         if not self.fused or not isinstance(self._conditioner, MADE) or len(self._conditioner_indices) > 0:
             return None
         tr = self._transformer
-        if type(tr) is AffineTransformer:
-            return _FUSED_AFFINE
-        if type(tr) is NeuralSplineTransformer:
-            # the rule of tfep_fused_supported: 8, 5 or 4 bins, every layout of at most 25 parameters per feature
-            if tr.host()['n_bins'] in (4, 5, 8) and tr.n_parameters_per_feature <= 25:
-                return _FUSED_SPLINE
-        return None
+        if type(tr) is MixedTransformer:
+            # every group on its own column tiles of the output GEMM, one fused launch per group
+            if all(self._transformer_fused_kind(t) is not None for t in tr._transformers):
+                return _FUSED_MIXED
+            return None
+        return self._transformer_fused_kind(tr)
 
     def prepack_async(self, device, stream, batch=None):
         """Start packing this layer's weights on ``stream`` for its next forward pass (called by SequentialFlow while
@@ -184,6 +194,10 @@ class AutoregressiveFlow(torch.nn.Module):
         return ops.split_gemm_enabled() and isinstance(made, MADE) and made.split_worthwhile(batch)
 
     def _fused_plan(self, device, kind, tables):
+        """Packed layout of the MADE output layer for the fused kernels.  The transformed features form GROUPS -- one for a
+        plain transformer, one per sub-transformer of a MixedTransformer (whose parameters come grouped by transformer,
+        mixed.py:64-68) -- and every group owns a run of column tiles (16 features x P parameters x FT) of ONE packed
+        weight matrix: one re-pack per forward, one fused launch per group on its row slice."""
         key = ('fused', str(device), kind)
         fp = self._dev.get(key)
         if fp is not None:
@@ -193,35 +207,49 @@ class AutoregressiveFlow(torch.nn.Module):
         mplan = made.plan(device)
         last = made.layers[-1]
         n_tr = tables['n_tr']
-        P = 2 if kind == _FUSED_AFFINE else self._transformer.n_parameters_per_feature
-        if last.out_features != P * n_tr:
-            raise ValueError('conditioner output does not match the transformer parameters')
-        desc = self._transformer.config(device).desc if kind == _FUSED_SPLINE else None
-        tile_cols = lib.tfep_fused_tile_columns(kind, ctypes.byref(desc) if desc is not None else None)
-        FT = tile_cols // (16 * P)
-        n_slots = ops.round_up(n_tr, 16 * FT)
-        deg_tr = made._degrees[-1][:n_tr].cpu()
-        order = torch.argsort(deg_tr, stable=True)                 # slot -> transformed feature
-        slot_of = torch.empty_like(order)
-        slot_of[order] = torch.arange(n_tr, device='cpu')
-        feat_tr = torch.zeros(n_slots, dtype=torch.long, device='cpu')
-        feat_tr[:n_tr] = order
-        feat_index = torch.full((n_slots,), -1, dtype=torch.long, device='cpu')
-        feat_index[:n_tr] = tables['tr'].cpu().long()[order]
-        s = slot_of.repeat(P)                                      # slot of output row o = p*n_tr + t
-        p = torch.arange(P, device='cpu').repeat_interleave(n_tr)
-        row_of_out = (s // (16 * FT)) * tile_cols + (((s // 16) % FT) * P + p) * 16 + (s % 16)
-        n_tiles = n_slots // (16 * FT)
+        tr = self._transformer
+        cols_tr = tables['tr'].cpu().long()                         # transformed feature -> column of x
+        if kind == _FUSED_MIXED:
+            members = [(self._transformer_fused_kind(t), t, ind.cpu().long(), off)
+                       for t, ind, off in zip(tr._transformers, tr._indices, tr.host_splits()) if len(ind) > 0]
+        else:
+            members = [(kind, tr, None, 0)]
         i32 = dict(device=device, dtype=torch.int32)
         li = len(mplan['n_pad']) - 1
-        fp = {
-            'kind': kind, 'P': P, 'FT': FT, 'n_slots': n_slots, 'n_rows': n_tiles * tile_cols,
-            'row_of_out': row_of_out.to(**i32), 'feat_index': feat_index.to(**i32), 'feat_tr': feat_tr.to(**i32),
-            'li': li,
-        }
-        fp['k_ranges'] = ops.mask_k_ranges(last.mask, tile_cols, n_tiles, mplan['k_pad'][li],
-                                           fp['row_of_out'], mplan['col_of_in'][li])
-        fp['tile_order'] = ops.heavy_first_order(fp['k_ranges'])
+        row_of_out = torch.full((last.out_features,), -1, dtype=torch.long, device='cpu')
+        groups, base = [], 0
+        for k_g, t_g, rel, off in members:
+            n_g = n_tr if rel is None else len(rel)
+            P = 2 if k_g == _FUSED_AFFINE else t_g.n_parameters_per_feature
+            if off + P * n_g > last.out_features:
+                raise ValueError('conditioner output does not match the transformer parameters')
+            desc = t_g.config(device).desc if k_g == _FUSED_SPLINE else None
+            tile_cols = lib.tfep_fused_tile_columns(k_g, ctypes.byref(desc) if desc is not None else None)
+            FT = tile_cols // (16 * P)
+            n_slots = ops.round_up(n_g, 16 * FT)
+            deg = made._degrees[-1][off:off + n_g].cpu()
+            order = torch.argsort(deg, stable=True)                # slot -> feature of the group
+            slot_of = torch.empty_like(order)
+            slot_of[order] = torch.arange(n_g, device='cpu')
+            feat_tr = torch.zeros(n_slots, dtype=torch.long, device='cpu')
+            feat_tr[:n_g] = order
+            feat_index = torch.full((n_slots,), -1, dtype=torch.long, device='cpu')
+            feat_index[:n_g] = (cols_tr if rel is None else cols_tr[rel])[order]
+            sl = slot_of.repeat(P)                                 # slot of output row o = off + p*n_g + t
+            pp = torch.arange(P, device='cpu').repeat_interleave(n_g)
+            local = (sl // (16 * FT)) * tile_cols + (((sl // 16) % FT) * P + pp) * 16 + (sl % 16)
+            n_tiles = n_slots // (16 * FT)
+            row_of_out[off:off + P * n_g] = base + local
+            grp = {'kind': k_g, 'transformer': t_g, 'P': P, 'FT': FT, 'n_slots': n_slots, 'n_rows': n_tiles * tile_cols,
+                   'base': base, 'feat_index': feat_index.to(**i32), 'feat_tr': feat_tr.to(**i32)}
+            grp['k_ranges'] = ops.mask_k_ranges(last.mask[off:off + P * n_g], tile_cols, n_tiles, mplan['k_pad'][li],
+                                                local.to(**i32), mplan['col_of_in'][li])
+            grp['tile_order'] = ops.heavy_first_order(grp['k_ranges'])
+            groups.append(grp)
+            base += grp['n_rows']
+        if bool((row_of_out < 0).any()):
+            raise ValueError('conditioner output does not match the transformer parameters')
+        fp = {'kind': kind, 'groups': groups, 'n_rows': base, 'row_of_out': row_of_out.to(**i32), 'li': li}
         self._dev[key] = fp
         return fp
 
@@ -243,16 +271,22 @@ class AutoregressiveFlow(torch.nn.Module):
         if prof is not None:                     # bench.py: HIP events around the fused launch
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record(torch.cuda.current_stream(x.device))
-        if kind == _FUSED_SPLINE:
-            cfg, hst = self._transformer.config(x.device), self._transformer.host()
-            spl = (cfg.x0, cfg.xf, cfg.y0, cfg.yf, hst['n_bins'], hst['circular'], hst['identity'], hst['learn_lower'],
-                   hst['learn_upper'], hst['min_bin'], hst['min_slope'])
-        else:
-            spl = (None, None, None, None, 0, False, False, False, False, 0.0, 0.0)
-        # torch.ops.tfep.fused_output_transformer = tfep_fused_output_transformer_forward[_split]
-        y, ldj = torch.ops.tfep.fused_output_transformer(
-            h, h_inv if split else None, w, w_inv if split else None, b, fp['k_ranges'], fp['tile_order'], kind, x,
-            x if self.has_fixed_indices else None, fp['feat_index'], fp['feat_tr'], fp['n_slots'], fp['n_rows'], *spl)
+        # torch.ops.tfep.fused_output_transformer = tfep_fused_output_transformer_forward[_split]; one launch per group
+        # on the group's rows of the packed weights, every launch writing its own columns of y
+        y = x.clone() if self.has_fixed_indices else torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        ldj = None
+        for grp in fp['groups']:
+            if grp['kind'] == _FUSED_SPLINE:
+                cfg, hst = grp['transformer'].config(x.device), grp['transformer'].host()
+                spl = (cfg.x0, cfg.xf, cfg.y0, cfg.yf, hst['n_bins'], hst['circular'], hst['identity'], hst['learn_lower'],
+                       hst['learn_upper'], hst['min_bin'], hst['min_slope'])
+            else:
+                spl = (None, None, None, None, 0, False, False, False, False, 0.0, 0.0)
+            r0, r1 = grp['base'], grp['base'] + grp['n_rows']
+            l = torch.ops.tfep.fused_output_transformer_(
+                h, h_inv if split else None, w[r0:r1], w_inv if split else None, b[r0:r1], grp['k_ranges'],
+                grp['tile_order'], grp['kind'], x, y, grp['feat_index'], grp['feat_tr'], grp['n_slots'], grp['n_rows'], *spl)
+            ldj = l if ldj is None else ldj + l
         if prof is not None:
             ev1.record(torch.cuda.current_stream(x.device))
             prof.append((ev0, ev1))

@@ -280,20 +280,13 @@ masked_linear.register_autograd(_ml_bwd, setup_context=_ml_setup)
 
 # ============================================================================= fused MADE output layer + transformer
 
-@custom_op('tfep::fused_output_transformer', mutates_args=(), device_types=_DEV)
-def fused_output_transformer(h: Tensor, h_inv_scale: Optional[Tensor], w: Tensor, w_inv_scale: Optional[Tensor],
-                             bias: Tensor, k_ranges: Tensor, tile_order: Tensor, kind: int, x: Tensor, y_init: Optional[Tensor],
-                             feat_index: Tensor, feat_tr: Tensor, n_slots: int, n_rows: int,
-                             x0: Optional[Tensor], xf: Optional[Tensor], y0: Optional[Tensor], yf: Optional[Tensor],
-                             n_bins: int, circular: bool, identity_boundary_slopes: bool, learn_lower_bound: bool,
-                             learn_upper_bound: bool, min_bin_size: float, min_slope: float) -> Tuple[Tensor, Tensor]:
-    """``tfep_fused_output_transformer_forward[_split]``: the MADE output-layer GEMM with the affine (kind 0) or RQ-spline
-    (kind 1) transformer and the log-det in its epilogue.  ``h`` / ``w``: last hidden activations and packed output
-    weights -- split-f16 rows when ``h_inv_scale`` / ``w_inv_scale`` are given, fp32 otherwise.  ``y_init``: the input
-    with its fixed features (copied through), or None when every feature is transformed."""
+def _fused_launch(h, h_inv_scale, w, w_inv_scale, bias, k_ranges, tile_order, kind, x, y, feat_index, feat_tr, n_slots,
+                  n_rows, x0, xf, y0, yf, n_bins, circular, identity_boundary_slopes, learn_lower_bound, learn_upper_bound,
+                  min_bin_size, min_slope):
     x, ldx = _lib.rows(x, 'x')
     B, D = x.shape
-    y = y_init.clone() if y_init is not None else torch.empty(B, D, dtype=x.dtype, device=x.device)
+    if y.shape != x.shape or y.stride(-1) != 1 or (B > 1 and y.stride(0) != D):
+        raise RuntimeError('fused_output_transformer: y must be a contiguous tensor of the shape of x')
     ldj = torch.empty(B, dtype=torch.float32, device=x.device)
     ws = torch.empty(n_slots // 16, B, dtype=torch.float64, device=x.device)
     desc = None
@@ -309,12 +302,49 @@ def fused_output_transformer(h: Tensor, h_inv_scale: Optional[Tensor], w: Tensor
                   _lib.ptr(w), w.shape[1], _lib.ptr(w_inv_scale), *tail)
     else:
         _lib.call('tfep_fused_output_transformer_forward', _lib.ptr(h), h.shape[1], _lib.ptr(w), w.shape[1], *tail)
+    return ldj
+
+
+@custom_op('tfep::fused_output_transformer', mutates_args=(), device_types=_DEV)
+def fused_output_transformer(h: Tensor, h_inv_scale: Optional[Tensor], w: Tensor, w_inv_scale: Optional[Tensor],
+                             bias: Tensor, k_ranges: Tensor, tile_order: Tensor, kind: int, x: Tensor, y_init: Optional[Tensor],
+                             feat_index: Tensor, feat_tr: Tensor, n_slots: int, n_rows: int,
+                             x0: Optional[Tensor], xf: Optional[Tensor], y0: Optional[Tensor], yf: Optional[Tensor],
+                             n_bins: int, circular: bool, identity_boundary_slopes: bool, learn_lower_bound: bool,
+                             learn_upper_bound: bool, min_bin_size: float, min_slope: float) -> Tuple[Tensor, Tensor]:
+    """``tfep_fused_output_transformer_forward[_split]``: the MADE output-layer GEMM with the affine (kind 0) or RQ-spline
+    (kind 1) transformer and the log-det in its epilogue.  ``h`` / ``w``: last hidden activations and packed output
+    weights -- split-f16 rows when ``h_inv_scale`` / ``w_inv_scale`` are given, fp32 otherwise.  ``y_init``: the input
+    with its fixed features (copied through), or None when every feature is transformed."""
+    y = y_init.clone() if y_init is not None else torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    ldj = _fused_launch(h, h_inv_scale, w, w_inv_scale, bias, k_ranges, tile_order, kind, x, y, feat_index, feat_tr, n_slots,
+                        n_rows, x0, xf, y0, yf, n_bins, circular, identity_boundary_slopes, learn_lower_bound,
+                        learn_upper_bound, min_bin_size, min_slope)
     return y, ldj
 
 
 @fused_output_transformer.register_fake
 def _(h, h_inv_scale, w, w_inv_scale, bias, k_ranges, tile_order, kind, x, y_init, *rest):
     return x.new_empty(x.shape), x.new_empty((x.shape[0],))
+
+
+@custom_op('tfep::fused_output_transformer_', mutates_args=('y',), device_types=_DEV)
+def fused_output_transformer_(h: Tensor, h_inv_scale: Optional[Tensor], w: Tensor, w_inv_scale: Optional[Tensor],
+                              bias: Tensor, k_ranges: Tensor, tile_order: Tensor, kind: int, x: Tensor, y: Tensor,
+                              feat_index: Tensor, feat_tr: Tensor, n_slots: int, n_rows: int,
+                              x0: Optional[Tensor], xf: Optional[Tensor], y0: Optional[Tensor], yf: Optional[Tensor],
+                              n_bins: int, circular: bool, identity_boundary_slopes: bool, learn_lower_bound: bool,
+                              learn_upper_bound: bool, min_bin_size: float, min_slope: float) -> Tensor:
+    """The same launch writing the columns ``feat_index`` of an existing ``y`` (in place) and returning the log-det of
+    those features: the groups of a mixed transformer are one launch each on their rows of the packed weights."""
+    return _fused_launch(h, h_inv_scale, w, w_inv_scale, bias, k_ranges, tile_order, kind, x, y, feat_index, feat_tr, n_slots,
+                         n_rows, x0, xf, y0, yf, n_bins, circular, identity_boundary_slopes, learn_lower_bound,
+                         learn_upper_bound, min_bin_size, min_slope)
+
+
+@fused_output_transformer_.register_fake
+def _(h, h_inv_scale, w, w_inv_scale, bias, k_ranges, tile_order, kind, x, y, *rest):
+    return x.new_empty((x.shape[0],))
 
 
 # ============================================================================= TFEP reductions
@@ -332,4 +362,4 @@ def _(target_potentials, log_det_J, ref_potentials, log_weights, bias, kT, ignor
 
 OPS = ('affine_forward', 'affine_inverse', 'affine_backward', 'spline_forward', 'spline_inverse', 'spline_backward',
        'moebius_forward', 'moebius_inverse', 'moebius_backward', 'masked_linear', 'masked_linear_backward',
-       'fused_output_transformer', 'tfep_reduce')
+       'fused_output_transformer', 'fused_output_transformer_', 'tfep_reduce')

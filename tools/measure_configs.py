@@ -181,6 +181,36 @@ if 'variants' in which:
                param_tensor_gb=round(B * P * D * 4 / 1e9, 2), roofline=mfma_roofline(flow, B, dt))
         del flow
 
+if 'variants' in which or 'mixed' in which:
+    # the transformer of the reference's MixedMAFMap (app/mixedmaf.py:770-811) on one cfg2-sized layer: four 5-bin
+    # spline groups (distances: identity slopes + learnable upper bound; angles: plain; torsions: circular; cartesians:
+    # identity slopes + both bounds learnable) -- one fused launch per group against the generic path
+    from tfep_amd.nn.transformers import MixedTransformer
+    D, B = 3000, 32768
+    torch.manual_seed(0)
+    perm = torch.randperm(D)
+    sizes = [999, 999, 900, 102]
+    idx = [perm[sum(sizes[:i]):sum(sizes[:i + 1])].sort().values for i in range(4)]
+    x = torch.rand(B, D, device=dev)
+    for name in ('MixedMAFMap transformer (4 spline groups, one fused launch each)', 'MixedMAFMap transformer, fused=False'):
+        torch.manual_seed(0)
+        members = [NeuralSplineTransformer(torch.zeros(sizes[0]), torch.ones(sizes[0]), 5, identity_boundary_slopes=True,
+                                           learn_upper_bound=True),
+                   NeuralSplineTransformer(torch.zeros(sizes[1]), torch.ones(sizes[1]), 5),
+                   NeuralSplineTransformer(torch.zeros(sizes[2]), torch.ones(sizes[2]), 5, circular=True),
+                   NeuralSplineTransformer(torch.zeros(sizes[3]), torch.ones(sizes[3]), 5, identity_boundary_slopes=True,
+                                           learn_lower_bound=True, learn_upper_bound=True)]
+        with torch.device(dev):
+            flow = SequentialFlow(MAF(generate_degrees(D, 'ascending'), transformer=MixedTransformer(members, idx),
+                                      initialize_identity=False))
+        if 'fused=False' in name:
+            flow[0].fused = False
+        with torch.no_grad():
+            dt, _ = timeit(lambda: flow(x), 1, 3)
+        report(f'one cfg2-sized layer, {name}', B, dt, fused=flow[0]._fused_kind() is not None,
+               out_features=flow[0]._conditioner.layers[-1].out_features, roofline=mfma_roofline(flow, B, dt))
+        del flow
+
 if 'train' in which:
     from tfep_amd.loss import BoltzmannKLDivLoss
     D = 3000
