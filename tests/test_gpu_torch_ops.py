@@ -252,6 +252,34 @@ def test_spline_layouts_outside_the_fused_kernels(K, identity, learn_lower, lear
     assert torch.isfinite(y).all() and torch.isfinite(l).all()
 
 
+def _mixed_maf(with_affine, D=83, order='descending', seed=11):
+    """A MAF layer over the mixed transformer of the reference's MixedMAFMap (app/mixedmaf.py:770-811): four 5-bin spline
+    layouts on interleaved feature groups, optionally a fifth affine group; and an input that covers domains and tails."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import AffineTransformer, MixedTransformer, NeuralSplineTransformer
+    torch.manual_seed(seed)
+    perm = torch.randperm(D)
+    sizes = [21, 17, 30, 15] if not with_affine else [21, 17, 20, 15, 10]
+    idx = [perm[sum(sizes[:i]):sum(sizes[:i + 1])].sort().values for i in range(len(sizes))]
+    members = [
+        NeuralSplineTransformer(torch.full((sizes[0],), 0.5), torch.full((sizes[0],), 3.0), 5, identity_boundary_slopes=True,
+                                learn_upper_bound=True),
+        NeuralSplineTransformer(torch.zeros(sizes[1]), torch.ones(sizes[1]), 5),
+        NeuralSplineTransformer(torch.zeros(sizes[2]), torch.ones(sizes[2]), 5, circular=True),
+        NeuralSplineTransformer(torch.full((sizes[3],), -2.0), torch.full((sizes[3],), 2.0), 5, identity_boundary_slopes=True,
+                                learn_lower_bound=True, learn_upper_bound=True),
+    ]
+    if with_affine:
+        members.append(AffineTransformer())
+    maf = MAF(generate_degrees(D, order), transformer=MixedTransformer(members, idx), hidden_layers=[150, 170],
+              initialize_identity=False).cuda()
+    x = torch.rand(300, D, device='cuda')
+    x[:, idx[0]] = x[:, idx[0]] * 3.5 + 0.25
+    x[:, idx[3]] = (x[:, idx[3]] - 0.5) * 5.0
+    return maf, members, x
+
+
 @pytest.mark.parametrize('with_affine', [False, True])
 def test_mixed_transformer_runs_one_fused_launch_per_group(with_affine):
     """A MixedTransformer whose members all have a fused epilogue (the four 5-bin spline layouts of the reference's
@@ -270,27 +298,8 @@ def test_mixed_transformer_runs_one_fused_launch_per_group(with_affine):
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
             self.seen.append(str(func))
             return func(*args, **(kwargs or {}))
-    torch.manual_seed(11)
-    D, B = 83, 300
-    perm = torch.randperm(D)
-    sizes = [21, 17, 30, 15] if not with_affine else [21, 17, 20, 15, 10]
-    idx = [perm[sum(sizes[:i]):sum(sizes[:i + 1])].sort().values for i in range(len(sizes))]
-    members = [
-        NeuralSplineTransformer(torch.full((sizes[0],), 0.5), torch.full((sizes[0],), 3.0), 5, identity_boundary_slopes=True,
-                                learn_upper_bound=True),
-        NeuralSplineTransformer(torch.zeros(sizes[1]), torch.ones(sizes[1]), 5),
-        NeuralSplineTransformer(torch.zeros(sizes[2]), torch.ones(sizes[2]), 5, circular=True),
-        NeuralSplineTransformer(torch.full((sizes[3],), -2.0), torch.full((sizes[3],), 2.0), 5, identity_boundary_slopes=True,
-                                learn_lower_bound=True, learn_upper_bound=True),
-    ]
-    if with_affine:
-        members.append(AffineTransformer())
-    maf = MAF(generate_degrees(D, 'descending'), transformer=MixedTransformer(members, idx), hidden_layers=[150, 170],
-              initialize_identity=False).cuda()
+    maf, members, x = _mixed_maf(with_affine)
     assert maf._fused_kind() == 2
-    x = torch.rand(B, D, device='cuda')
-    x[:, idx[0]] = x[:, idx[0]] * 3.5 + 0.25
-    x[:, idx[3]] = (x[:, idx[3]] - 0.5) * 5.0
     with torch.no_grad():
         for split in (False, True):
             maf.split_gemm = split
@@ -307,3 +316,19 @@ def test_mixed_transformer_runs_one_fused_launch_per_group(with_affine):
                 transformer=MixedTransformer([NeuralSplineTransformer(torch.zeros(3), torch.ones(3), 6), AffineTransformer()],
                                              [[0, 1, 2], [3, 4, 5]]), initialize_identity=False).cuda()
     assert other._fused_kind() is None
+
+
+@pytest.mark.parametrize('with_affine,order', [(False, 'descending'), (True, 'ascending')])
+def test_mixed_transformer_inverse_is_blocked(with_affine, order):
+    """The inverse of a layer over a mixed transformer of element-wise members runs the blocked forward substitution too
+    (one step per degree and member, on the member's rows of the degree-sorted output weights) instead of one full
+    conditioner pass per degree: same x and log-det as the pass-per-degree algorithm of the reference, and a round trip."""
+    maf, members, x = _mixed_maf(with_affine, order=order)
+    assert maf._blocked_ok()
+    with torch.no_grad():
+        y, l = maf(x)
+        xb, lb = maf.inverse(y)
+        maf.blocked_inverse = False
+        xr, lr = maf.inverse(y)
+    assert float((xb - xr).abs().max()) < 5e-5 and float((lb - lr).abs().max()) < 5e-4
+    assert float((xb - x).abs().max()) < 2e-4 and float((lb + l).abs().max()) < 2e-3

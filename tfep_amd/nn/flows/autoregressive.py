@@ -345,9 +345,10 @@ class AutoregressiveFlow(torch.nn.Module):
         With a MADE conditioner the inverse runs as a blocked forward substitution: pass ``k``
         evaluates only the rows of the three masked linears that belong to degree ``k`` (contiguous
         row slices of the degree-sorted packed weights), so the whole inverse costs about one forward
-        in flops instead of ``n_degrees`` forwards.  Otherwise (user conditioner, embedding, mixed
-        transformer, ``blocked_inverse=False``): one full conditioner pass per degree, like the
-        reference; the last pass' log-det is the total.
+        in flops instead of ``n_degrees`` forwards (a mixed transformer of affine / spline members: one
+        step per degree and member).  Otherwise (user conditioner, another embedding,
+        ``blocked_inverse=False``): one full conditioner pass per degree, like the reference; the
+        last pass' log-det is the total.
         """
         ops.check_device_tensor(y, 'y')
         self._check_features(y, 'y')
@@ -397,11 +398,14 @@ class AutoregressiveFlow(torch.nn.Module):
             deg = deg[deg != -1]
             d = tr.dimension
             return len(deg) % d == 0 and bool((deg.reshape(-1, d) == deg.reshape(-1, d)[:, :1]).all())
+        if type(tr) is MixedTransformer:
+            # element-wise members: every degree becomes one step per member that has features in it
+            return all(type(t) in (AffineTransformer, NeuralSplineTransformer) for t in tr._transformers)
         return False
 
-    def _sub_transformer(self, sel, device):
-        """The transformer restricted to the transformed features ``sel`` (a degree group)."""
-        tr = self._transformer
+    def _sub_transformer(self, sel, device, tr=None):
+        """The transformer (``tr``: a member of a mixed transformer) restricted to its features ``sel`` (a degree group)."""
+        tr = self._transformer if tr is None else tr
         if type(tr) is NeuralSplineTransformer:
             cfg, h = tr.config(device), tr.host()
             return ('spline', ops.SplineConfig(
@@ -509,16 +513,41 @@ class AutoregressiveFlow(torch.nn.Module):
         def r_hi(l, e):      # one past the last packed row of layer l with degree <= e
             return int(torch.searchsorted(hid[l], e, right=True))
 
-        # output rows grouped by degree ("inverse packing"): base[d] .. base[d+1]
+        # output rows grouped by degree ("inverse packing"): base[d] .. base[d+1].  A degree is one STEP of the
+        # substitution -- or, under a mixed transformer (parameters grouped by member, mixed.py:64-68), one step per
+        # member with features of that degree: `parts[d]` = [(features among the transformed ones, P, member, the
+        # features' positions inside the member, first output row)]
         sels = [torch.nonzero(deg_tr == d).flatten() for d in range(max_deg + 1)]
-        base = [0]
-        for sel in sels:
-            base.append(base[-1] + P * len(sel))
-        row_inv = torch.empty(P * n_tr, dtype=torch.long, device='cpu')
+        tr = self._transformer
+        mixed = type(tr) is MixedTransformer
+        if mixed:
+            splits = tr.host_splits() + [lins[-1].out_features]
+            member_of = torch.full((n_tr,), -1, dtype=torch.long)
+            local_of = torch.zeros(n_tr, dtype=torch.long)
+            for g, ind in enumerate(tr._indices):
+                ind = ind.cpu().long()
+                member_of[ind] = g
+                local_of[ind] = torch.arange(len(ind))
+            n_of = [len(ind) for ind in tr._indices]
+            P_of = [(splits[g + 1] - splits[g]) // max(n_of[g], 1) for g in range(len(n_of))]
+            P = max(P_of)
+        base, parts, cur = [0], [], 0
+        row_inv = torch.empty(lins[-1].out_features, dtype=torch.long, device='cpu')
         for d, sel in enumerate(sels):
-            n_d = len(sel)
-            for p in range(P):
-                row_inv[p * n_tr + sel] = base[d] + p * n_d + torch.arange(n_d, device='cpu')
+            if mixed:
+                here = [(sel[member_of[sel] == g], P_of[g], g) for g in range(len(n_of))]
+                here = [(s_, P_, g, local_of[s_]) for s_, P_, g in here if len(s_) > 0] or [(sel, P, None, None)]
+            else:
+                here = [(sel, P, None, None)]
+            parts.append([])
+            for s_, P_, g, loc in here:
+                n_d = len(s_)
+                for p in range(P_):
+                    rows = (p * n_tr + s_) if g is None else (splits[g] + p * n_of[g] + loc)
+                    row_inv[rows] = cur + p * n_d + torch.arange(n_d, device='cpu')
+                parts[-1].append((s_, P_, g, loc, cur))
+                cur += P_ * n_d
+            base.append(cur)
 
         kr = []               # all k-ranges, one entry per launch: every tile of a launch shares it
 
@@ -563,12 +592,13 @@ class AutoregressiveFlow(torch.nn.Module):
                     else:
                         kb, ke = kA[l], min(up(r_hi(l - 1, e)), mplan['k_pad'][l])
                     hidden.append(dict(layer=l, row0=r0, n_rows=r1 - r0, kr=rng(kb, ke)))
-                sel = sels[d]
                 ke = min(up(r_hi(L - 1, e)), mplan['k_pad'][L])
                 # the device-side tables of a step (index tensors, sliced transformer) are only needed by the per-step
                 # launches: built on first use (_step_tables), not for every degree of a layer the block kernel handles
-                blk['steps'].append(dict(hidden=hidden, out=dict(row0=base[d], n_rows=P * len(sel), kr=rng(kA[L], ke)),
-                                         n_d=len(sel), sel_host=sel, cols_host=tr_idx[sel]))
+                for i_, (sel, P_, g, loc, row0) in enumerate(parts[d]):
+                    blk['steps'].append(dict(hidden=hidden if i_ == 0 else [],
+                                             out=dict(row0=row0, n_rows=P_ * len(sel), kr=rng(kA[L], ke)),
+                                             n_d=len(sel), sel_host=sel, cols_host=tr_idx[sel], member=g, local_host=loc))
             blk['fused'] = self._fused_block_tables(d0, d1, blk, kA, r_lo, r_hi, base, sels, tr_idx, deg_in, mplan, L, P,
                                                     rng, up, i32, d0_prev=d0 - G if d0 > 0 else None)
             blocks.append(blk)
@@ -582,7 +612,7 @@ class AutoregressiveFlow(torch.nn.Module):
             cache_len = max(b_['fused']['cache_need'] for b_ in blocks)
             max_feats = max(b_['fused']['n_feats'] for b_ in blocks)
             fused_ok = 0 <= lib.tfep_inverse_block_lds_bytes(L, cache_len, max_feats) <= 160 * 1024
-        bp = dict(blocks=blocks, P=P, L=L, row_inv=row_inv.to(**i32), n_rows_out=P * n_tr,
+        bp = dict(blocks=blocks, P=P, L=L, row_inv=row_inv.to(**i32), n_rows_out=cur,
                   fused=dict(cache_len=cache_len, max_feats=max_feats) if fused_ok else None,
                   max_tiles=(max_rows + narrow - 1) // narrow,
                   k_ranges=torch.tensor(kr, dtype=torch.int32).reshape(-1, 2).to(device))
@@ -595,7 +625,11 @@ class AutoregressiveFlow(torch.nn.Module):
             sel, cols = st['sel_host'], st['cols_host']
             st['cols'] = cols.to(**i32)
             st['inputs'] = self._input_info(cols.tolist(), device)
-            st['sub'] = self._sub_transformer(sel.to(device), device)
+            if st.get('member') is None:
+                st['sub'] = self._sub_transformer(sel.to(device), device)
+            else:       # a member of a mixed transformer, sliced by the features' positions inside the member
+                st['sub'] = self._sub_transformer(st['local_host'].to(device), device,
+                                                  tr=self._transformer._transformers[st['member']])
             st['sel'] = sel.to(**i32)
         return st
 
@@ -655,7 +689,7 @@ class AutoregressiveFlow(torch.nn.Module):
     def _fused_block_tables(self, d0, d1, blk, kA, r_lo, r_hi, base, sels, tr_idx, deg_in, mplan, L, P, rng, up, i32,
                             d0_prev=None):
         """Device tables of ``tfep_inverse_block`` for the block of degrees [d0, d1) (see include/tfep_hip.h)."""
-        if not self._fused_inverse_supported(L):
+        if not self._fused_inverse_supported(L):        # (a mixed transformer: the per-step launches)
             return None
         lib = _lib.load()
         tk = lib.tfep_masked_linear_tile_k()
