@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFEP_HIP_ABI_VERSION 6
+#define TFEP_HIP_ABI_VERSION 7
 
 typedef enum tfep_status {
     TFEP_OK = 0,
@@ -352,7 +352,8 @@ int tfep_diag_split_cycles(unsigned long long* out);
  *   w[l], wout: packed masked weights (tfep_masked_weight_prepare; wout rows grouped by degree: p * n_d + f);
  *   steps: n_steps records of tfep_inverse_block_step_ints() int32:
  *     per layer l < 4: [row0, n, kb, ke] -- units [row0, row0 + n) of layer l from the first ke features of the
- *     block (l = 0) or the packed columns [kb, ke) of layer l - 1 (l >= 1); then [out_row0, n_d, kb, ke, feat_off, 0];
+ *     block (l = 0) or the packed columns [kb, ke) of layer l - 1 (l >= 1); then [out_row0, n_d, kb, ke, feat_off,
+ *     member] (member: kind 3 only, else 0);
  *   feat_cols / feat_sel: column in x / index in y and in the spline tables of every feature of the block, in step order;
  *   conditioner inputs: a new feature enters xpad as itself, or as (cos, sin) of (x - emb_lower) * 2 pi / (emb_upper -
  *     emb_lower) under a PeriodicEmbedding (mafembed.py:112-145).  in_cols: xpad column of every input ENTRY of the
@@ -363,7 +364,11 @@ int tfep_diag_split_cycles(unsigned long long* out);
  *     with 16-byte loads); cache_len / max_feats: LDS entries per layer / for the block's features
  *     (tfep_inverse_block_lds_bytes(n_layers, cache_len, max_feats) <= 160 KiB).
  *   kind: 0 affine, 1 spline (desc, n_bins <= 8), 2 Moebius (moebius.py:142-147: moebius_dim consecutive features of
- *     a degree form one vector, so every step's n_d must be a multiple of it).  log_det_J (B) is accumulated.
+ *     a degree form one vector, so every step's n_d must be a multiple of it), 3 RQ splines of several layouts (the
+ *     members of a mixed transformer, mixed.py:64-68: `spline` is an array of n_spline_groups <= 8 descriptors, every
+ *     step record names the member its features belong to -- a degree with features of m members is m steps, the
+ *     later ones without hidden units -- and feat_sel indexes the member's own x0 / xf / y0 / yf as well as y, so
+ *     the caller hands arrays laid out over all transformed features).  log_det_J (B) is accumulated.
  */
 typedef struct tfep_inverse_block_desc {
     int32_t B, n_layers, n_steps, kind;
@@ -392,6 +397,7 @@ typedef struct tfep_inverse_block_desc {
     float moebius_max_radius;
     int32_t rows_per_wave;      /* 64 (or 0): one sample row per lane; 16: four lanes per row, 4x the waves (for batches
                                    that leave SIMDs idle: the chain is bound by one wave's instruction issue rate) */
+    int32_t n_spline_groups;    /* kind 3: descriptors in `spline` */
 } tfep_inverse_block_desc;
 int tfep_inverse_block_step_ints(void);
 /* LDS bytes a launch with these sizes needs (activation cache + input entries + the weight stage); a block fits iff

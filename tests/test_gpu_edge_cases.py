@@ -207,7 +207,7 @@ def test_new_entry_points_reject_bad_arguments():
     small, big = lib.tfep_inverse_block_lds_bytes(2, 100, 16), lib.tfep_inverse_block_lds_bytes(2, 400, 64)
     assert 0 < small < 160 * 1024 < big                      # the second one must make the planner shrink its blocks
     ib2 = _lib.InverseBlockDesc()
-    ib2.B, ib2.n_layers, ib2.n_steps, ib2.kind = 8, 1, 1, 3
+    ib2.B, ib2.n_layers, ib2.n_steps, ib2.kind = 8, 1, 1, 4
     with pytest.raises(ValueError, match='kind must be 0'):
         _lib.call('tfep_inverse_block', ctypes.byref(ib2), _lib.stream_of(a))
 

@@ -325,10 +325,17 @@ def test_mixed_transformer_inverse_is_blocked(with_affine, order):
     conditioner pass per degree: same x and log-det as the pass-per-degree algorithm of the reference, and a round trip."""
     maf, members, x = _mixed_maf(with_affine, order=order)
     assert maf._blocked_ok()
+    # spline members only: the block kernel (kind 3: every step names its member), in both row layouts; with an affine
+    # member: the per-step launches
+    assert (maf._blocked_plan(x.device)['fused'] is not None) == (not with_affine)
     with torch.no_grad():
         y, l = maf(x)
-        xb, lb = maf.inverse(y)
         maf.blocked_inverse = False
         xr, lr = maf.inverse(y)
-    assert float((xb - xr).abs().max()) < 5e-5 and float((lb - lr).abs().max()) < 5e-4
-    assert float((xb - x).abs().max()) < 2e-4 and float((lb + l).abs().max()) < 2e-3
+        maf.blocked_inverse = True
+        for rows, fused_inverse in ((None, True), (64, True), (None, False)):
+            maf.inverse_rows_per_wave, maf.fused_inverse = rows, fused_inverse
+            maf._dev.clear()                       # (the plan depends on fused_inverse)
+            xb, lb = maf.inverse(y)
+            assert float((xb - xr).abs().max()) < 5e-5 and float((lb - lr).abs().max()) < 5e-4, (rows, fused_inverse)
+            assert float((xb - x).abs().max()) < 2e-4 and float((lb + l).abs().max()) < 2e-3, (rows, fused_inverse)

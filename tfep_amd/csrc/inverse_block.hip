@@ -27,6 +27,7 @@ namespace tfep {
 constexpr int IB_MAX_LAYERS = 4;
 constexpr int IB_STEP_INTS = 4 * IB_MAX_LAYERS + 6;
 constexpr int IB_MAX_P = 32;
+constexpr int IB_MAX_GROUPS = 8;       // kind 3: members of a mixed transformer (all RQ splines)
 
 struct InverseBlockArgs {
     int B, L, n_steps, kind, P;
@@ -57,6 +58,7 @@ struct InverseBlockArgs {
     int mb_dim, mb_unit_sphere;   // kind 2: Moebius
     float mb_max_radius;
     SplineArgs sp;
+    SplineArgs spg[IB_MAX_GROUPS];   // kind 3: one per member; the step record names the member of its features
 };
 
 __device__ inline float elu_ib(float v) { return v > 0.f ? v : expm1f(v); }
@@ -309,8 +311,10 @@ __device__ __forceinline__ void out_dot_mfma(float (&prm)[IB_MAX_P], const float
 
 // Step record: per layer l  [row0, n, kb, ke]: units [row0, row0 + n) of layer l are computed from the inputs
 //   l == 0: the first `ke` conditioner-input entries of the block (in_cols order);  l >= 1: packed columns [kb, ke) of layer l - 1
-// then [out_row0, n_d, out_kb, out_ke, feat_off, 0].
-// KIND: 0 affine, 1 spline, 2 Moebius (one instantiation each: the spline code needs most of the register file).
+// then [out_row0, n_d, out_kb, out_ke, feat_off, member].
+// KIND: 0 affine, 1 spline, 2 Moebius, 3 splines of several layouts (a mixed transformer: `member` of the step record
+// selects the flags, the parameter count and the domain arrays) -- one instantiation each: the spline code needs most
+// of the register file.
 template <int KIND>
 __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
     extern __shared__ float cache[];              // [L][cache_len][64] hidden activations, then [max_feats][64] x values
@@ -411,20 +415,22 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
             }
         } else {
         constexpr int MAXP = KIND == 0 ? 8 : IB_MAX_P;
+        const SplineArgs& spa = KIND == 3 ? a.spg[st[4 * IB_MAX_LAYERS + 5]] : a.sp;      // (wave uniform)
+        const int nP = KIND == 3 ? spa.P : a.P;
         for (int f = 0; f < n_d; ++f) {
             float prm[MAXP];
-            stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, n_d, a.P, okb, oke, lane);   // the feature's P rows at once
-            stage_z(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, n_d, a.P, a.zout_slabs, a.zout_slab_stride, lane);
-            if constexpr (KIND == 1) {
-                out_dot_mfma(prm, stg, gstride, zs, cp, olen, a.P, lane);
+            stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, n_d, nP, okb, oke, lane);   // the feature's P rows at once
+            stage_z(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, n_d, nP, a.zout_slabs, a.zout_slab_stride, lane);
+            if constexpr (KIND == 1 || KIND == 3) {
+                out_dot_mfma(prm, stg, gstride, zs, cp, olen, nP, lane);
             } else {
 #pragma unroll
                 for (int p0 = 0; p0 < MAXP; p0 += 8) {
                     float acc[8];
 #pragma unroll
                     for (int g = 0; g < 8; ++g) acc[g] = 0.f;
-                    if (p0 < a.P) {                                         // wave-uniform
-                        const int np = min(8, a.P - p0);
+                    if (p0 < nP) {                                          // wave-uniform
+                        const int np = min(8, nP - p0);
 #pragma unroll
                         for (int g = 0; g < 8; ++g)
                             if (g < np) acc[g] = zs[(p0 + g) * IB_Z_PITCH + lane];
@@ -441,7 +447,7 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
                 xv = (yv - prm[0]) * expf(-prm[1]);
                 ldj_acc -= (double)prm[1];
             } else {
-                const SplineFlags& fl = a.sp.f;
+                const SplineFlags& fl = spa.f;
                 const int K = fl.K;
                 float w[8], hh[8], sraw[9];
 #pragma unroll
@@ -458,11 +464,11 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
                     }
                 }
                 float last = 0.f, last2 = 0.f;
-                if (fl.circular || fl.learn_lower || fl.learn_upper) last = prm[a.P - 1];
-                if (fl.learn_lower && fl.learn_upper) last2 = prm[a.P - 2];
+                if (fl.circular || fl.learn_lower || fl.learn_upper) last = prm[nP - 1];
+                if (fl.learn_lower && fl.learn_upper) last2 = prm[nP - 2];
                 double ld;
-                xv = (float)rq_spline_element<8, true>(w, hh, sraw, last, last2, fl, a.sp.x0[sel], a.sp.xf[sel],
-                                                       a.sp.y0[sel], a.sp.yf[sel], yv, &ld);
+                xv = (float)rq_spline_element<8, true>(w, hh, sraw, last, last2, fl, spa.x0[sel], spa.xf[sel],
+                                                       spa.y0[sel], spa.yf[sel], yv, &ld);
                 ldj_acc -= ld;
             }
             // (emit, written out: the lambda call here costs the spline kernel ~50% -- different SGPR spill placement)
@@ -749,11 +755,13 @@ __global__ void __launch_bounds__(64) inverse_block_q4_kernel(InverseBlockArgs a
                 __builtin_amdgcn_wave_barrier();
             }
         } else {
+        const SplineArgs& spa = KIND == 3 ? a.spg[st[4 * IB_MAX_LAYERS + 5]] : a.sp;      // (wave uniform)
+        const int nP = KIND == 3 ? spa.P : a.P;
         for (int f = 0; f < n_d; ++f) {
             float prm[IB_MAX_P];
-            stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, n_d, a.P, okb, oke, lane);   // the feature's P rows at once
-            stage_z16(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, n_d, a.P, a.zout_slabs, a.zout_slab_stride, lane);
-            out_dot_mfma16(prm, stg, gstride, zs, cp, pb, olen, a.P, lane);
+            stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, n_d, nP, okb, oke, lane);   // the feature's P rows at once
+            stage_z16(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, n_d, nP, a.zout_slabs, a.zout_slab_stride, lane);
+            out_dot_mfma16(prm, stg, gstride, zs, cp, pb, olen, nP, lane);
             const int sel = a.feat_sel[foff + f];
             const float yv = a.y[r * a.ldy + sel];
             float xv;
@@ -761,7 +769,7 @@ __global__ void __launch_bounds__(64) inverse_block_q4_kernel(InverseBlockArgs a
                 xv = (yv - prm[0]) * expf(-prm[1]);
                 ldj_acc -= (double)prm[1];
             } else {
-                const SplineFlags& fl = a.sp.f;
+                const SplineFlags& fl = spa.f;
                 const int K = fl.K;
                 float w[8], hh[8], sraw[9];
 #pragma unroll
@@ -778,11 +786,11 @@ __global__ void __launch_bounds__(64) inverse_block_q4_kernel(InverseBlockArgs a
                     }
                 }
                 float last = 0.f, last2 = 0.f;
-                if (fl.circular || fl.learn_lower || fl.learn_upper) last = prm[a.P - 1];
-                if (fl.learn_lower && fl.learn_upper) last2 = prm[a.P - 2];
+                if (fl.circular || fl.learn_lower || fl.learn_upper) last = prm[nP - 1];
+                if (fl.learn_lower && fl.learn_upper) last2 = prm[nP - 2];
                 double ld;
-                xv = (float)rq_spline_element<8, true>(w, hh, sraw, last, last2, fl, a.sp.x0[sel], a.sp.xf[sel],
-                                                       a.sp.y0[sel], a.sp.yf[sel], yv, &ld);
+                xv = (float)rq_spline_element<8, true>(w, hh, sraw, last, last2, fl, spa.x0[sel], spa.xf[sel],
+                                                       spa.y0[sel], spa.yf[sel], yv, &ld);
                 ldj_acc -= ld;
             }
             const int col = a.feat_cols[foff + f];
@@ -828,7 +836,8 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
     TFEP_REQUIRE(d->B >= 0 && d->n_steps >= 0, "inverse_block: negative size");
     if (d->B == 0 || d->n_steps == 0) return TFEP_OK;
     TFEP_REQUIRE(d->n_layers >= 1 && d->n_layers <= IB_MAX_LAYERS, "inverse_block: 1..%d hidden layers", IB_MAX_LAYERS);
-    TFEP_REQUIRE(d->kind >= 0 && d->kind <= 2, "inverse_block: kind must be 0 (affine), 1 (spline) or 2 (Moebius)");
+    TFEP_REQUIRE(d->kind >= 0 && d->kind <= 3,
+                 "inverse_block: kind must be 0 (affine), 1 (spline), 2 (Moebius) or 3 (splines of several layouts)");
     TFEP_REQUIRE(d->x && d->xpad && d->y && d->zout && d->wout && d->log_det_J && d->steps && d->feat_cols && d->feat_sel,
                  "inverse_block: NULL pointer");
     InverseBlockArgs a = {};
@@ -860,6 +869,19 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
         if (rc) return rc;
         TFEP_REQUIRE(a.sp.f.K <= 8, "inverse_block: at most 8 spline bins");
         a.P = a.sp.P;
+    } else if (d->kind == 3) {
+        // members of a mixed transformer: d->spline is an array of n_spline_groups descriptors, the step records carry
+        // the member of their features (checked on the host side of the caller: it is device memory here)
+        TFEP_REQUIRE(d->spline && d->n_spline_groups >= 1 && d->n_spline_groups <= IB_MAX_GROUPS,
+                     "inverse_block: 1..%d spline groups", IB_MAX_GROUPS);
+        a.P = 0;
+        for (int g = 0; g < d->n_spline_groups; ++g) {
+            int rc = make_spline_args(&d->spline[g], &a.spg[g]);
+            if (rc) return rc;
+            TFEP_REQUIRE(a.spg[g].f.K <= 8, "inverse_block: at most 8 spline bins");
+            a.P = a.spg[g].P > a.P ? a.spg[g].P : a.P;
+        }
+        for (int g = d->n_spline_groups; g < IB_MAX_GROUPS; ++g) a.spg[g] = a.spg[0];      // (a stray member id stays in bounds)
     } else if (d->kind == 2) {
         TFEP_REQUIRE(d->moebius_dim >= 1 && d->moebius_dim <= MOEBIUS_MAX_DIM, "inverse_block: Moebius dimension=%d unsupported (1..%d)",
                      d->moebius_dim, MOEBIUS_MAX_DIM);
@@ -876,11 +898,13 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
                            : ib_lds_floats(d->n_layers, d->cache_len, d->max_feats)) * sizeof(float);
     a.lds_floats = (int)(lds / sizeof(float));
     TFEP_REQUIRE(lds <= 160 * 1024, "inverse_block: block needs %zu bytes of LDS (> 160 KiB)", lds);
-    static size_t lds_attr_on[6][TFEP_MAX_DEVICES] = {};       // per kernel and device: a process may drive several GPUs
-    size_t& lds_attr = lds_attr_on[d->kind + (q4 ? 3 : 0)][current_device_slot()];
+    static size_t lds_attr_on[8][TFEP_MAX_DEVICES] = {};       // per kernel and device: a process may drive several GPUs
+    size_t& lds_attr = lds_attr_on[d->kind + (q4 ? 4 : 0)][current_device_slot()];
     void (*kernel)(InverseBlockArgs) =
-        q4 ? (d->kind == 0 ? inverse_block_q4_kernel<0> : d->kind == 1 ? inverse_block_q4_kernel<1> : inverse_block_q4_kernel<2>)
-           : (d->kind == 0 ? inverse_block_kernel<0> : d->kind == 1 ? inverse_block_kernel<1> : inverse_block_kernel<2>);
+        q4 ? (d->kind == 0 ? inverse_block_q4_kernel<0> : d->kind == 1 ? inverse_block_q4_kernel<1>
+              : d->kind == 2 ? inverse_block_q4_kernel<2> : inverse_block_q4_kernel<3>)
+           : (d->kind == 0 ? inverse_block_kernel<0> : d->kind == 1 ? inverse_block_kernel<1>
+              : d->kind == 2 ? inverse_block_kernel<2> : inverse_block_kernel<3>);
     const int rows = q4 ? Q4_ROWS : 64;
     if (q4) a.stage_gstride = 8 * ib_stage_cols_q4(d->cache_len, d->max_feats);
     if (lds > lds_attr) {

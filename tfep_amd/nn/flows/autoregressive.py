@@ -599,7 +599,7 @@ class AutoregressiveFlow(torch.nn.Module):
                     blk['steps'].append(dict(hidden=hidden if i_ == 0 else [],
                                              out=dict(row0=row0, n_rows=P_ * len(sel), kr=rng(kA[L], ke)),
                                              n_d=len(sel), sel_host=sel, cols_host=tr_idx[sel], member=g, local_host=loc))
-            blk['fused'] = self._fused_block_tables(d0, d1, blk, kA, r_lo, r_hi, base, sels, tr_idx, deg_in, mplan, L, P,
+            blk['fused'] = self._fused_block_tables(d0, d1, blk, kA, r_lo, r_hi, parts, tr_idx, deg_in, mplan, L,
                                                     rng, up, i32, d0_prev=d0 - G if d0 > 0 else None)
             blocks.append(blk)
         narrow = lib.tfep_masked_linear_narrow_tile_n()
@@ -684,12 +684,41 @@ class AutoregressiveFlow(torch.nn.Module):
             return True
         if type(tr) is MoebiusTransformer:
             return 1 <= tr.dimension <= 8
+        if type(tr) is MixedTransformer:
+            # kind 3 of the block kernel: spline members only (one instantiation per transformer family), each step of
+            # the block names its member
+            return len(tr._transformers) <= 8 and all(type(t) is NeuralSplineTransformer and t.host()['n_bins'] <= 8
+                                                      for t in tr._transformers)
         return type(tr) is NeuralSplineTransformer and tr.host()['n_bins'] <= 8
 
-    def _fused_block_tables(self, d0, d1, blk, kA, r_lo, r_hi, base, sels, tr_idx, deg_in, mplan, L, P, rng, up, i32,
+    def _mixed_spline_descs(self, device):
+        """``tfep_inverse_block`` kind 3: one spline descriptor per member of the mixed transformer, all of them over
+        domain arrays laid out by TRANSFORMED FEATURE (the kernel indexes y and the domain with the same ``feat_sel``)."""
+        key = ('mixed_descs', str(device))
+        if key not in self._dev:
+            tr = self._transformer
+            n_tr = self._tables(device)['n_tr']
+            arrays = [torch.zeros(n_tr, dtype=torch.float32, device=device) for _ in range(4)]
+            arrays[1].fill_(1.0)
+            arrays[3].fill_(1.0)
+            for t, ind in zip(tr._transformers, tr._indices):
+                cfg = t.config(device)
+                ind = ind.to(device)
+                for dst, src in zip(arrays, (cfg.x0, cfg.xf, cfg.y0, cfg.yf)):
+                    dst[ind] = src
+            cfgs = []
+            for t in tr._transformers:
+                h = t.host()
+                cfgs.append(ops.SplineConfig(*arrays, h['n_bins'], h['circular'], h['identity'], h['learn_lower'],
+                                             h['learn_upper'], h['min_bin'], h['min_slope']))
+            descs = (_lib.SplineDesc * len(cfgs))(*[c.desc for c in cfgs])
+            self._dev[key] = (descs, cfgs)                 # (cfgs keep the arrays alive)
+        return self._dev[key][0]
+
+    def _fused_block_tables(self, d0, d1, blk, kA, r_lo, r_hi, parts, tr_idx, deg_in, mplan, L, rng, up, i32,
                             d0_prev=None):
         """Device tables of ``tfep_inverse_block`` for the block of degrees [d0, d1) (see include/tfep_hip.h)."""
-        if not self._fused_inverse_supported(L):        # (a mixed transformer: the per-step launches)
+        if not self._fused_inverse_supported(L):        # (e.g. a mixed transformer with an affine member: per-step launches)
             return None
         lib = _lib.load()
         tk = lib.tfep_masked_linear_tile_k()
@@ -720,19 +749,21 @@ class AutoregressiveFlow(torch.nn.Module):
         first, periodic, _ = self._input_columns()
         steps, cols, selv, feat_in, feat_per, in_cols = [], [], [], [], [], []
         for d in range(d0, d1):
-            e = d - 1
+          e = d - 1
+          # one record per degree -- under a mixed transformer one per member with features of the degree, the hidden
+          # units of the degree in the first of them
+          for i_, (sel, _, member, _, row0) in enumerate(parts[d]):
             rec = [0] * n_ints
             for l in range(L):
                 a, b = r_lo(l, e), r_hi(l, e)
-                rec[4 * l], rec[4 * l + 1] = a, max(0, b - a)
+                rec[4 * l], rec[4 * l + 1] = a, (max(0, b - a) if i_ == 0 else 0)
                 if l == 0:
                     rec[2], rec[3] = 0, len(in_cols)          # conditioner-input entries of the block known so far
                 else:
                     rec[4 * l + 2], rec[4 * l + 3] = c0[l - 1], max(c0[l - 1], r_hi(l - 1, e))
-            sel = sels[d]
             if type(self._transformer) is MoebiusTransformer and len(sel) % self._transformer.dimension:
                 return None                                   # a degree must hold whole vectors
-            rec[16:21] = [base[d], len(sel), c0[L - 1], max(c0[L - 1], r_hi(L - 1, e)), len(cols)]
+            rec[16:22] = [row0, len(sel), c0[L - 1], max(c0[L - 1], r_hi(L - 1, e)), len(cols), member or 0]
             steps.append(rec)
             for c in tr_idx[sel].tolist():
                 feat_in.append(len(in_cols))
@@ -900,10 +931,13 @@ class AutoregressiveFlow(torch.nn.Module):
                 z = zs[0]
                 S_out = S
                 tr = self._transformer
-                kind = {NeuralSplineTransformer: 1, MoebiusTransformer: 2}.get(type(tr), 0)
+                kind = {NeuralSplineTransformer: 1, MoebiusTransformer: 2, MixedTransformer: 3}.get(type(tr), 0)
                 spl = tr.config(dev).desc if kind == 1 else None
                 d = _lib.InverseBlockDesc()
                 d.B, d.n_layers, d.kind = B, L, kind
+                if kind == 3:       # one descriptor per member; the step records name the member
+                    spl = self._mixed_spline_descs(dev)
+                    d.n_spline_groups = len(spl)
                 if kind == 2:
                     d.moebius_dim, d.moebius_unit_sphere = tr.dimension, int(tr.unit_sphere)
                     d.moebius_max_radius = tr.max_radius
@@ -918,7 +952,7 @@ class AutoregressiveFlow(torch.nn.Module):
                 d.wout, d.ldwout = w_out.data_ptr(), w_out.shape[1]
                 d.cache_len, d.max_feats = fused['cache_len'], fused['max_feats']
                 d.rows_per_wave = rows_per_wave
-                d.spline = ctypes.cast(ctypes.pointer(spl), ctypes.c_void_p) if spl is not None else None
+                d.spline = None if spl is None else ctypes.cast(spl if kind == 3 else ctypes.pointer(spl), ctypes.c_void_p)
                 d.emb_lower, d.emb_upper = self._input_columns()[2]
                 stream = _lib.stream_of(y)
                 # ---- the output-layer block GEMM on split-f16 operands (see _split_inverse_bound)

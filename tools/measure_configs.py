@@ -210,16 +210,16 @@ if 'variants' in which or 'mixed' in which:
         report(f'one cfg2-sized layer, {name}', B, dt, fused=flow[0]._fused_kind() is not None,
                out_features=flow[0]._conditioner.layers[-1].out_features, roofline=mfma_roofline(flow, B, dt))
         if 'fused=False' not in name:
-            # its inverse: the blocked substitution with one step per degree and member (per-step launches; the
-            # pass-per-degree algorithm of the reference is 3000 conditioner passes, ~0.1 s each at this size)
+            # its inverse: the blocked substitution with one step per degree and member (block kernel kind 3, fp32 block
+            # GEMMs; the pass-per-degree algorithm of the reference is 3000 conditioner passes, ~0.1 s each at this size)
             Bi = 8192
             with torch.no_grad():
                 yi, _ = flow(x[:Bi])
                 dti, (xi, _) = timeit(lambda: flow.inverse(yi), 1, 2)
             roof = mfma_roofline(flow, Bi, dti)
             roof.update(peak=round(PEAK_F32, 1), frac=round(roof['achieved'] / PEAK_F32, 4), arithmetic='fp32 MFMA',
-                        note='launch bound: ~10 launches per degree on the per-step path')
-            report('one cfg2-sized layer, MixedMAFMap transformer: inverse (blocked, 3000 degrees, per-step launches)', Bi, dti,
+                        note='sequential in the degree: bound by the block kernel chain, see DESIGN 7')
+            report('one cfg2-sized layer, MixedMAFMap transformer: inverse (blocked, 3000 degrees, block kernel kind 3)', Bi, dti,
                    roundtrip_max_abs=float((xi - x[:Bi]).abs().max()), roofline=roof)
         del flow
 
