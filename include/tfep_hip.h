@@ -368,7 +368,9 @@ int tfep_diag_split_cycles(unsigned long long* out);
  *     members of a mixed transformer, mixed.py:64-68: `spline` is an array of n_spline_groups <= 8 descriptors, every
  *     step record names the member its features belong to -- a degree with features of m members is m steps, the
  *     later ones without hidden units -- and feat_sel indexes the member's own x0 / xf / y0 / yf as well as y, so
- *     the caller hands arrays laid out over all transformed features).  log_det_J (B) is accumulated.
+ *     the caller hands arrays laid out over all transformed features; a descriptor with n_bins = 0 is a plain shift
+ *     member, affine.py:366-456 without periodic features: one parameter, x = y - parameter, log-det 0).
+ *     log_det_J (B) is accumulated.
  */
 typedef struct tfep_inverse_block_desc {
     int32_t B, n_layers, n_steps, kind;

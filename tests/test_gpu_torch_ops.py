@@ -252,15 +252,19 @@ def test_spline_layouts_outside_the_fused_kernels(K, identity, learn_lower, lear
     assert torch.isfinite(y).all() and torch.isfinite(l).all()
 
 
-def _mixed_maf(with_affine, D=83, order='descending', seed=11):
+def _mixed_maf(with_affine, D=83, order='descending', seed=11, with_shift=False):
     """A MAF layer over the mixed transformer of the reference's MixedMAFMap (app/mixedmaf.py:770-811): four 5-bin spline
     layouts on interleaved feature groups, optionally a fifth affine group; and an input that covers domains and tails."""
     from tfep_amd.nn.conditioners import generate_degrees
     from tfep_amd.nn.flows import MAF
-    from tfep_amd.nn.transformers import AffineTransformer, MixedTransformer, NeuralSplineTransformer
+    from tfep_amd.nn.transformers import (AffineTransformer, MixedTransformer, NeuralSplineTransformer,
+                                          VolumePreservingShiftTransformer)
     torch.manual_seed(seed)
     perm = torch.randperm(D)
     sizes = [21, 17, 30, 15] if not with_affine else [21, 17, 20, 15, 10]
+    if with_shift:                                   # the reference-frame DOFs of MixedMAFMap (app/mixedmaf.py:815-821)
+        sizes[2] -= 6
+        sizes.append(6)
     idx = [perm[sum(sizes[:i]):sum(sizes[:i + 1])].sort().values for i in range(len(sizes))]
     members = [
         NeuralSplineTransformer(torch.full((sizes[0],), 0.5), torch.full((sizes[0],), 3.0), 5, identity_boundary_slopes=True,
@@ -272,6 +276,8 @@ def _mixed_maf(with_affine, D=83, order='descending', seed=11):
     ]
     if with_affine:
         members.append(AffineTransformer())
+    if with_shift:
+        members.append(VolumePreservingShiftTransformer())
     maf = MAF(generate_degrees(D, order), transformer=MixedTransformer(members, idx), hidden_layers=[150, 170],
               initialize_identity=False).cuda()
     x = torch.rand(300, D, device='cuda')
@@ -280,8 +286,8 @@ def _mixed_maf(with_affine, D=83, order='descending', seed=11):
     return maf, members, x
 
 
-@pytest.mark.parametrize('with_affine', [False, True])
-def test_mixed_transformer_runs_one_fused_launch_per_group(with_affine):
+@pytest.mark.parametrize('with_affine,with_shift', [(False, False), (True, False), (False, True)])
+def test_mixed_transformer_runs_one_fused_launch_per_group(with_affine, with_shift):
     """A MixedTransformer whose members all have a fused epilogue (the four 5-bin spline layouts of the reference's
     MixedMAFMap, app/mixedmaf.py:770-811; optionally an affine group) packs the output layer once, every group on its own
     column tiles, and launches the fused kernel once per group; same results as the generic path."""
@@ -298,7 +304,7 @@ def test_mixed_transformer_runs_one_fused_launch_per_group(with_affine):
         def __torch_dispatch__(self, func, types, args=(), kwargs=None):
             self.seen.append(str(func))
             return func(*args, **(kwargs or {}))
-    maf, members, x = _mixed_maf(with_affine)
+    maf, members, x = _mixed_maf(with_affine, with_shift=with_shift)       # (the shift: an affine group, log-scales zero)
     assert maf._fused_kind() == 2
     with torch.no_grad():
         for split in (False, True):
@@ -318,15 +324,16 @@ def test_mixed_transformer_runs_one_fused_launch_per_group(with_affine):
     assert other._fused_kind() is None
 
 
-@pytest.mark.parametrize('with_affine,order', [(False, 'descending'), (True, 'ascending')])
-def test_mixed_transformer_inverse_is_blocked(with_affine, order):
+@pytest.mark.parametrize('with_affine,order,with_shift', [(False, 'descending', False), (True, 'ascending', False),
+                                                          (False, 'ascending', True), (True, 'descending', True)])
+def test_mixed_transformer_inverse_is_blocked(with_affine, order, with_shift):
     """The inverse of a layer over a mixed transformer of element-wise members runs the blocked forward substitution too
     (one step per degree and member, on the member's rows of the degree-sorted output weights) instead of one full
     conditioner pass per degree: same x and log-det as the pass-per-degree algorithm of the reference, and a round trip."""
-    maf, members, x = _mixed_maf(with_affine, order=order)
+    maf, members, x = _mixed_maf(with_affine, order=order, with_shift=with_shift)
     assert maf._blocked_ok()
-    # spline members only: the block kernel (kind 3: every step names its member), in both row layouts; with an affine
-    # member: the per-step launches
+    # spline (and plain shift) members only: the block kernel (kind 3: every step names its member), in both row layouts;
+    # with an affine member: the per-step launches
     assert (maf._blocked_plan(x.device)['fused'] is not None) == (not with_affine)
     with torch.no_grad():
         y, l = maf(x)

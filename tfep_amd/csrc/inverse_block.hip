@@ -449,6 +449,9 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
             } else {
                 const SplineFlags& fl = spa.f;
                 const int K = fl.K;
+                if (KIND == 3 && K == 0) {                              // a plain shift member (affine.py:366-456): log-det 0
+                    xv = yv - prm[0];
+                } else {
                 float w[8], hh[8], sraw[9];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -470,6 +473,7 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
                 xv = (float)rq_spline_element<8, true>(w, hh, sraw, last, last2, fl, spa.x0[sel], spa.xf[sel],
                                                        spa.y0[sel], spa.yf[sel], yv, &ld);
                 ldj_acc -= ld;
+                }
             }
             // (emit, written out: the lambda call here costs the spline kernel ~50% -- different SGPR spill placement)
             const int col = a.feat_cols[foff + f];
@@ -771,6 +775,9 @@ __global__ void __launch_bounds__(64) inverse_block_q4_kernel(InverseBlockArgs a
             } else {
                 const SplineFlags& fl = spa.f;
                 const int K = fl.K;
+                if (KIND == 3 && K == 0) {                              // a plain shift member (affine.py:366-456): log-det 0
+                    xv = yv - prm[0];
+                } else {
                 float w[8], hh[8], sraw[9];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
@@ -792,6 +799,7 @@ __global__ void __launch_bounds__(64) inverse_block_q4_kernel(InverseBlockArgs a
                 xv = (float)rq_spline_element<8, true>(w, hh, sraw, last, last2, fl, spa.x0[sel], spa.xf[sel],
                                                        spa.y0[sel], spa.yf[sel], yv, &ld);
                 ldj_acc -= ld;
+                }
             }
             const int col = a.feat_cols[foff + f];
             const int e0 = a.feat_in[foff + f], icol = a.in_cols[e0];
@@ -876,6 +884,13 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
                      "inverse_block: 1..%d spline groups", IB_MAX_GROUPS);
         a.P = 0;
         for (int g = 0; g < d->n_spline_groups; ++g) {
+            if (d->spline[g].n_bins == 0) {            // a plain shift member: one parameter, x = y - parameter
+                a.spg[g] = SplineArgs{};
+                a.spg[g].f.K = 0;
+                a.spg[g].P = 1;
+                a.P = a.P > 1 ? a.P : 1;
+                continue;
+            }
             int rc = make_spline_args(&d->spline[g], &a.spg[g]);
             if (rc) return rc;
             TFEP_REQUIRE(a.spg[g].f.K <= 8, "inverse_block: at most 8 spline bins");

@@ -20,7 +20,7 @@ from ... import _lib, ops
 from ...utils.misc import ensure_tensor_sequence
 from ..conditioners.made import MADE
 from ..embeddings.mafembed import PeriodicEmbedding
-from ..transformers.affine import AffineTransformer
+from ..transformers.affine import AffineTransformer, VolumePreservingShiftTransformer
 from ..transformers.mixed import MixedTransformer
 from ..transformers.moebius import MoebiusTransformer
 from ..transformers.spline import NeuralSplineTransformer
@@ -156,13 +156,24 @@ class AutoregressiveFlow(torch.nn.Module):
             return _FUSED_SPLINE
         return None
 
+    @staticmethod
+    def _is_plain_shift(tr):
+        """A VolumePreservingShiftTransformer without periodic features: y = x + b, log-det 0 (affine.py:366-456)."""
+        return type(tr) is VolumePreservingShiftTransformer and tr.periodic_indices is None
+
+    @classmethod
+    def _member_fused_kind(cls, tr):
+        """Fused epilogue of a member of a mixed transformer: as above, and the plain shift (MixedMAFMap's transformer of
+        the reference-frame DOFs, app/mixedmaf.py:815-821) as an affine group whose log-scale rows stay zero."""
+        return _FUSED_AFFINE if cls._is_plain_shift(tr) else cls._transformer_fused_kind(tr)
+
     def _fused_kind(self):
         if not self.fused or not isinstance(self._conditioner, MADE) or len(self._conditioner_indices) > 0:
             return None
         tr = self._transformer
         if type(tr) is MixedTransformer:
             # every group on its own column tiles of the output GEMM, one fused launch per group
-            if all(self._transformer_fused_kind(t) is not None for t in tr._transformers):
+            if all(self._member_fused_kind(t) is not None for t in tr._transformers):
                 return _FUSED_MIXED
             return None
         return self._transformer_fused_kind(tr)
@@ -210,7 +221,7 @@ class AutoregressiveFlow(torch.nn.Module):
         tr = self._transformer
         cols_tr = tables['tr'].cpu().long()                         # transformed feature -> column of x
         if kind == _FUSED_MIXED:
-            members = [(self._transformer_fused_kind(t), t, ind.cpu().long(), off)
+            members = [(self._member_fused_kind(t), t, ind.cpu().long(), off)
                        for t, ind, off in zip(tr._transformers, tr._indices, tr.host_splits()) if len(ind) > 0]
         else:
             members = [(kind, tr, None, 0)]
@@ -220,8 +231,9 @@ class AutoregressiveFlow(torch.nn.Module):
         groups, base = [], 0
         for k_g, t_g, rel, off in members:
             n_g = n_tr if rel is None else len(rel)
-            P = 2 if k_g == _FUSED_AFFINE else t_g.n_parameters_per_feature
-            if off + P * n_g > last.out_features:
+            P = 2 if k_g == _FUSED_AFFINE else t_g.n_parameters_per_feature      # parameter rows of the kernel's tile
+            P_real = 1 if self._is_plain_shift(t_g) else P                       # rows the conditioner has (the shift:
+            if off + P_real * n_g > last.out_features:                           # its log-scale rows stay zero)
                 raise ValueError('conditioner output does not match the transformer parameters')
             desc = t_g.config(device).desc if k_g == _FUSED_SPLINE else None
             tile_cols = lib.tfep_fused_tile_columns(k_g, ctypes.byref(desc) if desc is not None else None)
@@ -235,14 +247,14 @@ class AutoregressiveFlow(torch.nn.Module):
             feat_tr[:n_g] = order
             feat_index = torch.full((n_slots,), -1, dtype=torch.long, device='cpu')
             feat_index[:n_g] = (cols_tr if rel is None else cols_tr[rel])[order]
-            sl = slot_of.repeat(P)                                 # slot of output row o = off + p*n_g + t
-            pp = torch.arange(P, device='cpu').repeat_interleave(n_g)
+            sl = slot_of.repeat(P_real)                            # slot of output row o = off + p*n_g + t
+            pp = torch.arange(P_real, device='cpu').repeat_interleave(n_g)
             local = (sl // (16 * FT)) * tile_cols + (((sl // 16) % FT) * P + pp) * 16 + (sl % 16)
             n_tiles = n_slots // (16 * FT)
-            row_of_out[off:off + P * n_g] = base + local
+            row_of_out[off:off + P_real * n_g] = base + local
             grp = {'kind': k_g, 'transformer': t_g, 'P': P, 'FT': FT, 'n_slots': n_slots, 'n_rows': n_tiles * tile_cols,
                    'base': base, 'feat_index': feat_index.to(**i32), 'feat_tr': feat_tr.to(**i32)}
-            grp['k_ranges'] = ops.mask_k_ranges(last.mask[off:off + P * n_g], tile_cols, n_tiles, mplan['k_pad'][li],
+            grp['k_ranges'] = ops.mask_k_ranges(last.mask[off:off + P_real * n_g], tile_cols, n_tiles, mplan['k_pad'][li],
                                                 local.to(**i32), mplan['col_of_in'][li])
             grp['tile_order'] = ops.heavy_first_order(grp['k_ranges'])
             groups.append(grp)
@@ -400,7 +412,8 @@ class AutoregressiveFlow(torch.nn.Module):
             return len(deg) % d == 0 and bool((deg.reshape(-1, d) == deg.reshape(-1, d)[:, :1]).all())
         if type(tr) is MixedTransformer:
             # element-wise members: every degree becomes one step per member that has features in it
-            return all(type(t) in (AffineTransformer, NeuralSplineTransformer) for t in tr._transformers)
+            return all(type(t) in (AffineTransformer, NeuralSplineTransformer) or self._is_plain_shift(t)
+                       for t in tr._transformers)
         return False
 
     def _sub_transformer(self, sel, device, tr=None):
@@ -413,6 +426,8 @@ class AutoregressiveFlow(torch.nn.Module):
                 h['learn_lower'], h['learn_upper'], h['min_bin'], h['min_slope']))
         if type(tr) is MoebiusTransformer:
             return ('moebius', tr)
+        if type(tr) is VolumePreservingShiftTransformer:
+            return ('shift', tr)
         return ('affine', tr)
 
     #: Degrees per block of the two-level blocked inverse.
@@ -687,8 +702,9 @@ class AutoregressiveFlow(torch.nn.Module):
         if type(tr) is MixedTransformer:
             # kind 3 of the block kernel: spline members only (one instantiation per transformer family), each step of
             # the block names its member
-            return len(tr._transformers) <= 8 and all(type(t) is NeuralSplineTransformer and t.host()['n_bins'] <= 8
-                                                      for t in tr._transformers)
+            return len(tr._transformers) <= 8 and all(
+                (type(t) is NeuralSplineTransformer and t.host()['n_bins'] <= 8) or self._is_plain_shift(t)
+                for t in tr._transformers)
         return type(tr) is NeuralSplineTransformer and tr.host()['n_bins'] <= 8
 
     def _mixed_spline_descs(self, device):
@@ -702,17 +718,22 @@ class AutoregressiveFlow(torch.nn.Module):
             arrays[1].fill_(1.0)
             arrays[3].fill_(1.0)
             for t, ind in zip(tr._transformers, tr._indices):
-                cfg = t.config(device)
-                ind = ind.to(device)
-                for dst, src in zip(arrays, (cfg.x0, cfg.xf, cfg.y0, cfg.yf)):
-                    dst[ind] = src
-            cfgs = []
+                if type(t) is NeuralSplineTransformer:
+                    cfg = t.config(device)
+                    ind = ind.to(device)
+                    for dst, src in zip(arrays, (cfg.x0, cfg.xf, cfg.y0, cfg.yf)):
+                        dst[ind] = src
+            cfgs, descs = [], []
             for t in tr._transformers:
-                h = t.host()
-                cfgs.append(ops.SplineConfig(*arrays, h['n_bins'], h['circular'], h['identity'], h['learn_lower'],
-                                             h['learn_upper'], h['min_bin'], h['min_slope']))
-            descs = (_lib.SplineDesc * len(cfgs))(*[c.desc for c in cfgs])
-            self._dev[key] = (descs, cfgs)                 # (cfgs keep the arrays alive)
+                if type(t) is NeuralSplineTransformer:
+                    h = t.host()
+                    cfgs.append(ops.SplineConfig(*arrays, h['n_bins'], h['circular'], h['identity'], h['learn_lower'],
+                                                 h['learn_upper'], h['min_bin'], h['min_slope']))
+                    descs.append(cfgs[-1].desc)
+                else:       # the plain shift: n_bins = 0 (x = y - parameter, log-det 0)
+                    descs.append(_lib.SplineDesc(*[a_.data_ptr() for a_ in arrays], 0, 0, 0, 0, 0, 0.0, 0.0))
+            descs = (_lib.SplineDesc * len(descs))(*descs)
+            self._dev[key] = (descs, cfgs, arrays)         # (keeps the arrays alive)
         return self._dev[key][0]
 
     def _fused_block_tables(self, d0, d1, blk, kA, r_lo, r_hi, parts, tr_idx, deg_in, mplan, L, rng, up, i32,
@@ -1077,6 +1098,8 @@ class AutoregressiveFlow(torch.nn.Module):
                     elif kind == 'moebius':
                         x_d, _ = ops.moebius(y_d, par, sub.dimension, sub.max_radius, sub.unit_sphere, inverse=True,
                                              log_det_J=ldj)
+                    elif kind == 'shift':       # (a member of a mixed transformer, no periodic features) log-det 0
+                        x_d, _ = ops.volume_preserving_shift(y_d, par, inverse=True)
                     else:
                         x_d, _ = ops.affine(y_d, par, inverse=True, log_det_J=ldj)
                     ops.scatter_columns(x_d, st['cols'], x)
