@@ -346,3 +346,62 @@ def test_mixed_transformer_inverse_is_blocked(with_affine, order, with_shift):
             xb, lb = maf.inverse(y)
             assert float((xb - xr).abs().max()) < 5e-5 and float((lb - lr).abs().max()) < 5e-4, (rows, fused_inverse)
             assert float((xb - x).abs().max()) < 2e-4 and float((lb + l).abs().max()) < 2e-3, (rows, fused_inverse)
+
+
+@pytest.mark.parametrize('order', ['ascending', 'descending'])
+def test_a_layer_built_like_mixedmafmap_runs_the_fused_and_blocked_paths(order):
+    """One MAF layer the way the reference's MixedMAFMap builds it (app/mixedmaf.py:330-360, 770-821): conditioning DOFs
+    (degree -1, passed through), torsions entering the conditioner through a PeriodicEmbedding and mapped by a circular
+    spline, distances / angles / cartesians on the other 5-bin layouts, the reference-frame DOFs on a volume-preserving
+    shift.  Forward: one fused launch per member; inverse: the block kernel with one step per degree and member -- against
+    the generic path and the reference's pass-per-degree inverse."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.embeddings import PeriodicEmbedding
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import MixedTransformer, NeuralSplineTransformer, VolumePreservingShiftTransformer
+    torch.manual_seed(5)
+    D = 64
+    perm = torch.randperm(D)
+    cond = perm[:5].sort().values                    # conditioning DOFs
+    mapped = perm[5:].sort().values                  # the 59 mapped DOFs, in feature order
+    # positions among the MAPPED features of every group
+    pos = torch.randperm(len(mapped))
+    sizes = dict(distances=14, angles=12, torsions=18, cartesians=9, reference=6)
+    idx, start = {}, 0
+    for k, n in sizes.items():
+        idx[k] = pos[start:start + n].sort().values
+        start += n
+    n = sizes
+    members = [
+        NeuralSplineTransformer(torch.full((n['distances'],), 0.8), torch.full((n['distances'],), 2.5), 5,
+                                identity_boundary_slopes=True, learn_upper_bound=True),
+        NeuralSplineTransformer(torch.zeros(n['angles']), torch.ones(n['angles']), 5),
+        NeuralSplineTransformer(torch.zeros(n['torsions']), torch.ones(n['torsions']), 5, circular=True),
+        NeuralSplineTransformer(torch.full((n['cartesians'],), -1.5), torch.full((n['cartesians'],), 1.5), 5,
+                                identity_boundary_slopes=True, learn_lower_bound=True, learn_upper_bound=True),
+        VolumePreservingShiftTransformer(),
+    ]
+    degrees = generate_degrees(D, order, conditioning_indices=cond.tolist())
+    torsion_cols = mapped[idx['torsions']]
+    maf = MAF(degrees, transformer=MixedTransformer(members, list(idx.values())), hidden_layers=[160, 160],
+              embedding=PeriodicEmbedding(D, limits=[0.0, 1.0], periodic_indices=torsion_cols.tolist()),
+              initialize_identity=False).cuda()
+    assert maf._fused_kind() == 2 and maf._blocked_ok() and maf._blocked_plan(torch.device('cuda', 0))['fused'] is not None
+    x = torch.rand(257, D, device='cuda')
+    x[:, mapped[idx['distances']]] = x[:, mapped[idx['distances']]] * 2.2 + 0.6
+    x[:, mapped[idx['cartesians']]] = (x[:, mapped[idx['cartesians']]] - 0.5) * 4.0
+    x[:, mapped[idx['reference']]] = 0.0
+    with torch.no_grad():
+        y, l = maf(x)
+        maf.fused = False
+        yg, lg = maf(x)
+        assert float((y - yg).abs().max()) < 2e-5 and float((l - lg).abs().max()) < 3e-4
+        assert torch.equal(y[:, cond], x[:, cond])
+        xb, lb = maf.inverse(y)
+        maf.blocked_inverse = False
+        xr, lr = maf.inverse(y)
+    assert float((xb - xr).abs().max()) < 5e-5 and float((lb - lr).abs().max()) < 5e-4
+    # torsions come back modulo the period
+    d = (xb - x).abs()
+    d[:, torsion_cols] = torch.minimum(d[:, torsion_cols], 1.0 - d[:, torsion_cols])
+    assert float(d.max()) < 2e-4 and float((lb + l).abs().max()) < 2e-3
