@@ -143,9 +143,17 @@ def test_modules_dispatch_through_torch_ops_and_trace_under_fake_tensors():
             return func(*args, **(kwargs or {}))
     flow = gu.build_flow('rq4', gu.load('flows.npz'))
     xin = torch.from_numpy(gu.load('flows.npz')['rq4/x'][:8]).cuda()
+    for layer in flow:
+        layer.fused = True              # (None, the default, picks by size: 8 rows would take the generic path)
     with torch.no_grad(), Spy() as spy:
         flow(xin)
     assert sum('tfep.fused_output_transformer' in s for s in spy.seen) == len(flow)
+    for layer in flow:
+        layer.fused = None
+    with torch.no_grad(), Spy() as spy:
+        flow(xin)
+    assert not any('tfep.fused_output_transformer' in s for s in spy.seen)       # too few workgroups to pay: generic path
+    assert sum('tfep.spline_forward' in s for s in spy.seen) == len(flow)
     # CPU tensors never reach a kernel: no CPU implementation is registered
     with pytest.raises((NotImplementedError, RuntimeError)):
         torch.ops.tfep.affine_forward(torch.zeros(2, 2), torch.zeros(2, 4))

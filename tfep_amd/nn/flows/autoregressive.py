@@ -72,7 +72,9 @@ class AutoregressiveFlow(torch.nn.Module):
         self.register_buffer('_fixed_indices', fixed_indices)
         self.register_buffer('_conditioner_indices', conditioner_indices)
         self._dev = {}
-        self.fused = True             # set False to force the generic (unfused) forward path
+        # True: the fused output-GEMM + transformer kernel wherever one exists; False: never (the generic path: three
+        # GEMMs + a transformer kernel); None: by size (_fused_pays)
+        self.fused = None
         self.blocked_inverse = True   # set False to force the reference's one-full-pass-per-degree inverse
         self.split_gemm = None        # None: TFEP_SPLIT_GEMM (default on); False: exact-fp32 MFMA GEMMs in forward
 
@@ -168,7 +170,7 @@ class AutoregressiveFlow(torch.nn.Module):
         return _FUSED_AFFINE if cls._is_plain_shift(tr) else cls._transformer_fused_kind(tr)
 
     def _fused_kind(self):
-        if not self.fused or not isinstance(self._conditioner, MADE) or len(self._conditioner_indices) > 0:
+        if self.fused is False or not isinstance(self._conditioner, MADE) or len(self._conditioner_indices) > 0:
             return None
         tr = self._transformer
         if type(tr) is MixedTransformer:
@@ -337,9 +339,29 @@ class AutoregressiveFlow(torch.nn.Module):
             raise RuntimeError(f'{type(self).__name__}: {name} has {x.shape[-1] if x.dim() else 0} features, the layer was '
                                f'built for {n} (degrees_in / dimension_in are those of the flow input, before any embedding)')
 
+    #: Workgroups of the fused launches below which ``fused = None`` takes the generic path (exact-fp32 kernels only).
+    fused_min_workgroups = 256
+
+    def _fused_pays(self, x, kind):
+        """Is the fused kernel the faster forward at this batch size?  Its point is that the (B, P D) parameter tensor never
+        reaches HBM; its price, on the exact-fp32 kernel, is an epilogue in which every lane evaluates 8 features one after
+        the other (2 on the affine tile) with nothing to overlap them.  With fewer workgroups than CUs that chain is the whole
+        run time -- a 5-bin spline launch takes ~235 us however small -- while the generic path spreads the same
+        evaluations over one wave per sample row (a 6-layer MixedMAFMap-like flow, D = 200, B = 1024: 9.1 ms fused, 4.0 ms
+        generic).  The split-f16 path is only taken for large products and always fuses."""
+        if self.fused is not None:
+            return bool(self.fused)
+        B = x.shape[0]
+        if self._use_split_gemm(B):
+            return True
+        fp = self._fused_plan(x.device, kind, self._tables(x.device))
+        tm = 128                                             # rows per workgroup of gemm_kernel<2, ...>
+        wgs = ((B + tm - 1) // tm) * sum(g['n_rows'] // (16 * g['P'] * g['FT']) for g in fp['groups'])
+        return wgs >= int(os.environ.get('TFEP_FUSED_MIN_WGS', self.fused_min_workgroups))
+
     def _forward_impl(self, x: torch.Tensor):
         kind = self._fused_kind()
-        if kind is not None:
+        if kind is not None and self._fused_pays(x, kind):
             return self._forward_fused(x, kind)
         parameters = self.get_transformer_parameters(x)
         if self.has_fixed_indices:
@@ -437,17 +459,23 @@ class AutoregressiveFlow(torch.nn.Module):
         """Where feature column c of x enters the conditioner input: ``(first_col[c], periodic[c], limits)``.  Without an
         embedding the input IS x; a PeriodicEmbedding puts the non-periodic features first and then a (cos, sin) pair
         per periodic feature (mafembed.py:137-145)."""
+        cached = self._dev.get('input_columns')         # (the index buffers live on the device: read them once -- a
+        if cached is not None:                          # device -> host copy per call also cannot be captured in a graph)
+            return cached
         emb = getattr(self._conditioner, 'embedding', None)
         D = self._inverse_masks.shape[1]
         if emb is None:
-            return list(range(D)), [False] * D, (0.0, 1.0)
-        non, per = emb._nonperiodic_indices.tolist(), emb._periodic_indices.tolist()
-        first, periodic = [0] * D, [False] * D
-        for pos, c in enumerate(non):
-            first[c] = pos
-        for pos, c in enumerate(per):
-            first[c], periodic[c] = len(non) + 2 * pos, True
-        return first, periodic, emb.host_limits()
+            res = list(range(D)), [False] * D, (0.0, 1.0)
+        else:
+            non, per = emb._nonperiodic_indices.tolist(), emb._periodic_indices.tolist()
+            first, periodic = [0] * D, [False] * D
+            for pos, c in enumerate(non):
+                first[c] = pos
+            for pos, c in enumerate(per):
+                first[c], periodic[c] = len(non) + 2 * pos, True
+            res = first, periodic, emb.host_limits()
+        self._dev['input_columns'] = res
+        return res
 
     def _input_info(self, x_cols, device):
         """Index tensors to write the features ``x_cols`` (a list, in the order of the value columns) into the

@@ -221,10 +221,15 @@ def narrow_tile_n():
 
 
 def few_wide_tiles(B, N):
-    """True when a (B x N) product is at most 8 of the 256 x 256 tiles but more than one 32-column tile wide: small enough
-    that one workgroup per wide tile leaves the chip idle, see ``masked_linear_packed``."""
+    """True when a (B x N) product is at most 128 of the 256 x 256 tiles, half the CUs (and more than one 32-column tile wide):
+    one workgroup per wide tile then leaves CUs idle and the run time is one workgroup's walk over k, see
+    ``masked_linear_packed``.  Measured (tools/probe/tile_choice.py, exact-fp32 kernels, dense): B 1024 x K 800 x N 800
+    (16 wide tiles) 214 us wide / 42 us narrow; 4096 x 800 x 800 (64) 221 / 73; 8192 x 800 x 800 (128) 227 / 119;
+    4096 x 800 x 3200 (208) 236 / 207."""
     tm, tn, _ = tile_sizes()
-    return ((B + tm - 1) // tm) * ((N + tn - 1) // tn) <= 8 and N > narrow_tile_n()
+    # (the narrow tile runs dense -- the mask tables are per wide tile -- so at ~200 tiles, where the two are level on a
+    # dense product, the wide tile with its k-ranges wins: the line is drawn at half the CUs)
+    return ((B + tm - 1) // tm) * ((N + tn - 1) // tn) <= 128 and N > narrow_tile_n()
 
 
 def masked_linear_packed(x_padded, w_packed, bias, n_out, k_ranges=None, col_map=None, act=0, out=None,
