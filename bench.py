@@ -177,7 +177,8 @@ def main():
 
     # ---------------------------------------------------------------- extra arms (same process, same device)
     extra = {}
-    if not args.no_extra_arms:
+    arms = set(os.environ.get('TFEP_BENCH_ARMS', 'cached,exact,inverse,train').split(','))     # (debugging: a subset)
+    if not args.no_extra_arms and 'cached' in arms:
         for l in flow:
             l._conditioner.cache_packed_weights = True
         t_c, _, ms_c, fl_c = timed(1, args.steps)
@@ -188,6 +189,8 @@ def main():
         for l in flow:
             l._conditioner.cache_packed_weights = False
             l._conditioner.invalidate_plan()            # frees the cached packs
+    if not args.no_extra_arms and 'exact' in arms:
+        for l in flow:
             l.split_gemm = False
         n_exact = min(3, args.steps)
         t_e, _, ms_e, fl_e = timed(1, n_exact)
@@ -223,8 +226,8 @@ def main():
                 return (time.perf_counter() - t0) / n
             with torch.no_grad():
                 y8, _ = layer(x[:8192])
-                t_i = clock(lambda: layer.inverse(y8), 2)
-                xi, _ = layer.inverse(y8)
+                t_i = clock(lambda: layer.inverse(y8), 2) if 'inverse' in arms else 1.0
+                xi, _ = layer.inverse(y8) if 'inverse' in arms else (x[:8192], None)
             other['inverse_one_layer'] = {
                 'rows': 8192, 'ms': 1e3 * t_i, 'samples_per_s': 8192 / t_i,
                 'roundtrip_max_abs': float((xi - x[:8192]).abs().max()),
@@ -244,8 +247,12 @@ def main():
                 BoltzmannKLDivLoss()((c * yt ** 2).sum(dim=1), lt).backward()
                 opt.step()          # parameters change: every step packs its weights again, as a real loop does
             t_t = clock(train_step, 2)
+            from tfep_amd.nn.flows import _backward
+            free_b, total_b = torch.cuda.mem_get_info(device)
             other['training_step_one_layer'] = {
                 'rows': 16384, 'ms': 1e3 * t_t, 'samples_per_s': 16384 / t_t,
+                'activations_kept': bool(_backward.saves_activations_at(layer, 16384)),
+                'free_memory_gib': round(free_b / 2 ** 30, 1),
                 'roofline': {'bound': 'mfma', 'achieved': 3.0 * flops_layer * 16384 / t_t / 1e12, 'peak': peak_other,
                              'unit': 'TFLOP/s', 'frac': 3.0 * flops_layer * 16384 / t_t / 1e12 / peak_other,
                              'note': 'forward + grad_input + grad_weight of every masked linear (activations kept, no recompute) + SGD '
