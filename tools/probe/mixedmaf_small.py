@@ -61,6 +61,15 @@ def timeit(fn, n=20):
     return (time.perf_counter() - t0) / n * 1e3, out
 
 
+if len(sys.argv) > 2 and sys.argv[2] == 'inverse-blocks':         # degrees per block of the blocked inverse
+    with torch.no_grad():
+        y, _ = flow(x)
+        for G in (4, 8, 16, 32, 64):
+            for lay in flow:
+                lay.inverse_block = G
+            print(G, round(timeit(lambda: flow.inverse(y), 5)[0], 2), 'ms', flush=True)
+    sys.exit(0)
+
 if len(sys.argv) > 2 and sys.argv[2] == 'forward-only':           # under rocprofv3: 20 fused forward passes, nothing else
     with torch.no_grad():
         print(timeit(lambda: flow(x))[0])
