@@ -241,10 +241,17 @@ def stream_of(t):
     """The current HIP stream of the tensor's device.  Kernels launch on the CURRENT device: a tensor that lives on
     another GPU is an error here (wrap the call in ``torch.cuda.device(tensor.device)``), never a silent cross-device
     launch."""
-    if t.device.index is not None and t.device.index != torch.cuda.current_device():
-        raise TfepHipError(f'tensor on {t.device} but the current device is cuda:{torch.cuda.current_device()}: '
+    cur = torch.cuda.current_device()
+    idx = t.device.index
+    if idx is not None and idx != cur:
+        raise TfepHipError(f'tensor on {t.device} but the current device is cuda:{cur}: '
                            'run under torch.cuda.device(tensor.device)')
-    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    # the raw handle without building a torch.cuda.Stream object: ~5 us less on each of the ~25 launches of a small layer
+    return c_void_p(_raw_stream(cur))
+
+
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (
+    lambda index: torch.cuda.current_stream(index).cuda_stream)
 
 
 def check_device_tensor(t, name, dtype=torch.float32):

@@ -70,6 +70,20 @@ if len(sys.argv) > 2 and sys.argv[2] == 'inverse-blocks':         # degrees per 
             print(G, round(timeit(lambda: flow.inverse(y), 5)[0], 2), 'ms', flush=True)
     sys.exit(0)
 
+if len(sys.argv) > 2 and sys.argv[2] == 'cprofile':               # host time of the eager forward
+    import cProfile
+    import pstats
+    with torch.no_grad():
+        timeit(lambda: flow(x))
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(20):
+            flow(x)
+        torch.cuda.synchronize()
+        pr.disable()
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
+    sys.exit(0)
+
 if len(sys.argv) > 2 and sys.argv[2] == 'forward-only':           # under rocprofv3: 20 fused forward passes, nothing else
     with torch.no_grad():
         print(timeit(lambda: flow(x))[0])
