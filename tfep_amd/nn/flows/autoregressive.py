@@ -340,7 +340,7 @@ class AutoregressiveFlow(torch.nn.Module):
                                f'built for {n} (degrees_in / dimension_in are those of the flow input, before any embedding)')
 
     #: Workgroups of the fused launches below which ``fused = None`` takes the generic path (exact-fp32 kernels only).
-    fused_min_workgroups = 256
+    fused_min_workgroups = 512
 
     def _fused_pays(self, x, kind):
         """Is the fused kernel the faster forward at this batch size?  Its point is that the (B, P D) parameter tensor never
@@ -348,7 +348,9 @@ class AutoregressiveFlow(torch.nn.Module):
         the other (2 on the affine tile) with nothing to overlap them.  With fewer workgroups than CUs that chain is the whole
         run time -- a 5-bin spline launch takes ~235 us however small -- while the generic path spreads the same
         evaluations over one wave per sample row (a 6-layer MixedMAFMap-like flow, D = 200, B = 1024: 9.1 ms fused, 4.0 ms
-        generic).  The split-f16 path is only taken for large products and always fuses."""
+        generic).  Crossover, tools/probe/fused_crossover.py (one 8-bin layer, fused / generic ms): 256 workgroups 0.41 / 0.32
+        and 1.59 / 1.26, 504 workgroups 3.71 / 3.66, 1024 workgroups 2.46 / 2.97, 4096 workgroups 5.7 / 7.6.  The
+        split-f16 path is only taken for large products and always fuses."""
         if self.fused is not None:
             return bool(self.fused)
         B = x.shape[0]
