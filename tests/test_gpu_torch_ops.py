@@ -413,3 +413,40 @@ def test_a_layer_built_like_mixedmafmap_runs_the_fused_and_blocked_paths(order):
     d = (xb - x).abs()
     d[:, torsion_cols] = torch.minimum(d[:, torsion_cols], 1.0 - d[:, torsion_cols])
     assert float(d.max()) < 2e-4 and float((lb + l).abs().max()) < 2e-3
+
+
+def test_fused_none_picks_the_path_by_size():
+    """``fused = None`` (the default): the fused output-GEMM + transformer kernel from 512 workgroups (or on the split-f16
+    path), the generic kernels below -- same results either way."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+
+    class Spy(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            self.seen.append(str(func))
+            return func(*args, **(kwargs or {}))
+    torch.manual_seed(0)
+    D = 128
+    maf = MAF(generate_degrees(D, 'ascending'), transformer=NeuralSplineTransformer(torch.full((D,), -5.0), torch.full((D,), 5.0), 8),
+              initialize_identity=False).cuda()
+    assert maf.fused is None and not maf._use_split_gemm(8192)      # (2.5 M weights: exact-fp32 kernels at these sizes)
+    for B, expect_fused in ((1024, False), (8192, True)):           # 8 x 8 = 64 and 64 x 8 = 512 workgroups
+        x = torch.randn(B, D, device='cuda').clamp_(-4.9, 4.9)
+        with torch.no_grad():
+            with Spy() as spy:
+                y, l = maf(x)
+            assert any('tfep.fused_output_transformer' in s for s in spy.seen) == expect_fused, B
+            maf.fused = not expect_fused
+            y2, l2 = maf(x)
+            maf.fused = None
+        assert float((y - y2).abs().max()) < 2e-5 and float((l - l2).abs().max()) < 2e-4
+    maf.split_gemm = True                                           # the split path always fuses
+    with torch.no_grad(), Spy() as spy:
+        maf(torch.randn(64, D, device='cuda').clamp_(-4.9, 4.9))
+    assert any('tfep.fused_output_transformer' in s for s in spy.seen)
