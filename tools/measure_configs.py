@@ -165,7 +165,7 @@ if 'variants' in which:
                      ('K=5 identity slopes, fused=False', dict(n_bins=5, **ident)),
                      ('K=5 learnable bounds', dict(n_bins=5, **both)),
                      ('K=5 learnable bounds, fused=False', dict(n_bins=5, **both)),
-                     ('K=5 identity slopes + learnable bounds (same count as plain: generic path)',
+                     ('K=5 identity slopes + both bounds learnable (16 parameters like the plain layout: its own epilogue kind)',
                       dict(n_bins=5, **ident, **both))):
         torch.manual_seed(0)
         with torch.device(dev):
