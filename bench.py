@@ -19,6 +19,8 @@ headline region the same process also times (a) the step with the packed weights
 (``cached_repack``; the headline re-packs every step), (b) the step on the exact-fp32 MFMA GEMMs (``exact_fp32``),
 (c) at N = 1 one layer's blocked inverse (8192 rows) and training step (16 384 rows) with their rooflines
 (``other_paths``) and (d), on rank 0 at N = 1, the CPU restatement of the path on the host cores (``cpu_baseline``).
+(``TFEP_BENCH_ARMS=cached,exact,inverse,train`` -- a subset -- selects which of the extra arms run, for debugging one of
+them; the default is all of them.)
 """
 import argparse
 import json
