@@ -70,6 +70,35 @@ if len(sys.argv) > 2 and sys.argv[2] == 'inverse-blocks':         # degrees per 
             print(G, round(timeit(lambda: flow.inverse(y), 5)[0], 2), 'ms', flush=True)
     sys.exit(0)
 
+if len(sys.argv) > 2 and sys.argv[2] == 'train':                  # a training step, eager and as one HIP graph
+    from tfep_amd.graphs import GraphedTrainingStep
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    c = torch.rand(D, device='cuda') * 0.3
+    opt = torch.optim.SGD(flow.parameters(), lr=1e-6)
+    loss_fn = BoltzmannKLDivLoss()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        y, l = flow(x)
+        loss = loss_fn((c * y ** 2).sum(dim=1), l)
+        loss.backward()
+        opt.step()
+        return loss
+    t_eager, loss = timeit(step, 10)
+    n_grads = sum(p.grad is not None for p in flow.parameters())
+    res = dict(D=D, batch=B, layers=n_layers, train_eager_ms=t_eager, loss=float(loss), params_with_grad=n_grads,
+               n_params=sum(1 for _ in flow.parameters()))
+    del loss
+    opt.zero_grad(set_to_none=True)
+    try:
+        g = GraphedTrainingStep(flow, lambda y, l: loss_fn((c * y ** 2).sum(dim=1), l), opt, B, D)
+        res['train_graph_ms'], lg = timeit(lambda: g(x), 10)
+        res['loss_graph'] = float(lg)
+    except Exception as e:
+        res['train_graph_failed'] = f'{type(e).__name__}: {str(e)[:200]}'
+    print(json.dumps(res))
+    sys.exit(0)
+
 if len(sys.argv) > 2 and sys.argv[2] == 'cprofile':               # host time of the eager forward
     import cProfile
     import pstats
