@@ -398,6 +398,15 @@ constexpr int LIN_MREP = 2, LIN_NREP = 16;          // 256 x 256 tile for the hi
 constexpr int NARROW_NREP = 2;                      // 256 x 32 tile: row slices of the blocked inverse
 
 
+// The 256 x 32 narrow tile at half height (128 x 32, MREP = 1) while the launch would have fewer workgroups than twice the
+// CUs: these products are bound by the latency of one workgroup's k-loop (a barrier and an LDS-DMA round trip per 16
+// columns), and two resident workgroups per CU overlap theirs.  (A/B: TFEP_NARROW_HALF=0.)
+static bool narrow_half_height(int B, int n_col_positions) {
+    static const int on = env_int("TFEP_NARROW_HALF", 1);
+    const long long wgs = (long long)((B + 255) / 256) * n_col_positions;
+    return on && wgs < 512;
+}
+
 template <int MREP, int NREP, int EPI, int P, int KSPL>
 static int launch_gemm(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStream_t s) {
     using T = Tile<MREP, NREP>;
@@ -530,6 +539,10 @@ int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int6
     if (tile_n == NARROW_BN) {
         // narrow column tile for the row slices of the blocked autoregressive inverse
         const int n_tiles = (N + tile_n - 1) / tile_n;
+        if (narrow_half_height(B, n_tiles)) {
+            if (act == 1) return launch_gemm<1, NARROW_NREP, EPI_ELU, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);
+            return launch_gemm<1, NARROW_NREP, EPI_LINEAR, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);
+        }
         if (act == 1) return launch_gemm<LIN_MREP, NARROW_NREP, EPI_ELU, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);
         return launch_gemm<LIN_MREP, NARROW_NREP, EPI_LINEAR, 1, 1>(g, n_rows_w, n_tiles, (hipStream_t)stream);
     }
@@ -572,6 +585,10 @@ int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
                  "masked_linear_gemm: tile_n=%d unsupported (0, %d or %d)", d->tile_n, WIDE_BN, NARROW_BN);
     if (d->tile_n == NARROW_BN) {
         const int n_tiles = (d->N + NARROW_BN - 1) / NARROW_BN;
+        if (!d->tile_live && narrow_half_height(d->B, n_tiles * (d->k_split > 1 ? d->k_split : 1))) {    // (tile_live: per 256-row tile)
+            if (d->act == 1) return launch_gemm<1, NARROW_NREP, EPI_ELU, 1, 1>(g, d->n_rows_w, n_tiles, (hipStream_t)stream);
+            return launch_gemm<1, NARROW_NREP, EPI_LINEAR, 1, 1>(g, d->n_rows_w, n_tiles, (hipStream_t)stream);
+        }
         if (d->act == 1) return launch_gemm<LIN_MREP, NARROW_NREP, EPI_ELU, 1, 1>(g, d->n_rows_w, n_tiles, (hipStream_t)stream);
         return launch_gemm<LIN_MREP, NARROW_NREP, EPI_LINEAR, 1, 1>(g, d->n_rows_w, n_tiles, (hipStream_t)stream);
     }
