@@ -548,3 +548,49 @@ def test_empty_batch_through_every_path(kind):
     loss = BoltzmannKLDivLoss()
     with pytest.raises(Exception):
         float(loss(l.detach(), l.detach()))              # the mean over no samples is not a number the reference returns either
+
+
+def test_graphed_training_step_with_adamw():
+    """The optimiser of the reference's maps is AdamW (app/base.py: configure_optimizers): with ``capturable=True`` its update
+    is part of the captured step; replays track the same steps run eagerly."""
+    import copy
+    from tfep_amd.graphs import GraphedTrainingStep
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF, SequentialFlow, _backward as bw
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    torch.manual_seed(3)
+    D, B = 24, 200
+    flow = SequentialFlow(*[MAF(generate_degrees(D, o), transformer=NeuralSplineTransformer(torch.full((D,), -4.0), torch.full((D,), 4.0), 5),
+                                initialize_identity=False) for o in ('ascending', 'descending')]).cuda()
+    twin = copy.deepcopy(flow)
+    xs = [(torch.rand(B, D, device='cuda') * 2 - 1) * 3.5 for _ in range(5)]
+    loss_mod = BoltzmannKLDivLoss()
+    c = torch.linspace(0.1, 0.5, D, device='cuda')
+
+    def loss_fn(y, ldj):
+        return loss_mod((c * y ** 2).sum(dim=1), ldj)
+    kw = dict(lr=1e-3, weight_decay=0.01, capturable=True)
+    opt, opt_twin = torch.optim.AdamW(flow.parameters(), **kw), torch.optim.AdamW(twin.parameters(), **kw)
+    step = GraphedTrainingStep(twin, loss_fn, opt_twin, B, D)
+    # the capture's warm-up took optimiser steps: same parameters and a fresh optimiser state on both arms
+    twin.load_state_dict(flow.state_dict())
+    for st in opt_twin.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+    save = bw._SAVE_BYTES
+    bw._SAVE_BYTES = 0
+    try:
+        for i, x in enumerate(xs):
+            opt.zero_grad(set_to_none=True)
+            loss = loss_fn(*flow(x))
+            loss.backward()
+            opt.step()
+            got = step(x)
+            assert abs(float(got) - float(loss.detach())) <= 1e-5 * abs(float(loss.detach())), i
+            del loss
+    finally:
+        bw._SAVE_BYTES = save
+    for (n, p), q in zip(flow.named_parameters(), twin.parameters()):
+        assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), n
