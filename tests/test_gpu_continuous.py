@@ -241,8 +241,10 @@ def test_flow_round_trip_and_adaptive_solver():
     assert stats['n_steps'] >= 1 and stats['n_evaluations'] >= 7
     # rtol = atol = 1e-4 on an RMS norm over the whole batch: individual coordinates end a few 1e-3 off (the reference's
     # own round-trip test uses atol 1e-3 on a much smoother toy dynamics)
-    assert float((y - y_ref).abs().max()) < 5e-3 and float((tr - tr_ref).abs().max()) < 1e-2
-    assert float((xi - x).abs().max()) < 5e-3 and float((tr + tri).abs().max()) < 1e-2
+    # (with the error weights of torchdiffeq's tableau -- Shampine's b* -- the accepted steps are a little longer than with
+    # Dormand & Prince's own: 6.7e-3 where those gave < 5e-3)
+    assert float((y - y_ref).abs().max()) < 1e-2 and float((tr - tr_ref).abs().max()) < 2e-2
+    assert float((xi - x).abs().max()) < 1e-2 and float((tr + tri).abs().max()) < 2e-2
     # fresh noise per integration unless fixed (continuous.py:223-229)
     hut = ContinuousFlow(dyn, solver='euler', solver_options={'step_size': 0.5}, regularization=False)
     with torch.no_grad():

@@ -479,12 +479,10 @@ def test_graphed_training_step_equals_eager_steps(kind):
         return loss_mod((c * y ** 2).sum(dim=1), ldj)
     opt, opt_twin = torch.optim.SGD(flow.parameters(), lr=1e-3, momentum=0.9), torch.optim.SGD(twin.parameters(), lr=1e-3, momentum=0.9)
     step = GraphedTrainingStep(twin, loss_fn, opt_twin, B, D)
-    # the capture's warm-up took optimiser steps: bring both arms to the same parameters and momentum buffers
-    twin.load_state_dict(flow.state_dict())
-    for st in opt_twin.state.values():
-        for v in st.values():
-            if torch.is_tensor(v):
-                v.zero_()
+    # construction leaves the model and the optimiser as it found them (the warm-up steps are undone in place)
+    for (n, p), q in zip(flow.named_parameters(), twin.parameters()):
+        assert torch.equal(p, q), n
+    assert all(float(v.abs().sum()) == 0.0 for st in opt_twin.state.values() for v in st.values() if torch.is_tensor(v))
     save = bw._SAVE_BYTES
     bw._SAVE_BYTES = 0                                  # (inside a capture the layers recompute their activations)
     try:
@@ -572,13 +570,10 @@ def test_graphed_training_step_with_adamw():
         return loss_mod((c * y ** 2).sum(dim=1), ldj)
     kw = dict(lr=1e-3, weight_decay=0.01, capturable=True)
     opt, opt_twin = torch.optim.AdamW(flow.parameters(), **kw), torch.optim.AdamW(twin.parameters(), **kw)
-    step = GraphedTrainingStep(twin, loss_fn, opt_twin, B, D)
-    # the capture's warm-up took optimiser steps: same parameters and a fresh optimiser state on both arms
-    twin.load_state_dict(flow.state_dict())
-    for st in opt_twin.state.values():
-        for v in st.values():
-            if torch.is_tensor(v):
-                v.zero_()
+    step = GraphedTrainingStep(twin, loss_fn, opt_twin, B, D, sample_input=xs[0])
+    for (n, p), q in zip(flow.named_parameters(), twin.parameters()):          # the warm-up steps were undone in place
+        assert torch.equal(p, q), n
+    assert all(float(v.abs().sum()) == 0.0 for st in opt_twin.state.values() for v in st.values() if torch.is_tensor(v))
     save = bw._SAVE_BYTES
     bw._SAVE_BYTES = 0
     try:

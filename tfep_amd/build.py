@@ -15,6 +15,10 @@ LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libtfep_hip.so')
 SOURCES = ['transformers.hip', 'masked_linear.hip', 'split_gemm.hip', 'split_gemm_layouts.hip', 'inverse_block.hip',
            'reduce.hip', 'backward.hip', 'egnn.hip']
+# Per-file flags.  egnn.hip: the edge kernels are bound by vector-instruction issue, and on gfx950 a packed fp32
+# instruction (v_pk_fma_f32 ...) is no cheaper than the two scalar ones it replaces (the fp32 vector peak is reached
+# without packing; beside MFMAs a packed op costs more) -- keep clang's SLP vectoriser from forming them.
+EXTRA_FLAGS = {'egnn.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():
@@ -48,7 +52,7 @@ def build_probe(out_path, extra_flags, verbose=True):
         obj = os.path.join(tmp, src.replace('.hip', '.o'))
         objs.append(obj)
         cmd = [_hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result',
-               *extra_flags, '-c', os.path.join(CSRC, src), '-o', obj]
+               *EXTRA_FLAGS.get(src, []), *extra_flags, '-c', os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))
@@ -85,7 +89,7 @@ def _build_locked(force, verbose):
             continue
         tmp = obj + f'.{os.getpid()}.tmp'
         cmd = [_hipcc(), '-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-fno-gpu-rdc',
-               '-Wno-unused-result', '-c', path, '-o', tmp]
+               '-Wno-unused-result', *EXTRA_FLAGS.get(src, []), '-c', path, '-o', tmp]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((src, tmp, obj, subprocess.Popen(cmd)))

@@ -26,12 +26,16 @@
 // images: the 16 bytes lane l needs for 4 consecutive MFMA k-steps of a row tile are contiguous, a wave reads 1 KB per
 // ds_read_b128 without bank conflicts.
 #include "common.h"
+#include <type_traits>
 
 namespace tfep {
 namespace {
 
 using f4 = __attribute__((ext_vector_type(4))) float;
 
+#ifndef TFEP_EGNN_FAST_GEOM
+#define TFEP_EGNN_FAST_GEOM 1
+#endif
 constexpr int EDGE_WAVES = 8;            // waves per workgroup of the edge kernel (2 per SIMD)
 constexpr int NODE_WAVES = 4;
 
@@ -136,6 +140,14 @@ __device__ inline void chain_gemm_split(const h8* __restrict__ img, const f4 (&x
         asm volatile("" : "+v"(acc[tp]));
         if (TAN) asm volatile("" : "+v"(dacc[tp]));
     }
+    // ... and so do the packed halves: without this pin the compiler is free to form a register of halves
+    // (v_cvt_pk_f16_f32) right in front of the product that reads it, below the wait states (seen with
+    // -fno-slp-vectorize in the reverse-pass kernel: NaN traces)
+#pragma unroll
+    for (int T = 0; T < NT2; ++T) {
+        asm volatile("" : "+v"(xh[T]), "+v"(xl[T]));
+        if (TAN) asm volatile("" : "+v"(dxh[T]), "+v"(dxl[T]));
+    }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 3" ::: "memory");
 #pragma unroll
@@ -151,6 +163,105 @@ __device__ inline void chain_gemm_split(const h8* __restrict__ img, const f4 (&x
             if (TAN) mfma16_acc(dacc[tp], wh, dxl[T]);
         }
     }
+    // leave the matrix pipe's result latency behind before anything reads the accumulators
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---- the forward edge kernel's version of the split product: operands arrive PRE-SCALED (the producers fold the x 16 into
+// arithmetic they do anyway), every fp32 -> (hi, lo) pair costs three vector instructions, and the first product of an
+// accumulator takes the inline constant 0 as SrcC (no zero fill of 2 x 16 NT registers per product).
+using u4 = __attribute__((ext_vector_type(4))) uint32_t;
+
+// (a, b) -> hi = (fp16(a), fp16(b)), lo = (fp16(a - hi_a), fp16(b - hi_b)); v_fma_mix reads the fp16 high half directly
+// (op_sel_hi marks src2 as fp16, op_sel picks its upper half), so there is no conversion back and no subtraction.
+__device__ inline void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(hi), "=&v"(lo) : "v"(a), "v"(b));
+}
+__device__ inline void mfma16_first(f4& acc, const u4& a, const u4& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+__device__ inline void mfma16_next(f4& acc, const u4& a, const u4& b) {
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <int NT>
+__device__ inline void split_tiles(const f4 (&x)[NT], u4 (&xh)[(NT + 1) / 2], u4 (&xl)[(NT + 1) / 2]) {
+#pragma unroll
+    for (int T = 0; T < (NT + 1) / 2; ++T) {
+        uint32_t h0, l0, h1, l1, h2 = 0u, l2 = 0u, h3 = 0u, l3 = 0u;
+        split_pair(x[2 * T].x, x[2 * T].y, h0, l0);
+        split_pair(x[2 * T].z, x[2 * T].w, h1, l1);
+        if (2 * T + 1 < NT) {
+            const f4& b = x[(2 * T + 1 < NT) ? 2 * T + 1 : 0];
+            split_pair(b.x, b.y, h2, l2);
+            split_pair(b.z, b.w, h3, l3);
+        }
+        xh[T] = u4{h0, h1, h2, h3};
+        xl[T] = u4{l0, l1, l2, l3};
+    }
+}
+// LDS byte address of a pointer into shared memory (the low 32 bits of a flat address in the LDS aperture are the offset)
+__device__ inline uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)p; }
+// the hi / lo weight fragments of one (row tile, k-tile pair) group, issued without waiting: the compiler does not know
+// these loads (nor count them), lds_wait_pair before the first use is what orders them
+template <int OFF_H, int OFF_L>
+__device__ inline void lds_read_pair(u4& wh, u4& wl, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %2 offset:%3\n\tds_read_b128 %1, %2 offset:%4"
+                 : "=&v"(wh), "=&v"(wl) : "v"(addr), "i"(OFF_H), "i"(OFF_L));
+}
+template <int N>
+__device__ inline void lds_wait_pair(u4& wh, u4& wl) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(wh), "+v"(wl) : "i"(N));
+}
+template <int I, int N, class F>
+__device__ inline void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// acc = W x, dacc = W dx for pre-scaled x, dx (acc / dacc need no initialisation).  The weight fragments are read one
+// group AHEAD of the products that use them (two register sets, counted lgkmcnt): left to the compiler every group was
+// "two ds_read_b128, wait, six MFMAs" -- 24 exposed LDS round trips per source with the matrix pipe idle behind each.
+template <int NT, bool TAN>
+__device__ inline void chain_gemm_split_pre(const u4* __restrict__ img, const f4 (&x)[NT], const f4 (&dx)[NT],
+                                            f4 (&acc)[NT], f4 (&dacc)[NT], int lane) {
+    constexpr int NT2 = (NT + 1) / 2, G = NT * NT2, LO = NT * NT2 * 64 * 16;
+    static_assert(LO + G * 1024 < 65536, "ds_read offset field");
+    u4 xh[NT2], xl[NT2], dxh[NT2], dxl[NT2];
+    split_tiles<NT>(x, xh, xl);
+    if (TAN) split_tiles<NT>(dx, dxh, dxl);
+    const uint32_t base = lds_addr(img) + (uint32_t)lane * 16u;
+    // the halves come from VALU instructions inside asm statements: keep them ahead of the first product and give the
+    // VALU -> MFMA operand hazard its wait states by hand (hipcc pads nothing around asm)
+#pragma unroll
+    for (int T = 0; T < NT2; ++T) {
+        asm volatile("" : "+v"(xh[T]), "+v"(xl[T]));
+        if (TAN) asm volatile("" : "+v"(dxh[T]), "+v"(dxl[T]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    u4 wh[2], wl[2];
+    lds_read_pair<0, LO>(wh[0], wl[0], base);
+    static_for<0, G>([&](auto gc) {
+        constexpr int g = decltype(gc)::value, tp = g / NT2, T = g % NT2, cur = g & 1;
+        if constexpr (g + 1 < G) lds_read_pair<(g + 1) * 1024, LO + (g + 1) * 1024>(wh[cur ^ 1], wl[cur ^ 1], base);
+        lds_wait_pair<(g + 1 < G) ? 2 : 0>(wh[cur], wl[cur]);
+        if (T == 0) {
+            mfma16_first(acc[tp], wh[cur], xh[T]);
+            if (TAN) mfma16_first(dacc[tp], wh[cur], dxh[T]);
+        } else {
+            mfma16_next(acc[tp], wh[cur], xh[T]);
+            if (TAN) mfma16_next(dacc[tp], wh[cur], dxh[T]);
+        }
+        mfma16_next(acc[tp], wl[cur], xh[T]);
+        if (TAN) mfma16_next(dacc[tp], wl[cur], dxh[T]);
+        mfma16_next(acc[tp], wh[cur], xl[T]);
+        if (TAN) mfma16_next(dacc[tp], wh[cur], dxl[T]);
+    });
     // leave the matrix pipe's result latency behind before anything reads the accumulators
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -174,6 +285,26 @@ __device__ inline void silu_tile(f4 (&z)[NT], f4 (&dz)[NT]) {
             const float sv = v * sig;
             z[t][r] = sv;
             if (TAN) dz[t][r] *= fmaf(sv, 1.0f - sig, sig);       // silu' = sig + silu (1 - sig)
+        }
+    }
+}
+
+// The same with the result scaled by XS = 2^LOG2S (the split products take their operands pre-scaled; XS = 1 is the plain
+// SiLU at the same instruction count): z <- XS silu(z), dz <- XS silu'(z) dz.  XS sigma = 1 / (1/XS + exp(-z) / XS), the
+// 1 / XS inside the exponent is an exact shift of the exp2 argument.
+template <int NT, bool TAN, int LOG2S>
+__device__ inline void silu_tile_scaled(f4 (&z)[NT], f4 (&dz)[NT]) {
+    constexpr float IS = 1.0f / (float)(1 << LOG2S);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = z[t][r];
+            const float e = __builtin_amdgcn_exp2f(fmaf(v, -1.44269504088896340736f, -(float)LOG2S));
+            const float sig = fast_rcp(e + IS);                  // XS sigma(v)
+            const float sv = v * sig;                            // XS silu(v)
+            z[t][r] = sv;
+            if (TAN) dz[t][r] *= fmaf(sv, fmaf(sig, -IS, 1.0f), sig);       // XS (sigma + silu (1 - sigma))
         }
     }
 }
@@ -397,10 +528,14 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
         (tan ? s_dq : s_q)[ee] = v;
     }
     const float att_b = a.packed[L.scal];
-    // split products come out scaled by (weight scale of the matrix) x 16: exact powers of two
-    const float inv1 = SPLIT ? 1.0f / (a.packed[L.scal + 1] * SPLIT_X_SCALE) : 1.0f;
-    const float inv2 = SPLIT ? 1.0f / (a.packed[L.scal + 2] * SPLIT_X_SCALE) : 1.0f;
-    const float inv3 = SPLIT ? 1.0f / (a.packed[L.scal + 3] * SPLIT_X_SCALE) : 1.0f;
+    // Activations enter the split products PRE-SCALED by XS = 16 (|activation| < 4094 fits fp16; the producers -- radial
+    // basis, SiLU -- fold the factor into arithmetic they do anyway); the products come out scaled by (weight scale of the
+    // matrix) x XS: exact powers of two, removed by the multiply that adds the bias.  The exact-fp32 chain uses XS = 1.
+    constexpr int LOG2S = SPLIT ? 4 : 0;
+    constexpr float XS = (float)(1 << LOG2S), IXS = 1.0f / XS;
+    const float inv1 = SPLIT ? 1.0f / (a.packed[L.scal + 1] * XS) : 1.0f;
+    const float inv2 = SPLIT ? 1.0f / (a.packed[L.scal + 2] * XS) : 1.0f;
+    const float inv3 = SPLIT ? 1.0f / (a.packed[L.scal + 3] * XS) : 1.0f;
     __syncthreads();
     const f4* const img_w1c = w_img;
     const f4* const img_w2 = w_img + IMG4;
@@ -412,27 +547,16 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
     const f4* const v_mu = v_x2 + FP / 4;
     const f4* const v_ga = v_mu + FP / 4;
     const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
-    // out = init + W x (and dout = dinit + W dx) through the exact-fp32 or the split-f16 chain product.  `init(t)` is read
-    // only when needed (before the fp32 chain, which accumulates onto it; after the split chain, which starts from zero and
-    // is un-scaled by an exact power of two) so that it is not live across the product.
-    auto product = [&](const f4* img, const f4 (&x)[NT], const f4 (&dx)[NT], f4 (&out)[NT], f4 (&dout)[NT], float inv,
-                       auto init, auto dinit) {
+    // out = W x, dout = W dx (raw: the caller un-scales and adds the bias in one fused multiply-add per element)
+    auto product = [&](const f4* img, const f4 (&x)[NT], const f4 (&dx)[NT], f4 (&out)[NT], f4 (&dout)[NT]) {
         if constexpr (SPLIT) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) { out[t] = zero4; dout[t] = zero4; }
-            chain_gemm_split<NT, TAN>(reinterpret_cast<const h8*>(img), x, dx, out, dout, lane);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                out[t] = out[t] * inv + init(t);
-                if (TAN) dout[t] = dout[t] * inv + dinit(t);
-            }
+            chain_gemm_split_pre<NT, TAN>(reinterpret_cast<const u4*>(img), x, dx, out, dout, lane);
         } else {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) { out[t] = init(t); dout[t] = TAN ? dinit(t) : zero4; }
+            for (int t = 0; t < NT; ++t) { out[t] = zero4; dout[t] = zero4; }
             chain_gemm<NT, TAN>(img, x, dx, out, dout, lane);
         }
     };
-    auto no_tangent = [&](int) { return zero4; };
 
     // ---- per-lane destination state
     const int j = jb * 16 + c;
@@ -445,7 +569,8 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
 #pragma unroll
     for (int t = 0; t < NT; ++t) { nm[t] = f4{0.f, 0.f, 0.f, 0.f}; dnm[t] = f4{0.f, 0.f, 0.f, 0.f}; }
     float disp0 = 0.f, disp1 = 0.f, disp2 = 0.f, dd0 = 0.f, dd1 = 0.f, dd2 = 0.f;
-    const float rc = a.r_cutoff, pi_rc = 3.14159265358979323846f / rc;
+    const float rc = a.r_cutoff, pi_rc = 3.14159265358979323846f / rc, half_rc = 0.5f / rc;
+    (void)half_rc;
     const float* const Pb = a.P + pq_b * FP;
     const float* const dPb = (TAN && a.dP != nullptr) ? a.dP + (int64_t)b * n * FP : nullptr;
     // source terms P_i (+ tangent) of the NEXT source are fetched one iteration ahead: with two waves per SIMD nothing
@@ -471,13 +596,24 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
     for (int i = wave; i < n; i += EDGE_WAVES) {
         // ---- geometry of the 16 edges (i -> j0 + c); the four q-groups compute it redundantly (a few dozen VALU)
         const float v0 = xj0 - s_pos[3 * i], v1 = xj1 - s_pos[3 * i + 1], v2 = xj2 - s_pos[3 * i + 2];
+#if TFEP_EGNN_FAST_GEOM
+        // square root, reciprocal, the switching function's sine / cosine and the attention's sigmoid on the
+        // transcendental unit (1 ulp each; v_sin_f32 / v_cos_f32 take their argument in revolutions): per-edge scalars
+        // that every lane of a column evaluates -- the IEEE division / libm forms cost ~100 instructions per 16 edges
+        const float d = __builtin_amdgcn_sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+#else
         const float d = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);              // graph.py:257
+#endif
         const bool keep = j_ok && (j != i) && (d <= rc);                 // graph.py:297 (and no self edges, :143)
         if (__ballot(keep) == 0ull) {                                    // wave-uniform: nothing survives the cutoff
             fetch_source(i + EDGE_WAVES);
             continue;
         }
+#if TFEP_EGNN_FAST_GEOM
+        const float inv_d = keep ? fast_rcp(d) : 0.0f;
+#else
         const float inv_d = keep ? 1.0f / d : 0.0f;
+#endif
         const float u0 = v0 * inv_d, u1 = v1 * inv_d, u2 = v2 * inv_d;   // normalised direction (graph.py:260)
         float ddist = 0.f, du0 = 0.f, du1 = 0.f, du2 = 0.f;
         if (TAN) {
@@ -486,66 +622,123 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
             du0 = (w0 - u0 * ddist) * inv_d; du1 = (w1 - u1 * ddist) * inv_d; du2 = (w2 - u2 * ddist) * inv_d;
         }
         float sn, cs;
+#if TFEP_EGNN_FAST_GEOM
+        {
+            const float rev = fminf(d, rc) * half_rc;                     // (pi d / rc) / (2 pi), in [0, 1/2]
+            sn = __builtin_amdgcn_sinf(rev);
+            cs = __builtin_amdgcn_cosf(rev);
+        }
+#else
         sincosf(pi_rc * d, &sn, &cs);
-        const float sw = 0.5f * cs + 0.5f;                                // radial.py:173
-        const float dsw = -0.5f * pi_rc * sn;                             // d sw / d dist
-        f4 rbf[NT], drbf[NT];
+#endif
+        const float sw = (0.5f * XS) * cs + (0.5f * XS);                  // XS x the switching function of radial.py:173
+        const float dsw = (-0.5f * XS) * pi_rc * sn;                      // XS d sw / d dist
+        f4 z[NT], dz[NT], y[NT], dy[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < NT; ++t) {                                    // y, dy <- XS rbf, XS d rbf
             const f4 mu = v_mu[4 * t + q], ga = v_ga[4 * t + q];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float dm = d - mu[r];
-                const float g = fast_exp(-ga[r] * dm * dm);               // radial.py:126-128
-                rbf[t][r] = g * sw;                                       // radial.py:291
-                if (TAN) drbf[t][r] = ddist * g * (dsw - 2.0f * ga[r] * dm * sw);
+                const float gd = ga[r] * dm;
+                const float g = __builtin_amdgcn_exp2f(gd * dm * -1.44269504088896340736f);   // radial.py:126-128
+                y[t][r] = g * sw;                                         // radial.py:291
+                if (TAN) dy[t][r] = (ddist * g) * fmaf(gd * -2.0f, sw, dsw);
             }
         }
         // ---- message MLP: z1 = P_i + Q_j + W1c rbf (egnn.py:246-251 with the first linear split by input block)
-        f4 z[NT], dz[NT];
-        product(img_w1c, rbf, drbf, z, dz, inv1,
-                [&](int t) { return Pn[t] + s_q[(4 * t + q) * 16 + c]; },
-                [&](int t) { return dPn[t] + s_dq[(4 * t + q) * 16 + c]; });
+        // (what the multiply-add after a product reads from LDS is fetched BEFORE the product: behind its scheduling
+        // barrier the round trip would be exposed, in front of it the 48 MFMAs cover it)
+        f4 cA[NT], cB[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {                                    // P_i + Q_j in the registers of P_i
+            const f4 qv = s_q[(4 * t + q) * 16 + c];
+            f4 dqv = zero4;
+            if (TAN) dqv = s_dq[(4 * t + q) * 16 + c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                Pn[t][r] += qv[r];
+                if (TAN) dPn[t][r] += dqv[r];
+            }
+        }
+        product(img_w1c, y, dy, z, dz);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                z[t][r] = fmaf(z[t][r], inv1, Pn[t][r]);
+                if (TAN) dz[t][r] = fmaf(dz[t][r], inv1, dPn[t][r]);
+            }
+        }
         fetch_source(i + EDGE_WAVES);                                    // P of the next source: lands under the rest of this one
-        silu_tile<NT, TAN>(z, dz);
-        f4 y[NT], dy[NT];
-        product(img_w2, z, dz, y, dy, inv2, [&](int t) { return v_b2[4 * t + q]; }, no_tangent);
-        silu_tile<NT, TAN>(y, dy);
+        silu_tile_scaled<NT, TAN, LOG2S>(z, dz);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cA[t] = v_b2[4 * t + q];
+        product(img_w2, z, dz, y, dy);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cB[t] = v_wa[4 * t + q];                 // (lands under the SiLU that comes first)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                y[t][r] = fmaf(y[t][r], inv2, cA[t][r]);
+                if (TAN) dy[t][r] *= inv2;
+            }
+        }
+        silu_tile_scaled<NT, TAN, LOG2S>(y, dy);                          // y = XS m2, dy = XS d m2
         // ---- attention (egnn.py:254-257, 323-325): m = m2 * sigmoid(wa . m2 + ba)
         float s = 0.f, ds = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const f4 wa = v_wa[4 * t + q];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s += wa[r] * y[t][r];
-                if (TAN) ds += wa[r] * dy[t][r];
+                s = fmaf(cB[t][r], y[t][r], s);
+                if (TAN) ds = fmaf(cB[t][r], dy[t][r], ds);
             }
         }
-        s = sum_over_q(s) + att_b;
+        s = sum_over_q(s) * IXS + att_b;
+#if TFEP_EGNN_FAST_GEOM
+        const float att = keep ? fast_rcp(1.0f + fast_exp(-s)) : 0.0f;    // pruned edges carry no message
+#else
         const float att = keep ? 1.0f / (1.0f + expf(-s)) : 0.0f;         // pruned edges carry no message
+#endif
         float datt = 0.f;
-        if (TAN) datt = att * (1.0f - att) * sum_over_q(ds);
+        if (TAN) datt = att * (1.0f - att) * (sum_over_q(ds) * IXS);
+        {
+            const float att_s = att * IXS, datt_s = datt * IXS;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
+            for (int t = 0; t < NT; ++t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (TAN) { dy[t][r] = dy[t][r] * att + y[t][r] * datt; dnm[t][r] += dy[t][r]; }
-                y[t][r] *= att;
-                nm[t][r] += y[t][r];                                      // segment sum over the sources (egnn.py:331)
+                for (int r = 0; r < 4; ++r) {                             // segment sum over the sources (egnn.py:331)
+                    nm[t][r] = fmaf(y[t][r], att_s, nm[t][r]);
+                    if (TAN) dnm[t][r] = fmaf(dy[t][r], att_s, fmaf(y[t][r], datt_s, dnm[t][r]));
+                }
             }
         }
-        // ---- displacement magnitude (egnn.py:260-267, 347-361): tanh(x2 . SiLU(X1 m + d1))
-        product(img_x1, y, dy, z, dz, inv3, [&](int t) { return v_d1[4 * t + q]; }, no_tangent);
-        silu_tile<NT, TAN>(z, dz);
+        // ---- displacement magnitude (egnn.py:260-267, 347-361): tanh(x2 . SiLU(X1 m + d1)).  X1 (att m2) = att (X1 m2):
+        // the product runs on m2 as it stands and the attention weight rides on the un-scaling multiply
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cA[t] = v_d1[4 * t + q];
+        product(img_x1, y, dy, z, dz);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cB[t] = v_x2[4 * t + q];
         s = 0.f; ds = 0.f;
+        {
+            const float ia = inv3 * att, ida = inv3 * datt;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const f4 x2 = v_x2[4 * t + q];
+            for (int t = 0; t < NT; ++t) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s += x2[r] * z[t][r];
-                if (TAN) ds += x2[r] * dz[t][r];
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaf(z[t][r], ia, cA[t][r]);
+                    const float e = __builtin_amdgcn_exp2f(v * -1.44269504088896340736f);
+                    const float sig = fast_rcp(1.0f + e);
+                    const float sv = v * sig;
+                    s = fmaf(cB[t][r], sv, s);
+                    if (TAN) {
+                        const float dv3 = fmaf(dz[t][r], ia, z[t][r] * ida);
+                        ds = fmaf(cB[t][r] * fmaf(sv, 1.0f - sig, sig), dv3, ds);
+                    }
+                }
             }
         }
         const float mag = tanhf(sum_over_q(s));

@@ -18,6 +18,12 @@ class GraphedFlow:
         self.inverse = inverse
         device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.static_in = torch.zeros(batch_size, n_features, dtype=torch.float32, device=device)
+        if sample_input is not None:
+            self.static_in.copy_(sample_input)
+        # what the warm-up steps must not leave behind: parameter values and optimiser state
+        saved_params = [p.detach().clone() for p in self.params]
+        saved_state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in optimizer.state.get(p, {}).items()}
+                       for p in self.params}
         fn = flow.inverse if inverse else flow.forward
         # Warm-up off the default stream: builds the execution plans (host-side index work, device->host
         # reads of masks) and sets kernel attributes -- none of which may happen during capture.
@@ -72,9 +78,16 @@ class GraphedTrainingStep:
     capturable ops (no ``.item()`` / host round trips); the optimiser must be capturable (SGD; Adam with
     ``capturable=True``).  No tensor computed from the parameters under grad mode may be alive when the step is constructed
     (checked: RuntimeError).  Activations are not kept across the forward inside a capture (the layer recomputes them), the
-    weights are packed on every replay."""
+    weights are packed on every replay.
 
-    def __init__(self, flow, loss_fn, optimizer, batch_size, n_features, device=None, warmup=3):
+    Construction leaves the model and the optimiser as it found them.  The capture needs ``warmup`` real steps first
+    (plans, kernel attributes, the optimiser's lazily created state) on ``sample_input`` (default: zeros); the parameters
+    and every optimiser state tensor that existed before are then restored IN PLACE (the graph holds their addresses), and
+    state the warm-up created (momentum buffers, Adam moments and step counters) is zeroed in place -- the value a fresh
+    optimiser starts from.  The first replay is therefore the first step of training.  ``.grad`` of the parameters is
+    owned by the graph afterwards (overwritten by every replay)."""
+
+    def __init__(self, flow, loss_fn, optimizer, batch_size, n_features, device=None, warmup=3, sample_input=None):
         self.flow, self.loss_fn, self.optimizer = flow, loss_fn, optimizer
         self.params = [p for group in optimizer.param_groups for p in group['params'] if p.requires_grad]
         if _held_by_a_live_graph(self.params):
@@ -86,6 +99,12 @@ class GraphedTrainingStep:
                                'from the flow outside torch.no_grad()?): delete it before capturing the step')
         device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.static_in = torch.zeros(batch_size, n_features, dtype=torch.float32, device=device)
+        if sample_input is not None:
+            self.static_in.copy_(sample_input)
+        # what the warm-up steps must not leave behind: parameter values and optimiser state
+        saved_params = [p.detach().clone() for p in self.params]
+        saved_state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in optimizer.state.get(p, {}).items()}
+                       for p in self.params}
         # Warm-up off the default stream (plans, kernel attributes, optimiser state), as torch's whole-network capture asks
         from .nn.flows import _backward
         side = torch.cuda.Stream(device)
@@ -103,6 +122,22 @@ class GraphedTrainingStep:
                 self.static_loss = self._step(self.static_in)
         finally:
             _backward.FORCE_RECOMPUTE = was
+            # (also on failure: a warm-up step that produced NaN must not stay in the weights)
+            with torch.no_grad():
+                for p, v in zip(self.params, saved_params):
+                    p.copy_(v)
+                for p in self.params:
+                    before = saved_state[id(p)]
+                    for k, v in optimizer.state.get(p, {}).items():
+                        if torch.is_tensor(v):
+                            if k in before:
+                                v.copy_(before[k])
+                            else:
+                                v.zero_()
+                        elif k in before:
+                            optimizer.state[p][k] = before[k]
+        if sample_input is None:
+            self.static_in.zero_()
 
     def _step(self, x):
         y, ldj = self.flow(x)

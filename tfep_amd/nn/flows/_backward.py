@@ -178,6 +178,11 @@ class MAFLayerFunction(torch.autograd.Function):
         del kept
         with torch.no_grad():
             gx, gparams = layer_backward(layer, x, gy, gldj, saved=saved)
+        # parameters this backward does not hand a gradient to (torch.autograd.grad(loss, [x]), a subset of the
+        # parameters): their hooks will not run, so their "already masked" tags must not outlive this call
+        for prm, needed in zip(trainable_tensors(layer), ctx.needs_input_grad[2:]):
+            if not needed:
+                prm.__dict__.pop(GRAD_IS_MASKED, None)
         return (None, gx, *gparams)
 
 
@@ -647,9 +652,11 @@ def layer_backward(layer, x, gy, gldj, saved=None):
                           _lib.ptr(row_of_out), _lib.ptr(col_of_in), _lib.ptr(gv), _lib.ptr(gg), stream)
             grads += [gg, gv]
             # (already masked by the kernel: the parameters' gradient hooks of masked_weight_norm need not do it again)
-            for prm in (lin.weight_g, lin.weight_v):
+            # The tag names THIS gradient (its storage address): a stale tag -- a backward that did not hand the
+            # parameter its gradient, an exception between layers -- cannot wave a later, unrelated gradient through.
+            for prm, grad in ((lin.weight_g, gg), (lin.weight_v, gv)):
                 if prm.requires_grad:
-                    prm.__dict__[GRAD_IS_MASKED] = True
+                    prm.__dict__[GRAD_IS_MASKED] = grad.data_ptr()
         else:
             gw = torch.empty_like(lin._parameters['weight'])
             if prefix:

@@ -22,14 +22,18 @@ ADAPTIVE = ('dopri5', 'bosh3', 'fehlberg2', 'adaptive_heun')
 # Embedded explicit Runge-Kutta pairs as published: (order of the propagated solution, nodes c, stage coefficients a,
 # weights b of the propagated solution, error weights e = b - b_embedded, first-same-as-last).
 _TABLEAUS = {
-    # Dormand & Prince 1980, 5(4), 7 stages, FSAL
+    # Dormand & Prince 1980, 5(4), 7 stages, FSAL.  The error weights are Shampine's variant of the embedded pair
+    # (b - b*, b* = (1951/21600, 0, 22642/50085, 451/720, -12231/42400, 649/6300, 1/60)): the one torchdiffeq's `dopri5`
+    # tabulates as `c_error` (restated from its published tableau; torchdiffeq itself is absent, so the accepted /
+    # rejected step sequence remains unverified against it -- "ODE-solve parity unpinned").
     'dopri5': (5, (0.0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1.0, 1.0),
                ((), (1 / 5,), (3 / 40, 9 / 40), (44 / 45, -56 / 15, 32 / 9),
                 (19372 / 6561, -25360 / 2187, 64448 / 6561, -212 / 729),
                 (9017 / 3168, -355 / 33, 46732 / 5247, 49 / 176, -5103 / 18656),
                 (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84)),
                (35 / 384, 0.0, 500 / 1113, 125 / 192, -2187 / 6784, 11 / 84, 0.0),
-               (71 / 57600, 0.0, -71 / 16695, 71 / 1920, -17253 / 339200, 22 / 525, -1 / 40), True),
+               (35 / 384 - 1951 / 21600, 0.0, 500 / 1113 - 22642 / 50085, 125 / 192 - 451 / 720,
+                -2187 / 6784 + 12231 / 42400, 11 / 84 - 649 / 6300, -1 / 60), True),
     # Bogacki & Shampine 1989, 3(2), 4 stages, FSAL
     'bosh3': (3, (0.0, 1 / 2, 3 / 4, 1.0),
               ((), (1 / 2,), (0.0, 3 / 4), (2 / 9, 1 / 3, 4 / 9)),
@@ -87,8 +91,13 @@ def _scaled(err, y0, y1, rtol, atol):
 def odeint(f, y0, t0, t1, method='dopri5', options=None, rtol=1e-4, atol=1e-4, axpy=None, stats=None):
     """Integrate ``y' = f(t, y)`` from ``t0`` to ``t1`` (either order); returns the state at ``t1``.
 
-    ``options``: ``step_size`` (fixed grid), ``first_step`` / ``max_num_steps`` (dopri5).  ``stats``: a dict that
-    receives ``n_steps``, ``n_rejected`` and ``n_evaluations``."""
+    ``options``: ``step_size`` (fixed grid), ``first_step`` / ``max_num_steps`` (adaptive pairs; ``max_num_steps``
+    counts accepted + rejected steps and defaults to 100 000 -- every one costs a full set of dynamics evaluations).
+    ``stats``: a dict that receives ``n_steps``, ``n_rejected`` and ``n_evaluations``.
+
+    The adaptive pairs stop loudly instead of spinning: a non-finite state or error estimate (a NaN sample in the batch
+    poisons the whole-state RMS norm) and a step size that underflows (``t + dt == t``: a finite-time blow-up, a stiff
+    problem) both raise ``RuntimeError``, as torchdiffeq's assertions do."""
     options = dict(options or {})
     y = tuple(y0)
     sign = 1.0 if t1 >= t0 else -1.0
@@ -115,7 +124,7 @@ def odeint(f, y0, t0, t1, method='dopri5', options=None, rtol=1e-4, atol=1e-4, a
     elif method in ADAPTIVE:
         order, C, A, Bw, E, fsal = _TABLEAUS[method]
         n_stages = len(C)
-        max_steps = int(options.pop('max_num_steps', 2 ** 31 - 1))
+        max_steps = int(options.pop('max_num_steps', 100_000))
         t = t0
         k1 = fe(t, y)
         h = options.pop('first_step', None)
@@ -133,6 +142,9 @@ def odeint(f, y0, t0, t1, method='dopri5', options=None, rtol=1e-4, atol=1e-4, a
                 raise RuntimeError(f'{method}: max_num_steps exceeded')
             h = min(h, abs(t1 - t))
             dt = sign * h
+            if t + dt == t:
+                raise RuntimeError(f'{method}: underflow in dt ({dt!r} at t = {t!r}): the step size control cannot meet '
+                                   f'rtol = {rtol}, atol = {atol} (a finite-time blow-up or a stiff problem)')
             ks = [k1]
             for s_ in range(1, n_stages):
                 ks.append(fe(t + C[s_] * dt, _combine(axpy, y, ks, A[s_], dt)))
@@ -140,6 +152,10 @@ def odeint(f, y0, t0, t1, method='dopri5', options=None, rtol=1e-4, atol=1e-4, a
             y_new = _combine(axpy, y, ks, Bw, dt)
             err = [sum(dt * e * k[c] for e, k in zip(E, ks) if e != 0.0) for c in range(len(y))]
             ratio = _rms(_scaled(err, y, y_new, rtol, atol))
+            if not math.isfinite(ratio):
+                raise RuntimeError(f'{method}: non-finite state or error estimate at t = {t!r} (step {dt!r}); the error '
+                                   'norm runs over the whole batch, so a single NaN / inf sample stops the integration '
+                                   '-- remove such samples before the flow (the loss has ignore_nan for its own inputs)')
             if ratio <= 1.0:
                 t, y = t + dt, y_new
                 k1 = ks[-1] if fsal else fe(t, y)

@@ -178,7 +178,8 @@ class MaskedLinear(torch.nn.Linear):
 # WEIGHT NORMALIZATION
 # =============================================================================
 
-#: attribute set on a parameter by a backward that returns its gradient already masked (consumed by the hooks below)
+#: attribute set on a parameter by a backward that returns its gradient already masked: the ``data_ptr()`` of that
+#: gradient (consumed by the hooks below, which pass exactly that tensor through and mask anything else)
 GRAD_IS_MASKED = '_tfep_grad_is_masked'
 
 
@@ -207,7 +208,7 @@ def masked_weight_norm(module, name='weight', dim=0):
         # and says so on the parameter (GRAD_IS_MASKED): the hook then passes the gradient through instead of re-masking
         # 4.5 GB per cfg2 output layer and step.
         def _g_hook(grad, module=module, g=g):
-            if g.__dict__.pop(GRAD_IS_MASKED, False):
+            if g.__dict__.pop(GRAD_IS_MASKED, None) == grad.data_ptr():
                 return grad
             m = module.mask
             key = (m._version, m.data_ptr())
@@ -217,7 +218,7 @@ def masked_weight_norm(module, name='weight', dim=0):
             return grad * cached[1].to(dtype=grad.dtype, device=grad.device)
 
         def _v_hook(grad, module=module, v=v):
-            if v.__dict__.pop(GRAD_IS_MASKED, False):
+            if v.__dict__.pop(GRAD_IS_MASKED, None) == grad.data_ptr():
                 return grad
             return grad.masked_fill(module.mask.to(grad.device) == 0, 0.0)
 
