@@ -301,6 +301,13 @@ int tfep_split_rows(const float* src, int64_t ld_src, int64_t rows, int64_t cols
  * HIP graph).  mode 0: out[row] = max_k |src[row, k]| (rows floats);  mode 1: out[0] = max_row sum_k |src[row, k]|. */
 int tfep_abs_reduce(const float* src, int64_t ld_src, int64_t rows, int64_t cols, int mode, float* out, void* stream);
 
+/* Data-aware guard of the split-f16 GEMMs (they stand in for the fp32 products of reference tfep/nn/masked.py:265-277,
+ * 279-302): count[0] += number of rows of src (rows, >= cols) that hold a non-zero element below 2^-bits of the row's
+ * largest magnitude, or a non-finite one.  With one power-of-two scale per row such elements are carried with fewer than 22
+ * significant bits (bits = 19 for the fp16 hi + lo format); the host routes a flagged batch to the exact-fp32 kernels.
+ * count is NOT cleared (several tensors may add to one counter); plain kernel, no workspace. */
+int tfep_range_flag(const float* src, int64_t ld_src, int64_t rows, int64_t cols, int bits, int32_t* count, void* stream);
+
 /* Columns [col0, col0 + cols) (col0 % 8 == 0; whole groups of 8 are converted) of fp32 rows into the same columns of split
  * rows, with the per-row scale given by the caller (inv_scale[row], a power of two, e.g. from a bound on the row): for
  * operands that are filled incrementally -- the hidden-activation panels of the blocked inverse

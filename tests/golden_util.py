@@ -407,3 +407,20 @@ def continuous_state(npz, name, dtype=None):
             t = torch.from_numpy(np.ascontiguousarray(npz[k]))
             out[k[len(f'{name}/sd/'):]] = t.to(dtype) if t.is_floating_point() else t
     return out
+
+
+def wide_parameters(module, seed):
+    """The parameters of the wide gradient golden (tests/golden/grads_wide.npz): a function of (parameter order, shape,
+    seed) only -- the same construction as ``tools/gen_golden.py::wide_parameters`` on the reference's modules (two layers
+    of 13.9 M weights are not shipped as a fixture)."""
+    import torch
+    with torch.no_grad():
+        for i, (n, p) in enumerate(module.named_parameters()):
+            g = torch.Generator().manual_seed(seed + i)
+            if n.endswith('weight_v') or n.endswith('.weight'):
+                v = (torch.rand(p.shape, generator=g) * 2 - 1) / p.shape[1] ** 0.5
+            elif n.endswith('weight_g'):
+                v = torch.rand(p.shape, generator=g) + 0.5
+            else:
+                v = (torch.rand(p.shape, generator=g) * 2 - 1) * 0.05
+            p.copy_(v.to(device=p.device, dtype=p.dtype))

@@ -72,6 +72,113 @@ def test_training_step_gradients_match_reference_autograd(name, split):
             assert torch.all(wv.grad[lin.mask == 0] == 0)
 
 
+@pytest.mark.parametrize('name', ['affine', 'spline', 'circular', 'identslopes', 'moebius', 'mixed', 'learnlow', 'learnup', 'learnboth'])
+def test_inverse_is_differentiable_like_the_reference(name):
+    """``flow.inverse`` under autograd (reference autoregressive.py:179-229 is plain differentiable torch): values, the
+    gradient of y and of EVERY parameter against the reference's float64 autograd through its own inverse
+    (tests/golden/inv_grads.npz: loss = KL(u(x), log_det_J_inv) with a quadratic u).  The blocked inverse (no graph) must
+    return the same numbers as the differentiable route."""
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    g = gu.load('inv_grads.npz')
+    flow = gu.build_flow(name, g, configs=gu.grad_flow_configs())
+    y = torch.from_numpy(g[f'{name}/y']).cuda().requires_grad_(True)
+    c, d = torch.from_numpy(g[f'{name}/c']).cuda(), torch.from_numpy(g[f'{name}/d']).cuda()
+    x, ldj = flow.inverse(y)
+    assert x.requires_grad and ldj.requires_grad
+    assert rel(x.detach().cpu(), g[f'{name}/x_f64']) < 2e-5
+    np.testing.assert_allclose(ldj.detach().cpu().numpy(), g[f'{name}/ldj_f64'], rtol=2e-5, atol=2e-5)
+    with torch.no_grad():
+        xb, lb = flow.inverse(y.detach())
+    assert torch.equal(xb, x.detach()) and torch.equal(lb, ldj.detach())          # values: the fast path either way
+    loss = BoltzmannKLDivLoss()((c * x ** 2 + d * x).sum(dim=1), ldj)
+    np.testing.assert_allclose(float(loss.detach()), float(g[f'{name}/loss_f64']), rtol=2e-5)
+    loss.backward()
+    assert rel(y.grad.cpu(), g[f'{name}/gy_f64']) < 1e-4, rel(y.grad.cpu(), g[f'{name}/gy_f64'])
+    for k, p in flow.named_parameters():
+        ref = g[f'{name}/grad/{k}']
+        assert p.grad is not None and tuple(p.grad.shape) == ref.shape, k
+        scale = max(np.abs(ref).max(), 1e-8)
+        err = np.abs(p.grad.cpu().numpy().astype(np.float64) - ref).max() / scale
+        assert err < 3e-4, (k, err)
+
+
+def _wide_flow():
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF, SequentialFlow
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    D = 300
+    flow = SequentialFlow(*[MAF(generate_degrees(D, o), transformer=NeuralSplineTransformer(torch.full((D,), -5.0), torch.full((D,), 5.0), 8),
+                                initialize_identity=False) for o in ('ascending', 'descending')])
+    gu.wide_parameters(flow, 400)
+    return flow.cuda()
+
+
+@pytest.mark.parametrize('arithmetic', ['exact', 'split', 'default'])
+def test_wide_layer_gradients_and_adamw_step_against_reference(arithmetic):
+    """a 2-layer RQ-8 MAF at D = 300 with the default hidden width (1498; 13.9 M weights per layer) -- the
+    size at which the backward's k-ranges, prefix packs and split transposes are multi-tile -- against the reference's
+    float64 autograd (tests/golden/grads_wide.npz: whole small tensors, 4096 sampled entries of the big ones, the
+    reference's own float32 results beside them).  Per tensor: relative L2 <= max(1e-5, 4 x the reference's float32
+    noise), and COMPONENT-WISE every entry above 1e-4 of the tensor's maximum within 2e-3 relative (the reference's float32
+    entries are held to the same bound: it is what fp32 accumulation over 256 samples gives); then one AdamW step from the
+    same state: the parameter deltas (Adam normalises every entry by its own magnitude) at the same entries."""
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    g = gu.load('grads_wide.npz')
+    flow = _wide_flow()
+    for layer in flow:
+        layer.split_gemm = {'exact': False, 'split': True, 'default': None}[arithmetic]
+    x = torch.from_numpy(g['x']).cuda().requires_grad_(True)
+    c, d = torch.from_numpy(g['c']).cuda(), torch.from_numpy(g['d']).cuda()
+    before = {k: p.detach().clone() for k, p in flow.named_parameters()}
+    y, ldj = flow(x)
+    loss = BoltzmannKLDivLoss()((c * y ** 2 + d * y).sum(dim=1), ldj)
+    np.testing.assert_allclose(float(loss.detach()), float(g['loss_f64']), rtol=1e-5)
+    loss.backward()
+    assert rel(x.grad.cpu(), g['gx_f64']) < max(1e-5, 4 * rel(g['gx_f32'], g['gx_f64']))
+    report = {}
+    for k, p in flow.named_parameters():
+        ours = p.grad.detach().double().cpu().numpy()
+        if f'full/{k}' in g:
+            ref, ref32, ours_s = g[f'full/{k}'], g[f'full32/{k}'], ours
+        else:
+            idx = g[f'idx/{k}']
+            ref, ref32, ours_s = g[f'val/{k}'], g[f'val32/{k}'], ours.reshape(-1)[idx]
+            # the whole tensor's norm against the reference's (the samples cannot see a wrong tile elsewhere)
+            assert abs(np.linalg.norm(ours) / float(g[f'norm/{k}']) - 1.0) < 1e-5, k
+        noise = float(g[f'noise/{k}'])
+        r = np.linalg.norm(ours_s - ref) / np.linalg.norm(ref)
+        mx = float(g[f'max/{k}'])
+        row = [r, noise]
+        for thr in (1e-2, 1e-4):                       # entries above 1e-2 / 1e-4 of the tensor's largest gradient
+            big = np.abs(ref) > thr * mx
+            row += [float((np.abs(ours_s - ref)[big] / np.abs(ref)[big]).max()), float((np.abs(ref32 - ref)[big] / np.abs(ref)[big]).max())]
+        report[k] = row
+    for k, (r, noise, cw2, cw2_32, cw4, cw4_32) in report.items():
+        print(f'{arithmetic:8s} {k:38s} rel L2 {r:.2e} (ref fp32 {noise:.2e})  component-wise > 1e-2 max: {cw2:.2e} (ref fp32 {cw2_32:.2e})'
+              f'  > 1e-4 max: {cw4:.2e} (ref fp32 {cw4_32:.2e})')
+    for k, (r, noise, cw2, cw2_32, cw4, cw4_32) in report.items():
+        assert r <= max(1e-5, 4 * noise), (k, r, noise)
+        # component-wise: an entry is a sum over 256 samples with cancellation, so its error scales with sum |g x|, not with
+        # the entry; the reference's own float32 run is held to the same bounds (its worst entries are beside ours)
+        assert cw2 <= max(5e-4, 8 * cw2_32), (k, cw2, cw2_32)
+        assert cw4 <= max(2e-2, 8 * cw4_32), (k, cw4, cw4_32)
+    # one AdamW step (lr 1e-3, weight decay 0.01: the golden's) from the same state
+    opt = torch.optim.AdamW(flow.parameters(), lr=1e-3, weight_decay=0.01)
+    opt.step()
+    for k, p in flow.named_parameters():
+        delta = (p.detach() - before[k]).double().cpu().numpy().reshape(-1)
+        if f'full/{k}' in g:
+            ref_d, gref = g[f'adamw/{k}'].reshape(-1), g[f'full/{k}'].reshape(-1)
+        else:
+            delta, ref_d, gref = delta[g[f'idx/{k}']], g[f'adamw/{k}'], g[f'val/{k}']
+        # where the gradient is far above Adam's epsilon the step is -lr (sign(g) + wd p) to rounding: compare per entry
+        # (masked entries have exactly zero gradient on both sides: their step is the weight decay alone)
+        clear = (np.abs(gref) > 1e-6) | (gref == 0)
+        assert clear.mean() > 0.9, k
+        err = np.abs(delta - ref_d)[clear].max()
+        assert err < 2e-3 * 1e-3, (k, err)          # 0.2 % of the step length lr
+
+
 def test_optimizer_step_runs_and_lowers_the_loss():
     """A few AdamW steps on a fixed batch (the loop of TFEPMapBase.training_step / configure_optimizers)."""
     from tfep_amd.loss import BoltzmannKLDivLoss

@@ -269,8 +269,9 @@ def test_flow_api_schema_and_errors():
     x = torch.randn(3, 6, device='cuda')
     y, tr, reg = flow(x)                                      # identity initialisation: nothing moves
     assert torch.equal(y.detach(), x) and float(tr.abs().max()) == 0.0 and float(reg.abs().max()) == 0.0
-    with pytest.raises(NotImplementedError):
-        y.sum().backward()                                   # loud, not silent
+    (y.sum() + tr.sum() + reg.sum()).backward()              # trainable: under grad mode the flow takes the autograd route
+    grads = [p.grad for p in flow.parameters() if p.grad is not None]
+    assert grads and all(torch.isfinite(gr).all() for gr in grads)
     with pytest.raises(ValueError):
         ContinuousFlow(dyn, solver='adams')(x.detach())
     with pytest.raises(_lib_error()):
@@ -450,3 +451,86 @@ def test_empty_batch_through_the_dynamics_and_the_flow():
             out = flow(x)
             assert len(out) == (3 if reg else 2) and out[0].shape == (0, 12) and all(o.shape == (0,) for o in out[1:])
             assert flow.inverse(out[0])[0].shape == (0, 12)
+
+
+# ------------------------------------------------------------------ training: the differentiable route
+
+@pytest.mark.parametrize('name', ['tiny', 'cutoff', 'pair', 'default'])
+def test_torch_route_equals_the_kernels_and_the_reference(name):
+    """``EGNNDynamics.torch_forward`` (what runs under grad mode) against the kernels and the reference's float64 velocity."""
+    g = gu.load('continuous.npz')
+    dyn, cfg = build_dynamics(name, g, split=False)
+    x, t = dev(g[f'{name}/x']), float(g[f'{name}/t'][0])
+    with torch.no_grad():
+        vel_k = dyn(torch.tensor(t), x)
+    xg = x.clone().requires_grad_(True)
+    vel_t = dyn(torch.tensor(t), xg)
+    assert vel_t.requires_grad
+    assert rel_l2(vel_t, g[f'{name}/vel_f64']) <= 2e-6
+    assert rel_l2(vel_t, vel_k.cpu().numpy().astype(np.float64)) <= 2e-6
+    # and in float64 (the route is plain torch): the golden to round-off
+    dyn64 = dyn.double()
+    vel64 = dyn64(torch.tensor(t, dtype=torch.float64), x.double().requires_grad_(True))
+    # (the fixed Gaussian means are float32-rounded buffers here; the reference built them in float64: 1e-8 relative)
+    assert rel_l2(vel64, g[f'{name}/vel_f64']) <= 2e-7
+
+
+@pytest.mark.parametrize('estimator,n_hut', [('hutchinson', 2), ('exact', 1)])
+@pytest.mark.parametrize('name', ['tiny', 'cutoff', 'pair'])
+def test_integrand_gradients_match_reference_double_backward(name, estimator, n_hut):
+    """What a training step differentiates at every solver stage: loss = <a, vel> + <b, trace> + <c, reg> of the ODE
+    function's integrands (continuous.py:231-278 with ``create_graph``), gradients of x and of every parameter against the
+    reference's float64 autograd (tests/golden/continuous_grads.npz) -- second derivatives of the dynamics.  Float32 on the
+    device and float64 on the device."""
+    from tfep_amd.nn.flows import ContinuousFlow
+    g, gg = gu.load('continuous.npz'), gu.load('continuous_grads.npz')
+    for dt, tol in ((torch.float32, 5e-4), (torch.float64, 1e-6)):        # (float64: float32-rounded fixed buffers, see above)
+        dyn, cfg = build_dynamics(name, g, split=False)
+        dyn = dyn.to(dt)
+        flow = ContinuousFlow(dyn, trace_estimator=estimator, n_hutchinson_samples=n_hut, regularization=True, requires_backward=True)
+        f = flow.ode_func
+        x = dev(g[f'{name}/x']).to(dt).requires_grad_(True)
+        B = x.shape[0]
+        f._eps = dev(g[f'{name}/eps'][:n_hut]).to(dt)
+        a, b, c = (dev(gg[f'{name}/{k}']).to(dt) for k in 'abc')
+        vel, trace, reg = f(torch.tensor(float(g[f'{name}/t'][0]), dtype=dt), (x, x.new_zeros(B), x.new_zeros(B)))
+        loss = (a * vel).sum() + (b * trace).sum() + (c * reg).sum()
+        key = f'{name}/{estimator}'
+        np.testing.assert_allclose(float(loss.detach()), float(gg[f'{key}/loss']), rtol=max(tol, 2e-5), atol=1e-5)
+        loss.backward()
+        assert rel_l2(x.grad, gg[f'{key}/gx']) <= tol
+        for k, p in dyn.named_parameters():
+            ref = gg[f'{key}/grad/{k}']
+            got = np.zeros_like(ref) if p.grad is None else p.grad.detach().cpu().numpy().astype(np.float64)
+            scale = max(np.abs(ref).max(), 1e-12)
+            assert np.abs(got - ref).max() / scale <= 4 * tol, (k, np.abs(got - ref).max() / scale)
+
+
+def test_continuous_flow_trains():
+    """A few optimiser steps of a ContinuousFlow over the EGNN dynamics (fixed-grid rk4, Hutchinson trace with fixed
+    noise, the reference's regulariser in the loss): gradients reach every parameter, the loss goes down, and the
+    kernels (``torch.no_grad()``) evaluate the trained flow to the same numbers as the route that trained it."""
+    from tfep_amd.nn.flows import ContinuousFlow
+    g = gu.load('continuous.npz')
+    dyn, cfg = build_dynamics('tiny', g, split=False)
+    x = dev(g['tiny/x'])
+    flow = ContinuousFlow(dyn, solver='rk4', solver_options={'step_size': 0.5}, n_hutchinson_samples=2, regularization=True)
+    flow.ode_func.fixed_noise = dev(g['tiny/eps'][:2])
+    opt = torch.optim.Adam(flow.parameters(), lr=2e-3)
+    target = torch.roll(x, 3, dims=1).detach()
+    losses = []
+    for _ in range(6):
+        opt.zero_grad()
+        y, tr, reg = flow(x)
+        loss = ((y - target) ** 2).sum(dim=1).mean() - tr.mean() + 0.01 * reg.mean()
+        loss.backward()
+        # (the node-feature update of the LAST layer does not reach the velocity: no gradient there, as in the reference)
+        assert sum(p.grad is not None for p in flow.parameters()) >= len(list(flow.parameters())) - 4
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0]
+    y_t, tr_t, reg_t = [o.detach() for o in flow(x)]
+    with torch.no_grad():
+        y_k, tr_k, reg_k = flow(x)
+    assert torch.allclose(y_k, y_t, rtol=1e-4, atol=1e-5) and torch.allclose(tr_k, tr_t, rtol=1e-3, atol=1e-4)
+    assert torch.allclose(reg_k, reg_t, rtol=1e-3, atol=1e-4)

@@ -274,7 +274,8 @@ def test_graph_replay_of_the_blocked_inverse_equals_the_eager_inverse(split, loo
             layer.inverse_lookahead, layer.inverse_rows_per_wave = True, 64
     x = torch.randn(B, D, device='cuda') * 1.3
     y, _ = flow(x)                                   # (grad mode on: like a training script that then samples)
-    xe, le = flow.inverse(y)
+    xe, le = flow.inverse(y)                         # (values from the blocked path; only a backward() would pay more)
+    xe, le = xe.detach(), le.detach()
     with torch.no_grad():
         for layer in flow:
             assert layer._blocked_plan(y.device)['fused'] is not None
@@ -327,19 +328,27 @@ def test_checkpoint_from_another_degree_order_loads_into_consistent_plans(transf
         assert torch.allclose(xa, x, atol=2e-4)
 
 
-def test_inverse_under_autograd_fails_loudly_at_backward():
+def test_inverse_under_autograd_is_differentiable_and_agrees_with_the_blocked_inverse():
+    """Under grad mode ``inverse`` returns the blocked substitution's values on a node whose backward re-runs the
+    differentiable route (the reference's pass per degree, flows/_backward.py); the gradient passes a finite-difference check along a random
+    direction of y (parity against the reference's autograd: tests/test_gpu_backward.py::test_inverse_is_differentiable...)."""
     from tfep_amd.nn.conditioners import generate_degrees
     from tfep_amd.nn.flows import MAF
     torch.manual_seed(0)
     maf = MAF(generate_degrees(6, 'ascending'), initialize_identity=False).cuda()
-    y = torch.randn(9, 6, device='cuda')
-    x, l = maf.inverse(y)                                 # values are computed ...
+    y = torch.randn(9, 6, device='cuda', requires_grad=True)
+    x, l = maf.inverse(y)
     assert x.requires_grad and torch.isfinite(x).all()
-    with pytest.raises(NotImplementedError):
-        (x.sum() + l.sum()).backward()                    # ... differentiating them raises
+    w = torch.randn(9, 6, device='cuda')
+    (gy,) = torch.autograd.grad((w * x).sum() + l.sum(), y)
     with torch.no_grad():
-        x2, _ = maf.inverse(y)
-    assert not x2.requires_grad and torch.equal(x2, x.detach())
+        x2, l2 = maf.inverse(y.detach())
+        assert not x2.requires_grad and torch.equal(x2, x.detach()) and torch.equal(l2, l.detach())
+        v = torch.randn(9, 6, device='cuda')
+        h = 1e-2
+        f = lambda yy: float(((w * maf.inverse(yy)[0]).double().sum() + maf.inverse(yy)[1].double().sum()))
+        fd = (f(y.detach() + h * v) - f(y.detach() - h * v)) / (2 * h)
+    assert abs(fd - float((gy * v).double().sum())) < 2e-3 * max(1.0, abs(fd))
 
 
 @pytest.mark.parametrize('order', ['ascending', 'descending', 'random'])
@@ -589,3 +598,48 @@ def test_graphed_training_step_with_adamw():
         bw._SAVE_BYTES = save
     for (n, p), q in zip(flow.named_parameters(), twin.parameters()):
         assert torch.allclose(p, q, rtol=1e-5, atol=1e-7), n
+
+
+def test_cached_packed_weights_notice_updates_through_data():
+    """``MADE.cache_packed_weights``: served from the cache while nothing changed (bit-identical), re-packed after an
+    in-place update -- one that bumps ``Tensor._version`` (``p.mul_`` under no_grad, what optimisers do) and one that does
+    not (a write through ``p.data``, which the version counter cannot see: the strided checksum does)."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    torch.manual_seed(4)
+    D = 40
+    layer = MAF(generate_degrees(D, 'ascending'), transformer=NeuralSplineTransformer(torch.full((D,), -4.0), torch.full((D,), 4.0), 8),
+                initialize_identity=False).cuda()
+    x = torch.randn(300, D, device='cuda').clamp_(-3.9, 3.9)
+    made = layer._conditioner
+
+    def fresh():
+        made.cache_packed_weights = False
+        made.invalidate_plan()
+        with torch.no_grad():
+            out = layer(x)
+        made.cache_packed_weights = True
+        return out
+    for split in (False, True):
+        layer.split_gemm = split
+        y0, l0 = fresh()
+        with torch.no_grad():
+            y1, l1 = layer(x)                       # fills the cache
+            y2, l2 = layer(x)                       # served from it
+        assert torch.equal(y0, y1) and torch.equal(y1, y2) and torch.equal(l1, l2)
+        for how in ('versioned', 'data'):
+            with torch.no_grad():
+                for p in made.parameters():
+                    if how == 'versioned':
+                        p.mul_(1.01)
+                    else:
+                        v = p._version
+                        p.data.mul_(0.97)
+                        assert p._version == v       # (the hazard: nothing in the version says the values changed)
+                y3, l3 = layer(x)
+            y4, l4 = fresh()
+            assert torch.equal(y3, y4) and torch.equal(l3, l4), (split, how)
+            assert not torch.equal(y3, y1)
+            y1 = y3
+    made.cache_packed_weights = False

@@ -116,6 +116,86 @@ def test_split_gemm_rows_spanning_ten_decades_under_a_triangular_mask():
     assert cw_split_big < 1e-3                    # ... and component-wise wherever the entries are not dwarfed
 
 
+def test_default_path_is_guarded_against_rows_the_split_format_cannot_carry():
+    """The DEFAULT arithmetic is data-aware: a layer large enough for the size rule to pick the
+    split-f16 GEMMs checks the scales of the input FEATURES first (``AutoregressiveFlow.split_guard``: the largest magnitude
+    of every feature over the batch; a lone small value in a row does not count).  Ordinary data:
+    the guard passes, the result IS the split path's, bit for bit.  Rows spanning 10 decades (what the test above shows the
+    split format cannot carry component-wise): the call runs on the exact-fp32 kernels, bit for bit the ``split_gemm =
+    False`` result, and the first masked linear is accurate COMPONENT-wise on that default path (error relative to
+    sum_k |x_k w_jk| over the entries each output sees) -- forced split is not."""
+    import warnings
+    from tfep_amd import ops
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    torch.manual_seed(11)
+    D, B = 200, 512
+    layer = MAF(generate_degrees(D, 'ascending'), transformer=NeuralSplineTransformer(torch.full((D,), -5.0), torch.full((D,), 5.0), 8),
+                initialize_identity=False).cuda()
+    assert layer._conditioner.split_worthwhile(B) and layer.split_gemm is None            # the size rule says split
+    x_ok = torch.randn(B, D, device='cuda').clamp_(-4.9, 4.9)
+    x_ok[7, 3] = 1e-9                                      # a lone tiny value: not what the guard is about
+    decades = 10.0 * torch.arange(D, device='cuda') / (D - 1) - 10.0                     # 1e-10 ... 1 along the features
+    x_wide = torch.randn(B, D, device='cuda').clamp_(-4.9, 4.9) * torch.pow(10.0, decades)[None, :]
+
+    def run(x, split):
+        layer.split_gemm = split
+        with torch.no_grad():
+            out = layer(x)
+        layer.split_gemm = None
+        return out
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter('always')
+        y_d, l_d = run(x_ok, None)
+        assert layer.last_split_guard == dict(feature_scales_out_of_range=False, exact=False) and not caught
+        y_s, l_s = run(x_ok, True)
+        assert torch.equal(y_d, y_s) and torch.equal(l_d, l_s)
+        y_d, l_d = run(x_wide, None)
+        assert layer.last_split_guard['exact'] and layer.last_split_guard['feature_scales_out_of_range']
+        assert any('exact-fp32' in str(w.message) for w in caught)
+    y_e, l_e = run(x_wide, False)
+    assert torch.equal(y_d, y_e) and torch.equal(l_d, l_e)
+    # component-wise accuracy of the first masked linear on the path the default takes for this data
+    made = layer._conditioner
+    lin = made.layers[0]
+    w_eff = (lin.mask * lin.weight_v * (lin.weight_g / lin.weight_v.norm(dim=1, keepdim=True))).double()
+    w_eff = torch.where(lin.mask == 0, torch.zeros_like(w_eff), w_eff)
+    pre = x_wide.double() @ w_eff.T + lin.bias.double()
+    comp = x_wide.double().abs() @ w_eff.abs().T + lin.bias.double().abs()
+
+    def first_layer(split):
+        layer.split_gemm = split
+        with torch.no_grad(), layer._range_guard(x_wide):
+            use = layer._use_split_gemm(B)
+            plan = made.plan(x_wide.device)
+            h = ops.pad_columns(x_wide, plan['k_pad'][0])
+            if use:
+                ws, w_inv, b, _ = made._pack_layer_split(plan, 0, lin)
+                hs, h_inv = ops.split_rows(h, plan['k_pad'][0])
+                out = ops.masked_linear_split(hs, h_inv, ws, w_inv, b, plan['n_pad'][0], k_ranges=plan['k_ranges'][0], act=0,
+                                              tile_order=plan['tile_order'][0])
+            else:
+                w, b = made._pack_layer(plan, 0, lin)
+                out = ops.masked_linear_packed(h, w, b, plan['n_pad'][0], k_ranges=plan['k_ranges'][0], act=0,
+                                               tile_order=plan['tile_order'][0])
+        layer.split_gemm = None
+        row_of = plan['row_of_out'][0] if plan.get('row_of_out') is not None else None
+        return out, use, row_of
+    out_d, used_split, row_of = first_layer(None)
+    assert not used_split                                          # the guard sent this data to the exact kernel
+    got = out_d[:, row_of.long()].double()                         # packed position of hidden unit u: row_of[u]
+    cw_default = float(((got - pre).abs() / comp).max())
+    out_s, used_split, _ = first_layer(True)
+    assert used_split
+    cw_forced_split = float(((out_s[:, row_of.long()].double() - pre).abs() / comp).max())
+    print(f'first masked linear, 10-decade rows: component-wise error default path {cw_default:.2e}, forced split {cw_forced_split:.2e}')
+    assert cw_default < 2e-6
+    # (inside a MADE the exact fp32 bias of every unit dominates sums that see only tiny inputs: forced split is not worse
+    # HERE, 2.4e-7 -- the guard is for the product itself, see the test above with zero bias: component-wise error 1.0)
+    assert cw_forced_split < 1e-3
+
+
 def test_split_gemm_with_mask_k_ranges_and_tile_order():
     """Block-triangular mask (sorted MADE degrees): k-ranges in units of 32 skip tiles; results as the dense product."""
     from tfep_amd import ops

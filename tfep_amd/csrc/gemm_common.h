@@ -40,7 +40,7 @@ struct GemmArgs {
     int64_t ldy;
     int B, N, k_padded;
     const int32_t* tile_order; // optional: launch position -> column tile (heaviest k-range first), or NULL
-    int map_mode;              // 0: row-tile fastest; 1: XCD-aware 8x4 super-tiles
+    int map_mode;              // 0: row-tile fastest; 1 / 2: XCD-aware 8x4 super-tiles, row / column super-tiles fastest
     int m_tiles, n_tiles;
     const float* aux;          // linear epilogue: if set, y = acc * elu'(aux) with elu'(h) = h > 0 ? 1 : h + 1
     int64_t ldaux;             //   (ELU backward from the saved activation h; same indexing as y)
@@ -72,13 +72,17 @@ __device__ inline bool map_block(const GemmArgs& g, int& mt, int& ntp) {
     // co-resident on one XCD form an 8 (row tiles) x 4 (column tiles) super-tile: 8 activation
     // panels + 4 weight panels are fetched once into that L2 instead of 32 + 1.  Pure speed: any
     // placement gives the same result.
-    if (g.map_mode == 1) {
+    if (g.map_mode == 1 || g.map_mode == 2) {
         const int id = blockIdx.x;
         const int xcd = id & 7, seq = id >> 3;
         const int S = (seq >> 5) * 8 + xcd, w = seq & 31;
-        const int SM = (g.m_tiles + 7) >> 3;
-        mt = (S % SM) * 8 + (w & 7);
-        ntp = (S / SM) * 4 + (w >> 3);
+        const int SM = (g.m_tiles + 7) >> 3, SN = (g.n_tiles + 3) >> 2;
+        // mode 1: the 8 XCDs walk 8 ROW super-tiles of one column super-tile at a time (its 4 weight panels stay in the
+        // Infinity Cache, the activation panels stream from HBM once per column super-tile); mode 2: 8 COLUMN super-tiles
+        // of one row super-tile (the 123 MB activation panel of a cfg2 layer stays resident, the weights stream)
+        const int sm = g.map_mode == 1 ? S % SM : S / SN, sn = g.map_mode == 1 ? S / SM : S % SN;
+        mt = sm * 8 + (w & 7);
+        ntp = sn * 4 + (w >> 3);
         if (mt >= g.m_tiles || ntp >= g.n_tiles) return false;
     } else {
         mt = blockIdx.x % g.m_tiles;
@@ -187,7 +191,7 @@ inline int block_map_mode() { static int m = env_int("TFEP_BLOCK_MAP", 1); retur
 
 // Grid size for map_block().
 inline long long gemm_grid_blocks(int map_mode, int m_tiles, int n_tiles) {
-    if (map_mode == 1) {
+    if (map_mode == 1 || map_mode == 2) {
         const long long SM = (m_tiles + 7) / 8, SN = (n_tiles + 3) / 4;
         return ((SM * SN + 7) / 8) * 8 * 32;
     }

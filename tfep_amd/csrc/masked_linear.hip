@@ -255,18 +255,7 @@ __global__ void __launch_bounds__(THREADS, (MREP == 1 ? 4 : 2)) gemm_kernel(Gemm
     // panels + 4 weight panels are fetched once into that L2 instead of 32 + 1.  Pure speed: any
     // placement gives the same result.
     int mt, ntp;
-    if (g.map_mode == 1) {
-        const int id = blockIdx.x;
-        const int xcd = id & 7, seq = id >> 3;
-        const int S = (seq >> 5) * 8 + xcd, w = seq & 31;
-        const int SM = (g.m_tiles + 7) >> 3;
-        mt = (S % SM) * 8 + (w & 7);
-        ntp = (S / SM) * 4 + (w >> 3);
-        if (mt >= g.m_tiles || ntp >= g.n_tiles) return;
-    } else {
-        mt = blockIdx.x % g.m_tiles;
-        ntp = blockIdx.x / g.m_tiles;
-    }
+    if (!map_block(g, mt, ntp)) return;
     int nt = g.tile_order ? g.tile_order[ntp] : ntp;
     // split-K (short-and-wide products, e.g. the block GEMMs of the inverse: too few output tiles to fill 256 CUs):
     // the launch has ksplit x as many column positions; position -> (column tile, k slice)

@@ -186,6 +186,34 @@ __global__ void __launch_bounds__(256) abs_reduce_kernel(const float* __restrict
     }
 }
 
+// Rows whose own dynamic range is wider than the split format keeps at fp32 accuracy: with one power-of-two scale per row
+// an element below 2^-bits of the row maximum (bits = 19: its low half leaves the normal fp16 range) is carried with
+// fewer than 22 significant bits, and an output that sees ONLY such elements (possible under MADE's prefix masks) inherits
+// that error component-wise.  count[0] += rows with a non-zero element below the threshold (non-finite rows count too: they
+// belong to the exact kernel's NaN semantics).  One wave per row, atomics only from flagged rows.
+__global__ void __launch_bounds__(256) range_flag_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int64_t cols,
+                                                         float ratio, int* __restrict__ count) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* sr = src + row * ld;
+    float amax = 0.f, amin = 3.0e38f;
+    bool bad = false;
+    for (int64_t i = lane; i < cols; i += 64) {
+        const float a = fabsf(sr[i]);
+        bad |= !(a <= 3.0e38f);
+        amax = fmaxf(amax, a);
+        if (a > 0.f) amin = fminf(amin, a);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        amin = fminf(amin, __shfl_xor(amin, off, 64));
+    }
+    const bool flagged = __any(bad) || (amax > 0.f && amin < amax * ratio);
+    if (lane == 0 && flagged) atomicAdd(count, 1);
+}
+
 // Columns [g0 * 8, (g0 + n_groups) * 8) of fp32 rows -> the same columns of split rows, with a scale the CALLER fixed
 // beforehand (inv_scale[row], a power of two): the hidden-activation panels of the blocked inverse grow by a few columns
 // per block, so their row scale has to be known before the values are (a bound; see flows/autoregressive.py).
@@ -480,6 +508,17 @@ int tfep_abs_reduce(const float* src, int64_t ld_src, int64_t rows, int64_t cols
         abs_reduce_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(src, ld_src, rows, cols, mode, out);
     }
     return check_launch("abs_reduce_kernel");
+}
+
+int tfep_range_flag(const float* src, int64_t ld_src, int64_t rows, int64_t cols, int bits, int32_t* count, void* stream) {
+    TFEP_REQUIRE(rows >= 0 && cols >= 0 && bits > 0 && bits < 60, "range_flag: bad size / bits");
+    TFEP_REQUIRE(count && (src || rows == 0 || cols == 0), "range_flag: NULL pointer");
+    TFEP_REQUIRE(ld_src >= cols, "range_flag: ld_src < cols");
+    if (rows == 0 || cols == 0) return TFEP_OK;
+    TFEP_REQUIRE((rows + 3) / 4 <= 0x7fffffffLL, "range_flag: grid too large");
+    range_flag_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(src, ld_src, rows, cols, ldexpf(1.0f, -bits),
+                                                                              count);
+    return check_launch("range_flag_kernel");
 }
 
 int tfep_split_columns_scaled(const float* src, int64_t ld_src, int64_t rows, int64_t col0, int64_t cols, void* dst,

@@ -18,12 +18,6 @@ class GraphedFlow:
         self.inverse = inverse
         device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.static_in = torch.zeros(batch_size, n_features, dtype=torch.float32, device=device)
-        if sample_input is not None:
-            self.static_in.copy_(sample_input)
-        # what the warm-up steps must not leave behind: parameter values and optimiser state (ADVICE r2)
-        saved_params = [p.detach().clone() for p in self.params]
-        saved_state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in optimizer.state.get(p, {}).items()}
-                       for p in self.params}
         fn = flow.inverse if inverse else flow.forward
         # Warm-up off the default stream: builds the execution plans (host-side index work, device->host
         # reads of masks) and sets kernel attributes -- none of which may happen during capture.
@@ -99,6 +93,12 @@ class GraphedTrainingStep:
                                'from the flow outside torch.no_grad()?): delete it before capturing the step')
         device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.static_in = torch.zeros(batch_size, n_features, dtype=torch.float32, device=device)
+        if sample_input is not None:
+            self.static_in.copy_(sample_input)
+        # what the warm-up steps must not leave behind: parameter values and optimiser state (ADVICE r2)
+        saved_params = [p.detach().clone() for p in self.params]
+        saved_state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in optimizer.state.get(p, {}).items()}
+                       for p in self.params}
         if sample_input is not None:
             self.static_in.copy_(sample_input)
         # what the warm-up steps must not leave behind: parameter values and optimiser state

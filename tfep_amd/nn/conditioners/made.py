@@ -148,7 +148,8 @@ class MADE(Conditioner):
         self._plans = {}
         self._frozen = False
         #: Keep the packed (weight-normed, masked, permuted, split) weights across forwards while no parameter or mask
-        #: has been updated in place (``Tensor._version``); default off: re-pack on every forward like the reference's
+        #: has been updated: ``Tensor._version`` + storage address, and a strided checksum for writes through ``.data``
+        #: that the version cannot see (``_keep_packed``); default off: re-pack on every forward like the reference's
         #: pre-hook (masked.py:397-398).  SURVEY.md section 8(b) sanctions caches invalidated by parameter version.
         self.cache_packed_weights = False
         #: Let the choice between split-f16 and exact-fp32 GEMMs also depend on the batch size (see ``split_worthwhile``);
@@ -442,11 +443,31 @@ class MADE(Conditioner):
         if not self.cache_packed_weights or torch.cuda.is_current_stream_capturing():
             return False
         versions = self._param_versions()
-        if plan.get('packed_versions') != versions:
+        # ``Tensor._version`` does not see in-place writes through ``.data`` (legacy loops: ``p.data.add_(...)``): a
+        # strided device checksum of every parameter (every 1021st entry: ~1 M reads per cfg2 layer, one host comparison)
+        # catches any update that touches a tensor broadly -- every optimiser step does.  A write to a SINGLE entry
+        # through ``.data`` is the one thing that can still go unseen; ``invalidate_plan()`` is the explicit remedy.
+        fingerprint = self._param_fingerprint()
+        stale = plan.get('packed_versions') != versions
+        if not stale:
+            old = plan.get('packed_fingerprint')
+            stale = old is None or not torch.equal(old, fingerprint)
+        if stale:
             for k in [k for k in plan if isinstance(k, tuple) and k[0] in ('packed', 'packed_split')]:
                 del plan[k]
             plan['packed_versions'] = versions
+        plan['packed_fingerprint'] = fingerprint
         return True
+
+    def _param_fingerprint(self):
+        """Strided checksums (float64 sums of every 1021st entry, and of the first 64) of every parameter: a device tensor."""
+        parts = []
+        for lin in self._linears():
+            for t in lin.parameters():
+                flat = t.detach().reshape(-1)
+                parts.append(flat[::1021].double().sum())
+                parts.append(flat[:64].double().sum())
+        return torch.stack(parts) if parts else torch.zeros(0)
 
     def _mask_prefix_cuts(self, plan, li, lin):
         """``col_cut`` of ``tfep_masked_weight_prepare_split`` for layer ``li``, or None.

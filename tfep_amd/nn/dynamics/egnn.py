@@ -11,10 +11,12 @@ order, so the same seed gives the reference's initial values); the arithmetic is
                       the continuous flow are built from (``e . (J e)`` is the Hutchinson estimate, continuous.py:307-324)
 
 Per call: the parameters are re-packed (``tfep_egnn_pack_layer``), one embedding kernel, one edge kernel per layer, one
-node kernel between layers, one finishing kernel.  No edge list, no scatter_add.  There is no CPU path and no autograd
-through the kernels: differentiating the outputs raises.
+node kernel between layers, one finishing kernel.  No edge list, no scatter_add.  There is no autograd through the
+kernels: under grad mode ``forward`` is ``torch_forward``, the same map as differentiable torch operators (what makes a
+``ContinuousFlow`` over these dynamics trainable: its loss differentiates a trace of the Jacobian).
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -81,8 +83,63 @@ class EGNNDynamics(FixedGraph):
     def forward(self, t, x):
         """Velocity ``(batch_size, n_nodes*3)`` at time ``t`` and positions ``x``."""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return _NotDifferentiable.apply(self, t, x, *[p for p in self.parameters() if p.requires_grad])
+            return self.torch_forward(t, x)                    # differentiable (to any order): see there
         return self._run(t, x)[0]
+
+    def torch_forward(self, t, x):
+        """The same velocity as a composite of torch operators on the device -- the DIFFERENTIABLE route.
+
+        The kernels have forward-mode and reverse-mode products with respect to the positions but no parameter gradients,
+        and the loss of a continuous flow needs the gradient of a trace of the Jacobian: second derivatives.  Under grad
+        mode the dynamics therefore run the way the reference itself does -- plain torch ops that autograd differentiates,
+        ``create_graph`` included (egnn.py:143-194, 272-369; continuous.py:231-278) -- in a DENSE formulation: every
+        ordered pair ``[b, source i, destination j]`` of a sample with a "kept" mask (``i != j``, distance <= cutoff)
+        instead of an edge list and ``scatter_add``.  Same numbers as the kernels to float32 rounding
+        (tests/test_gpu_continuous.py), the reference's memory appetite (B n^2 (2F + G) floats per layer): meant for the
+        sizes at which the reference can train; inference goes through the kernels (``torch.no_grad()``)."""
+        import torch.nn.functional as Fn
+        _lib.check_device_tensor(x, 'x', dtype=x.dtype)        # (no CPU path here either)
+        B = x.shape[0]
+        n = self.n_nodes
+        if x.dim() != 2 or x.shape[1] != 3 * n:
+            raise ValueError(f'x must have shape (batch_size, {3 * n}), got {tuple(x.shape)}')
+        dt, dev = x.dtype, x.device
+        t = torch.as_tensor(t, dtype=dt, device=dev).reshape(1)
+        te = self.time_embedding
+        t_emb = torch.exp(-torch.exp(te._log_gammas.to(dt)) * (t[:, None] - te._means.to(dt)) ** 2)[0]      # radial.py:110-130
+        one_hot = self._node_types_one_hot.to(dt)
+        h = self.h_embedding(torch.cat([one_hot, t_emb[None].expand(n, -1)], dim=-1))[None].expand(B, -1, -1)  # egnn.py:196-219
+        pos0 = x.reshape(B, n, 3)
+        pos = pos0
+        off = ~torch.eye(n, dtype=torch.bool, device=dev)
+        zero, one = torch.zeros((), dtype=dt, device=dev), torch.ones((), dtype=dt, device=dev)
+        for layer in self._layers():
+            emb = layer.distance_embedding
+            rc = float(emb.r_cutoff)
+            diff = pos[:, None, :, :] - pos[:, :, None, :]                  # x[dest j] - x[src i]   (graph.py:254)
+            # (the i == j diagonal is not an edge: distance 1 there keeps non-finite values out of the autograd graph)
+            d = torch.sqrt(torch.where(off[None], (diff * diff).sum(-1), one))
+            keep = off[None] & (d <= rc)                                    # graph.py:297
+            direction = diff / d[..., None]                                 # graph.py:260
+            sw = 0.5 * torch.cos(math.pi / rc * d) + 0.5                    # radial.py:161-176
+            if emb.force_zero_after_cutoff:
+                sw = torch.where(d > rc, zero, sw)
+            rbf = torch.exp(-torch.exp(emb._log_gammas.to(dt)) * (d[..., None] - emb._means.to(dt)) ** 2) * sw[..., None]
+            F = h.shape[-1]
+            w0 = layer.message_mlp[0]
+            # first linear of the message MLP by input block: [h_src, h_dest, rbf] (egnn.py:246-251)
+            z1 = (Fn.linear(h, w0.weight[:, :F])[:, :, None, :] + Fn.linear(h, w0.weight[:, F:2 * F], w0.bias)[:, None, :, :]
+                  + Fn.linear(rbf, w0.weight[:, 2 * F:]))
+            m = Fn.silu(layer.message_mlp[2](Fn.silu(z1)))
+            m = m * torch.sigmoid(layer.attention_mlp[0](m))                # egnn.py:323-325
+            node_msg = torch.where(keep[..., None], m, zero).sum(dim=1)     # messages arriving at dest j (egnn.py:331)
+            upd = layer.update_h_mlp[2](Fn.silu(layer.update_h_mlp[0](torch.cat([h, node_msg], dim=-1))))
+            mag = torch.tanh(layer.update_x_mlp[2](Fn.silu(layer.update_x_mlp[0](m))))
+            disp = torch.where(keep[..., None], layer.speed_factor * direction * mag, zero).sum(dim=1)      # egnn.py:355-361
+            h, pos = h + upd, pos + disp
+        vel = pos - pos0                                                    # translation invariance (egnn.py:185)
+        vel = vel - vel.mean(dim=1, keepdim=True)                           # centre of geometry preserved (:189-191)
+        return vel.reshape(B, 3 * n)
 
     def jvp(self, t, x, v, trace=None, frobenius=None, scale=1.0, velocity_squared_norm=None, need_jvp=True):
         """``(velocity, J v)`` with ``J = d velocity / d x``; optionally ``trace += scale v . (J v)``,
@@ -349,17 +406,3 @@ def _run_vjp(self, t, x, g, trace=None, frob=None, scale=1.0, vel_sq=None):
 
 
 EGNNDynamics._run_vjp = _run_vjp
-
-
-class _NotDifferentiable(torch.autograd.Function):
-    """The velocity under autograd: the values are computed, differentiating them raises (no backward kernels yet)."""
-
-    @staticmethod
-    def forward(ctx, module, t, x, *params):
-        with torch.no_grad():
-            return module._run(t, x)[0]
-
-    @staticmethod
-    def backward(ctx, g):
-        raise NotImplementedError('tfep_amd: EGNNDynamics has no backward on the HIP path (forward, Jacobian-vector '
-                                  'products and the flow trace are available); call it under torch.no_grad().')

@@ -164,6 +164,7 @@ class MAFLayerFunction(torch.autograd.Function):
             else:
                 y, ldj = layer._forward_impl(x)
         ctx.layer = layer
+        ctx.guard_exact = layer._guard_exact            # the range guard's verdict on this call's data: the backward keeps it
         # the kept activations go through save_for_backward like x: released with the graph / right after backward (as
         # plain attributes of ctx they sat in a reference cycle until Python's garbage collector ran: 6.6 GB per step)
         ctx.n_hidden = -1 if saved is None else len(saved['h'])
@@ -176,7 +177,8 @@ class MAFLayerFunction(torch.autograd.Function):
         x, *kept = ctx.saved_tensors
         saved = None if ctx.n_hidden < 0 else dict(h=kept[:ctx.n_hidden], theta=kept[ctx.n_hidden])
         del kept
-        with torch.no_grad():
+        from .autoregressive import _RangeGuard
+        with torch.no_grad(), _RangeGuard(layer, x, force=ctx.guard_exact):
             gx, gparams = layer_backward(layer, x, gy, gldj, saved=saved)
         # parameters this backward does not hand a gradient to (torch.autograd.grad(loss, [x]), a subset of the
         # parameters): their hooks will not run, so their "already masked" tags must not outlive this call
@@ -252,6 +254,135 @@ def generic_forward(layer, x):
         y_tr, ldj = apply(_GatherColumns.apply(x, t['tr']))
         return _ReplaceColumns.apply(x, y_tr, t['tr']), ldj
     return apply(x)
+
+
+def _elementwise(tr):
+    """Transformers whose Jacobian with respect to x is diagonal (one feature in, one feature out)."""
+    if type(tr) in (AffineTransformer, NeuralSplineTransformer, VolumePreservingShiftTransformer):
+        return True
+    return type(tr) is MixedTransformer and all(_elementwise(t) for t in tr._transformers)
+
+
+class TransformerInverseFunction(torch.autograd.Function):
+    """``x, log_det_J = transformer.inverse(y, theta)`` on the HIP kernels as one graph node, for the element-wise
+    transformers (affine, RQ spline in every layout, volume-preserving shift, mixed transformers of those).
+
+    The backward needs no kernel of its own.  With y = tau(x; theta) and L = log tau_x (per feature), the inverse returns
+    (x, -sum_f L), and dx = (dy - tau_theta dtheta) / tau_x.  For cotangents (gx, gl) of its two outputs:
+
+        u = (gx - gl L_x) / tau_x,        g_y = u,        g_theta = -(tau_theta^T u + gl L_theta)
+
+    The forward VJP kernel called with cotangents (a, b) returns (tau_x a + L_x b, tau_theta^T a + L_theta^T b): (1, 0)
+    yields tau_x, (0, gl) yields gl L_x, and (u, gl) yields -g_theta."""
+
+    @staticmethod
+    def forward(ctx, tr, y, theta):
+        y, theta = y.detach().contiguous(), theta.detach().contiguous()
+        with torch.no_grad():
+            x, ldj = tr.inverse(y, theta)
+        ctx.tr = tr
+        ctx.save_for_backward(x, theta)
+        return x, ldj
+
+    @staticmethod
+    def backward(ctx, gx, gldj):
+        x, theta = ctx.saved_tensors
+        B, D = x.shape
+        f32 = dict(dtype=torch.float32, device=x.device)
+        stream = _lib.stream_of(x)
+        gx = ops.zeros(B, D, **f32) if gx is None else gx.contiguous()
+        gl = ops.zeros(B, **f32) if gldj is None else gldj.contiguous()
+        with torch.no_grad():
+            scratch = ops.zeros(*theta.shape, **f32)
+            tau_x = torch.empty(B, D, **f32)
+            transformer_vjp(ctx.tr, x, theta, 0, theta.shape[1], torch.ones(B, D, **f32), ops.zeros(B, **f32), scratch, tau_x, stream)
+            lx = torch.empty(B, D, **f32)
+            transformer_vjp(ctx.tr, x, theta, 0, theta.shape[1], ops.zeros(B, D, **f32), gl, scratch, lx, stream)
+            u = ((gx - lx) / tau_x).contiguous()
+            gtheta = ops.zeros(*theta.shape, **f32)
+            dump = torch.empty(B, D, **f32)
+            transformer_vjp(ctx.tr, x, theta, 0, theta.shape[1], u, gl, gtheta, dump, stream)
+        return None, u, -gtheta
+
+
+def generic_inverse(layer, y):
+    """Differentiable ``AutoregressiveFlow.inverse``: the reference's algorithm (autoregressive.py:179-229: one full
+    conditioner pass per autoregressive degree, the degree's columns committed after each pass, the log-det of the LAST
+    pass returned) with every piece recorded by autograd -- the conditioner through its ``MaskedLinear`` modules (any other
+    conditioner as the torch module it is), the transformer inverse through ``TransformerInverseFunction`` (Moebius: the
+    forward function on negated parameters, as reference moebius.py:142-147 defines its inverse), the column plumbing
+    through the differentiable gather / replace of ``flows/partial.py``.  This is the reference's cost (n_degrees
+    conditioner passes kept for the backward), not the blocked substitution's: meant for the sizes at which the reference
+    itself can train through an inverse."""
+    from .partial import _GatherColumns, _ReplaceColumns
+    t = layer._tables(y.device)
+    tr = layer._transformer
+    made = layer._conditioner
+
+    def conditioner(x):
+        cond_in = _GatherColumns.apply(x, t['cond']) if len(layer._conditioner_indices) > 0 else x
+        return made.layers(made._embed(cond_in)) if isinstance(made, MADE) else made(cond_in)
+    if type(tr) is MoebiusTransformer:
+        def inverse(y_tr, theta):
+            return TransformerFunction.apply(tr, y_tr, -theta)
+    elif _elementwise(tr):
+        def inverse(y_tr, theta):
+            return TransformerInverseFunction.apply(tr, y_tr, theta)
+    elif not isinstance(tr, _HIP_TRANSFORMERS):              # a user's torch transformer: plain autograd
+        def inverse(y_tr, theta):
+            return tr.inverse(y_tr, theta)
+    else:
+        raise NotImplementedError('tfep_amd: no backward for the inverse of ' + type(tr).__name__ + ' (a mixed transformer '
+                                  'with a Moebius member, or a subclass of a HIP-backed transformer)')
+    if layer.has_fixed_indices:
+        x = _ReplaceColumns.apply(torch.zeros_like(y), _GatherColumns.apply(y, t['fixed']), t['fixed'])
+        y_tr = _GatherColumns.apply(y, t['tr'])
+    else:
+        x, y_tr = torch.zeros_like(y), y
+    log_det_J = None
+    for cols, pos in layer._inverse_steps(y.device):
+        x_temp, log_det_J = inverse(y_tr, conditioner(x))
+        x = _ReplaceColumns.apply(x, _GatherColumns.apply(x_temp, pos), cols)
+    return x, log_det_J
+
+
+class LazyInverseFunction(torch.autograd.Function):
+    """``layer.inverse(y)`` under grad mode: the VALUES come from the fast path (the blocked substitution: no graph, about
+    one forward of flops), and only a ``backward()`` that actually arrives pays for the differentiable route -- it re-runs
+    ``generic_inverse`` under autograd from the saved ``y`` and back-propagates the incoming cotangents through it.  A
+    script that samples with grad mode left on (the common case) costs what it cost under ``torch.no_grad()``; one that
+    trains through the inverse gets the reference's gradients (autoregressive.py:179-229) at the reference's cost.  (First
+    order only: the backward itself is not differentiable.)"""
+
+    @staticmethod
+    def forward(ctx, layer, y, *params):
+        with torch.no_grad():
+            x, ldj = layer._inverse_impl(y)
+        ctx.layer, ctx.params = layer, params
+        ctx.save_for_backward(y)
+        return x, ldj
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gx, gldj):
+        (y,) = ctx.saved_tensors
+        layer, params = ctx.layer, ctx.params
+        with torch.enable_grad():
+            y_ = y.detach().requires_grad_(True)
+            x2, l2 = generic_inverse(layer, y_)
+            outs, cots = [], []
+            if gx is not None:
+                outs.append(x2)
+                cots.append(gx)
+            if gldj is not None:
+                outs.append(l2)
+                cots.append(gldj)
+            wrt = [y_] + [p for p in params if p.requires_grad]
+            grads = torch.autograd.grad(outs, wrt, cots, allow_unused=True)
+        gy = grads[0] if ctx.needs_input_grad[1] else None
+        it = iter(grads[1:])
+        gparams = [next(it) if p.requires_grad else None for p in params]
+        return (None, gy, *gparams)
 
 
 class UnsupportedBackward(torch.autograd.Function):

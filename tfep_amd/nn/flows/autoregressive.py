@@ -203,8 +203,33 @@ class AutoregressiveFlow(torch.nn.Module):
         kernel."""
         if self.split_gemm is not None:
             return bool(self.split_gemm)
+        if self._guard_exact:                      # this call's data failed the range guard (``_range_guard``)
+            return False
         made = self._conditioner
         return ops.split_gemm_enabled() and isinstance(made, MADE) and made.split_worthwhile(batch)
+
+    #: Data-aware guard of the split-f16 DEFAULT (``split_gemm = None``): ``None`` = on unless ``TFEP_SPLIT_GUARD=0``.
+    #: The split format carries each activation row with ONE power-of-two scale: elements below 2^-19 of their row's maximum
+    #: lose significance, and an output that sees only such elements (MADE's prefix masks make that possible) inherits the
+    #: error component-wise (tests/test_gpu_split_gemm.py).  That is a property of FEATURES, not of single values (a lone
+    #: small value in one row is harmless: 2 % of the rows of a 3000-feature Gaussian batch hold one, and every unit adds an
+    #: exact fp32 bias and sees other features): before a forward that the size rule would send to the split kernels, the
+    #: largest magnitude of every feature over the batch is taken, and if the non-zero ones span more than 2^19
+    #: (``tfep_range_flag``) THIS call runs on the exact-fp32 MFMA kernels instead (``last_split_guard`` says so; one
+    #: warning per layer).  Costs one read of x and one host synchronisation per layer call -- skipped inside a HIP-graph
+    #: capture, where the host cannot wait, and when the arithmetic was chosen explicitly (``split_gemm = True / False``).
+    #: The backward of a guarded forward stays exact too.
+    #: Not guarded: the hidden activations (sums over many inputs plus an fp32 bias: no output sees "only small entries")
+    #: and the weights (one scale per matrix from max |g|; an entry below 2^-19 of it contributes < 2^-19 max|w| |x| to a
+    #: pre-activation that carries an exact fp32 bias) -- the wide-layer gradient goldens hold the default path to the
+    #: reference's own float32 accuracy entry by entry (tests/test_gpu_backward.py).
+    split_guard = None
+    _guard_exact = False
+    last_split_guard = None
+
+    def _range_guard(self, x):
+        """Context manager around one forward call: decides ``_guard_exact`` from the data (see ``split_guard``)."""
+        return _RangeGuard(self, x)
 
     def _fused_plan(self, device, kind, tables):
         """Packed layout of the MADE output layer for the fused kernels.  The transformed features form GROUPS -- one for a
@@ -319,17 +344,18 @@ class AutoregressiveFlow(torch.nn.Module):
         ops.check_device_tensor(x, 'x')
         self._check_features(x, 'x')
         self._sync_conditioner()
-        if torch.is_grad_enabled():
-            from . import _backward
-            params = _backward.trainable_tensors(self) if isinstance(self._conditioner, MADE) else \
-                [p for p in self._conditioner.parameters()]
-            if x.requires_grad or any(p.requires_grad for p in params):
-                if _backward.supported(self):
-                    return _backward.MAFLayerFunction.apply(self, x, *params)
-                if _backward.generic_supported(self):
-                    return _backward.generic_forward(self, x)          # conditioner by autograd, transformer VJP kernel
-                return _backward.UnsupportedBackward.apply(self, x, *params)
-        return self._forward_impl(x)
+        with self._range_guard(x):
+            if torch.is_grad_enabled():
+                from . import _backward
+                params = _backward.trainable_tensors(self) if isinstance(self._conditioner, MADE) else \
+                    [p for p in self._conditioner.parameters()]
+                if x.requires_grad or any(p.requires_grad for p in params):
+                    if _backward.supported(self):
+                        return _backward.MAFLayerFunction.apply(self, x, *params)
+                    if _backward.generic_supported(self):
+                        return _backward.generic_forward(self, x)          # conditioner by autograd, transformer VJP kernel
+                    return _backward.UnsupportedBackward.apply(self, x, *params)
+            return self._forward_impl(x)
 
     def _check_features(self, x, name):
         """The kernels index ``x`` by the layer's own feature tables: a tensor of another width must never reach them
@@ -378,7 +404,9 @@ class AutoregressiveFlow(torch.nn.Module):
     def inverse(self, y: torch.Tensor):
         """``(x, log_det_J)`` of the inverse map (reference autoregressive.py:179-229).
 
-        With a MADE conditioner the inverse runs as a blocked forward substitution: pass ``k``
+        Under autograd (grad mode on and ``y`` or a parameter requires grad) the outputs are differentiable like the
+        reference's (``_backward.LazyInverseFunction``: the values still come from the fast path, a backward pays for the
+        reference's pass per degree).  With a MADE conditioner the values come from a blocked forward substitution: pass ``k``
         evaluates only the rows of the three masked linears that belong to degree ``k`` (contiguous
         row slices of the degree-sorted packed weights), so the whole inverse costs about one forward
         in flops instead of ``n_degrees`` forwards (a mixed transformer of affine / spline members: one
@@ -392,9 +420,11 @@ class AutoregressiveFlow(torch.nn.Module):
         if torch.is_grad_enabled():
             params = [p for p in self.parameters() if p.requires_grad]
             if y.requires_grad or params:
-                # The inverse kernels record no autograd graph (the reference's inverse is differentiable): the
-                # outputs carry a node whose backward fails loudly instead of silently dropping the gradient.
-                return _InverseNotDifferentiable.apply(self, y, *params)
+                # Values from the fast path; a backward() that actually arrives re-runs the reference's own algorithm
+                # (one conditioner pass per degree) built from differentiable pieces and back-propagates through it
+                # (flows/_backward.py: LazyInverseFunction, generic_inverse).
+                from . import _backward
+                return _backward.LazyInverseFunction.apply(self, y, *params)
         return self._inverse_impl(y)
 
     def _inverse_impl(self, y: torch.Tensor):
@@ -1145,19 +1175,46 @@ class AutoregressiveFlow(torch.nn.Module):
         return self._conditioner(x)
 
 
-class _InverseNotDifferentiable(torch.autograd.Function):
-    """``inverse`` under autograd: the values are computed, differentiating them raises."""
+class _RangeGuard:
+    def __init__(self, layer, x, force=None):
+        self.layer, self.x, self.force = layer, x, force
 
-    @staticmethod
-    def forward(ctx, layer, y, *params):
+    def __enter__(self):
+        layer = self.layer
+        self.prev = layer._guard_exact
+        if self.force is not None:                      # the backward of a guarded forward: same arithmetic
+            layer._guard_exact = bool(self.force)
+            return self
+        layer._guard_exact = False
+        on = layer.split_guard if layer.split_guard is not None else os.environ.get('TFEP_SPLIT_GUARD', '1') != '0'
+        x = self.x
+        if (not on or layer.split_gemm is not None or x.shape[0] == 0 or not layer._use_split_gemm(x.shape[0])
+                or torch.cuda.is_current_stream_capturing()):
+            return self
         with torch.no_grad():
-            return layer._inverse_impl(y)
+            # per-FEATURE magnitudes over the batch (a single small value in one row is harmless -- every unit adds an
+            # exact fp32 bias and sees other features; what the per-row scale cannot carry is a feature that is small in
+            # EVERY row next to one that is large in every row)
+            col_max = x.detach().abs().amax(dim=0).reshape(1, -1).contiguous()
+            n_x = ops.range_flag([col_max], bits=19)
+        layer.last_split_guard = dict(feature_scales_out_of_range=bool(n_x), exact=bool(n_x))
+        if n_x:
+            layer._guard_exact = True
+            drop = getattr(layer._conditioner, 'drop_packed_ahead', None)
+            if drop is not None:
+                drop()                                  # split weights packed ahead for this call: not used
+            if not layer.__dict__.get('_guard_warned'):
+                layer.__dict__['_guard_warned'] = True
+                import warnings
+                warnings.warn('tfep_amd: the input features differ in scale by more than 2^19 (largest magnitude per feature over '
+                              'the batch): more than the split-f16 GEMMs carry at fp32 accuracy with one scale per row; this '
+                              'layer call runs on the exact-fp32 MFMA kernels (3x slower).  layer.split_gemm = True / False '
+                              'pins the arithmetic.')
+        return self
 
-    @staticmethod
-    def backward(ctx, gx, gldj):
-        raise NotImplementedError(
-            'tfep_amd: AutoregressiveFlow.inverse has no backward on the HIP path (training goes through forward(), '
-            'which has one); call inverse under torch.no_grad() or detach its outputs.')
+    def __exit__(self, *a):
+        self.layer._guard_exact = self.prev
+        return False
 
 
 class _null_context:

@@ -9,7 +9,8 @@ inverse negated, :176-180), the ``ode_func`` submodule (``ode_func.dynamics.*`` 
   (``dynamics.vjp``) when the regulariser is requested, the trace alone from the cheaper forward-mode pass
   (``dynamics.jvp``: ``e . (J e)``, the same number); exact trace ``sum_k e_k . (J e_k)`` and Frobenius norm
   ``sum_k |J e_k|^2`` (:285-304) from one forward-mode pass per coordinate; regulariser ``|v|^2 + |J|_F^2`` (:262-268).
-  Not differentiable with respect to the parameters: backward raises.
+  These serve ``torch.no_grad()`` calls; under grad mode (training) the flow takes the second path with
+  ``dynamics.torch_forward`` -- the same map as differentiable torch operators.
 * any other ``dynamics(t, x)`` torch module: velocity and vector-Jacobian products by autograd on the device, as the
   reference does; differentiable with ``adjoint=False`` semantics (plain backpropagation through the steps).
 
@@ -61,11 +62,15 @@ class ContinuousFlow(torch.nn.Module):
         t0, t1 = (1.0, 0.0) if inverse else (0.0, 1.0)
         f = self.ode_func
         hip = f.uses_kernels()
-        # kernels: float32 HIP tensors; a user-supplied torch dynamics: any floating dtype, but still on the device
-        _lib.check_device_tensor(x, 'x', dtype=torch.float32 if hip else x.dtype)
         if hip and torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            params = [p for p in self.parameters() if p.requires_grad]
-            return list(_FlowNotDifferentiable.apply(self, x, inverse, *params))
+            # Training: the reference's own route -- the integrands by autograd through the dynamics as torch operators
+            # (``dynamics.torch_forward``), ``create_graph`` when ``requires_backward``, plain backpropagation through the
+            # solver's steps (``adjoint`` is accepted for API compatibility: there is no adjoint solve).  The kernels serve
+            # ``torch.no_grad()`` calls.
+            hip = False
+        # kernels: float32 HIP tensors; the autograd route (training, or a user-supplied torch dynamics): any floating
+        # dtype, but still on the device
+        _lib.check_device_tensor(x, 'x', dtype=torch.float32 if hip else x.dtype)
         return self._integrate(x, t0, t1, hip)
 
     def _integrate(self, x, t0, t1, hip):
@@ -136,7 +141,7 @@ class _ODEFunc(torch.nn.Module):
     def forward(self, t, state):
         regularization = len(state) == 3
         x = state[0]
-        if self.uses_kernels():
+        if self.uses_kernels() and not torch.is_grad_enabled():
             return self._kernel_integrands(float(t), x, regularization)
         return self._autograd_integrands(t, x, regularization)
 
@@ -224,16 +229,3 @@ def _axpy_kernel(x, terms):
         _lib.call('tfep_ode_axpy', _lib.ptr(out), ptrs, coef, len(vs), x.numel(), _lib.ptr(y), _lib.stream_of(x))
         out = y
     return out
-
-
-class _FlowNotDifferentiable(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, flow, x, inverse, *params):
-        t0, t1 = (1.0, 0.0) if inverse else (0.0, 1.0)
-        with torch.no_grad():
-            return tuple(flow._integrate(x, t0, t1, True))
-
-    @staticmethod
-    def backward(ctx, *grads):
-        raise NotImplementedError('tfep_amd: a ContinuousFlow over HIP dynamics has no backward yet (forward, inverse and '
-                                  'the trace are available); call it under torch.no_grad().')

@@ -307,6 +307,23 @@ def split_columns_scaled(x, col0, cols, out, inv_scale):
     return out
 
 
+def range_flag(tensors, bits=19):
+    """Number of rows, over the 2-D fp32 ``tensors``, whose own dynamic range exceeds what the split-f16 operand format
+    carries at fp32 accuracy (a non-zero element below ``2^-bits`` of the row maximum, or a non-finite element):
+    ``tfep_range_flag`` into one device counter, read back once (ONE host synchronisation for the whole list)."""
+    tensors = [t for t in tensors if t is not None and t.numel() > 0]
+    if not tensors:
+        return 0
+    count = torch.zeros(1, dtype=torch.int32, device=tensors[0].device)
+    for t in tensors:
+        check_device_tensor(t, 'range_flag input')
+        if t.dim() != 2 or t.stride(1) != 1:
+            t = t.reshape(t.shape[0], -1).contiguous() if t.dim() > 1 else t.reshape(1, -1).contiguous()
+        call('tfep_range_flag', ptr(t), t.stride(0) if t.shape[0] > 1 else t.shape[1], t.shape[0], t.shape[1], int(bits),
+             ptr(count), stream_of(t))
+    return int(count.item())
+
+
 def abs_reduce(x, what):
     """``what='row_max'``: max_k |x[row, k]| per row;  ``'max_row_sum'``: max_row sum_k |x[row, k]| as a 1-element tensor
     (``tfep_abs_reduce``: plain kernels, capturable in a HIP graph, unlike torch's multi-block reductions whose semaphores are

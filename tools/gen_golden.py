@@ -592,17 +592,9 @@ def gen_flows():
 # 4b. gradients of one training step (reference autograd, float64)
 # -----------------------------------------------------------------------------
 
-def gen_grads():
-    """loss = BoltzmannKLDivLoss()(u_B(y), log_det_J) with the synthetic potential
-    u_B(y) = sum_f (c_f y_f^2 + d_f y_f), backward through the reference flow in float64.
-    Stores d loss / d(every trainable parameter) and d loss / d x."""
+def grad_flows(D=10):
+    """The flow configurations of the gradient goldens (forward and inverse): name -> constructor(dtype)."""
     from tfep.nn.conditioners.made import generate_degrees as gd
-    out = {}
-    D = 10
-
-    def quad(y, c, d):
-        return (c * y ** 2 + d * y).sum(dim=1)
-
     flows = {
         'affine': lambda dt: SequentialFlow(
             MAF(degrees_in=gd(D, 'ascending'), initialize_identity=False),
@@ -645,6 +637,21 @@ def gen_grads():
                 transformer=NeuralSplineTransformer(x0=torch.full((D,), -3.0).to(dt), xf=torch.full((D,), 3.0).to(dt),
                                                     n_bins=6, learn_lower_bound=ll, learn_upper_bound=lu),
                 initialize_identity=False)))(ll, lu)
+    return flows
+
+
+def gen_grads():
+    """loss = BoltzmannKLDivLoss()(u_B(y), log_det_J) with the synthetic potential
+    u_B(y) = sum_f (c_f y_f^2 + d_f y_f), backward through the reference flow in float64.
+    Stores d loss / d(every trainable parameter) and d loss / d x."""
+    from tfep.nn.conditioners.made import generate_degrees as gd
+    out = {}
+    D = 10
+
+    def quad(y, c, d):
+        return (c * y ** 2 + d * y).sum(dim=1)
+
+    flows = grad_flows(D)
     for name, make in flows.items():
         torch.manual_seed(20)
         f32 = make(torch.float32)
@@ -693,6 +700,130 @@ def gen_grads():
     out.update({'ml/x': npy(x), 'ml/w': npy(w), 'ml/b': npy(b), 'ml/mask': npy(mask), 'ml/gy': npy(gy),
                 'ml/gx': npy(x.grad), 'ml/gw': npy(w.grad), 'ml/gb': npy(b.grad)})
     np.savez_compressed(os.path.join(OUT, 'grads.npz'), **out)
+
+
+def gen_inv_grads():
+    """Gradients THROUGH THE INVERSE (reference autoregressive.py:179-229 is plain differentiable torch): loss =
+    BoltzmannKLDivLoss()(u(x), log_det_J_inv) with (x, log_det_J_inv) = flow.inverse(y) and u(x) = sum_f (c_f x_f^2 + d_f x_f),
+    backward in float64.  Stores d loss / d y and d loss / d(every trainable parameter)."""
+    out = {}
+    D = 10
+
+    def quad(y, c, d):
+        return (c * y ** 2 + d * y).sum(dim=1)
+    for name, make in grad_flows(D).items():
+        torch.manual_seed(20)
+        f32 = make(torch.float32)
+        perturb_weight_g(f32, 21)
+        B = 24
+        g = gen(23)
+        Dn = 12 if name == 'moebius' else D
+        if name == 'circular':
+            y = torch.rand(B, Dn, generator=g)
+        elif name == 'moebius':
+            ang = torch.rand(B, 6, generator=g) * 2 * np.pi
+            y = torch.stack([torch.cos(ang), torch.sin(ang)], dim=2).reshape(B, 12)
+        else:
+            y = torch.randn(B, Dn, generator=g) * 1.5
+            y[-1] = 5.0            # out-of-domain rows (both tails)
+            y[-2] = -4.5
+        c = torch.rand(Dn, generator=g) * 0.3
+        d = torch.randn(Dn, generator=g) * 0.2
+        with f64():
+            m = make(torch.float64)
+            m.load_state_dict(to_double_sd(f32.state_dict()))
+            yd = y.double().requires_grad_(True)
+            x, ldj = m.inverse(yd)
+            loss = BoltzmannKLDivLoss()(quad(x, c.double(), d.double()), ldj)
+            loss.backward()
+            out[f'{name}/loss_f64'] = npy(loss)
+            out[f'{name}/gy_f64'] = npy(yd.grad)
+            out[f'{name}/x_f64'], out[f'{name}/ldj_f64'] = npy(x), npy(ldj)
+            for k, p in m.named_parameters():
+                out[f'{name}/grad/{k}'] = npy(p.grad)
+        out[f'{name}/y'] = npy(y)
+        out[f'{name}/c'], out[f'{name}/d'] = npy(c), npy(d)
+        for k, v in f32.state_dict().items():
+            if not k.endswith('.mask'):
+                out[f'{name}/sd/{k}'] = npy(v)
+    np.savez_compressed(os.path.join(OUT, 'inv_grads.npz'), **out)
+
+
+def wide_parameters(module, seed):
+    """Deterministic parameters for the wide gradient case, a function of (name order, shape, seed) only -- the test builds
+    the same tensors on its side instead of shipping 2 x 14 M weights: v ~ U(-1, 1) / sqrt(fan_in) (masked by the module's
+    own pre-hook), g ~ U(0.5, 1.5) x row norm of the masked v, bias ~ U(-1, 1) / sqrt(fan_in)."""
+    with torch.no_grad():
+        for i, (n, p) in enumerate(module.named_parameters()):
+            g = gen(seed + i)
+            if n.endswith('weight_v') or n.endswith('.weight'):
+                p.copy_(((torch.rand(p.shape, generator=g) * 2 - 1) / p.shape[1] ** 0.5).to(p.dtype))
+            elif n.endswith('weight_g'):
+                p.copy_((torch.rand(p.shape, generator=g) + 0.5).to(p.dtype))         # (relative to norm 1 rows: see below)
+            else:
+                p.copy_(((torch.rand(p.shape, generator=g) * 2 - 1) * 0.05).to(p.dtype))
+
+
+def gen_grads_wide():
+    """Gradients of a 2-layer RQ-8 MAF at D = 300 with the default hidden width (1498; 13.9 M weights per layer): the
+    size at which the backward's k-ranges, prefix packs and split transposes are multi-tile.  The parameters are a
+    function of a seed (``wide_parameters``), so only SAMPLES of the big gradients are stored: per tensor its float64 L2
+    norm and maximum, 4096 random entries (index, float64 value, the reference's own float32 value) and the float32-vs-
+    float64 relative L2 of the whole tensor (the noise floor); small tensors (biases, weight_g, d loss / d x) whole.
+    Also one AdamW step from identical state: the parameter deltas at the same sampled entries."""
+    out = {}
+    D, B, K = 300, 256, 8
+
+    def make(dt):
+        return SequentialFlow(*[
+            MAF(degrees_in=generate_degrees(D, order=o),
+                transformer=NeuralSplineTransformer(x0=torch.full((D,), -5.0).to(dt), xf=torch.full((D,), 5.0).to(dt), n_bins=K),
+                initialize_identity=False) for o in ('ascending', 'descending')])
+    g = gen(41)
+    x = (torch.randn(B, D, generator=g)).clamp_(-4.9, 4.9)
+    c = torch.rand(D, generator=g) * 0.3
+    d = torch.randn(D, generator=g) * 0.2
+
+    def loss_of(m, xx, cc, dd):
+        y, ldj = m(xx)
+        return BoltzmannKLDivLoss()((cc * y ** 2 + dd * y).sum(dim=1), ldj)
+    torch.manual_seed(40)
+    f32 = make(torch.float32)
+    wide_parameters(f32, 400)
+    x32 = x.clone().requires_grad_(True)
+    l32 = loss_of(f32, x32, c, d)
+    l32.backward()
+    with f64():
+        m = make(torch.float64)
+        m.load_state_dict(to_double_sd(f32.state_dict()))
+        xd = x.double().requires_grad_(True)
+        loss = loss_of(m, xd, c.double(), d.double())
+        loss.backward()
+        # one AdamW step (the optimiser of the reference's maps, app/base.py) from this state, float64
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+        before = {k: p.detach().clone() for k, p in m.named_parameters()}
+        opt.step()
+    out['loss_f64'], out['loss_f32'] = npy(loss), npy(l32)
+    out['x'], out['c'], out['d'] = npy(x), npy(c), npy(d)
+    out['gx_f64'], out['gx_f32'] = npy(xd.grad), npy(x32.grad)
+    p32 = dict(f32.named_parameters())
+    for i, (k, p) in enumerate(m.named_parameters()):
+        g64, g32 = p.grad, p32[k].grad.double()
+        out[f'norm/{k}'] = npy(g64.norm())
+        out[f'max/{k}'] = npy(g64.abs().max())
+        out[f'noise/{k}'] = npy((g32 - g64).norm() / g64.norm())
+        delta = (p.detach() - before[k])
+        if p.numel() <= 16384:
+            out[f'full/{k}'] = npy(g64)
+            out[f'full32/{k}'] = npy(g32)
+            out[f'adamw/{k}'] = npy(delta)
+        else:
+            idx = torch.randint(0, p.numel(), (4096,), generator=gen(500 + i))
+            out[f'idx/{k}'] = npy(idx)
+            out[f'val/{k}'] = npy(g64.flatten()[idx])
+            out[f'val32/{k}'] = npy(g32.flatten()[idx])
+            out[f'adamw/{k}'] = npy(delta.flatten()[idx])
+    np.savez_compressed(os.path.join(OUT, 'grads_wide.npz'), **out)
 
 
 # -----------------------------------------------------------------------------
@@ -1095,6 +1226,52 @@ def gen_continuous():
     np.savez_compressed(os.path.join(OUT, 'continuous.npz'), **out)
 
 
+def gen_continuous_grads():
+    """Gradients through the ODE function of the continuous flow (reference continuous.py:231-278 with ``create_graph``:
+    what ``loss.backward()`` of a training step differentiates at every solver stage).  For the dynamics of
+    ``continuous.npz`` (same parameters): integrands (vel, trace, reg) at (t, x) with the Hutchinson (2 samples) and the
+    exact estimator, loss = <a, vel> + <b, trace> + <c, reg> with stored random a, b, c; d loss / d x and d loss / d(every
+    parameter) in float64 -- second derivatives of the dynamics (the trace is a first derivative already)."""
+    from tfep.nn.dynamics.egnn import EGNNDynamics
+    from tfep.nn.flows.continuous import ContinuousFlow
+    base = np.load(os.path.join(OUT, 'continuous.npz'))
+    out = {}
+    for name, cfg in continuous_configs().items():
+        if name == 'default':
+            continue                                    # 36 coordinates x 64 features: covered by the smaller ones
+        kw = {k: cfg[k] for k in ('node_types', 'r_cutoff', 'time_feat_dim', 'node_feat_dim', 'distance_feat_dim',
+                                  'n_layers', 'speed_factor')}
+        x32, t32, eps32 = torch.from_numpy(base[f'{name}/x']), torch.from_numpy(base[f'{name}/t']), torch.from_numpy(base[f'{name}/eps'])
+        B, D = x32.shape
+        g = gen(900 + cfg['seed'])
+        a, b, c = torch.randn(B, D, generator=g), torch.randn(B, generator=g), torch.randn(B, generator=g) * 0.1
+        out[f'{name}/a'], out[f'{name}/b'], out[f'{name}/c'] = npy(a), npy(b), npy(c)
+        with f64():
+            dyn = EGNNDynamics(initialize_identity=False, **kw)
+            sd = {k[len(name) + 4:]: torch.from_numpy(base[k]) for k in base.files if k.startswith(f'{name}/sd/')}
+            dyn.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
+            for est, n_hut in (('hutchinson', 2), ('exact', 1)):
+                flow = ContinuousFlow(dyn, trace_estimator=est, n_hutchinson_samples=n_hut, regularization=True,
+                                      requires_backward=True)
+                f = flow.ode_func
+                if est == 'hutchinson':
+                    f._eps = eps32[:n_hut].double()
+                else:
+                    f._cached_eye = torch.eye(D)
+                for prm in dyn.parameters():
+                    prm.grad = None
+                x = x32.double().requires_grad_(True)
+                vel, trace, reg = f(t32.double()[0], (x, x.new_zeros(B), x.new_zeros(B)))
+                loss = (a.double() * vel).sum() + (b.double() * trace).sum() + (c.double() * reg).sum()
+                loss.backward()
+                key = f'{name}/{est}'
+                out[f'{key}/loss'] = npy(loss)
+                out[f'{key}/gx'] = npy(x.grad)
+                for k, prm in dyn.named_parameters():
+                    out[f'{key}/grad/{k}'] = npy(prm.grad if prm.grad is not None else torch.zeros_like(prm))
+    np.savez_compressed(os.path.join(OUT, 'continuous_grads.npz'), **out)
+
+
 # -----------------------------------------------------------------------------
 # 13. PCAWhitenedFlow around a MAF (reference flows/pca.py): forward / inverse, blackened or not, gradients
 # -----------------------------------------------------------------------------
@@ -1143,12 +1320,15 @@ if __name__ == '__main__':
     gen_transformers()
     gen_flows()
     gen_grads()
+    gen_inv_grads()
+    gen_grads_wide()
     gen_loss()
     gen_wrappers()
     gen_embeddings()
     gen_bootstrap()
     gen_logger()
     gen_continuous()
+    gen_continuous_grads()
     gen_pca()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
