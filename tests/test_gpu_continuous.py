@@ -276,8 +276,10 @@ def test_flow_api_schema_and_errors():
         ContinuousFlow(dyn, solver='adams')(x.detach())
     with pytest.raises(_lib_error()):
         flow(x.cpu())                                        # no CPU fallback
-    with pytest.raises(NotImplementedError):
-        EGNNDynamics([0, 1], r_cutoff=3.0, node_feat_dim=65).cuda()(0.0, x.detach())
+    wide = EGNNDynamics([0, 1], r_cutoff=3.0, node_feat_dim=65).cuda()
+    with pytest.raises(NotImplementedError), torch.no_grad():
+        wide(0.0, x.detach())                                # the kernels stop at 64 features (loudly) ...
+    assert wide(0.0, x.detach()).shape == x.shape            # ... the differentiable torch route (grad mode) takes any width
 
 
 def _lib_error():
@@ -534,3 +536,46 @@ def test_continuous_flow_trains():
         y_k, tr_k, reg_k = flow(x)
     assert torch.allclose(y_k, y_t, rtol=1e-4, atol=1e-5) and torch.allclose(tr_k, tr_t, rtol=1e-3, atol=1e-4)
     assert torch.allclose(reg_k, reg_t, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize('cutoff', [None, 0.6])
+def test_split_exact_and_float64_oracle_at_64_atoms(cutoff):
+    """the default (split-f16) and the exact-fp32 edge products against the float64 oracle at a size
+    where every workgroup walks many sources -- 3 x 64 atoms on a jittered lattice, default widths (4 layers, 64 features,
+    64 radial functions), 8 rows; all pairs inside the cutoff, and a 0.6 nm cutoff that prunes most of them.  Velocity,
+    directional derivative J v and the Hutchinson term v . (J v)."""
+    from tfep_amd.nn.dynamics import EGNNDynamics
+    n, B = 64, 8
+    gen = torch.Generator().manual_seed(11)
+    side, a = 4, 0.215
+    grid = torch.stack(torch.meshgrid(*[torch.arange(side, dtype=torch.float32)] * 3, indexing='ij'), -1).reshape(-1, 3)[:n]
+    x = (grid[None] * a + (torch.rand(B, n, 3, generator=gen) - 0.5) * 0.3 * a).reshape(B, 3 * n)
+    v = torch.randn(B, 3 * n, generator=gen)
+    rc = 2.0 * side * a if cutoff is None else cutoff
+    torch.manual_seed(1)
+    dyn = EGNNDynamics(node_types=[i % 4 for i in range(n)], r_cutoff=rc, initialize_identity=False)
+    with torch.no_grad():
+        for prm in dyn.parameters():
+            prm.add_(0.05 * torch.randn(prm.shape, generator=gen))
+    cfg = dict(r_cutoff=rc, time_feat_dim=16, distance_feat_dim=64, n_layers=4, speed_factor=1.0)
+    sd64 = {k: (t.double() if t.is_floating_point() else t) for k, t in dyn.state_dict().items()}
+    odyn = lambda t, z: oe.egnn_dynamics(t, z, sd64, cfg)
+    t = torch.tensor(0.37, dtype=torch.float64)
+    vel64 = odyn(t, x.double())
+    jv64 = oe.jvp(odyn, t, x.double(), v.double())
+    if cutoff is not None:                                  # the cutoff really prunes
+        d = (x.reshape(B, n, 3)[:, :, None] - x.reshape(B, n, 3)[:, None]).norm(dim=-1)
+        assert 0.05 < float(((d <= rc) & (d > 0)).float().mean()) < 0.6
+    dyn = dyn.cuda()
+    errs = {}
+    for name, split in (('split', True), ('exact', False), ('default', None)):
+        dyn.split_gemm = split
+        with torch.no_grad():
+            vel, jv = dyn.jvp(0.37, x.cuda(), v.cuda())
+        errs[name] = (rel_l2(vel, vel64.numpy()), rel_l2(jv, jv64.numpy()))
+        hut = (jv.double().cpu() * v.double()).sum(dim=1)
+        np.testing.assert_allclose(hut.numpy(), (jv64 * v.double()).sum(dim=1).numpy(), rtol=2e-5, atol=2e-5 * float(jv64.abs().max()))
+    print(f'64 atoms, cutoff {cutoff}: rel L2 (velocity, J v) ' + ', '.join(f'{k} {a:.1e} / {b:.1e}' for k, (a, b) in errs.items()))
+    for name, (ev, ej) in errs.items():
+        assert ev <= 5e-6 and ej <= 1e-5, (name, ev, ej)
+    assert errs['default'] == errs['split']                 # the default arithmetic of the dynamics is the split chain

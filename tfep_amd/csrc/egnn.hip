@@ -94,79 +94,12 @@ __device__ inline void chain_gemm(const f4* __restrict__ img, const f4 (&x)[NT],
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
 constexpr float SPLIT_X_SCALE = 16.0f;       // activations enter the split products as x * 16: |x| < 4094 fits fp16
 
-// v * s = hi + lo with hi = fp16(v s), lo = fp16(v s - hi): 22 significant bits in two fp16 halves
-__device__ inline void split8(const f4& a, const f4& b, float s, h8& hi, h8& lo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float va = a[j] * s, vb = b[j] * s;
-        const _Float16 ha = (_Float16)va, hb = (_Float16)vb;
-        hi[j] = ha; hi[j + 4] = hb;
-        lo[j] = (_Float16)(va - (float)ha);
-        lo[j + 4] = (_Float16)(vb - (float)hb);
-    }
-}
-
-// acc += A B on v_mfma_f32_16x16x32_f16, accumulating IN PLACE (vDst == SrcC).  Inline asm on purpose: with the builtin,
-// hipcc (ROCm 7.2) gave destination and SrcC different registers and re-used the SrcC registers of the last products two
-// wait states later (a 64-bit shift, then the next source's global loads) while those MFMAs were still in flight -- the
-// tangent of the split chain came out different from run to run (caught by the bitwise row-independence check of
+// Inline-asm MFMAs on purpose: with the builtin, hipcc (ROCm 7.2) gave destination and SrcC different registers and re-used the
+// SrcC registers of the last products two wait states later while those MFMAs were still in flight -- the tangent of the
+// split chain came out different from run to run (caught by the bitwise row-independence check of
 // tests/test_gpu_continuous.py::test_cfg5_full_size_properties; the value tests against the goldens at 1e-5 passed).
-// In place there is no separate SrcC to clobber; A / B are read when the instruction issues.  hipcc pads nothing around
-// an asm statement: chain_gemm_split puts the wait states before the first product and after the last itself.
-__device__ inline void mfma16_acc(f4& acc, const h8& a, const h8& b) {
-    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-}
-
-// The same chain product on v_mfma_f32_16x16x32_f16 with every fp32 operand as two fp16 halves: hi*hi + lo*hi + hi*lo
-// (the dropped lo*lo is 2^-22 relative), fp32 accumulation.  One MFMA covers TWO of the 16-feature k tiles: k slot j of
-// lane group q is feature 16 (2T + (j >> 2)) + 4q + (j & 3) -- the accumulator registers of tiles 2T and 2T + 1.
-// acc / dacc must enter as zero; the caller un-scales (weights carry a per-matrix power of two, activations 16).
-template <int NT, bool TAN>
-__device__ inline void chain_gemm_split(const h8* __restrict__ img, const f4 (&x)[NT], const f4 (&dx)[NT], f4 (&acc)[NT],
-                                        f4 (&dacc)[NT], int lane) {
-    constexpr int NT2 = (NT + 1) / 2;
-    const f4 zero4 = f4{0.f, 0.f, 0.f, 0.f};
-    h8 xh[NT2], xl[NT2], dxh[NT2], dxl[NT2];
-#pragma unroll
-    for (int T = 0; T < NT2; ++T) {
-        split8(x[2 * T], (2 * T + 1 < NT) ? x[(2 * T + 1 < NT) ? 2 * T + 1 : 0] : zero4, SPLIT_X_SCALE, xh[T], xl[T]);
-        if (TAN) split8(dx[2 * T], (2 * T + 1 < NT) ? dx[(2 * T + 1 < NT) ? 2 * T + 1 : 0] : zero4, SPLIT_X_SCALE, dxh[T], dxl[T]);
-    }
-    const h8* img_lo = img + NT * NT2 * 64;
-    // the fp16 halves above come from VALU conversions: keep them (and everything else) ahead of the first product and
-    // give the VALU -> MFMA operand hazard its wait states by hand
-#pragma unroll
-    for (int tp = 0; tp < NT; ++tp) {                     // the (zero) accumulators exist in registers from here on
-        asm volatile("" : "+v"(acc[tp]));
-        if (TAN) asm volatile("" : "+v"(dacc[tp]));
-    }
-    // ... and so do the packed halves: without this pin the compiler is free to form a register of halves
-    // (v_cvt_pk_f16_f32) right in front of the product that reads it, below the wait states (seen with
-    // -fno-slp-vectorize in the reverse-pass kernel: NaN traces)
-#pragma unroll
-    for (int T = 0; T < NT2; ++T) {
-        asm volatile("" : "+v"(xh[T]), "+v"(xl[T]));
-        if (TAN) asm volatile("" : "+v"(dxh[T]), "+v"(dxl[T]));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_nop 3" ::: "memory");
-#pragma unroll
-    for (int tp = 0; tp < NT; ++tp) {
-#pragma unroll
-        for (int T = 0; T < NT2; ++T) {
-            const h8 wh = img[(tp * NT2 + T) * 64 + lane], wl = img_lo[(tp * NT2 + T) * 64 + lane];
-            mfma16_acc(acc[tp], wh, xh[T]);
-            if (TAN) mfma16_acc(dacc[tp], wh, dxh[T]);
-            mfma16_acc(acc[tp], wl, xh[T]);
-            if (TAN) mfma16_acc(dacc[tp], wl, dxh[T]);
-            mfma16_acc(acc[tp], wh, xl[T]);
-            if (TAN) mfma16_acc(dacc[tp], wh, dxl[T]);
-        }
-    }
-    // leave the matrix pipe's result latency behind before anything reads the accumulators
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
+// Accumulating in place there is no separate SrcC to clobber; A / B are read when the instruction issues.  hipcc pads nothing
+// around an asm statement: the chain puts the wait states before the first product and after the last itself.
 
 // ---- the forward edge kernel's version of the split product: operands arrive PRE-SCALED (the producers fold the x 16 into
 // arithmetic they do anyway), every fp32 -> (hi, lo) pair costs three vector instructions, and the first product of an
@@ -265,6 +198,24 @@ __device__ inline void chain_gemm_split_pre(const u4* __restrict__ img, const f4
     // leave the matrix pipe's result latency behind before anything reads the accumulators
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
+}
+
+// The same product for UNSCALED operands (the reverse-pass kernel: cotangents have no producer to fold the factor into):
+// one multiply per element in front of the pre-scaled chain.  acc / dacc need no initialisation; the caller un-scales
+// (weights carry a per-matrix power of two, activations SPLIT_X_SCALE).
+template <int NT, bool TAN>
+__device__ inline void chain_gemm_split(const h8* __restrict__ img, const f4 (&x)[NT], const f4 (&dx)[NT], f4 (&acc)[NT],
+                                        f4 (&dacc)[NT], int lane) {
+    f4 xs[NT], dxs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            xs[t][r] = x[t][r] * SPLIT_X_SCALE;
+            if (TAN) dxs[t][r] = dx[t][r] * SPLIT_X_SCALE;
+        }
+    }
+    chain_gemm_split_pre<NT, TAN>(reinterpret_cast<const u4*>(img), xs, dxs, acc, dacc, lane);
 }
 
 // exp and 1/x on the transcendental unit (v_exp_f32 / v_rcp_f32, 1 ulp each; the argument scaling x * log2(e) adds
@@ -1030,19 +981,35 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_bwd_kernel(tfep_
         // v = x_dest - x_src (graph.py:254): the lane's node is the destination (dest-owned) or the source
         const float sg = SRC_OWNED ? -1.0f : 1.0f;
         const float v0 = sg * (xa0 - s_pos[3 * i]), v1 = sg * (xa1 - s_pos[3 * i + 1]), v2 = sg * (xa2 - s_pos[3 * i + 2]);
+#if TFEP_EGNN_FAST_GEOM
+        const float d = __builtin_amdgcn_sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+#else
         const float d = sqrtf(v0 * v0 + v1 * v1 + v2 * v2);
+#endif
         const bool keep = a_ok && (an != i) && (d <= rc);
         if (__ballot(keep) == 0ull) {
             fetch_loop(i + EDGE_WAVES);
             continue;
         }
+#if TFEP_EGNN_FAST_GEOM
+        const float inv_d = keep ? fast_rcp(d) : 0.0f;
+#else
         const float inv_d = keep ? 1.0f / d : 0.0f;
+#endif
         const float u0 = v0 * inv_d, u1 = v1 * inv_d, u2 = v2 * inv_d;
         // cotangent of the DESTINATION's output position
         const float gp0 = SRC_OWNED ? s_gpos[3 * i] : gpa0, gp1 = SRC_OWNED ? s_gpos[3 * i + 1] : gpa1,
                     gp2 = SRC_OWNED ? s_gpos[3 * i + 2] : gpa2;
         float sn, cs;
+#if TFEP_EGNN_FAST_GEOM
+        {
+            const float rev = fminf(d, rc) * (0.5f / rc);                 // (pi d / rc) / (2 pi)
+            sn = __builtin_amdgcn_sinf(rev);
+            cs = __builtin_amdgcn_cosf(rev);
+        }
+#else
         sincosf(pi_rc * d, &sn, &cs);
+#endif
         const float sw = 0.5f * cs + 0.5f;
         const float dsw = -0.5f * pi_rc * sn;
         // ---- forward chain, keeping the activation derivatives (registers are the scarce resource of this kernel: the
@@ -1072,7 +1039,11 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_bwd_kernel(tfep_
             for (int r = 0; r < 4; ++r) e += wa[r] * a2[t][r];
         }
         e = sum_over_q(e) + att_b;
+#if TFEP_EGNN_FAST_GEOM
+        const float sig_e = fast_rcp(1.0f + fast_exp(-e));
+#else
         const float sig_e = 1.0f / (1.0f + expf(-e));
+#endif
         const float att = keep ? sig_e : 0.0f;
         f4 m[NT];
 #pragma unroll
