@@ -407,6 +407,10 @@ typedef struct tfep_inverse_block_desc {
     int32_t rows_per_wave;      /* 64 (or 0): one sample row per lane; 16: four lanes per row, 4x the waves (for batches
                                    that leave SIMDs idle: the chain is bound by one wave's instruction issue rate) */
     int32_t n_spline_groups;    /* kind 3: descriptors in `spline` */
+    int32_t waves_per_workgroup;/* rows_per_wave = 16 only: 1 (or 0), 2, 4, 8 independent waves per workgroup (each with its own
+                                   rows and its own LDS region: LDS per workgroup = waves x tfep_inverse_block_lds_bytes_rows).
+                                   Packs the launch onto fewer CUs, so that the look-ahead GEMMs of the next block -- whose
+                                   waves need a SIMD's whole register file -- find empty CUs beside it. */
 } tfep_inverse_block_desc;
 int tfep_inverse_block_step_ints(void);
 /* LDS bytes a launch with these sizes needs (activation cache + input entries + the weight stage); a block fits iff

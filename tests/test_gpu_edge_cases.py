@@ -353,7 +353,7 @@ def test_inverse_under_autograd_is_differentiable_and_agrees_with_the_blocked_in
 
 @pytest.mark.parametrize('order', ['ascending', 'descending', 'random'])
 @pytest.mark.parametrize('periodic', [False, True])
-@pytest.mark.parametrize('rows', [64, 16])
+@pytest.mark.parametrize('rows', [64, 16, (16, 4)])
 def test_lookahead_inverse_equals_the_in_order_inverse(order, periodic, rows):
     """The blocked inverse overlaps the wide GEMMs of block k + 1 (over the hidden units that were complete before block
     k) with block k's kernel on a side stream; what block k adds follows as one more split-K slab.  Same products, one
@@ -381,8 +381,16 @@ def test_lookahead_inverse_equals_the_in_order_inverse(order, periodic, rows):
         assert any(looks) or order == 'random' or periodic
         assert maf.inverse_lookahead is None                     # default: by batch, layer size and row layout; forced here
         maf.inverse_lookahead = True
-        maf.inverse_rows_per_wave = rows                          # (the default pairs look-ahead with 64-row waves)
+        # (the default pairs look-ahead with 64-row waves, or with 16-row waves packed four to a workgroup: the packed
+        # launch -- independent waves, each with its own LDS region -- must give the bits of the unpacked one)
+        rows, wpw = rows if isinstance(rows, tuple) else (rows, None)
+        maf.inverse_rows_per_wave, maf.inverse_waves_per_workgroup = rows, wpw
         x1, l1 = maf.inverse(y)
+        if wpw:
+            maf.inverse_waves_per_workgroup = None
+            xu, lu = maf.inverse(y)
+            assert torch.equal(xu, x1) and torch.equal(lu, l1)
+            maf.inverse_waves_per_workgroup = wpw
         x2, l2 = maf.inverse(y)
         maf.inverse_lookahead = False
         x0, l0 = maf.inverse(y)

@@ -50,7 +50,7 @@ class InverseBlockDesc(Structure):
                 ('cache_col0', c_int32 * 4), ('cache_n_old', c_int32 * 4),
                 ('cache_len', c_int32), ('max_feats', c_int32), ('spline', c_void_p),
                 ('moebius_dim', c_int32), ('moebius_unit_sphere', c_int32), ('moebius_max_radius', c_float),
-                ('rows_per_wave', c_int32), ('n_spline_groups', c_int32)]
+                ('rows_per_wave', c_int32), ('n_spline_groups', c_int32), ('waves_per_workgroup', c_int32)]
 
 
 class SplineDesc(Structure):

@@ -673,11 +673,16 @@ __device__ __forceinline__ void out_dot_mfma16(float (&prm)[IB_MAX_P], const flo
 }
 
 template <int KIND>
-__global__ void __launch_bounds__(64) inverse_block_q4_kernel(InverseBlockArgs a) {
-    extern __shared__ float cache[];              // [L][cache_len][16] hidden activations, then [max_feats][16] x values
-    const int lane = threadIdx.x;
+__global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs a) {
+    extern __shared__ float cache_all[];          // per wave: [L][cache_len][16] hidden activations, then [max_feats][16] x values
+    // blockDim.x / 64 INDEPENDENT waves per workgroup (no workgroup barrier anywhere below): wave w of the launch owns rows
+    // [16 w, 16 w + 16) and its own LDS region.  More than one wave per workgroup only packs the launch onto fewer CUs.
+    const int lane = threadIdx.x & 63;
+    const int wave_in_wg = threadIdx.x >> 6;
+    float* const cache = cache_all + (size_t)wave_in_wg * a.lds_floats;
     const int s = lane >> 2, part = lane & 3;
-    const int wave_row0 = blockIdx.x * Q4_ROWS;
+    const int wave_row0 = (blockIdx.x * (blockDim.x >> 6) + wave_in_wg) * Q4_ROWS;
+    if (wave_row0 >= a.B) return;
     const int row = wave_row0 + s;
     const bool live = row < a.B;
     const bool writer = live && part == 0;
@@ -909,7 +914,7 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
     TFEP_REQUIRE(d->rows_per_wave == 0 || d->rows_per_wave == 16 || d->rows_per_wave == 64,
                  "inverse_block: rows_per_wave must be 64 (or 0: one sample row per lane) or 16 (four lanes per row)");
     const bool q4 = d->rows_per_wave == 16;
-    const size_t lds = (q4 ? ib_lds_floats_q4(d->n_layers, d->cache_len, d->max_feats)
+    size_t lds = (q4 ? ib_lds_floats_q4(d->n_layers, d->cache_len, d->max_feats)
                            : ib_lds_floats(d->n_layers, d->cache_len, d->max_feats)) * sizeof(float);
     a.lds_floats = (int)(lds / sizeof(float));
     TFEP_REQUIRE(lds <= 160 * 1024, "inverse_block: block needs %zu bytes of LDS (> 160 KiB)", lds);
@@ -922,12 +927,18 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
               : d->kind == 2 ? inverse_block_kernel<2> : inverse_block_kernel<3>);
     const int rows = q4 ? Q4_ROWS : 64;
     if (q4) a.stage_gstride = 8 * ib_stage_cols_q4(d->cache_len, d->max_feats);
+    int wpw = d->waves_per_workgroup > 1 ? d->waves_per_workgroup : 1;
+    TFEP_REQUIRE(wpw == 1 || (q4 && (wpw == 2 || wpw == 4 || wpw == 8)), "inverse_block: waves_per_workgroup must be 1, 2, 4 or 8 (16-row layout)");
+    const size_t lds_wave = lds;
+    lds = lds_wave * wpw;
+    TFEP_REQUIRE(lds <= 160 * 1024, "inverse_block: %d waves per workgroup need %zu bytes of LDS (> 160 KiB)", wpw, lds);
     if (lds > lds_attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));
         lds_attr = lds;
     }
-    kernel<<<(unsigned)((d->B + rows - 1) / rows), 64, lds, (hipStream_t)stream>>>(a);
+    const long long n_waves = (d->B + rows - 1) / rows;
+    kernel<<<(unsigned)((n_waves + wpw - 1) / wpw), 64 * wpw, lds, (hipStream_t)stream>>>(a);
     return check_launch("inverse_block_kernel");
 }
 

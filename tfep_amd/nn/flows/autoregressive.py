@@ -714,6 +714,10 @@ class AutoregressiveFlow(torch.nn.Module):
     #: Sample rows per wave of the block kernel: 64 (one per lane) or 16 (four lanes per row); None: by batch size.
     inverse_rows_per_wave = None
 
+    #: 16-row layout: independent waves per workgroup of the block kernel (1, 2, 4, 8; halved until the workgroup's LDS fits).
+    #: More than one only packs the launch onto fewer CUs (see ``inverse_lookahead``).  None: one.
+    inverse_waves_per_workgroup = None
+
     #: Overlap the wide GEMMs of the next block with the block kernel of the current one (side stream; results are the
     #: same sums in a different association: one more split-K slab).  None: when it pays (see ``_inverse_blocked``).
     inverse_lookahead = None
@@ -995,6 +999,7 @@ class AutoregressiveFlow(torch.nn.Module):
                 # look-ahead: the long "old" part of block k + 1's wide GEMMs runs on a side stream WHILE block k's kernel
                 # (one wave per 64 samples: half the CUs at batch 8192) runs; what block k added follows as one short
                 # GEMM into an extra slab.  Two sets of slabs, alternating between blocks.
+                pack4 = False
                 look = self.inverse_lookahead
                 if os.environ.get('TFEP_INV_LOOKAHEAD') is not None:
                     look = os.environ['TFEP_INV_LOOKAHEAD'] != '0'
@@ -1006,6 +1011,17 @@ class AutoregressiveFlow(torch.nn.Module):
                     # 16-row waves sit on every CU: the GEMMs (a whole SIMD's registers per wave) find no room beside them
                     # (cfg2 layer at B = 8192, hidden GEMMs on split operands: 125.5 ms in order, 140 ms with look-ahead)
                     look = rows_per_wave == 64 and (B + 63) // 64 <= 160 and max(mplan['k_pad']) >= 4096
+                    # round 3: 16-row waves PACKED four to a workgroup (each wave its own LDS region, 39 KB at cfg2: four
+                    # fill a CU's LDS) leave whole CUs to the GEMMs: cfg2 layer at B = 8192 107.3 -> 102.5 ms (the block
+                    # kernel on 128 CUs, the look-ahead GEMMs on the other 128 now bound the block: 8 waves per CU would
+                    # need half the LDS per wave; tools/probe/inv_pack.py, profiles/r03_inverse_pack.txt)
+                    if not look and rows_per_wave == 16 and self.inverse_waves_per_workgroup is None and \
+                            not os.environ.get('TFEP_INV_WPW') and max(mplan['k_pad']) >= 4096:
+                        lds16 = _lib.load().tfep_inverse_block_lds_bytes_rows(L, fused['cache_len'], fused['max_feats'], 16)
+                        n_waves = (B + 15) // 16
+                        if 0 < 4 * lds16 <= 160 * 1024 and 128 < n_waves <= 4 * 160:
+                            # onto ~128 CUs: two waves per workgroup up to 4096 rows (92.2 -> 86.1 ms), four up to 10 240
+                            look, pack4 = True, (2 if n_waves <= 256 else 4)
                 look = bool(look) and len(bp['blocks']) > 1
                 n_par = 2 if look else 1
                 zs = [[torch.empty(S + 1, B, ops.round_up(wz[l], 4), **f32) for l in range(L)] for _ in range(n_par)]
@@ -1033,6 +1049,16 @@ class AutoregressiveFlow(torch.nn.Module):
                 d.wout, d.ldwout = w_out.data_ptr(), w_out.shape[1]
                 d.cache_len, d.max_feats = fused['cache_len'], fused['max_feats']
                 d.rows_per_wave = rows_per_wave
+                wpw = self.inverse_waves_per_workgroup
+                if os.environ.get('TFEP_INV_WPW'):
+                    wpw = int(os.environ['TFEP_INV_WPW'])
+                if wpw is None and pack4 and look:
+                    wpw = int(pack4)
+                if rows_per_wave == 16 and wpw:
+                    lds16 = _lib.load().tfep_inverse_block_lds_bytes_rows(L, fused['cache_len'], fused['max_feats'], 16)
+                    while wpw > 1 and wpw * lds16 > 160 * 1024:
+                        wpw //= 2
+                    d.waves_per_workgroup = max(1, int(wpw))
                 d.spline = None if spl is None else ctypes.cast(spl if kind == 3 else ctypes.pointer(spl), ctypes.c_void_p)
                 d.emb_lower, d.emb_upper = self._input_columns()[2]
                 stream = _lib.stream_of(y)
