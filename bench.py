@@ -59,7 +59,7 @@ def build_flow(D, n_layers, n_bins, device, seed=0):
 def cpu_baseline(flow, D, n_bins, chunks):
     """Time the torch-CPU restatement of the path (``oracle/torch_cpu.py``: fp32, no autograd, every host core through
     torch's intra-op pool / MKL) for ONE MAF layer on a chunk of samples and scale to all layers,
-    once per chunk size in ``chunks``: 1024 is BASELINE.md's protocol; a larger chunk amortises the per-call weight passes
+    once per chunk size in ``chunks`` (default 1024 and 4096): 1024 is BASELINE.md's protocol; a larger chunk amortises the per-call weight passes
     (weight-norm + mask over 5.6 GB per layer, ~2 s whatever the chunk) and is the CPU's best case.  ``value`` is the
     BEST of the runs.  kind 'port': the CPU restatement of the reference algorithm, not the reference itself."""
     from oracle import torch_cpu
@@ -210,7 +210,7 @@ def main():
                     help='strong (BASELINE cfg3): the batch is sharded over the ranks; weak: --batch rows per rank')
     ap.add_argument('--layers', type=int, default=4)
     ap.add_argument('--bins', type=int, default=8)
-    ap.add_argument('--cpu-chunks', type=int, nargs='+', default=[1024, 8192])
+    ap.add_argument('--cpu-chunks', type=int, nargs='+', default=[1024, 4096])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extra-arms', action='store_true',
                     help='skip the cached-repack and exact-fp32 arms and the one-layer inverse / training-step lines')
@@ -392,7 +392,7 @@ def main():
         # dense fp16 peak
         peak = PEAK_F16_MFMA_TFLOPS / 3.0
         kernel = 'split_gemm_kernel<25,EPI_SPLINE> (fused MADE output layer + RQ spline + log-det; 3 x v_mfma_f32_16x16x32_f16 per fp32 product)'
-        tnames = ('r02_pmc_traffic.json', 'r01_final_pmc_traffic.json')
+        tnames = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_final_pmc_traffic.json')
     else:
         peak = PEAK_FP32_MFMA_TFLOPS
         kernel = 'gemm_kernel<2,25,EPI_SPLINE> (fused MADE output layer + RQ spline + log-det; v_mfma_f32_16x16x4_f32)'

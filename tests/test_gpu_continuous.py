@@ -276,10 +276,17 @@ def test_flow_api_schema_and_errors():
         ContinuousFlow(dyn, solver='adams')(x.detach())
     with pytest.raises(_lib_error()):
         flow(x.cpu())                                        # no CPU fallback
-    wide = EGNNDynamics([0, 1], r_cutoff=3.0, node_feat_dim=65).cuda()
-    with pytest.raises(NotImplementedError), torch.no_grad():
-        wide(0.0, x.detach())                                # the kernels stop at 64 features (loudly) ...
-    assert wide(0.0, x.detach()).shape == x.shape            # ... the differentiable torch route (grad mode) takes any width
+    # the kernels stop at 64 features; wider dynamics run on the torch route (with or without grad mode), a flow over
+    # them on autograd like any torch dynamics; the kernel-only products say so loudly
+    wide = EGNNDynamics([0, 1], r_cutoff=3.0, node_feat_dim=65, initialize_identity=False).cuda()
+    assert not wide.kernels_supported() and dyn.cuda().kernels_supported()
+    with torch.no_grad():
+        v0 = wide(0.0, x.detach())
+        yw, tw = ContinuousFlow(wide, solver='rk4', solver_options={'step_size': 0.5}, regularization=False)(x.detach())
+    assert v0.shape == x.shape and torch.allclose(wide(0.0, x.detach()).detach(), v0, rtol=1e-5, atol=1e-6)
+    assert yw.shape == x.shape and bool(torch.isfinite(tw).all())
+    with pytest.raises(NotImplementedError):
+        wide.jvp(0.0, x.detach(), torch.ones_like(x))
 
 
 def _lib_error():

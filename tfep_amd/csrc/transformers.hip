@@ -132,32 +132,48 @@ __global__ void __launch_bounds__(256) spline_kernel(const float* __restrict__ x
 }
 
 // ---------------------------------------------------------------- Moebius (moebius.py:374-478)
-// One lane per d-vector; the map and its closed-form log|det J| are in moebius.h.
+// One lane per d-vector; the map and its closed-form log|det J| are in moebius.h.  DIM > 0: the dimension is a compile-time
+// constant (d = 2, 3: the loops of moebius_vector unroll to d steps instead of MOEBIUS_MAX_DIM predicated ones; the
+// d = 2 vector is one 8-byte load / store) -- the same arithmetic in the same order, bit for bit; DIM = 0: any d.
+template <int DIM>
 __global__ void __launch_bounds__(256) moebius_kernel(const float* __restrict__ x, int64_t ldx,
-                                                      const float* __restrict__ params, int64_t ldp, int dim,
+                                                      const float* __restrict__ params, int64_t ldp, int dim_rt,
                                                       float max_radius, int unit_sphere, float sign,
                                                       float* __restrict__ y, int64_t ldy, float* __restrict__ ldj,
                                                       int accumulate, int B, int D) {
     const int b = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (b >= B) return;
     const int lane = threadIdx.x & 63;
+    const int dim = DIM > 0 ? DIM : dim_rt;
     const int nvec = D / dim;
     const float* xr = x + (int64_t)b * ldx;
     const float* pr = params + (int64_t)b * ldp;
     float* yr = y + (int64_t)b * ldy;
+    // (8-byte accesses for d = 2 when the three rows start on 8-byte boundaries: wave uniform)
+    const bool vec2 = DIM == 2 && (((uintptr_t)xr | (uintptr_t)pr | (uintptr_t)yr) & 7u) == 0;
     double acc = 0.0;
     for (int v = lane; v < nvec; v += 64) {
         double xv[MOEBIUS_MAX_DIM], wv[MOEBIUS_MAX_DIM], yv[MOEBIUS_MAX_DIM];
+        if (vec2) {
+            const float2 xx = reinterpret_cast<const float2*>(xr)[v], pp = reinterpret_cast<const float2*>(pr)[v];
+            xv[0] = (double)xx.x; xv[1] = (double)xx.y;
+            wv[0] = (double)(sign * pp.x); wv[1] = (double)(sign * pp.y);
+        } else {
 #pragma unroll
-        for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
-            if (i < dim) {
-                xv[i] = (double)xr[v * dim + i];
-                wv[i] = (double)(sign * pr[v * dim + i]);
-            }
+            for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+                if (i < dim) {
+                    xv[i] = (double)xr[v * dim + i];
+                    wv[i] = (double)(sign * pr[v * dim + i]);
+                }
+        }
         acc += moebius_vector(xv, wv, dim, max_radius, unit_sphere, yv);
+        if (vec2) {
+            reinterpret_cast<float2*>(yr)[v] = float2{(float)yv[0], (float)yv[1]};
+        } else {
 #pragma unroll
-        for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
-            if (i < dim) yr[v * dim + i] = (float)yv[i];
+            for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+                if (i < dim) yr[v * dim + i] = (float)yv[i];
+        }
     }
     acc = wave_sum(acc);
     if (ldj) store_ldj(ldj, b, acc, accumulate);
@@ -289,9 +305,9 @@ int tfep_moebius_forward(const float* x, int64_t ldx, const float* params, int64
     TFEP_REQUIRE(D % dimension == 0, "moebius: n_features=%d is not a multiple of dimension=%d", D, dimension);
     TFEP_REQUIRE(sign == 1 || sign == -1, "moebius: sign must be +1 or -1");
     if (B == 0) return TFEP_OK;
-    moebius_kernel<<<row_blocks(B), 256, 0, (hipStream_t)stream>>>(x, ldx, params, ldp, dimension, max_radius,
-                                                                   unit_sphere, (float)sign, y, ldy, log_det_J,
-                                                                   accumulate, B, D);
+    auto kernel = dimension == 2 ? moebius_kernel<2> : dimension == 3 ? moebius_kernel<3> : moebius_kernel<0>;
+    kernel<<<row_blocks(B), 256, 0, (hipStream_t)stream>>>(x, ldx, params, ldp, dimension, max_radius, unit_sphere, (float)sign, y,
+                                                           ldy, log_det_J, accumulate, B, D);
     return check_launch("moebius_kernel");
 }
 

@@ -84,7 +84,15 @@ class EGNNDynamics(FixedGraph):
         """Velocity ``(batch_size, n_nodes*3)`` at time ``t`` and positions ``x``."""
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return self.torch_forward(t, x)                    # differentiable (to any order): see there
+        if not self.kernels_supported():
+            return self.torch_forward(t, x)                    # widths beyond the kernels' 64: the same map, slower
         return self._run(t, x)[0]
+
+    def kernels_supported(self):
+        """The HIP kernels cover ``node_feat_dim, distance_feat_dim <= 64`` (one wave holds a feature column in
+        registers); wider dynamics run on ``torch_forward`` (and a ``ContinuousFlow`` over them on autograd, like any
+        user-supplied torch dynamics).  ``jvp`` / ``vjp`` exist for the kernels only."""
+        return _lib.load().tfep_egnn_tile(self._dims[1], self._dims[2]) != 0
 
     def torch_forward(self, t, x):
         """The same velocity as a composite of torch operators on the device -- the DIFFERENTIABLE route.

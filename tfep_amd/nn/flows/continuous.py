@@ -125,7 +125,11 @@ class _ODEFunc(torch.nn.Module):
             raise ValueError('trace_estimator must be one of {}'.format([e.name for e in self.TraceEstimators]))
 
     def uses_kernels(self):
-        return callable(getattr(self.dynamics, 'jvp', None)) and hasattr(self.dynamics, '_run')
+        dyn = self.dynamics
+        if not (callable(getattr(dyn, 'jvp', None)) and hasattr(dyn, '_run')):
+            return False
+        supported = getattr(dyn, 'kernels_supported', None)
+        return True if supported is None else bool(supported())
 
     def before_odeint(self, x):
         """New Hutchinson noise for a new integration (continuous.py:223-229)."""
