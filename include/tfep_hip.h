@@ -411,12 +411,16 @@ typedef struct tfep_inverse_block_desc {
                                    rows and its own LDS region: LDS per workgroup = waves x tfep_inverse_block_lds_bytes_rows).
                                    Packs the launch onto fewer CUs, so that the look-ahead GEMMs of the next block -- whose
                                    waves need a SIMD's whole register file -- find empty CUs beside it. */
+    int32_t paired;             /* rows_per_wave = 16 only: every workgroup is a PAIR of waves on the same 16 rows -- a consumer
+                                   (the chain) and a loader that stages the next stage's weights and pre-activations into
+                                   the other half of a double-buffered LDS stage (LDS: tfep_inverse_block_lds_bytes_paired) */
 } tfep_inverse_block_desc;
 int tfep_inverse_block_step_ints(void);
 /* LDS bytes a launch with these sizes needs (activation cache + input entries + the weight stage); a block fits iff
  * this is <= 160 KiB.  -1 for invalid arguments.  (_rows: for the given rows_per_wave; the plain form is 64.) */
 int64_t tfep_inverse_block_lds_bytes(int n_layers, int cache_len, int max_feats);
 int64_t tfep_inverse_block_lds_bytes_rows(int n_layers, int cache_len, int max_feats, int rows_per_wave);
+int64_t tfep_inverse_block_lds_bytes_paired(int n_layers, int cache_len, int max_feats);
 int tfep_inverse_block(const tfep_inverse_block_desc* desc, void* stream);
 
 /* ------------------------------------------------------------------------- */

@@ -353,7 +353,7 @@ def test_inverse_under_autograd_is_differentiable_and_agrees_with_the_blocked_in
 
 @pytest.mark.parametrize('order', ['ascending', 'descending', 'random'])
 @pytest.mark.parametrize('periodic', [False, True])
-@pytest.mark.parametrize('rows', [64, 16, (16, 4)])
+@pytest.mark.parametrize('rows', [64, 16, (16, 4), (16, 'paired')])
 def test_lookahead_inverse_equals_the_in_order_inverse(order, periodic, rows):
     """The blocked inverse overlaps the wide GEMMs of block k + 1 (over the hidden units that were complete before block
     k) with block k's kernel on a side stream; what block k adds follows as one more split-K slab.  Same products, one
@@ -383,14 +383,18 @@ def test_lookahead_inverse_equals_the_in_order_inverse(order, periodic, rows):
         maf.inverse_lookahead = True
         # (the default pairs look-ahead with 64-row waves, or with 16-row waves packed four to a workgroup: the packed
         # launch -- independent waves, each with its own LDS region -- must give the bits of the unpacked one)
+        # ... and a PAIRED launch (a loader wave beside every chain wave, double-buffered stage, one workgroup barrier per
+        # stage) the bits of the single-wave one: the consumer does the same arithmetic in the same order
         rows, wpw = rows if isinstance(rows, tuple) else (rows, None)
-        maf.inverse_rows_per_wave, maf.inverse_waves_per_workgroup = rows, wpw
+        paired = wpw == 'paired'
+        wpw = None if paired else wpw
+        maf.inverse_rows_per_wave, maf.inverse_waves_per_workgroup, maf.inverse_paired = rows, wpw, paired
         x1, l1 = maf.inverse(y)
-        if wpw:
-            maf.inverse_waves_per_workgroup = None
+        if wpw or paired:
+            maf.inverse_waves_per_workgroup, maf.inverse_paired = None, False
             xu, lu = maf.inverse(y)
             assert torch.equal(xu, x1) and torch.equal(lu, l1)
-            maf.inverse_waves_per_workgroup = wpw
+            maf.inverse_waves_per_workgroup, maf.inverse_paired = wpw, paired
         x2, l2 = maf.inverse(y)
         maf.inverse_lookahead = False
         x0, l0 = maf.inverse(y)
@@ -449,6 +453,13 @@ def test_block_kernel_row_layouts_agree(kind):
             out[rows] = maf.inverse(y)
             again = maf.inverse(y)
             assert torch.equal(out[rows][0], again[0]) and torch.equal(out[rows][1], again[1])
+        # the 16-row layout with and without the loader wave (every kind of the block kernel): the same bits
+        maf.inverse_rows_per_wave = 16
+        for paired in (True, False):
+            maf.inverse_paired = paired
+            xp, lp = maf.inverse(y)
+            assert torch.equal(xp, out[16][0]) and torch.equal(lp, out[16][1]), paired
+        maf.inverse_paired = None
     assert float((out[16][0] - out[64][0]).abs().max()) < 5e-5 and float((out[16][1] - out[64][1]).abs().max()) < 5e-4
     assert float((out[16][0] - x).abs().max(dim=1).values.median()) < 1e-3
     # the entry point rejects any other layout

@@ -50,7 +50,7 @@ class InverseBlockDesc(Structure):
                 ('cache_col0', c_int32 * 4), ('cache_n_old', c_int32 * 4),
                 ('cache_len', c_int32), ('max_feats', c_int32), ('spline', c_void_p),
                 ('moebius_dim', c_int32), ('moebius_unit_sphere', c_int32), ('moebius_max_radius', c_float),
-                ('rows_per_wave', c_int32), ('n_spline_groups', c_int32), ('waves_per_workgroup', c_int32)]
+                ('rows_per_wave', c_int32), ('n_spline_groups', c_int32), ('waves_per_workgroup', c_int32), ('paired', c_int32)]
 
 
 class SplineDesc(Structure):
@@ -144,6 +144,7 @@ _SIGNATURES = {
     'tfep_inverse_block_step_ints': (c_int, []),
     'tfep_inverse_block_lds_bytes': (c_int64, [c_int, c_int, c_int]),
     'tfep_inverse_block_lds_bytes_rows': (c_int64, [c_int, c_int, c_int, c_int]),
+    'tfep_inverse_block_lds_bytes_paired': (c_int64, [c_int, c_int, c_int]),
     'tfep_inverse_block': (c_int, [POINTER(InverseBlockDesc), _P]),
     'tfep_diag_mfma_peak': (c_int, [_P, c_int, c_int, _P]),
     'tfep_masked_linear_gemm': (c_int, [POINTER(GemmDesc), _P]),

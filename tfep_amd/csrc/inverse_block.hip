@@ -527,6 +527,12 @@ __host__ __device__ inline size_t ib_lds_floats_q4(int L, int cache_len, int max
            IB_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH + (size_t)IB_MAX_P * Q4_P_PITCH;
 }
 
+// the paired (loader + consumer) launch: a second weight stage and a second pre-activation stage
+__host__ __device__ inline size_t ib_lds_floats_q4_paired(int L, int cache_len, int max_feats) {
+    return ib_lds_floats_q4(L, cache_len, max_feats) + (size_t)IB_STAGE_ROWS * ib_stage_cols_q4(cache_len, max_feats) + IB_LDS_SLACK +
+           (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
+}
+
 // zs[v * Q4_Z_PITCH + i] = sum_s z[s * slab_stride + (wave_row0 + i) * ldz + base + v * vstride],  v < nv <= 32, i < 16
 __device__ __forceinline__ void stage_z16(float* __restrict__ zs, const float* __restrict__ z, int64_t ldz, int wave_row0, int n_rows_total,
                                           int base, int vstride, int nv, int slabs, int64_t slab_stride, int lane) {
@@ -672,17 +678,30 @@ __device__ __forceinline__ void out_dot_mfma16(float (&prm)[IB_MAX_P], const flo
     __builtin_amdgcn_wave_barrier();                                     // (the next feature overwrites pb)
 }
 
-template <int KIND>
+// PAIR: the workgroup is TWO waves on the same 16 rows -- a CONSUMER (the chain: dots, transformer inverse, stores) and a
+// LOADER that stages the weights and pre-activations of the NEXT stage into the other half of a double-buffered stage while
+// the consumer works on the current one.  Nothing the loader fetches depends on the chain (packed weights, the block GEMMs'
+// slabs), and a lone wave issues a vector instruction only every ~8 cycles (tools/probe/valu_rate_probe.hip): the staging
+// was 48 % of the chain's instructions (probe build without it: cfg2 layer, B = 8192, 106.8 -> 81.3 ms).  One workgroup
+// barrier per stage: the loader fills buffer t & 1 then meets the barrier, the consumer meets it then reads buffer t & 1;
+// the loader's next fill (t + 1, the other buffer) overlaps the consumer's stage t, and its fill t + 2 comes after barrier
+// t + 1, which the consumer reaches only when it is done with buffer t & 1.  Measured (cfg2 layer): B = 8192 107.3 -> 95.7 ms,
+// 4096 92.2 -> 81.0, 2048 88.5 -> 77.5 -- less than the probe's 81 at 8192 because the loader is ONE stage ahead and the
+// stages of a degree are unequal: the big fill (output rows) overlaps the small hidden-layer dot and the big dot + spline
+// overlaps a small fill.  A loader a whole degree ahead needs four stage buffers (96 KB per pair: one pair per CU) or a
+// dedicated double buffer for the output rows; not built.
+template <int KIND, bool PAIR>
 __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs a) {
-    extern __shared__ float cache_all[];          // per wave: [L][cache_len][16] hidden activations, then [max_feats][16] x values
-    // blockDim.x / 64 INDEPENDENT waves per workgroup (no workgroup barrier anywhere below): wave w of the launch owns rows
+    extern __shared__ float cache_all[];          // per wave (pair): [L][cache_len][16] hidden activations, then [max_feats][16] x values
+    // not PAIR: blockDim.x / 64 INDEPENDENT waves per workgroup (no workgroup barrier): wave w of the launch owns rows
     // [16 w, 16 w + 16) and its own LDS region.  More than one wave per workgroup only packs the launch onto fewer CUs.
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = threadIdx.x >> 6;
-    float* const cache = cache_all + (size_t)wave_in_wg * a.lds_floats;
+    const bool consumer = !PAIR || wave_in_wg == 0, loader = !PAIR || wave_in_wg == 1;
+    float* const cache = cache_all + (PAIR ? (size_t)0 : (size_t)wave_in_wg * a.lds_floats);
     const int s = lane >> 2, part = lane & 3;
-    const int wave_row0 = (blockIdx.x * (blockDim.x >> 6) + wave_in_wg) * Q4_ROWS;
-    if (wave_row0 >= a.B) return;
+    const int wave_row0 = (PAIR ? (int)blockIdx.x : (int)(blockIdx.x * (blockDim.x >> 6) + wave_in_wg)) * Q4_ROWS;
+    if (wave_row0 >= a.B) return;                  // (both waves of a pair alike)
     const int row = wave_row0 + s;
     const bool live = row < a.B;
     const bool writer = live && part == 0;
@@ -690,19 +709,41 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
     const bool live16 = wave_row0 + (lane & 15) < a.B;
     const int64_t r16 = live16 ? wave_row0 + (lane & 15) : 0;
     float* xc = cache + (size_t)a.L * a.cache_len * Q4_ROWS;
-    float* stg = xc + (size_t)a.max_feats * Q4_ROWS;
+    float* const stg0 = xc + (size_t)a.max_feats * Q4_ROWS;
     const int gstride = a.stage_gstride;
-    float* zs = stg + (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK;
-    float* pb = zs + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
+    float* const zs0 = stg0 + (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* pb = zs0 + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
+    // PAIR: the second stage buffers follow the single-wave layout
+    float* const stg1 = pb + (size_t)IB_MAX_P * Q4_P_PITCH;
+    float* const zs1 = stg1 + (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK;
+    const int lds_total = a.lds_floats + (PAIR ? (int)((size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH) : 0);
+    float* stg = stg0;
+    float* zs = zs0;
+    int parity = 0;
+    auto stage_done = [&]() __attribute__((always_inline)) {       // PAIR: the hand-over of one stage (see the kernel's header)
+        // (__syncthreads(), vmcnt drain included: a barrier that waits for LDS only -- s_waitcnt lgkmcnt(0); s_barrier --
+        // measured SLOWER, 95.7 -> 98.2 ms per cfg2 layer at B = 8192)
+        if (PAIR) __syncthreads();
+    };
+    auto next_stage = [&]() __attribute__((always_inline)) {
+        if (PAIR) {
+            parity ^= 1;
+            stg = parity ? stg1 : stg0;
+            zs = parity ? zs1 : zs0;
+        }
+    };
 
-    for (int j = lane * 4; j < a.lds_floats; j += 256) *(ib_f4_alias*)(cache + j) = ib_f4{0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_wave_barrier();
-    for (int l = 0; l < a.L; ++l) {
-        const float* hr = a.h[l] + r * a.ldh[l] + a.c0[l];
-        float* cl = cache + (size_t)l * a.cache_len * Q4_ROWS;
-        for (int j = part; j < a.n_old[l]; j += 4) cl[j * Q4_ROWS + s] = hr[j];
+    if (consumer) {
+        for (int j = lane * 4; j < lds_total; j += 256) *(ib_f4_alias*)(cache + j) = ib_f4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_wave_barrier();
+        for (int l = 0; l < a.L; ++l) {
+            const float* hr = a.h[l] + r * a.ldh[l] + a.c0[l];
+            float* cl = cache + (size_t)l * a.cache_len * Q4_ROWS;
+            for (int j = part; j < a.n_old[l]; j += 4) cl[j * Q4_ROWS + s] = hr[j];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
+    if (PAIR) __syncthreads();                      // (the loader's first fill must not meet the zero fill)
 
     double ldj_acc = 0.0;
     for (int st_i = 0; st_i < a.n_steps; ++st_i) {
@@ -716,13 +757,21 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
             const int len = ib_round8(l == 0 ? ke : ke - kb);
             for (int ub = row0; ub < row0 + n; ub += IB_STAGE_ROWS) {
                 const int nb = min(IB_STAGE_ROWS, row0 + n - ub);
-                if (l == 0) stage_gather(stg, gstride, a.w[0], a.ldw[0], ub, nb, a.in_cols, ke, lane);
-                else stage_rows(stg, gstride, a.w[l], a.ldw[l], ub, 1, nb, kb, ke, lane);
-                stage_z16(zs, a.z[l], a.ldz[l], wave_row0, a.B, ub, 1, nb, a.z_slabs[l], a.z_slab_stride[l], lane);
-                for (int u0 = ub; u0 < ub + nb; u0 += 16)
-                    hidden_mfma16(stg, gstride, u0 - ub, zs, act, len, min(16, ub + nb - u0), cl + (size_t)(u0 - a.c0[l]) * Q4_ROWS,
-                                  h16 + u0, live16, lane);
-                __builtin_amdgcn_wave_barrier();
+#ifndef TFEP_PROBE_NO_STAGE          // (timing probe, wrong results: what a loader wave could take off the chain)
+                if (loader) {
+                    if (l == 0) stage_gather(stg, gstride, a.w[0], a.ldw[0], ub, nb, a.in_cols, ke, lane);
+                    else stage_rows(stg, gstride, a.w[l], a.ldw[l], ub, 1, nb, kb, ke, lane);
+                    stage_z16(zs, a.z[l], a.ldz[l], wave_row0, a.B, ub, 1, nb, a.z_slabs[l], a.z_slab_stride[l], lane);
+                }
+#endif
+                stage_done();
+                if (consumer) {
+                    for (int u0 = ub; u0 < ub + nb; u0 += 16)
+                        hidden_mfma16(stg, gstride, u0 - ub, zs, act, len, min(16, ub + nb - u0), cl + (size_t)(u0 - a.c0[l]) * Q4_ROWS,
+                                      h16 + u0, live16, lane);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                next_stage();
             }
         }
         // ---- parameters and transformer inverse of this degree's features
@@ -746,30 +795,45 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
         if constexpr (KIND == 2) {
             const int dim = a.mb_dim;
             for (int f = 0; f < n_d; f += dim) {
-                stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, 1, dim, okb, oke, lane);
-                stage_z16(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, 1, dim, a.zout_slabs, a.zout_slab_stride, lane);
-                float acc[IB_MAX_P];
-                out_dot_mfma16(acc, stg, gstride, zs, cp, pb, olen, dim, lane);
-                double yv[MOEBIUS_MAX_DIM], wv[MOEBIUS_MAX_DIM], xv[MOEBIUS_MAX_DIM];
+                if (loader) {
+                    stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, 1, dim, okb, oke, lane);
+                    stage_z16(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, 1, dim, a.zout_slabs, a.zout_slab_stride, lane);
+                }
+                stage_done();
+                if (consumer) {
+                    float acc[IB_MAX_P];
+                    out_dot_mfma16(acc, stg, gstride, zs, cp, pb, olen, dim, lane);
+                    double yv[MOEBIUS_MAX_DIM], wv[MOEBIUS_MAX_DIM], xv[MOEBIUS_MAX_DIM];
 #pragma unroll
-                for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
-                    if (i < dim) {
-                        yv[i] = (double)a.y[r * a.ldy + a.feat_sel[foff + f + i]];
-                        wv[i] = (double)(-acc[i]);
-                    }
-                ldj_acc += moebius_vector(yv, wv, dim, a.mb_max_radius, a.mb_unit_sphere, xv);
+                    for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+                        if (i < dim) {
+                            yv[i] = (double)a.y[r * a.ldy + a.feat_sel[foff + f + i]];
+                            wv[i] = (double)(-acc[i]);
+                        }
+                    ldj_acc += moebius_vector(yv, wv, dim, a.mb_max_radius, a.mb_unit_sphere, xv);
 #pragma unroll
-                for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
-                    if (i < dim) emit(foff + f + i, (float)xv[i]);
-                __builtin_amdgcn_wave_barrier();
+                    for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+                        if (i < dim) emit(foff + f + i, (float)xv[i]);
+                    __builtin_amdgcn_wave_barrier();
+                }
+                next_stage();
             }
         } else {
         const SplineArgs& spa = KIND == 3 ? a.spg[st[4 * IB_MAX_LAYERS + 5]] : a.sp;      // (wave uniform)
         const int nP = KIND == 3 ? spa.P : a.P;
         for (int f = 0; f < n_d; ++f) {
             float prm[IB_MAX_P];
-            stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, n_d, nP, okb, oke, lane);   // the feature's P rows at once
-            stage_z16(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, n_d, nP, a.zout_slabs, a.zout_slab_stride, lane);
+#ifndef TFEP_PROBE_NO_STAGE
+            if (loader) {
+                stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, n_d, nP, okb, oke, lane);   // the feature's P rows at once
+                stage_z16(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, n_d, nP, a.zout_slabs, a.zout_slab_stride, lane);
+            }
+#endif
+            stage_done();
+            if (!consumer) {                     // (PAIR: the loader goes on to the next stage's fetches)
+                next_stage();
+                continue;
+            }
             out_dot_mfma16(prm, stg, gstride, zs, cp, pb, olen, nP, lane);
             const int sel = a.feat_sel[foff + f];
             const float yv = a.y[r * a.ldy + sel];
@@ -819,10 +883,11 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
                 if (per) a.xpad[r * a.ldxpad + icol + 1] = in1;
             }
             __builtin_amdgcn_wave_barrier();
+            next_stage();
         }
         }
     }
-    if (writer) a.ldj[row] = (float)((double)a.ldj[row] + ldj_acc);
+    if (consumer && writer) a.ldj[row] = (float)((double)a.ldj[row] + ldj_acc);
 }
 
 }  // namespace tfep
@@ -836,6 +901,11 @@ int tfep_inverse_block_step_ints(void) { return IB_STEP_INTS; }
 int64_t tfep_inverse_block_lds_bytes(int n_layers, int cache_len, int max_feats) {
     if (n_layers < 1 || cache_len < 0 || max_feats < 0) return -1;
     return (int64_t)(ib_lds_floats(n_layers, cache_len, max_feats) * sizeof(float));
+}
+
+int64_t tfep_inverse_block_lds_bytes_paired(int n_layers, int cache_len, int max_feats) {
+    if (n_layers < 1 || cache_len < 0 || max_feats < 0) return -1;
+    return (int64_t)(ib_lds_floats_q4_paired(n_layers, cache_len, max_feats) * sizeof(float));
 }
 
 int64_t tfep_inverse_block_lds_bytes_rows(int n_layers, int cache_len, int max_feats, int rows_per_wave) {
@@ -918,19 +988,24 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
                            : ib_lds_floats(d->n_layers, d->cache_len, d->max_feats)) * sizeof(float);
     a.lds_floats = (int)(lds / sizeof(float));
     TFEP_REQUIRE(lds <= 160 * 1024, "inverse_block: block needs %zu bytes of LDS (> 160 KiB)", lds);
-    static size_t lds_attr_on[8][TFEP_MAX_DEVICES] = {};       // per kernel and device: a process may drive several GPUs
-    size_t& lds_attr = lds_attr_on[d->kind + (q4 ? 4 : 0)][current_device_slot()];
+    static size_t lds_attr_on[12][TFEP_MAX_DEVICES] = {};      // per kernel and device: a process may drive several GPUs
+    const bool pair = q4 && d->paired != 0;
+    size_t& lds_attr = lds_attr_on[d->kind + (q4 ? 4 : 0) + (pair ? 4 : 0)][current_device_slot()];
     void (*kernel)(InverseBlockArgs) =
-        q4 ? (d->kind == 0 ? inverse_block_q4_kernel<0> : d->kind == 1 ? inverse_block_q4_kernel<1>
-              : d->kind == 2 ? inverse_block_q4_kernel<2> : inverse_block_q4_kernel<3>)
-           : (d->kind == 0 ? inverse_block_kernel<0> : d->kind == 1 ? inverse_block_kernel<1>
-              : d->kind == 2 ? inverse_block_kernel<2> : inverse_block_kernel<3>);
+        pair ? (d->kind == 0 ? inverse_block_q4_kernel<0, true> : d->kind == 1 ? inverse_block_q4_kernel<1, true>
+                : d->kind == 2 ? inverse_block_q4_kernel<2, true> : inverse_block_q4_kernel<3, true>)
+        : q4 ? (d->kind == 0 ? inverse_block_q4_kernel<0, false> : d->kind == 1 ? inverse_block_q4_kernel<1, false>
+                : d->kind == 2 ? inverse_block_q4_kernel<2, false> : inverse_block_q4_kernel<3, false>)
+             : (d->kind == 0 ? inverse_block_kernel<0> : d->kind == 1 ? inverse_block_kernel<1>
+                : d->kind == 2 ? inverse_block_kernel<2> : inverse_block_kernel<3>);
     const int rows = q4 ? Q4_ROWS : 64;
     if (q4) a.stage_gstride = 8 * ib_stage_cols_q4(d->cache_len, d->max_feats);
     int wpw = d->waves_per_workgroup > 1 ? d->waves_per_workgroup : 1;
     TFEP_REQUIRE(wpw == 1 || (q4 && (wpw == 2 || wpw == 4 || wpw == 8)), "inverse_block: waves_per_workgroup must be 1, 2, 4 or 8 (16-row layout)");
+    TFEP_REQUIRE(!d->paired || (q4 && wpw == 1), "inverse_block: paired needs rows_per_wave = 16 and one pair per workgroup");
     const size_t lds_wave = lds;
-    lds = lds_wave * wpw;
+    lds = pair ? ib_lds_floats_q4_paired(d->n_layers, d->cache_len, d->max_feats) * sizeof(float) : lds_wave * wpw;
+    if (pair) wpw = 2;                                  // the pair: consumer + loader on the same rows
     TFEP_REQUIRE(lds <= 160 * 1024, "inverse_block: %d waves per workgroup need %zu bytes of LDS (> 160 KiB)", wpw, lds);
     if (lds > lds_attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -938,7 +1013,7 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
         lds_attr = lds;
     }
     const long long n_waves = (d->B + rows - 1) / rows;
-    kernel<<<(unsigned)((n_waves + wpw - 1) / wpw), 64 * wpw, lds, (hipStream_t)stream>>>(a);
+    kernel<<<(unsigned)(pair ? n_waves : (n_waves + wpw - 1) / wpw), 64 * wpw, lds, (hipStream_t)stream>>>(a);
     return check_launch("inverse_block_kernel");
 }
 

@@ -714,6 +714,9 @@ class AutoregressiveFlow(torch.nn.Module):
     #: Sample rows per wave of the block kernel: 64 (one per lane) or 16 (four lanes per row); None: by batch size.
     inverse_rows_per_wave = None
 
+    #: 16-row layout: a loader wave beside every chain wave (see ``_inverse_blocked``).  None: while every pair is resident.
+    inverse_paired = None
+
     #: 16-row layout: independent waves per workgroup of the block kernel (1, 2, 4, 8; halved until the workgroup's LDS fits).
     #: More than one only packs the launch onto fewer CUs (see ``inverse_lookahead``).  None: one.
     inverse_waves_per_workgroup = None
@@ -1000,6 +1003,18 @@ class AutoregressiveFlow(torch.nn.Module):
                 # (one wave per 64 samples: half the CUs at batch 8192) runs; what block k added follows as one short
                 # GEMM into an extra slab.  Two sets of slabs, alternating between blocks.
                 pack4 = False
+                # round 3: a LOADER wave beside every 16-row wave (``tfep_inverse_block`` paired): staging the weights and the
+                # block GEMMs' slabs was 48 % of the chain's instructions, and a lone wave issues one vector instruction per
+                # ~8 cycles -- the second wave takes that half off the chain.  While every pair is resident at once.
+                paired = self.inverse_paired
+                if os.environ.get('TFEP_INV_PAIRED') is not None:
+                    paired = os.environ['TFEP_INV_PAIRED'] != '0'
+                if rows_per_wave != 16:
+                    paired = False
+                elif paired is None:
+                    ldsp = _lib.load().tfep_inverse_block_lds_bytes_paired(L, fused['cache_len'], fused['max_feats'])
+                    fitp = (160 * 1024) // max(int(ldsp), 1)
+                    paired = 0 < ldsp and fitp >= 1 and (B + 15) // 16 <= 256 * min(fitp, 4)
                 look = self.inverse_lookahead
                 if os.environ.get('TFEP_INV_LOOKAHEAD') is not None:
                     look = os.environ['TFEP_INV_LOOKAHEAD'] != '0'
@@ -1015,7 +1030,7 @@ class AutoregressiveFlow(torch.nn.Module):
                     # fill a CU's LDS) leave whole CUs to the GEMMs: cfg2 layer at B = 8192 107.3 -> 102.5 ms (the block
                     # kernel on 128 CUs, the look-ahead GEMMs on the other 128 now bound the block: 8 waves per CU would
                     # need half the LDS per wave; tools/probe/inv_pack.py, profiles/r03_inverse_pack.txt)
-                    if not look and rows_per_wave == 16 and self.inverse_waves_per_workgroup is None and \
+                    if not look and not paired and rows_per_wave == 16 and self.inverse_waves_per_workgroup is None and \
                             not os.environ.get('TFEP_INV_WPW') and max(mplan['k_pad']) >= 4096:
                         lds16 = _lib.load().tfep_inverse_block_lds_bytes_rows(L, fused['cache_len'], fused['max_feats'], 16)
                         n_waves = (B + 15) // 16
@@ -1054,6 +1069,8 @@ class AutoregressiveFlow(torch.nn.Module):
                     wpw = int(os.environ['TFEP_INV_WPW'])
                 if wpw is None and pack4 and look:
                     wpw = int(pack4)
+                if paired:
+                    wpw, d.paired = None, 1
                 if rows_per_wave == 16 and wpw:
                     lds16 = _lib.load().tfep_inverse_block_lds_bytes_rows(L, fused['cache_len'], fused['max_feats'], 16)
                     while wpw > 1 and wpw * lds16 > 160 * 1024:
