@@ -447,7 +447,10 @@ class MADE(Conditioner):
         # strided device checksum of every parameter (every 1021st entry: ~1 M reads per cfg2 layer, one host comparison)
         # catches any update that touches a tensor broadly -- every optimiser step does.  A write to a SINGLE entry
         # through ``.data`` is the one thing that can still go unseen; ``invalidate_plan()`` is the explicit remedy.
-        fingerprint = self._param_fingerprint()
+        fingerprint = self.__dict__.get('_fp_memo')          # one checksum per layer call (begin_call), not one per linear
+        if fingerprint is None:
+            fingerprint = self._param_fingerprint()
+            self.__dict__['_fp_memo'] = fingerprint
         stale = plan.get('packed_versions') != versions
         if not stale:
             old = plan.get('packed_fingerprint')
@@ -459,14 +462,19 @@ class MADE(Conditioner):
         plan['packed_fingerprint'] = fingerprint
         return True
 
+    def begin_call(self):
+        """Start of one forward / inverse / backward call of the owning layer (or of ``forward`` itself): the parameter
+        checksum of ``cache_packed_weights`` is taken at most once per call."""
+        self.__dict__['_fp_memo'] = None
+
     def _param_fingerprint(self):
         """Strided checksums (float64 sums of every 1021st entry, and of the first 64) of every parameter: a device tensor."""
         parts = []
         for lin in self._linears():
             for t in lin.parameters():
                 flat = t.detach().reshape(-1)
-                parts.append(flat[::1021].double().sum())
-                parts.append(flat[:64].double().sum())
+                parts.append(flat[::1021].sum(dtype=torch.float64))
+                parts.append(flat[:64].sum(dtype=torch.float64))
         return torch.stack(parts) if parts else torch.zeros(0)
 
     def _mask_prefix_cuts(self, plan, li, lin):
@@ -596,6 +604,7 @@ class MADE(Conditioner):
     def forward(self, x, split=None):
         """Transformer parameters ``(..., n_out)`` (reference made.py:355).  ``split``: run the GEMMs on split-f16
         operands (fp32-equivalent, ``csrc/split_gemm.hip``); None = the ``TFEP_SPLIT_GEMM`` default."""
+        self.begin_call()
         lead = x.shape[:-1]
         x2 = x.reshape(-1, x.shape[-1])
         split = (ops.split_gemm_enabled() and self.split_worthwhile(x2.shape[0])) if split is None else bool(split)

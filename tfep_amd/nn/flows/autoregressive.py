@@ -101,6 +101,8 @@ class AutoregressiveFlow(torch.nn.Module):
         degrees come from this layer's own ``_inverse_masks`` (feature c is transformed at step d iff
         ``_inverse_masks[d, c]``; every other feature conditions: -1), mapped through the embedding if there is one."""
         made = self._conditioner
+        if isinstance(made, MADE):
+            made.begin_call()
         if not isinstance(made, MADE) or not made._degrees_stale:
             return
         self._dev = {}
