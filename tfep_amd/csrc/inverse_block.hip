@@ -529,8 +529,10 @@ __host__ __device__ inline size_t ib_lds_floats_q4(int L, int cache_len, int max
 
 // the paired (loader + consumer) launch: a second weight stage and a second pre-activation stage
 __host__ __device__ inline size_t ib_lds_floats_q4_paired(int L, int cache_len, int max_feats) {
-    return ib_lds_floats_q4(L, cache_len, max_feats) + (size_t)IB_STAGE_ROWS * ib_stage_cols_q4(cache_len, max_feats) + IB_LDS_SLACK +
-           (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
+    const size_t cols = ib_stage_cols_q4(cache_len, max_feats);
+    const size_t h = 8 * cols + IB_LDS_SLACK + 8 * (size_t)Q4_Z_PITCH;                                   // hidden-layer stage (8 rows)
+    const size_t o = (size_t)IB_STAGE_ROWS * cols + IB_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;   // output-rows stage
+    return ((size_t)L * ib_round4(cache_len) + ib_round4(max_feats)) * Q4_ROWS + (size_t)IB_MAX_P * Q4_P_PITCH + 2 * h + 2 * o;
 }
 
 // zs[v * Q4_Z_PITCH + i] = sum_s z[s * slab_stride + (wave_row0 + i) * ldz + base + v * vstride],  v < nv <= 32, i < 16
@@ -685,11 +687,13 @@ __device__ __forceinline__ void out_dot_mfma16(float (&prm)[IB_MAX_P], const flo
 // was 48 % of the chain's instructions (probe build without it: cfg2 layer, B = 8192, 106.8 -> 81.3 ms).  One workgroup
 // barrier per stage: the loader fills buffer t & 1 then meets the barrier, the consumer meets it then reads buffer t & 1;
 // the loader's next fill (t + 1, the other buffer) overlaps the consumer's stage t, and its fill t + 2 comes after barrier
-// t + 1, which the consumer reaches only when it is done with buffer t & 1.  Measured (cfg2 layer): B = 8192 107.3 -> 95.7 ms,
-// 4096 92.2 -> 81.0, 2048 88.5 -> 77.5 -- less than the probe's 81 at 8192 because the loader is ONE stage ahead and the
-// stages of a degree are unequal: the big fill (output rows) overlaps the small hidden-layer dot and the big dot + spline
-// overlaps a small fill.  A loader a whole degree ahead needs four stage buffers (96 KB per pair: one pair per CU) or a
-// dedicated double buffer for the output rows; not built.
+// t + 1, which the consumer reaches only when it is done with buffer t & 1.  The stages of a degree are unequal -- small
+// hidden-layer stages, then per feature a big one (its P output rows; the dot + transformer inverse) -- so with ONE kind of
+// buffer the big fill met a small dot and the big dot a small fill (cfg2 layer, B = 8192: 107.3 -> 95.7 ms only).  The output
+// rows therefore have their own double buffer, filled a whole FEATURE ahead: right after the barrier that hands feature j to
+// the consumer the loader fetches feature j + 1's rows (the next step's if need be), beside the consumer's dot and spline;
+// the hidden-layer stages keep a small double buffer (8 rows per chunk).  LDS per pair 75 KB at cfg2 (two pairs per CU).
+// Measured: B = 8192 107.3 -> 89.4 ms, 4096 92.2 -> 72.0, 2048 88.5 -> 68.1; bit-identical to the single-wave kernel.
 template <int KIND, bool PAIR>
 __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs a) {
     extern __shared__ float cache_all[];          // per wave (pair): [L][cache_len][16] hidden activations, then [max_feats][16] x values
@@ -709,14 +713,24 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
     const bool live16 = wave_row0 + (lane & 15) < a.B;
     const int64_t r16 = live16 ? wave_row0 + (lane & 15) : 0;
     float* xc = cache + (size_t)a.L * a.cache_len * Q4_ROWS;
-    float* const stg0 = xc + (size_t)a.max_feats * Q4_ROWS;
     const int gstride = a.stage_gstride;
-    float* const zs0 = stg0 + (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK;
-    float* pb = zs0 + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
-    // PAIR: the second stage buffers follow the single-wave layout
-    float* const stg1 = pb + (size_t)IB_MAX_P * Q4_P_PITCH;
-    float* const zs1 = stg1 + (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK;
-    const int lds_total = a.lds_floats + (PAIR ? (int)((size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH) : 0);
+    // not PAIR: one weight stage (IB_STAGE_ROWS rows) + one pre-activation stage.  PAIR: two SMALL stages for the hidden
+    // layers (8 rows: a degree has a handful of units per layer; more go through in chunks of 8), alternating, and two
+    // FULL stages for the output rows of a feature, alternating per feature -- the loader fills the output stage of the
+    // NEXT feature while the consumer works on the current one (the big fill beside the big dot + transformer inverse).
+    constexpr int HROWS = PAIR ? 8 : IB_STAGE_ROWS;
+    const size_t h_floats = (size_t)HROWS * (gstride >> 3) + IB_LDS_SLACK + (size_t)HROWS * Q4_Z_PITCH;
+    const size_t o_floats = (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
+    float* const stg0 = xc + (size_t)a.max_feats * Q4_ROWS;
+    float* const zs0 = stg0 + (size_t)HROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* pb = zs0 + (size_t)HROWS * Q4_Z_PITCH;
+    float* const stg1 = pb + (size_t)IB_MAX_P * Q4_P_PITCH;                      // PAIR only from here on
+    float* const zs1 = stg1 + (size_t)HROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* const ostg0 = stg0 + (PAIR ? 2 * h_floats + (size_t)IB_MAX_P * Q4_P_PITCH : 0);
+    float* const ozs0 = ostg0 + (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* const ostg1 = ostg0 + o_floats;
+    float* const ozs1 = ozs0 + o_floats;
+    const int lds_total = a.lds_floats;                 // (per wave, or per pair: ib_lds_floats_q4 / _paired)
     float* stg = stg0;
     float* zs = zs0;
     int parity = 0;
@@ -745,6 +759,36 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
     }
     if (PAIR) __syncthreads();                      // (the loader's first fill must not meet the zero fill)
 
+    // PAIR: the output stages form one sequence over the features of all steps; stage j lives in output buffer j & 1.
+    int oj = 0;
+    auto fill_out = [&](int step, int f, int buf) __attribute__((always_inline)) {
+        const int32_t* sr = a.steps + step * IB_STEP_INTS;
+        const int o_row0 = sr[4 * IB_MAX_LAYERS], o_nd = sr[4 * IB_MAX_LAYERS + 1], o_kb = sr[4 * IB_MAX_LAYERS + 2],
+                  o_ke = sr[4 * IB_MAX_LAYERS + 3];
+        float* os = buf ? ostg1 : ostg0;
+        float* oz = buf ? ozs1 : ozs0;
+        if constexpr (KIND == 2) {
+            stage_rows(os, gstride, a.wout, a.ldwout, o_row0 + f, 1, a.mb_dim, o_kb, o_ke, lane);
+            stage_z16(oz, a.zout, a.ldzout, wave_row0, a.B, o_row0 + f, 1, a.mb_dim, a.zout_slabs, a.zout_slab_stride, lane);
+        } else {
+            const int o_P = KIND == 3 ? a.spg[sr[4 * IB_MAX_LAYERS + 5]].P : a.P;
+            stage_rows(os, gstride, a.wout, a.ldwout, o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
+            stage_z16(oz, a.zout, a.ldzout, wave_row0, a.B, o_row0 + f, o_nd, o_P, a.zout_slabs, a.zout_slab_stride, lane);
+        }
+    };
+    // the output stage after feature f of step `step`: the next feature of the step, or the first one of a later step
+    auto fill_next_out = [&](int step, int f) __attribute__((always_inline)) {
+        const int df = KIND == 2 ? a.mb_dim : 1;
+        int ns = step, nf = f + df;
+        while (ns < a.n_steps && nf >= a.steps[ns * IB_STEP_INTS + 4 * IB_MAX_LAYERS + 1]) { ++ns; nf = 0; }
+        if (ns < a.n_steps) fill_out(ns, nf, (oj + 1) & 1);
+    };
+    if (PAIR && loader) {                               // the first output stage: before anything is handed over
+        int ns = 0;
+        while (ns < a.n_steps && a.steps[ns * IB_STEP_INTS + 4 * IB_MAX_LAYERS + 1] <= 0) ++ns;
+        if (ns < a.n_steps) fill_out(ns, 0, 0);
+    }
+
     double ldj_acc = 0.0;
     for (int st_i = 0; st_i < a.n_steps; ++st_i) {
         const int32_t* st = a.steps + st_i * IB_STEP_INTS;
@@ -755,8 +799,8 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
             float* h16 = a.h[l] + r16 * a.ldh[l];                    // the matrix-core phases: lane = sample row lane % 16
             const float* act = l == 0 ? xc : cache + ((size_t)(l - 1) * a.cache_len + (kb - a.c0[l - 1])) * Q4_ROWS;
             const int len = ib_round8(l == 0 ? ke : ke - kb);
-            for (int ub = row0; ub < row0 + n; ub += IB_STAGE_ROWS) {
-                const int nb = min(IB_STAGE_ROWS, row0 + n - ub);
+            for (int ub = row0; ub < row0 + n; ub += HROWS) {
+                const int nb = min(HROWS, row0 + n - ub);
 #ifndef TFEP_PROBE_NO_STAGE          // (timing probe, wrong results: what a loader wave could take off the chain)
                 if (loader) {
                     if (l == 0) stage_gather(stg, gstride, a.w[0], a.ldw[0], ub, nb, a.in_cols, ke, lane);
@@ -795,14 +839,16 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
         if constexpr (KIND == 2) {
             const int dim = a.mb_dim;
             for (int f = 0; f < n_d; f += dim) {
-                if (loader) {
+                if (!PAIR) {
                     stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, 1, dim, okb, oke, lane);
                     stage_z16(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, 1, dim, a.zout_slabs, a.zout_slab_stride, lane);
                 }
-                stage_done();
+                stage_done();                                           // PAIR: output stage oj was filled a feature ago
+                if (PAIR && loader) fill_next_out(st_i, f);
                 if (consumer) {
                     float acc[IB_MAX_P];
-                    out_dot_mfma16(acc, stg, gstride, zs, cp, pb, olen, dim, lane);
+                    out_dot_mfma16(acc, PAIR ? ((oj & 1) ? ostg1 : ostg0) : stg, gstride, PAIR ? ((oj & 1) ? ozs1 : ozs0) : zs, cp, pb,
+                                   olen, dim, lane);
                     double yv[MOEBIUS_MAX_DIM], wv[MOEBIUS_MAX_DIM], xv[MOEBIUS_MAX_DIM];
 #pragma unroll
                     for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
@@ -816,7 +862,7 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
                         if (i < dim) emit(foff + f + i, (float)xv[i]);
                     __builtin_amdgcn_wave_barrier();
                 }
-                next_stage();
+                ++oj;
             }
         } else {
         const SplineArgs& spa = KIND == 3 ? a.spg[st[4 * IB_MAX_LAYERS + 5]] : a.sp;      // (wave uniform)
@@ -824,17 +870,19 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
         for (int f = 0; f < n_d; ++f) {
             float prm[IB_MAX_P];
 #ifndef TFEP_PROBE_NO_STAGE
-            if (loader) {
+            if (!PAIR) {
                 stage_rows(stg, gstride, a.wout, a.ldwout, out_row0 + f, n_d, nP, okb, oke, lane);   // the feature's P rows at once
                 stage_z16(zs, a.zout, a.ldzout, wave_row0, a.B, out_row0 + f, n_d, nP, a.zout_slabs, a.zout_slab_stride, lane);
             }
 #endif
-            stage_done();
-            if (!consumer) {                     // (PAIR: the loader goes on to the next stage's fetches)
-                next_stage();
+            stage_done();                                               // PAIR: output stage oj was filled a feature ago
+            if (!consumer) {                     // (PAIR: the loader fetches the NEXT feature's rows beside this one's dot)
+                fill_next_out(st_i, f);
+                ++oj;
                 continue;
             }
-            out_dot_mfma16(prm, stg, gstride, zs, cp, pb, olen, nP, lane);
+            out_dot_mfma16(prm, PAIR ? ((oj & 1) ? ostg1 : ostg0) : stg, gstride, PAIR ? ((oj & 1) ? ozs1 : ozs0) : zs, cp, pb, olen,
+                           nP, lane);
             const int sel = a.feat_sel[foff + f];
             const float yv = a.y[r * a.ldy + sel];
             float xv;
@@ -883,7 +931,7 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
                 if (per) a.xpad[r * a.ldxpad + icol + 1] = in1;
             }
             __builtin_amdgcn_wave_barrier();
-            next_stage();
+            ++oj;
         }
         }
     }
@@ -1005,7 +1053,10 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
     TFEP_REQUIRE(!d->paired || (q4 && wpw == 1), "inverse_block: paired needs rows_per_wave = 16 and one pair per workgroup");
     const size_t lds_wave = lds;
     lds = pair ? ib_lds_floats_q4_paired(d->n_layers, d->cache_len, d->max_feats) * sizeof(float) : lds_wave * wpw;
-    if (pair) wpw = 2;                                  // the pair: consumer + loader on the same rows
+    if (pair) {
+        wpw = 2;                                        // the pair: consumer + loader on the same rows
+        a.lds_floats = (int)(lds / sizeof(float));
+    }
     TFEP_REQUIRE(lds <= 160 * 1024, "inverse_block: %d waves per workgroup need %zu bytes of LDS (> 160 KiB)", wpw, lds);
     if (lds > lds_attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
