@@ -136,6 +136,11 @@ int tfep_masked_linear_narrow_tile_n(void);
  *   accumulate: add into y (gradient accumulation over batch chunks);
  *   tile_live: optional (ceil(B/tile_m) x ceil(N/tile_n)) bytes, 0 = output tile entirely masked, skipped
  *     (grad_weight of a block-triangular mask).
+ *   tile_list / n_tile_list: optional launch order of the output tiles, position p -> (row tile, column tile) =
+ *     (tile_list[2p], tile_list[2p + 1]), negative = none; tiles not listed are not computed.  Workgroups go
+ *     round-robin to the 8 XCDs: list the live tiles of a block-triangular grad_weight in groups of 32 neighbours,
+ *     group k at positions ((k / 8) * 32 + w) * 8 + k % 8, and every XCD gets the same share (wide tile only,
+ *     no tile_order / k_split).
  *   pre_add: partial pre-activations added before the activation (two-level blocked inverse: the block's
  *     contribution of all earlier degrees is computed once, each degree adds only its own block's part).
  * Other fields as in tfep_masked_linear_forward.
@@ -163,6 +168,8 @@ typedef struct tfep_gemm_desc {
     int32_t k_split;                            /* > 1: split-K for products with few output tiles: slice s of the  */
     int64_t slab_stride;                        /*   k-range writes its partial sums to y + s * slab_stride (bias and */
                                                 /*   pre_add in slice 0); the caller adds the k_split slabs           */
+    const int32_t* tile_list;                   /* optional (2 * n_tile_list): launch position -> (row tile, column tile) */
+    int32_t n_tile_list;
 } tfep_gemm_desc;
 int tfep_masked_linear_gemm(const tfep_gemm_desc* desc, void* stream);
 int tfep_masked_linear_tile_k(void);

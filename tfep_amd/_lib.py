@@ -32,7 +32,8 @@ class GemmDesc(Structure):
                 ('pre_add', c_void_p), ('ld_pre_add', c_int64), ('tile_n', c_int32),
                 ('split', c_int32), ('x_inv_scale', c_void_p), ('w_inv_scale', c_void_p),
                 ('split_out', c_int32), ('y_inv_scale', c_void_p), ('w_l1max', c_void_p), ('bias_absmax', c_void_p),
-                ('k_split', c_int32), ('slab_stride', c_int64)]
+                ('k_split', c_int32), ('slab_stride', c_int64),
+                ('tile_list', c_void_p), ('n_tile_list', c_int32)]
 
 
 class InverseBlockDesc(Structure):

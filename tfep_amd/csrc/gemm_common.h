@@ -48,6 +48,9 @@ struct GemmArgs {
     const float* pre_add;      // linear epilogue: added BEFORE the activation (partial pre-activations of the
     int64_t ld_pre_add;        //   two-level blocked inverse); same indexing as y
     const uint8_t* tile_live;  // optional (m_tiles x n_tiles): 0 = the whole output tile is masked, skip it
+    const int32_t* tile_list;  // optional: launch position p -> (row tile, column tile) = tile_list[2p], tile_list[2p + 1]
+    int n_tile_list;           //   (negative = no tile); replaces map_mode / tile_order / tile_live: the host lists the
+                               //   live tiles of a block-triangular product so that every XCD gets the same number
     int diag;                  // diagnostics only (TFEP_DIAG): 1 = skip the epilogue, 4 = skip the LDS-DMA,
                                // 8 = skip the barriers (garbage results; timing only)
     int ksplit;                // linear epilogues: > 1 = split-K: launch position (column tile, k slice); slice s writes
@@ -67,6 +70,15 @@ __device__ inline float elu_f(float v) { return v > 0.f ? v : expm1f(v); }
 
 // Workgroup -> (row tile, position in the column-tile order); false = nothing to do.
 __device__ inline bool map_block(const GemmArgs& g, int& mt, int& ntp) {
+    if (g.tile_list) {
+        // Workgroup ids are dealt round-robin over the 8 XCDs, each XCD works through its own share: a triangular live
+        // region under the super-tile walk below leaves some XCDs with twice the tiles of others (8 row super-tiles on
+        // 8 XCDs: one row of super-tiles each).  The host's list holds the live tiles only, 32 neighbours per XCD turn.
+        if ((int)blockIdx.x >= g.n_tile_list) return false;
+        mt = g.tile_list[2 * blockIdx.x];
+        ntp = g.tile_list[2 * blockIdx.x + 1];
+        return mt >= 0 && mt < g.m_tiles && ntp >= 0 && ntp < g.n_tiles;
+    }
     // Workgroup -> (row tile, column tile).  Workgroups are dealt round-robin over the 8 XCDs
     // (id % 8 labels the XCD) and each XCD has its own L2, so in mode 1 the 32 workgroups that are
     // co-resident on one XCD form an 8 (row tiles) x 4 (column tiles) super-tile: 8 activation
@@ -190,7 +202,8 @@ inline int env_int(const char* name, int dflt) {
 inline int block_map_mode() { static int m = env_int("TFEP_BLOCK_MAP", 1); return m; }
 
 // Grid size for map_block().
-inline long long gemm_grid_blocks(int map_mode, int m_tiles, int n_tiles) {
+inline long long gemm_grid_blocks(int map_mode, int m_tiles, int n_tiles, int n_tile_list = 0) {
+    if (n_tile_list > 0) return n_tile_list;
     if (map_mode == 1 || map_mode == 2) {
         const long long SM = (m_tiles + 7) / 8, SN = (n_tiles + 3) / 4;
         return ((SM * SN + 7) / 8) * 8 * 32;

@@ -413,7 +413,7 @@ static int launch_gemm(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStre
     ga.n_tiles = n_col_tiles * (g.ksplit > 1 ? g.ksplit : 1);
     ga.map_mode = block_map_mode();
     ga.diag = env_int("TFEP_DIAG", 0);
-    const long long blocks = gemm_grid_blocks(ga.map_mode, ga.m_tiles, ga.n_tiles);
+    const long long blocks = gemm_grid_blocks(ga.map_mode, ga.m_tiles, ga.n_tiles, ga.tile_list ? ga.n_tile_list : 0);
     if (blocks > 0x7fffffffLL) return fail(TFEP_ERR_INVALID_ARGUMENT, "gemm: grid too large");
     kern<<<dim3((unsigned)blocks), THREADS, T::LDS_BYTES, s>>>(ga, n_rows_w);
     return check_launch("gemm_kernel");
@@ -553,6 +553,11 @@ int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
     g.col_map = d->col_map; g.y = d->y; g.ldy = d->ldy; g.B = d->B; g.N = d->N; g.k_padded = d->k_padded;
     g.tile_order = d->tile_order; g.aux = d->elu_grad_of; g.ldaux = d->ld_elu_grad_of; g.accumulate = d->accumulate;
     g.tile_live = d->tile_live; g.pre_add = d->pre_add; g.ld_pre_add = d->ld_pre_add;
+    if (d->tile_list) {
+        TFEP_REQUIRE(d->n_tile_list > 0 && !d->tile_order && d->k_split <= 1 && (d->tile_n == 0 || d->tile_n == Tile<LIN_MREP, LIN_NREP>::BN),
+                     "masked_linear_gemm: tile_list needs n_tile_list > 0, the wide tile, no tile_order and no k_split");
+        g.tile_list = d->tile_list; g.n_tile_list = d->n_tile_list;
+    }
     if (d->k_split > 1) {
         TFEP_REQUIRE(!d->split_out && !d->accumulate && !d->tile_order && !d->tile_live && !d->elu_grad_of && d->act == 0,
                      "masked_linear_gemm: k_split needs a plain linear product (no activation / accumulate / tile_order / tile_live)");

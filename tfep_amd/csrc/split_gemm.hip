@@ -423,6 +423,9 @@ int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s)
     constexpr int NARROW = 8;
     if (g.N <= STile<NARROW>::BN && env_int("TFEP_SPLIT_NARROW", 1))
         return launch_split<NARROW, EPI_LINEAR, 1, 1>(g, n_rows_w, 1, s);
+    // TIMING EXPERIMENT: the 400-column tile of the fused kernel for a plain dense product (no per-tile tables)
+    if (env_int("TFEP_SPLIT_WIDE_TILE", 0) && !g.k_ranges && !g.tile_live && !g.tile_order && g.ksplit <= 1)
+        return launch_split<25, EPI_LINEAR, 1, 1>(g, n_rows_w, (g.N + STile<25>::BN - 1) / STile<25>::BN, s);
     return launch_split<NREP, EPI_LINEAR, 1, 1>(g, n_rows_w, n_tiles, s);
 }
 

@@ -442,13 +442,23 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
             __builtin_amdgcn_wave_barrier();
         });
     } else {
-        // the other epilogues get a copy they may index from unrolled loops
-        f32x4 out[NREP][SMREP];
-        static_for<0, NREP * SMREP>([&](auto ic) __attribute__((always_inline)) {
-            constexpr int n = ic.value / SMREP, m = ic.value % SMREP;
-            out[n][m] = acc[n][m] * rs[m];
-        });
-        gemm_epilogue<SMREP, NREP, EPI, P, KSPL>(g, out, nt, n0, wrow0, lane, k_slice);
+        if constexpr ((EPI == EPI_LINEAR || EPI == EPI_ELU) && NREP > 16) {
+            // a wide tile has no registers for a copy of its accumulators: one column group at a time
+            static_for<0, NREP>([&](auto nc) __attribute__((always_inline)) {
+                constexpr int n = nc.value;
+                f32x4 out1[1][SMREP];
+                static_for<0, SMREP>([&](auto mc) __attribute__((always_inline)) { out1[0][mc.value] = acc[n][mc.value] * rs[mc.value]; });
+                gemm_epilogue<SMREP, 1, EPI, P, KSPL>(g, out1, nt, n0 + n * 16, wrow0, lane, k_slice);
+            });
+        } else {
+            // the other epilogues get a copy they may index from unrolled loops
+            f32x4 out[NREP][SMREP];
+            static_for<0, NREP * SMREP>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int n = ic.value / SMREP, m = ic.value % SMREP;
+                out[n][m] = acc[n][m] * rs[m];
+            });
+            gemm_epilogue<SMREP, NREP, EPI, P, KSPL>(g, out, nt, n0, wrow0, lane, k_slice);
+        }
     }
     if (epi_is_spline(EPI) && (g.diag & 16) && threadIdx.x == 0) {
         const unsigned long long t_end = __builtin_readcyclecounter();
@@ -513,7 +523,7 @@ static int launch_split(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStr
     ga.n_tiles = n_col_tiles * (g.ksplit > 1 ? g.ksplit : 1);
     ga.map_mode = block_map_mode();
     ga.diag = env_int("TFEP_DIAG", 0);
-    const long long blocks = gemm_grid_blocks(ga.map_mode, ga.m_tiles, ga.n_tiles);
+    const long long blocks = gemm_grid_blocks(ga.map_mode, ga.m_tiles, ga.n_tiles, ga.tile_list ? ga.n_tile_list : 0);
     if (blocks > 0x7fffffffLL) return fail(TFEP_ERR_INVALID_ARGUMENT, "split gemm: grid too large");
     kern<<<dim3((unsigned)blocks), STHREADS, LDS, s>>>(ga, n_rows_w);
     return check_launch("split_gemm_kernel");

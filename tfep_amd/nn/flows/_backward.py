@@ -402,7 +402,7 @@ class UnsupportedBackward(torch.autograd.Function):
 
 
 def _gemm(x, w, y, B, N, n_rows_w, bias=None, k_ranges=None, act=0, accumulate=0, elu_grad_of=None, tile_live=None,
-          split=False, w_split=None, x_split=None):
+          split=False, w_split=None, x_split=None, tile_list=None):
     """``split``: run on split-f16 operands (x converted here with one scale per row; ``w_split`` / ``x_split`` = already
     converted ``(rows, inv_scale)`` of w / x, else w is converted here with one scale for the matrix)."""
     d = _lib.GemmDesc()
@@ -421,11 +421,14 @@ def _gemm(x, w, y, B, N, n_rows_w, bias=None, k_ranges=None, act=0, accumulate=0
     if elu_grad_of is not None:
         d.elu_grad_of, d.ld_elu_grad_of = elu_grad_of.data_ptr(), elu_grad_of.shape[1]
     d.tile_live = tile_live.data_ptr() if tile_live is not None else None
+    if tile_list is not None:
+        d.tile_list, d.n_tile_list = tile_list.data_ptr(), tile_list.shape[0]
     if not split and ops.few_wide_tiles(B, N):
         # a cfg1-sized product is one or two 256 x 256 tiles: one workgroup walks the whole k range while 255 CUs idle
         # (130 us for a 224 x 224 x 1024 grad_weight).  The 32-column tile spreads it over the columns; the mask tables are
         # per 256-column tile and only save work (masked weights are zeros, masked gradients are dropped later): dense.
         d.tile_n, d.k_ranges, d.tile_live = ops.narrow_tile_n(), None, None
+        d.tile_list, d.n_tile_list = None, 0
     _lib.call('tfep_masked_linear_gemm', ctypes.byref(d), _lib.stream_of(x))
     return y
 
@@ -471,7 +474,7 @@ def _backward_plan(layer, device):
         k_ranges[L] = ops.mask_k_ranges(lins[L].mask, tn, (n_out_pad + tn - 1) // tn, mplan['k_pad'][L], row_of_out,
                                         mplan['col_of_in'][L])
     bp['k_ranges'] = k_ranges
-    dx_ranges, live = [], []
+    dx_ranges, live, live_list = [], [], []
     for li, lin in enumerate(lins):
         kr = k_ranges[li].cpu().long()                            # per 256-row tile of W: [kb, ke)
         is_out = li == L
@@ -482,6 +485,8 @@ def _backward_plan(layer, device):
         hi = lo + tn
         hit = (kr[:, 0:1] < hi[None, :]) & (kr[:, 1:2] > lo[None, :])          # (row tiles, col tiles)
         live.append(hit.to(torch.uint8).contiguous().to(device))
+        # the same tiles as a launch list that gives every XCD an equal share (grad_weight: all tiles cost the same)
+        live_list.append(ops.xcd_balanced_tile_list(hit).to(device) if os.environ.get('TFEP_TILE_LIST', '1') != '0' else None)
         # grad_input GEMM: output column tile j (over k) needs the rows n of the tiles that touch it
         rng = torch.zeros(n_col_tiles, 2, dtype=torch.int32)
         for j in range(n_col_tiles):
@@ -490,7 +495,7 @@ def _backward_plan(layer, device):
                 rng[j, 0] = int(rows.min()) * tn
                 rng[j, 1] = min((int(rows.max()) + 1) * tn, n_pad)
         dx_ranges.append(rng.to(device))
-    bp.update(dx_ranges=dx_ranges, live=live)
+    bp.update(dx_ranges=dx_ranges, live=live, live_list=live_list)
     layer._dev[key] = bp
     return bp
 
@@ -722,13 +727,14 @@ def layer_backward(layer, x, gy, gldj, saved=None):
                           None, _lib.ptr(hT_inv), stream)
                 # grad_weight (packed) += g^T h   [rows n, cols k], masked tiles skipped
                 _gemm(gTs, hTs, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=1, tile_live=bplan['live'][l], split=True,
-                      x_split=(gTs, gT_inv), w_split=(hTs, hT_inv))
+                      x_split=(gTs, gT_inv), w_split=(hTs, hT_inv), tile_list=bplan['live_list'][l])
                 del gTs, hTs, cmax
             else:
                 _lib.call('tfep_column_sums', _lib.ptr(g), g.shape[1], Bc, n_pad[l], _lib.ptr(gb[l]), 1, stream)
                 gT = _transpose(g, Bc, n_pad[l], ops.zeros(n_pad[l], Bc_pad, **f32))
                 hT = _transpose(h[l], Bc, k_pad[l], ops.zeros(k_pad[l], Bc_pad, **f32))
-                _gemm(gT, hT, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=1, tile_live=bplan['live'][l])
+                _gemm(gT, hT, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=1, tile_live=bplan['live'][l],
+                      tile_list=bplan['live_list'][l])
                 del gT, hT
             # grad_input = g W  (x ELU'(h) for hidden inputs)
             gin = torch.empty(Bc, k_pad[l], **f32)

@@ -214,6 +214,33 @@ def heavy_first_order(k_ranges):
     return order.to(device=k_ranges.device, dtype=torch.int32)
 
 
+def xcd_balanced_tile_list(live, n_xcd=8, group=32):
+    """Launch order of the live output tiles of a block-sparse product (``tile_list`` of ``tfep_gemm_desc``).
+
+    ``live``: (row tiles, column tiles) bool / uint8 CPU tensor.  Workgroup ids go round-robin to the 8 XCDs and each XCD
+    works through its own share, so the live tiles are listed in the order of the 8 x 4 super-tile walk (neighbours share
+    operand panels in the XCD's L2), cut into groups of 32, and group k is placed at the positions of XCD k % 8: every XCD
+    gets the same number of tiles whatever the shape of the live region.  Returns an int32 (n_positions, 2) CPU tensor,
+    -1 = no tile."""
+    live = torch.as_tensor(live).cpu().bool()
+    M, N = live.shape
+    seq = []
+    for sn in range((N + 3) // 4):
+        for sm in range((M + 7) // 8):
+            for w in range(32):
+                mt, nt = sm * 8 + (w & 7), sn * 4 + (w >> 3)
+                if mt < M and nt < N and live[mt, nt]:
+                    seq.append((mt, nt))
+    n_groups = (len(seq) + group - 1) // group
+    n_rounds = max(1, (n_groups + n_xcd - 1) // n_xcd)
+    out = torch.full((n_rounds * group * n_xcd, 2), -1, dtype=torch.int32)
+    for i, (mt, nt) in enumerate(seq):
+        k, w = divmod(i, group)
+        pos = ((k // n_xcd) * group + w) * n_xcd + k % n_xcd
+        out[pos, 0], out[pos, 1] = mt, nt
+    return out
+
+
 def narrow_tile_n():
     if 'narrow' not in _TILES:
         _TILES['narrow'] = _lib.load().tfep_masked_linear_narrow_tile_n()
