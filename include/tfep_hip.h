@@ -126,6 +126,9 @@ int tfep_masked_linear_forward(const float* x, int64_t ldx, const float* w, int6
                                int k_padded, int act, int tile_n, void* stream);
 int tfep_masked_linear_tile_n(void);
 int tfep_masked_linear_narrow_tile_n(void);
+/* Widest column tile of the split-f16 kernel (400: the fused spline kernel's tile for a plain linear product, tile_n of
+ * tfep_gemm_desc with split = 1, act = 0; k_ranges / tile_live / tile_list then count tiles of this width). */
+int tfep_split_wide_tile_n(void);
 
 /*
  * General form of the same GEMM, used by the backward pass (MaskedLinearFunc.backward,
@@ -157,7 +160,7 @@ typedef struct tfep_gemm_desc {
     const float* elu_grad_of; int64_t ld_elu_grad_of;
     const uint8_t* tile_live;
     const float* pre_add; int64_t ld_pre_add;   /* optional, layout of y: y = act(x w^T + bias + pre_add) */
-    int32_t tile_n;                             /* 0 / wide (default) or tfep_masked_linear_narrow_tile_n() */
+    int32_t tile_n;                             /* 0 / wide (default), tfep_masked_linear_narrow_tile_n(), or (split) tfep_split_wide_tile_n() */
     int32_t split;                              /* 1: x and w are split-f16 rows (tfep_split_rows), wide tile only */
     const float* x_inv_scale;                   /*    (B) per-row 1/scale of x                                     */
     const float* w_inv_scale;                   /*    (1) 1/scale of w                                             */
@@ -347,6 +350,23 @@ int tfep_fused_output_transformer_forward_split(const void* h_split, int64_t ldh
                                                 const int32_t* feat_index, const int32_t* feat_tr, int n_feature_slots,
                                                 double* ldj_partial, float* log_det_J, int accumulate, int B,
                                                 int n_rows_w, int k_padded, void* stream);
+
+/* The same launch for the forward of a TRAINING step (RQ splines): also writes the transformer parameters the backward
+ * needs (MaskedLinear output incl. bias, masked.py:265-277) to theta_out (B, ld_theta), column slot * P + p for the live
+ * feature slots, from the epilogue -- no separate output GEMM + spline kernel.  w_feature_major (must be 1): the rows of
+ * w_split / bias_packed inside a column tile are feature-major (row = slot * P + p, the packing of the backward's
+ * grad_input GEMM) instead of parameter-major (p * 16 + slot); k_ranges count the same 16 P-row tiles.  theta_out may be
+ * NULL.  The live slots must be the first ones; padding slots (feat_index < 0) write nothing. */
+int tfep_fused_saving_supported(const tfep_spline_desc* desc);      /* the plain and circular layouts of 8, 5 or 4 bins */
+int tfep_fused_output_transformer_forward_split_saving(const void* h_split, int64_t ldh, const float* h_inv_scale,
+                                                       const void* w_split, int64_t ldw, const float* w_inv_scale,
+                                                       const float* bias_packed, const int32_t* k_ranges,
+                                                       const int32_t* tile_order, const tfep_spline_desc* desc,
+                                                       const float* x, int64_t ldx, float* y, int64_t ldy,
+                                                       const int32_t* feat_index, const int32_t* feat_tr, int n_feature_slots,
+                                                       double* ldj_partial, float* log_det_J, int accumulate, int B,
+                                                       int n_rows_w, int k_padded, int w_feature_major, float* theta_out,
+                                                       int64_t ld_theta, void* stream);
 
 /* Diagnostic: matrix-pipe ceiling of this device for the split GEMM's instruction mix (cf. tfep_diag_mfma_peak). */
 int tfep_diag_split_mfma_peak(float* scratch, int blocks, int iters, void* stream);

@@ -492,11 +492,12 @@ def test_backward_in_several_batch_chunks_equals_one_chunk(monkeypatch, split, e
     for n, a, b, b2 in zip(names, one, many, again):
         scale = float(a.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-7, n
-        assert torch.equal(b, b2), n
+        assert torch.equal(b, b2), (n, float((b - b2).abs().max()), int(((b - b2) != 0).sum()),
+                                    torch.nonzero((b - b2) != 0)[:6].tolist())
 
 
 @pytest.mark.parametrize('split', [False, True])
-@pytest.mark.parametrize('kind', ['spline', 'affine', 'fixed+periodic'])
+@pytest.mark.parametrize('kind', ['spline', 'affine', 'fixed+periodic', 'fixed+periodic+5bins'])
 def test_activation_saving_forward_equals_the_recomputing_one(monkeypatch, split, kind):
     """A training forward keeps the hidden activations and transformer parameters for its backward when they fit
     ``_SAVE_BYTES`` (un-fused kernels on the backward's weight packing); otherwise the backward recomputes them.  Same
@@ -518,7 +519,8 @@ def test_activation_saving_forward_equals_the_recomputing_one(monkeypatch, split
         fixed = [3, 17, 40]
         deg = generate_degrees(D, 'ascending', conditioning_indices=fixed)
         emb = PeriodicEmbedding(D, limits=[-4.0, 4.0], periodic_indices=list(range(1, D, 4)))
-        tr = NeuralSplineTransformer(torch.full((D - 3,), -4.0), torch.full((D - 3,), 4.0), 6)
+        # (5 bins: one of the fused layouts -- the saving forward is then ONE launch of the fused kernel; 6: un-fused)
+        tr = NeuralSplineTransformer(torch.full((D - 3,), -4.0), torch.full((D - 3,), 4.0), 5 if kind.endswith('5bins') else 6)
     maf = MAF(deg, transformer=tr, embedding=emb, hidden_layers=[140, 170], initialize_identity=False).cuda()
     maf.split_gemm = split
     x0 = (torch.randn(B, D) * 1.3).clamp(-3.9, 3.9).cuda()
@@ -535,6 +537,20 @@ def test_activation_saving_forward_equals_the_recomputing_one(monkeypatch, split
     assert bw.saves_activations(maf, x0)
     ys, ls, gs = step()
     assert ('bwd_weights', str(x0.device)) in maf._dev
+    # split-f16 operands + a fused spline layout: output layer, spline and parameter store in one launch on the backward's
+    # feature-major packing (tfep_fused_output_transformer_forward_split_saving); same numbers as the un-fused kernels
+    fused_saving = maf._dev.get(('fused_saving', str(x0.device)))
+    assert (fused_saving is not None) == (split and kind in ('spline', 'fixed+periodic+5bins'))
+    if fused_saving is not None:
+        monkeypatch.setenv('TFEP_FUSED_SAVING', '0')
+        maf._dev.pop(('fused_saving', str(x0.device)))
+        yu, lu, gu = step()
+        assert maf._dev[('fused_saving', str(x0.device))] is None
+        monkeypatch.delenv('TFEP_FUSED_SAVING')
+        maf._dev.pop(('fused_saving', str(x0.device)))
+        assert float((ys - yu).abs().max()) < 2e-5 and float((ls - lu).abs().max()) < 2e-4
+        for n, a, b in zip(['x'] + [n for n, _ in maf.named_parameters()], gs, gu):
+            assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-8, n
     monkeypatch.setattr(bw, '_SAVE_BYTES', 0)
     assert not bw.saves_activations(maf, x0)
     yr, lr, gr = step()

@@ -106,6 +106,7 @@ _SIGNATURES = {
                                            c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     'tfep_masked_linear_narrow_tile_n': (c_int, []),
     'tfep_masked_linear_tile_n': (c_int, []),
+    'tfep_split_wide_tile_n': (c_int, []),
     'tfep_masked_linear_tile_k': (c_int, []),
     'tfep_masked_linear_tile_m': (c_int, []),
     'tfep_affine_forward': (c_int, [_P, c_int64, _P, ParamLayout, _P, c_int64, _P, c_int, c_int, c_int, _P]),
@@ -140,6 +141,11 @@ _SIGNATURES = {
                                                             POINTER(SplineDesc), _P, c_int64, _P, c_int64,
                                                             _P, _P, c_int, _P, _P, c_int,
                                                             c_int, c_int, c_int, _P]),
+    'tfep_fused_saving_supported': (c_int, [POINTER(SplineDesc)]),
+    'tfep_fused_output_transformer_forward_split_saving': (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P,
+                                                                   POINTER(SplineDesc), _P, c_int64, _P, c_int64,
+                                                                   _P, _P, c_int, _P, _P, c_int,
+                                                                   c_int, c_int, c_int, c_int, _P, c_int64, _P]),
     'tfep_diag_split_mfma_peak': (c_int, [_P, c_int, c_int, _P]),
     'tfep_diag_split_cycles': (c_int, [_P]),
     'tfep_inverse_block_step_ints': (c_int, []),

@@ -26,6 +26,12 @@ struct FusedArgs {
     double* ldj_partial;       // (n_col_tiles, B)
     const float *x0, *xf, *y0, *yf;
     SplineFlags sf;
+    // split spline kernels only (the activation-saving forward of a training step):
+    int feature_major;         // the packed weight / bias rows of a column tile are feature-major (row = slot * P + p, the
+                               //   backward's packing) instead of parameter-major (row = p * 16 + slot): the weight DMA
+                               //   gathers the tile's rows in the kernel's order, one packing serves forward and backward
+    float* theta_out;          // optional (B, ld_theta): the transformer parameters (bias included), column slot * P + p of
+    int64_t ld_theta;          //   the live feature slots -- what the backward needs, written from the epilogue's records
 };
 
 struct GemmArgs {
@@ -214,8 +220,10 @@ inline long long gemm_grid_blocks(int map_mode, int m_tiles, int n_tiles, int n_
 constexpr int FUSED_TILE_FEATURES = 16;
 
 // split_gemm.hip: the same GEMMs on split-f16 operands (g.a / g.w point to split rows, g.a_inv_scale / g.w_inv_scale set)
-int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s);
+int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s, bool wide_tile = false);
+int split_wide_tile_n();
 int launch_split_fused(const GemmArgs& g, int n_rows_w, int kind, int n_col_tiles, hipStream_t s);
+bool split_fused_saving_supported(const SplineFlags& f);
 // (split_gemm_layouts.hip) the spline layouts with identity boundary slopes / learnable bounds: P != 3 K + 1
 int launch_split_fused_layouts(const GemmArgs& g, int n_rows_w, int K, int P, int n_col_tiles, hipStream_t s);
 

@@ -454,6 +454,7 @@ int tfep_masked_linear_tile_n(void) { return Tile<LIN_MREP, LIN_NREP>::BN; }
 // Alignment of k_padded and of the k-ranges: the larger of the two kernels' k-tiles (fp32: 16, split-f16: 32).
 int tfep_masked_linear_tile_k(void) { return 2 * BK; }
 int tfep_masked_linear_narrow_tile_n(void) { return Tile<LIN_MREP, NARROW_NREP>::BN; }
+int tfep_split_wide_tile_n(void) { return split_wide_tile_n(); }
 int tfep_fused_tile_features(void) { return FUSED_TILE_FEATURES; }
 
 int tfep_masked_weight_prepare(const float* weight_v, const float* weight_g, const float* mask, int out_features,
@@ -554,8 +555,9 @@ int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
     g.tile_order = d->tile_order; g.aux = d->elu_grad_of; g.ldaux = d->ld_elu_grad_of; g.accumulate = d->accumulate;
     g.tile_live = d->tile_live; g.pre_add = d->pre_add; g.ld_pre_add = d->ld_pre_add;
     if (d->tile_list) {
-        TFEP_REQUIRE(d->n_tile_list > 0 && !d->tile_order && d->k_split <= 1 && (d->tile_n == 0 || d->tile_n == Tile<LIN_MREP, LIN_NREP>::BN),
-                     "masked_linear_gemm: tile_list needs n_tile_list > 0, the wide tile, no tile_order and no k_split");
+        TFEP_REQUIRE(d->n_tile_list > 0 && !d->tile_order && d->k_split <= 1 &&
+                         (d->tile_n == 0 || d->tile_n == Tile<LIN_MREP, LIN_NREP>::BN || (d->split && d->tile_n == split_wide_tile_n())),
+                     "masked_linear_gemm: tile_list needs n_tile_list > 0, a wide tile, no tile_order and no k_split");
         g.tile_list = d->tile_list; g.n_tile_list = d->n_tile_list;
     }
     if (d->k_split > 1) {
@@ -566,13 +568,17 @@ int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
     }
     if (d->split) {
         constexpr int SPLIT_BN = Tile<LIN_MREP, LIN_NREP>::BN;
-        TFEP_REQUIRE(d->tile_n == 0 || d->tile_n == SPLIT_BN, "masked_linear_gemm: split operands need the wide tile");
+        const bool xwide = d->tile_n == split_wide_tile_n();
+        TFEP_REQUIRE(d->tile_n == 0 || d->tile_n == SPLIT_BN || xwide, "masked_linear_gemm: split operands need the wide tile (0, %d or %d)",
+                     SPLIT_BN, split_wide_tile_n());
+        TFEP_REQUIRE(!xwide || (d->act == 0 && !d->split_out && d->k_split <= 1),
+                     "masked_linear_gemm: the %d-column tile takes the plain linear product only", split_wide_tile_n());
         g.a_inv_scale = d->x_inv_scale; g.w_inv_scale = d->w_inv_scale;
         if (d->split_out) {
             TFEP_REQUIRE(d->act == 1 && d->y_inv_scale, "masked_linear_gemm: split_out needs act = 1 (ELU) and y_inv_scale");
             g.y_inv_scale = d->y_inv_scale; g.w_l1max = d->w_l1max; g.bias_absmax = d->bias_absmax;
         }
-        return launch_split_linear(g, d->n_rows_w, d->act, (hipStream_t)stream);
+        return launch_split_linear(g, d->n_rows_w, d->act, (hipStream_t)stream, xwide);
     }
     constexpr int WIDE_BN = Tile<LIN_MREP, LIN_NREP>::BN, NARROW_BN = Tile<LIN_MREP, NARROW_NREP>::BN;
     TFEP_REQUIRE(d->tile_n == 0 || d->tile_n == WIDE_BN || d->tile_n == NARROW_BN,
@@ -625,7 +631,8 @@ static int fused_forward(const float* h, int64_t ldh, const float* w, int64_t ld
                          const float* x, int64_t ldx, float* y, int64_t ldy, const int32_t* feat_index,
                          const int32_t* feat_tr, int n_feature_slots, double* ldj_partial, float* log_det_J,
                          int accumulate, int B, int n_rows_w, int k_padded, bool split, const float* h_inv_scale,
-                         const float* w_inv_scale, void* stream) {
+                         const float* w_inv_scale, void* stream, int feature_major = 0, float* theta_out = nullptr,
+                         int64_t ld_theta = 0) {
     TFEP_REQUIRE(n_feature_slots > 0 && n_feature_slots % FUSED_TILE_FEATURES == 0,
                  "fused: n_feature_slots=%d must be a positive multiple of %d", n_feature_slots, FUSED_TILE_FEATURES);
     if (!tfep_fused_supported(kind, desc)) return fail(TFEP_ERR_UNSUPPORTED, "fused: unsupported transformer configuration");
@@ -640,6 +647,7 @@ static int fused_forward(const float* h, int64_t ldh, const float* w, int64_t ld
     g.B = B; g.k_padded = k_padded; g.tile_order = tile_order;
     g.fu.x = x; g.fu.ldx = ldx; g.fu.y = y; g.fu.ldy = ldy; g.fu.feat_index = feat_index; g.fu.feat_tr = feat_tr;
     g.fu.ldj_partial = ldj_partial;
+    g.fu.feature_major = feature_major; g.fu.theta_out = theta_out; g.fu.ld_theta = ld_theta;
     g.a_inv_scale = h_inv_scale; g.w_inv_scale = w_inv_scale;
     const int n_groups = n_feature_slots / FUSED_TILE_FEATURES;
     if (kind == TFEP_FUSED_AFFINE) {
@@ -652,7 +660,9 @@ static int fused_forward(const float* h, int64_t ldh, const float* w, int64_t ld
     } else {
         const int KS = desc->n_bins, P = desc_n_params(desc);
         TFEP_REQUIRE(feat_tr && desc->x0 && desc->xf && desc->y0 && desc->yf, "fused spline: NULL descriptor arrays");
-        TFEP_REQUIRE(n_rows_w >= n_feature_slots * P, "fused: weight has too few rows");
+        // (feature-major rows: the dead slots of the last tile lie past the packing; the kernel reads them as zeros)
+        TFEP_REQUIRE(n_rows_w >= (feature_major ? n_feature_slots - FUSED_TILE_FEATURES + 1 : n_feature_slots) * P,
+                     "fused: weight has too few rows");
         g.N = n_feature_slots * P;
         g.fu.x0 = desc->x0; g.fu.xf = desc->xf; g.fu.y0 = desc->y0; g.fu.yf = desc->yf;
         g.fu.sf.K = KS; g.fu.sf.circular = desc->circular != 0; g.fu.sf.identity = desc->identity_boundary_slopes != 0;
@@ -708,6 +718,35 @@ int tfep_fused_output_transformer_forward_split(const void* h_split, int64_t ldh
     return fused_forward((const float*)h_split, ldh, (const float*)w_split, ldw, bias_packed, k_ranges, tile_order, kind,
                          desc, x, ldx, y, ldy, feat_index, feat_tr, n_feature_slots, ldj_partial, log_det_J, accumulate, B,
                          n_rows_w, k_padded, true, h_inv_scale, w_inv_scale, stream);
+}
+
+int tfep_fused_saving_supported(const tfep_spline_desc* d) {
+    if (!d || !tfep_fused_supported(TFEP_FUSED_SPLINE, d)) return 0;
+    SplineFlags f = {};
+    f.K = d->n_bins; f.circular = d->circular != 0; f.identity = d->identity_boundary_slopes != 0;
+    f.learn_lower = d->learn_lower_bound != 0; f.learn_upper = d->learn_upper_bound != 0;
+    return split_fused_saving_supported(f) ? 1 : 0;
+}
+
+int tfep_fused_output_transformer_forward_split_saving(const void* h_split, int64_t ldh, const float* h_inv_scale,
+                                                       const void* w_split, int64_t ldw, const float* w_inv_scale,
+                                                       const float* bias_packed, const int32_t* k_ranges,
+                                                       const int32_t* tile_order, const tfep_spline_desc* desc,
+                                                       const float* x, int64_t ldx, float* y, int64_t ldy,
+                                                       const int32_t* feat_index, const int32_t* feat_tr, int n_feature_slots,
+                                                       double* ldj_partial, float* log_det_J, int accumulate, int B,
+                                                       int n_rows_w, int k_padded, int w_feature_major, float* theta_out,
+                                                       int64_t ld_theta, void* stream) {
+    TFEP_REQUIRE(h_inv_scale && w_inv_scale, "fused split: NULL scale pointer");
+    TFEP_REQUIRE(desc, "fused saving: NULL spline descriptor");
+    TFEP_REQUIRE(w_feature_major, "fused saving: the kernel takes feature-major weight rows (w_feature_major = 1) only");
+    if (theta_out)
+        TFEP_REQUIRE(ld_theta >= (int64_t)(n_feature_slots - FUSED_TILE_FEATURES + 1) * desc_n_params(desc),
+                     "fused saving: theta rows too short");
+    return fused_forward((const float*)h_split, ldh, (const float*)w_split, ldw, bias_packed, k_ranges, tile_order,
+                         TFEP_FUSED_SPLINE, desc, x, ldx, y, ldy, feat_index, feat_tr, n_feature_slots, ldj_partial, log_det_J,
+                         accumulate, B, n_rows_w, k_padded, true, h_inv_scale, w_inv_scale, stream, w_feature_major ? 1 : 0,
+                         theta_out, ld_theta);
 }
 
 }  // extern "C"

@@ -406,9 +406,17 @@ int check_split_operands(const GemmArgs& g) {
     return TFEP_OK;
 }
 
-int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s) {
+int split_wide_tile_n() { return STile<25>::BN; }
+
+int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s, bool wide_tile) {
     int rc = check_split_operands(g);
     if (rc) return rc;
+    if (wide_tile) {
+        // the 400-column tile of the fused spline kernel for a plain product: a wave's A fragments serve 25 column groups
+        // instead of 16 (+5 % on a dense 16 384 x 76 800 x 9 024 product: 468 -> 494 TFLOP/s)
+        TFEP_REQUIRE(act == 0 && !g.y_inv_scale && g.ksplit <= 1, "split gemm: the 400-column tile takes the plain linear product only");
+        return launch_split<25, EPI_LINEAR, 1, 1>(g, n_rows_w, (g.N + STile<25>::BN - 1) / STile<25>::BN, s);
+    }
     constexpr int NREP = 16;
     const int n_tiles = (g.N + STile<NREP>::BN - 1) / STile<NREP>::BN;
     if (act == 1 && g.y_inv_scale) {
@@ -423,10 +431,12 @@ int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s)
     constexpr int NARROW = 8;
     if (g.N <= STile<NARROW>::BN && env_int("TFEP_SPLIT_NARROW", 1))
         return launch_split<NARROW, EPI_LINEAR, 1, 1>(g, n_rows_w, 1, s);
-    // TIMING EXPERIMENT: the 400-column tile of the fused kernel for a plain dense product (no per-tile tables)
-    if (env_int("TFEP_SPLIT_WIDE_TILE", 0) && !g.k_ranges && !g.tile_live && !g.tile_order && g.ksplit <= 1)
-        return launch_split<25, EPI_LINEAR, 1, 1>(g, n_rows_w, (g.N + STile<25>::BN - 1) / STile<25>::BN, s);
     return launch_split<NREP, EPI_LINEAR, 1, 1>(g, n_rows_w, n_tiles, s);
+}
+
+bool split_fused_saving_supported(const SplineFlags& f) {
+    const int P = spline_n_params(f.K, f.circular, f.identity, f.learn_lower, f.learn_upper);
+    return (f.K == 8 || f.K == 5 || f.K == 4) && P == 3 * f.K + 1 && !f.identity;
 }
 
 int launch_split_fused(const GemmArgs& g, int n_rows_w, int kind, int n_col_tiles, hipStream_t s) {
@@ -438,6 +448,13 @@ int launch_split_fused(const GemmArgs& g, int n_rows_w, int kind, int n_col_tile
     // (spline_n_params; split_gemm_layouts.hip, also for identity slopes + both bounds, whose count is 3 K + 1 again)
     const SplineFlags& f = g.fu.sf;
     const int K = f.K, P = spline_n_params(K, f.circular, f.identity, f.learn_lower, f.learn_upper);
+    if (g.fu.feature_major) {
+        // the training forward (tfep_fused_output_transformer_forward_split_saving): plain and circular layouts
+        if (!split_fused_saving_supported(g.fu.sf)) return fail(TFEP_ERR_UNSUPPORTED, "fused split saving: unsupported spline layout");
+        if (K == 8) return launch_split<25, EPI_SPLINE, 25, 8, true>(g, n_rows_w, n_col_tiles, s);
+        if (K == 5) return launch_split<16, EPI_SPLINE, 16, 5, true>(g, n_rows_w, n_col_tiles, s);
+        return launch_split<13, EPI_SPLINE, 13, 4, true>(g, n_rows_w, n_col_tiles, s);
+    }
     if (P != 3 * K + 1 || f.identity) return launch_split_fused_layouts(g, n_rows_w, K, P, n_col_tiles, s);
     if (K == 8) return launch_split<25, EPI_SPLINE, 25, 8>(g, n_rows_w, n_col_tiles, s);
     if (K == 5) return launch_split<16, EPI_SPLINE, 16, 5>(g, n_rows_w, n_col_tiles, s);

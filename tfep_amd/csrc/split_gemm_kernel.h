@@ -81,6 +81,15 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const f16x8& a, const f16x8& 
 
 __device__ __forceinline__ void keep_alive(const f32x4& v) { asm volatile("" ::"v"(v)); }
 
+// An empty asm that re-defines an accumulator where it lives: what follows depends on a value made HERE (see the kernel).
+template <bool IN_AGPR>
+__device__ __forceinline__ void redefine(f32x4& v) {
+    if constexpr (IN_AGPR)
+        asm volatile("" : "+a"(v));
+    else
+        asm volatile("" : "+v"(v));
+}
+
 // TFEP_DIAG & 16: per-phase cycle totals of the fused kernel (wave 0 of every workgroup): [k-loop, epilogue, workgroups]
 static __device__ unsigned long long g_split_cycles[4];   // (per translation unit) [3]: workgroup lifetimes in 100 MHz real-time ticks
 
@@ -126,7 +135,7 @@ constexpr int split_lds_bytes() {
     return stages;
 }
 
-template <int KSPL, int P, bool IDB>
+template <int KSPL, int P, bool IDB, bool SAVE>
 __device__ __forceinline__ void split_spline_epilogue(const GemmArgs& g, f32x4 (&acc)[P][SMREP],
                                                       const f32x4 (&rs)[SMREP], int nt, int n0, int wrow0, int lane,
                                                       float* rec_base) {
@@ -139,9 +148,12 @@ __device__ __forceinline__ void split_spline_epilogue(const GemmArgs& g, f32x4 (
     const int fcol = fu.feat_index[slot];
     const bool live = fcol >= 0;
     float bias_p[P];
+    // SAVE (the training forward): a feature-major tile -- its dead slots lie past the packed bias
+    constexpr bool fmaj = SAVE;
     static_for<0, P>([&](auto pc) __attribute__((always_inline)) {
-        bias_p[pc.value] = g.bias ? g.bias[n0 + pc.value * 16 + cj] : 0.f;
+        bias_p[pc.value] = !g.bias ? 0.f : fmaj ? (live ? g.bias[n0 + cj * P + pc.value] : 0.f) : g.bias[n0 + pc.value * 16 + cj];
     });
+    float* theta_col = (SAVE && fu.theta_out) ? fu.theta_out + (int64_t)slot * P : nullptr;
     float x0 = 0.f, xf = 1.f, y0 = 0.f, yf = 1.f;
     if (live) {
         const int ftr = fu.feat_tr[slot];
@@ -177,6 +189,17 @@ __device__ __forceinline__ void split_spline_epilogue(const GemmArgs& g, f32x4 (
                 prm[e][4 * q4 + 2] = q[2];
                 prm[e][4 * q4 + 3] = q[3];
             });
+            if constexpr (SAVE) {
+                // the parameters the backward needs: this lane's two records, straight from the registers just loaded
+                static_for<0, 2>([&](auto ec) __attribute__((always_inline)) {
+                    constexpr int e = ec.value;
+                    const int row = wrow0 + m * 16 + gq * 4 + i0 + e;
+                    if (theta_col && live && row < g.B) {
+                        float* th = theta_col + (int64_t)row * fu.ld_theta;
+                        static_for<0, P>([&](auto pc) __attribute__((always_inline)) { th[pc.value] = prm[e][pc.value]; });
+                    }
+                });
+            }
             double ld[2];
             float outv[2];
             static_for<0, 2>([&](auto ec) __attribute__((always_inline)) {
@@ -192,6 +215,7 @@ __device__ __forceinline__ void split_spline_epilogue(const GemmArgs& g, f32x4 (
                 const int row = wrow0 + m * 16 + gq * 4 + i0 + e;
                 const bool ok = live && row < g.B;
                 if (ok) fu.y[(int64_t)row * fu.ldy + fcol] = outv[e];
+
                 double l = ok ? ld[e] : 0.0;
 #pragma unroll
                 for (int off = 8; off > 0; off >>= 1) l += __shfl_xor(l, off, 64);
@@ -201,7 +225,9 @@ __device__ __forceinline__ void split_spline_epilogue(const GemmArgs& g, f32x4 (
     });
 }
 
-template <int NREP, int EPI, int P, int KSPL>
+// SAVE: the spline kernels of a training forward (feature-major weight rows, parameter store) -- instantiations of their
+// own, so that the inference kernels keep their register allocation
+template <int NREP, int EPI, int P, int KSPL, bool SAVE = false>
 __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int n_rows_w) {
     using T = STile<NREP>;
     extern __shared__ __attribute__((aligned(16))) char slds[];
@@ -259,6 +285,17 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
         sc.vw = (uint32_t)(((int64_t)drow * g.ldw) * 4) + (((wave & 1) ? (p0 ^ 4) : p0) * 16);
         sc.piece_a = (uint32_t)(8 * g.lda * 4);
         sc.piece_w = (uint32_t)(8 * g.ldw * 4);
+        if constexpr (SAVE && epi_is_spline(EPI)) {
+            {
+                // Tile row q = p * 16 + j (what the accumulator layout wants) sits at packed row j * P + p.  Chunk
+                // c = wave + 4 e holds q = 8 c + drow: p = c >> 1 = (wave >> 1) + 2 e, j = 8 (wave & 1) + drow, so its rows
+                // are ((8 (wave & 1) + drow) P + (wave >> 1) + 2 e) -- with c * piece_w = (wave + 4 e) * 2 ldw bytes the
+                // e-dependent part is 2 rows per step, the rest goes into the per-lane offset (mod 2^32 arithmetic).
+                sc.piece_w = (uint32_t)(2 * g.ldw);
+                sc.vw = (uint32_t)(((int64_t)((8 * (wave & 1) + drow) * P + (wave >> 1)) * g.ldw) * 4) - (uint32_t)wave * sc.piece_w +
+                        (((wave & 1) ? (p0 ^ 4) : p0) * 16);
+            }
+        }
     }
     char* a_wave = slds + wave * A_WAVE_BYTES;
     char* b_base = slds + T::A_BYTES;
@@ -341,9 +378,20 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
     };
     static_assert(T::N_DMA <= 3 * NREP, "not enough DMA slots in a k-tile");
     for (int t = 0; t + 1 < nk; ++t) tile(std::true_type{}, t);
-    if (nk > 0) tile(std::false_type{}, nk - 1);
-    // The MFMAs are inline asm: leave the matrix pipe's result latency behind before anything reads acc.
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    if (nk > 0) {
+        tile(std::false_type{}, nk - 1);
+        // The MFMAs are inline asm: the compiler neither knows their result latency nor pads for it.  Leave it behind IN THE
+        // BLOCK OF THE LAST MFMAS, then re-define every accumulator through an (empty) asm: each later use -- the epilogue's
+        // arithmetic, the copies that merge this path with the nk == 0 one, and above all the register allocator's SPILL
+        // stores, which it otherwise places right after the last MFMAs, ahead of the wait (seen: scratch_store and v_mov
+        // of accumulator registers before the s_nop; the last products of a few rows then miss from a result, ~1e-7
+        // relative and different from run to run) -- depends on a value that exists only after the wait.
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+        static_for<0, NREP * SMREP>([&](auto ic) __attribute__((always_inline)) {
+            constexpr int n = ic.value / SMREP, m = ic.value % SMREP;
+            redefine<(n < N_ACC_AGPR)>(acc[n][m]);
+        });
+    }
 
     if (g.diag & 1) {   // timing-only build of the main loop: keep the accumulators alive, store nothing
         static_for<0, NREP * SMREP>([&](auto ic) __attribute__((always_inline)) {
@@ -373,7 +421,7 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
     if constexpr (epi_is_spline(EPI)) {
         static_assert(SWAVES * spl_wave_bytes<P>() <= split_lds_bytes<NREP, EPI, P>(), "epilogue records do not fit in LDS");
         __syncthreads();                        // every wave is done with the operand stages: LDS is reused below
-        split_spline_epilogue<KSPL, P, EPI == EPI_SPLINE_IDB>(g, acc, rs, nt, n0, wrow0, lane, (float*)(slds + wave * spl_wave_bytes<P>()));
+        split_spline_epilogue<KSPL, P, EPI == EPI_SPLINE_IDB, SAVE>(g, acc, rs, nt, n0, wrow0, lane, (float*)(slds + wave * spl_wave_bytes<P>()));
     } else if constexpr (EPI == EPI_ELU_SPLIT) {
         // y = ELU(x W^T + b) written straight as split rows for the next GEMM.  The row scale cannot wait for the row
         // maximum (other workgroups hold the other columns), so it comes from a bound every workgroup can compute:
@@ -504,10 +552,10 @@ __global__ void __launch_bounds__(STHREADS, 1) split_peak_kernel(float* out, int
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-template <int NREP, int EPI, int P, int KSPL>
+template <int NREP, int EPI, int P, int KSPL, bool SAVE = false>
 static int launch_split(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStream_t s) {
     using T = STile<NREP>;
-    auto kern = split_gemm_kernel<NREP, EPI, P, KSPL>;
+    auto kern = split_gemm_kernel<NREP, EPI, P, KSPL, SAVE>;
     constexpr int LDS = split_lds_bytes<NREP, EPI, P>();
     // per device: a process may drive several GPUs
     static bool attr_set_on[TFEP_MAX_DEVICES] = {};

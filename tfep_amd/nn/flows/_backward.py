@@ -402,7 +402,7 @@ class UnsupportedBackward(torch.autograd.Function):
 
 
 def _gemm(x, w, y, B, N, n_rows_w, bias=None, k_ranges=None, act=0, accumulate=0, elu_grad_of=None, tile_live=None,
-          split=False, w_split=None, x_split=None, tile_list=None):
+          split=False, w_split=None, x_split=None, tile_list=None, tile_n=0):
     """``split``: run on split-f16 operands (x converted here with one scale per row; ``w_split`` / ``x_split`` = already
     converted ``(rows, inv_scale)`` of w / x, else w is converted here with one scale for the matrix)."""
     d = _lib.GemmDesc()
@@ -423,6 +423,7 @@ def _gemm(x, w, y, B, N, n_rows_w, bias=None, k_ranges=None, act=0, accumulate=0
     d.tile_live = tile_live.data_ptr() if tile_live is not None else None
     if tile_list is not None:
         d.tile_list, d.n_tile_list = tile_list.data_ptr(), tile_list.shape[0]
+    d.tile_n = tile_n                  # (0 = the default 256 columns; the tables above count tiles of this width)
     if not split and ops.few_wide_tiles(B, N):
         # a cfg1-sized product is one or two 256 x 256 tiles: one workgroup walks the whole k range while 255 CUs idle
         # (130 us for a 224 x 224 x 1024 grad_weight).  The 32-column tile spreads it over the columns; the mask tables are
@@ -474,28 +475,46 @@ def _backward_plan(layer, device):
         k_ranges[L] = ops.mask_k_ranges(lins[L].mask, tn, (n_out_pad + tn - 1) // tn, mplan['k_pad'][L], row_of_out,
                                         mplan['col_of_in'][L])
     bp['k_ranges'] = k_ranges
-    dx_ranges, live, live_list = [], [], []
-    for li, lin in enumerate(lins):
-        kr = k_ranges[li].cpu().long()                            # per 256-row tile of W: [kb, ke)
-        is_out = li == L
-        n_pad = ops.round_up(lin.out_features, tk) if is_out else mplan['n_pad'][li]
-        k_pad = mplan['k_pad'][li]
-        n_col_tiles = (k_pad + tn - 1) // tn
-        lo = torch.arange(n_col_tiles) * tn
-        hi = lo + tn
-        hit = (kr[:, 0:1] < hi[None, :]) & (kr[:, 1:2] > lo[None, :])          # (row tiles, col tiles)
-        live.append(hit.to(torch.uint8).contiguous().to(device))
-        # the same tiles as a launch list that gives every XCD an equal share (grad_weight: all tiles cost the same)
-        live_list.append(ops.xcd_balanced_tile_list(hit).to(device) if os.environ.get('TFEP_TILE_LIST', '1') != '0' else None)
-        # grad_input GEMM: output column tile j (over k) needs the rows n of the tiles that touch it
-        rng = torch.zeros(n_col_tiles, 2, dtype=torch.int32)
-        for j in range(n_col_tiles):
-            rows = torch.nonzero(hit[:, j]).flatten()
-            if len(rows):
-                rng[j, 0] = int(rows.min()) * tn
-                rng[j, 1] = min((int(rows.max()) + 1) * tn, n_pad)
-        dx_ranges.append(rng.to(device))
-    bp.update(dx_ranges=dx_ranges, live=live, live_list=live_list)
+    use_list = os.environ.get('TFEP_TILE_LIST', '1') != '0'
+
+    def tables(col_width):
+        """Per layer: live output tiles of grad_weight (256 rows of W x ``col_width`` columns of k), the same as an
+        XCD-balanced launch list, and the W-row range each column tile of grad_input needs."""
+        dx_ranges, live, live_list = [], [], []
+        for li, lin in enumerate(lins):
+            kr = k_ranges[li].cpu().long()                            # per 256-row tile of W: [kb, ke)
+            n_pad = ops.round_up(lin.out_features, tk) if li == L else mplan['n_pad'][li]
+            k_pad = mplan['k_pad'][li]
+            n_col_tiles = (k_pad + col_width - 1) // col_width
+            lo = torch.arange(n_col_tiles) * col_width
+            hi = lo + col_width
+            hit = (kr[:, 0:1] < hi[None, :]) & (kr[:, 1:2] > lo[None, :])          # (row tiles, col tiles)
+            live.append(hit.to(torch.uint8).contiguous().to(device))
+            # the same tiles as a launch list that gives every XCD an equal share (grad_weight: all tiles cost the same)
+            live_list.append(ops.xcd_balanced_tile_list(hit).to(device) if use_list else None)
+            # grad_input GEMM: output column tile j (over k) needs the rows n of the tiles that touch it
+            rng = torch.zeros(n_col_tiles, 2, dtype=torch.int32)
+            for j in range(n_col_tiles):
+                rows = torch.nonzero(hit[:, j]).flatten()
+                if len(rows):
+                    rng[j, 0] = int(rows.min()) * tn
+                    rng[j, 1] = min((int(rows.max()) + 1) * tn, n_pad)
+            dx_ranges.append(rng.to(device))
+        return dict(dx_ranges=dx_ranges, live=live, live_list=live_list)
+
+    bp.update(tables(tn))
+    # The split-f16 kernel's 400-column tile for the plain linear products of a training step (the saving forward's output
+    # layer, grad_input, grad_weight): the same tables counted in tiles of that width.
+    bp['wide'] = None
+    if os.environ.get('TFEP_SPLIT_WIDE_TILE', '1') != '0':
+        tw = ops.split_wide_tile_n()
+        wide = tables(tw)
+        wide['tile_n'] = tw
+        row_of_out = bp.get('row_of_out', mplan['row_of_out'][L])
+        n_out_pad = ops.round_up(n_out, tk)
+        wide['k_ranges_out'] = ops.mask_k_ranges(lins[L].mask, tw, (n_out_pad + tw - 1) // tw, mplan['k_pad'][L], row_of_out,
+                                                 mplan['col_of_in'][L])
+        bp['wide'] = wide
     layer._dev[key] = bp
     return bp
 
@@ -568,7 +587,9 @@ def _conditioner_forward(layer, wts, cin, Bc):
         h.append(_gemm(h[-1], wts['W'][l], torch.empty(Bc, n_pad[l], **f32), Bc, n_pad[l], n_pad[l], bias=wts['bias'][l],
                        k_ranges=mplan['k_ranges'][l], act=1, split=split, w_split=wts['Ws'][l]))
     theta = torch.empty(Bc, n_out_pad, **f32)
-    _gemm(h[-1], wts['W'][L], theta, Bc, n_out_pad, n_pad[L], bias=wts['bias'][L], k_ranges=bplan['k_ranges'][L],
+    wide = bplan['wide'] if split else None
+    _gemm(h[-1], wts['W'][L], theta, Bc, n_out_pad, n_pad[L], bias=wts['bias'][L],
+          k_ranges=wide['k_ranges_out'] if wide else bplan['k_ranges'][L], tile_n=wide['tile_n'] if wide else 0,
           split=split, w_split=wts['Ws'][L])
     return h, theta
 
@@ -604,10 +625,41 @@ def saves_activations_at(layer, batch):
     return need <= 0.15 * free
 
 
+def _fused_saving_plan(layer, dev):
+    """Tables of the fused output-layer launch on the BACKWARD's packing (feature-major rows in degree-sorted slot order),
+    or None when the layer's forward has no fused split kernel of that form (anything but a plain RQ-spline transformer
+    in one of the fused layouts)."""
+    key = ('fused_saving', str(dev))
+    if key in layer._dev:
+        return layer._dev[key]
+    from ..transformers.spline import NeuralSplineTransformer
+    from .autoregressive import _FUSED_SPLINE
+    plan = None
+    bplan = _backward_plan(layer, dev)
+    if type(layer._transformer) is NeuralSplineTransformer and bplan['sorted_out'] and layer._fused_kind() == _FUSED_SPLINE \
+            and os.environ.get('TFEP_FUSED_SAVING', '1') != '0':
+        made = layer._conditioner
+        mplan, lins, L, n_out, n_out_pad, n_pad, k_pad = _dims(layer, dev)
+        grp = layer._fused_plan(dev, _FUSED_SPLINE, layer._tables(dev))['groups'][0]
+        P = grp['P']
+        n_tr = layer._tables(dev)['n_tr']
+        # the fused plan and the backward sort the features the same way (stable argsort of their degrees)
+        same = torch.equal(grp['feat_tr'][:n_tr].cpu().long(), bplan['order'].cpu().long())
+        desc = layer._transformer.config(dev).desc
+        if same and P * n_tr == n_out and _lib.load().tfep_fused_saving_supported(ctypes.byref(desc)):
+            n_tiles = grp['n_slots'] // 16
+            k_ranges = ops.mask_k_ranges(lins[L].mask, 16 * P, n_tiles, k_pad[L], bplan['row_of_out'], mplan['col_of_in'][L])
+            plan = dict(grp=grp, P=P, k_ranges=k_ranges, tile_order=ops.heavy_first_order(k_ranges))
+    layer._dev[key] = plan
+    return plan
+
+
 def forward_saving(layer, x):
-    """``(y, log_det_J, saved)`` of the layer by the un-fused kernels on the backward's weight packing; ``saved`` holds
-    the hidden activations and the transformer parameters for ``layer_backward``."""
-    x, _ = _lib.rows(x, 'x')
+    """``(y, log_det_J, saved)`` of the layer on the backward's weight packing; ``saved`` holds the hidden activations and
+    the transformer parameters for ``layer_backward``.  RQ splines on split-f16 operands: the output layer, the spline and
+    the parameter store are ONE launch of the fused kernel (``tfep_fused_output_transformer_forward_split_saving``);
+    otherwise the un-fused kernels."""
+    x, ldx = _lib.rows(x, 'x')
     dev = x.device
     B, D = x.shape
     made = layer._conditioner
@@ -619,6 +671,29 @@ def forward_saving(layer, x):
     P = n_out // n_tr
     wts = _weights(layer, dev)
     cin = emb(x) if emb is not None else x
+    fs = _fused_saving_plan(layer, dev) if wts['split'] else None
+    if fs is not None:
+        f32 = dict(dtype=torch.float32, device=dev)
+        h = [ops.pad_columns(cin, k_pad[0])]
+        for l in range(L):
+            h.append(_gemm(h[-1], wts['W'][l], torch.empty(B, n_pad[l], **f32), B, n_pad[l], n_pad[l], bias=wts['bias'][l],
+                           k_ranges=mplan['k_ranges'][l], act=1, split=True, w_split=wts['Ws'][l]))
+        hs, h_inv = ops.split_rows(h[-1], h[-1].shape[1])
+        theta = torch.empty(B, n_out_pad, **f32)
+        if n_out_pad > n_out:
+            theta[:, n_out:] = 0.0
+        y = x.clone() if layer.has_fixed_indices else torch.empty(B, D, **f32)
+        ldj = torch.empty(B, **f32)
+        grp = fs['grp']
+        ws = torch.empty(grp['n_slots'] // 16, B, dtype=torch.float64, device=dev)
+        desc = layer._transformer.config(dev).desc
+        w_s, w_inv = wts['Ws'][L]
+        _lib.call('tfep_fused_output_transformer_forward_split_saving', _lib.ptr(hs), hs.shape[1], _lib.ptr(h_inv),
+                  _lib.ptr(w_s), w_s.shape[1], _lib.ptr(w_inv), _lib.ptr(wts['bias'][L]), _lib.ptr(fs['k_ranges']),
+                  _lib.ptr(fs['tile_order']), ctypes.byref(desc), _lib.ptr(x), ldx, _lib.ptr(y), D,
+                  _lib.ptr(grp['feat_index']), _lib.ptr(grp['feat_tr']), grp['n_slots'], _lib.ptr(ws), _lib.ptr(ldj), 0, B,
+                  n_pad[L], k_pad[L], 1, _lib.ptr(theta), n_out_pad, _lib.stream_of(x))
+        return y, ldj, dict(h=h, theta=theta)
     h, theta = _conditioner_forward(layer, wts, cin, B)
     x_tr = ops.gather_columns(x, tables['tr']) if layer.has_fixed_indices else x
     xs = ops.gather_columns(x_tr, bplan['order'])
@@ -663,7 +738,9 @@ def layer_backward(layer, x, gy, gldj, saved=None):
     W, WT, bias, Ws, WTs, split = wts['W'], wts['WT'], wts['bias'], wts['Ws'], wts['WTs'], wts['split']
     sorted_out = bplan['sorted_out']
     # (ops.zeros: fill kernels, not memsets -- a captured training step replays them; see ops.zeros)
-    gW = [ops.zeros(n_pad[l], k_pad[l], **f32) for l in range(L + 1)]
+    # The packed weight gradients are written (first chunk) or accumulated (later chunks) over the live tiles only, and only
+    # those are read afterwards (weight_norm_backward*: the live prefix, or a select on the mask): no 5.5 GB clear.
+    gW = [(ops.zeros if B == 0 else torch.empty)(n_pad[l], k_pad[l], **f32) for l in range(L + 1)]      # (empty batch: no chunk writes)
     gb = [ops.zeros(n_pad[l], **f32) for l in range(L + 1)]
     gx = torch.empty(B, D, **f32)
     emb_generic = emb is not None and type(emb) is not PeriodicEmbedding
@@ -697,7 +774,13 @@ def layer_backward(layer, x, gy, gldj, saved=None):
             x_tr, gy_tr = ops.gather_columns(xc, tables['tr']), ops.gather_columns(gyc, tables['tr'])
         else:
             x_tr, gy_tr = xc, gyc
-        gtheta = ops.zeros(Bc, n_out_pad, **f32)
+        if sorted_out:
+            # affine / spline: the kernel writes every parameter of every feature; only the padding columns need zeros
+            gtheta = torch.empty(Bc, n_out_pad, **f32)
+            if n_out_pad > n_out:
+                gtheta[:, n_out:] = 0.0
+        else:
+            gtheta = ops.zeros(Bc, n_out_pad, **f32)
         gx_dir = torch.empty(Bc, n_tr, **f32)
         x_tr, gy_tr = x_tr.contiguous(), gy_tr.contiguous()
         if sorted_out:
@@ -726,20 +809,22 @@ def layer_backward(layer, x, gy, gldj, saved=None):
                 _lib.call('tfep_transpose_split', _lib.ptr(h[l]), h[l].shape[1], Bc, k_pad[l], _lib.ptr(hTs), Bc_pad, Bc_pad, 1,
                           None, _lib.ptr(hT_inv), stream)
                 # grad_weight (packed) += g^T h   [rows n, cols k], masked tiles skipped
-                _gemm(gTs, hTs, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=1, tile_live=bplan['live'][l], split=True,
-                      x_split=(gTs, gT_inv), w_split=(hTs, hT_inv), tile_list=bplan['live_list'][l])
+                tbl = bplan['wide'] or bplan
+                _gemm(gTs, hTs, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=int(b0 > 0), tile_live=tbl['live'][l], split=True,
+                      x_split=(gTs, gT_inv), w_split=(hTs, hT_inv), tile_list=tbl['live_list'][l], tile_n=tbl.get('tile_n', 0))
                 del gTs, hTs, cmax
             else:
                 _lib.call('tfep_column_sums', _lib.ptr(g), g.shape[1], Bc, n_pad[l], _lib.ptr(gb[l]), 1, stream)
                 gT = _transpose(g, Bc, n_pad[l], ops.zeros(n_pad[l], Bc_pad, **f32))
                 hT = _transpose(h[l], Bc, k_pad[l], ops.zeros(k_pad[l], Bc_pad, **f32))
-                _gemm(gT, hT, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=1, tile_live=bplan['live'][l],
+                _gemm(gT, hT, gW[l], n_pad[l], k_pad[l], k_pad[l], accumulate=int(b0 > 0), tile_live=bplan['live'][l],
                       tile_list=bplan['live_list'][l])
                 del gT, hT
             # grad_input = g W  (x ELU'(h) for hidden inputs)
             gin = torch.empty(Bc, k_pad[l], **f32)
-            _gemm(g, WT[l], gin, Bc, k_pad[l], k_pad[l], k_ranges=bplan['dx_ranges'][l],
-                  elu_grad_of=h[l] if l > 0 else None, split=split, w_split=WTs[l])
+            tbl = (bplan['wide'] if split else None) or bplan
+            _gemm(g, WT[l], gin, Bc, k_pad[l], k_pad[l], k_ranges=tbl['dx_ranges'][l],
+                  elu_grad_of=h[l] if l > 0 else None, split=split, w_split=WTs[l], tile_n=tbl.get('tile_n', 0))
             g = gin
 
         # ---- gradient w.r.t. the layer input: through the conditioner + direct

@@ -241,6 +241,13 @@ def xcd_balanced_tile_list(live, n_xcd=8, group=32):
     return out
 
 
+def split_wide_tile_n():
+    """Widest column tile of the split-f16 kernel's plain linear product (400)."""
+    if 'xwide' not in _TILES:
+        _TILES['xwide'] = _lib.load().tfep_split_wide_tile_n()
+    return _TILES['xwide']
+
+
 def narrow_tile_n():
     if 'narrow' not in _TILES:
         _TILES['narrow'] = _lib.load().tfep_masked_linear_narrow_tile_n()
