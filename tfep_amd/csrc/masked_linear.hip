@@ -571,7 +571,7 @@ int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
         const bool xwide = d->tile_n == split_wide_tile_n();
         TFEP_REQUIRE(d->tile_n == 0 || d->tile_n == SPLIT_BN || xwide, "masked_linear_gemm: split operands need the wide tile (0, %d or %d)",
                      SPLIT_BN, split_wide_tile_n());
-        TFEP_REQUIRE(!xwide || (d->act == 0 && !d->split_out && d->k_split <= 1),
+        TFEP_REQUIRE(!xwide || (d->act == 0 && !d->split_out),
                      "masked_linear_gemm: the %d-column tile takes the plain linear product only", split_wide_tile_n());
         g.a_inv_scale = d->x_inv_scale; g.w_inv_scale = d->w_inv_scale;
         if (d->split_out) {

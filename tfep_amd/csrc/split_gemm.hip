@@ -414,7 +414,7 @@ int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s,
     if (wide_tile) {
         // the 400-column tile of the fused spline kernel for a plain product: a wave's A fragments serve 25 column groups
         // instead of 16 (+5 % on a dense 16 384 x 76 800 x 9 024 product: 468 -> 494 TFLOP/s)
-        TFEP_REQUIRE(act == 0 && !g.y_inv_scale && g.ksplit <= 1, "split gemm: the 400-column tile takes the plain linear product only");
+        TFEP_REQUIRE(act == 0 && !g.y_inv_scale, "split gemm: the 400-column tile takes the plain linear product only");
         return launch_split<25, EPI_LINEAR, 1, 1>(g, n_rows_w, (g.N + STile<25>::BN - 1) / STile<25>::BN, s);
     }
     constexpr int NREP = 16;
