@@ -317,6 +317,9 @@ int tfep_abs_reduce(const float* src, int64_t ld_src, int64_t rows, int64_t cols
  * significant bits (bits = 19 for the fp16 hi + lo format); the host routes a flagged batch to the exact-fp32 kernels.
  * count is NOT cleared (several tensors may add to one counter); plain kernel, no workspace. */
 int tfep_range_flag(const float* src, int64_t ld_src, int64_t rows, int64_t cols, int bits, int32_t* count, void* stream);
+/* out[c] = max_r |src[r, c]| (cols floats; a NaN in a column survives): the per-feature magnitudes the guard above is run on
+ * (one pass over the batch at HBM rate; plain kernels, no workspace). */
+int tfep_column_absmax(const float* src, int64_t ld_src, int64_t rows, int64_t cols, float* out, void* stream);
 
 /* Columns [col0, col0 + cols) (col0 % 8 == 0; whole groups of 8 are converted) of fp32 rows into the same columns of split
  * rows, with the per-row scale given by the caller (inv_scale[row], a power of two, e.g. from a bound on the row): for

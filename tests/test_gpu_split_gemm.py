@@ -545,3 +545,23 @@ def test_transpose_split_equals_split_of_the_transpose():
     assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R - 8, R, 0, _lib.ptr(w_inv), None, None) != 0   # rows too short
     assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R, R, 0, None, None, None) != 0
     assert lib.tfep_transpose_split(_lib.ptr(src), ld, R, C, _lib.ptr(out), R, R, 3, _lib.ptr(w_inv), None, None) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape', [(1, 1), (7, 5), (513, 1024), (4100, 1030), (33, 4099)])
+def test_column_absmax_matches_torch(shape):
+    """``tfep_column_absmax`` (the per-feature magnitudes of the split-path guard): equal to torch's, on aligned and
+    unaligned rows / row strides; a NaN in a column survives (the guard then routes the batch to the exact kernels)."""
+    import torch
+    from tfep_amd import ops
+    torch.manual_seed(3)
+    R, C = shape
+    x = torch.randn(R, C, device='cuda') * torch.logspace(-6, 3, C, device='cuda')
+    assert torch.equal(ops.column_absmax(x)[0], x.abs().amax(dim=0))
+    big = torch.randn(R, C + 3, device='cuda')
+    view = big[:, 1:C + 1]                              # row stride C + 3, rows start 4 bytes off the 16-byte grid
+    assert torch.equal(ops.column_absmax(view)[0], view.abs().amax(dim=0))
+    x[R // 2, C // 2] = float('nan')
+    out = ops.column_absmax(x)[0]
+    assert bool(torch.isnan(out[C // 2])) and int(torch.isnan(out).sum()) == 1
+    assert ops.column_absmax(torch.empty(0, 5, device='cuda')).tolist() == [[0.0] * 5]

@@ -136,6 +136,7 @@ _SIGNATURES = {
     'tfep_split_rows': (c_int, [_P, c_int64, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P]),
     'tfep_abs_reduce': (c_int, [_P, c_int64, c_int64, c_int64, c_int, _P, _P]),
     'tfep_range_flag': (c_int, [_P, c_int64, c_int64, c_int64, c_int, _P, _P]),
+    'tfep_column_absmax': (c_int, [_P, c_int64, c_int64, c_int64, _P, _P]),
     'tfep_split_columns_scaled': (c_int, [_P, c_int64, c_int64, c_int64, c_int64, _P, c_int64, _P, _P]),
     'tfep_fused_output_transformer_forward_split': (c_int, [_P, c_int64, _P, _P, c_int64, _P, _P, _P, _P, c_int,
                                                             POINTER(SplineDesc), _P, c_int64, _P, c_int64,

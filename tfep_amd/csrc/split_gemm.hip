@@ -25,6 +25,10 @@ namespace tfep {
 __global__ void zero_u32_kernel(uint32_t* p, int n = 1) {
     for (int i = 0; i < n; ++i) p[i] = 0u;
 }
+__global__ void zero_u32_n_kernel(uint32_t* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
 
 __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int64_t cols,
                                                      uint32_t* __restrict__ out_bits) {
@@ -48,6 +52,50 @@ __global__ void __launch_bounds__(256) absmax_kernel(const float* __restrict__ s
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     // non-negative floats order like their bits; look before the atomic (same-address atomics serialise in L2)
     if (lane == 0 && __float_as_uint(m) > __atomic_load_n(out_bits, __ATOMIC_RELAXED)) atomicMax(out_bits, __float_as_uint(m));
+}
+
+// out_bits[c] = max_r |src[r, c]| as bits (cleared by zero_u32_kernel first; the integer maximum of the magnitudes' bits:
+// non-negative floats order like their bits and a NaN, above them all, survives).  A workgroup covers 1024 columns
+// (16-byte loads when the rows allow) and every gridDim.y-th row: 4 KB contiguous per row, running maxima in registers, one
+// atomic per column and workgroup at the end.
+__global__ void __launch_bounds__(256) column_absmax_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int64_t cols,
+                                                            uint32_t* __restrict__ out_bits, int vec4) {
+    const int64_t c0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c0 >= cols) return;
+    uint32_t m[4] = {0u, 0u, 0u, 0u};
+    const int nc = (int)(cols - c0 < 4 ? cols - c0 : 4);
+    if (vec4 && nc == 4) {
+        // 16 rows in flight per lane (one load per iteration leaves the kernel latency bound: 2.8 TB/s)
+        constexpr int U = 16;
+        // a contiguous slab of rows per workgroup
+        const int64_t per = (rows + gridDim.y - 1) / gridDim.y;
+        const int64_t step = 1, r_end = min(rows, (int64_t)(blockIdx.y + 1) * per);
+        int64_t r = (int64_t)blockIdx.y * per;
+        for (; r + (U - 1) * step < r_end; r += U * step) {
+            float4 q[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) q[u] = *reinterpret_cast<const float4*>(src + (r + u * step) * ld + c0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                m[0] = max(m[0], __float_as_uint(fabsf(q[u].x)));
+                m[1] = max(m[1], __float_as_uint(fabsf(q[u].y)));
+                m[2] = max(m[2], __float_as_uint(fabsf(q[u].z)));
+                m[3] = max(m[3], __float_as_uint(fabsf(q[u].w)));
+            }
+        }
+        for (; r < r_end; r += step) {
+            const float4 q = *reinterpret_cast<const float4*>(src + r * ld + c0);
+            m[0] = max(m[0], __float_as_uint(fabsf(q.x)));
+            m[1] = max(m[1], __float_as_uint(fabsf(q.y)));
+            m[2] = max(m[2], __float_as_uint(fabsf(q.z)));
+            m[3] = max(m[3], __float_as_uint(fabsf(q.w)));
+        }
+    } else {
+        for (int64_t r = blockIdx.y; r < rows; r += gridDim.y)
+            for (int j = 0; j < nc; ++j) m[j] = max(m[j], __float_as_uint(fabsf(src[r * ld + c0 + j])));
+    }
+    for (int j = 0; j < nc; ++j)
+        if (m[j] > __atomic_load_n(out_bits + c0 + j, __ATOMIC_RELAXED)) atomicMax(out_bits + c0 + j, m[j]);
 }
 
 // One wave per row.  per_tensor: the scale comes from *tensor_max_bits (absmax_kernel) and inv_scale[0] is written
@@ -528,6 +576,26 @@ int tfep_abs_reduce(const float* src, int64_t ld_src, int64_t rows, int64_t cols
         abs_reduce_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(src, ld_src, rows, cols, mode, out);
     }
     return check_launch("abs_reduce_kernel");
+}
+
+int tfep_column_absmax(const float* src, int64_t ld_src, int64_t rows, int64_t cols, float* out, void* stream) {
+    TFEP_REQUIRE(rows >= 0 && cols >= 0, "column_absmax: negative size");
+    if (cols == 0) return TFEP_OK;
+    TFEP_REQUIRE(out && (rows == 0 || src) && ld_src >= cols, "column_absmax: bad arguments");
+    TFEP_REQUIRE(cols <= 0x7fffffffLL, "column_absmax: too many columns");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* bits = reinterpret_cast<uint32_t*>(out);
+    zero_u32_n_kernel<<<(unsigned)((cols + 255) / 256), 256, 0, s>>>(bits, (int)cols);
+    if (rows > 0) {
+        const unsigned gx = (unsigned)((cols + 1023) / 1024);
+        // ~512 workgroups: more of them only queue up on the final atomics (measured, 512 MB: 256 WGs 121 us, 512 131,
+        // 2048 165, 8192 217; torch's reduction 238: tools/probe/colmax_bench.py)
+        const int64_t want = (env_int("TFEP_COLMAX_WGS", 512) + gx - 1) / gx;
+        const unsigned gy = (unsigned)(rows < want ? rows : want);
+        const int vec4 = ((uintptr_t)src % 16 == 0 && ld_src % 4 == 0) ? 1 : 0;
+        column_absmax_kernel<<<dim3(gx, gy), 256, 0, s>>>(src, ld_src, rows, cols, bits, vec4);
+    }
+    return check_launch("column_absmax_kernel");
 }
 
 int tfep_range_flag(const float* src, int64_t ld_src, int64_t rows, int64_t cols, int bits, int32_t* count, void* stream) {

@@ -1240,7 +1240,7 @@ class _RangeGuard:
             # per-FEATURE magnitudes over the batch (a single small value in one row is harmless -- every unit adds an
             # exact fp32 bias and sees other features; what the per-row scale cannot carry is a feature that is small in
             # EVERY row next to one that is large in every row)
-            col_max = torch.linalg.vector_norm(x.detach(), ord=float('inf'), dim=0).reshape(1, -1).contiguous()   # max |x| per feature, no (B, D) temporary
+            col_max = ops.column_absmax(x.detach())          # max |x| per feature: one pass at HBM rate, no temporary
             n_x = ops.range_flag([col_max], bits=19)
         layer.last_split_guard = dict(feature_scales_out_of_range=bool(n_x), exact=bool(n_x))
         if n_x:

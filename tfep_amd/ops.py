@@ -341,6 +341,14 @@ def split_columns_scaled(x, col0, cols, out, inv_scale):
     return out
 
 
+def column_absmax(x):
+    """``max_r |x[r, c]|`` per column of a 2-D tensor as a (1, cols) float32 tensor (``tfep_column_absmax``; NaN survives)."""
+    x, ldx = rows(x, 'x')
+    out = torch.empty(1, x.shape[1], dtype=torch.float32, device=x.device)
+    call('tfep_column_absmax', ptr(x), ldx, x.shape[0], x.shape[1], ptr(out), stream_of(x))
+    return out
+
+
 def range_flag(tensors, bits=19):
     """Number of rows, over the 2-D fp32 ``tensors``, whose own dynamic range exceeds what the split-f16 operand format
     carries at fp32 accuracy (a non-zero element below ``2^-bits`` of the row maximum, or a non-finite element):
