@@ -9,7 +9,7 @@ needs 11 wait states for an 8-pass MFMA, 19 for a 16-pass one; no hardware inter
 program order (a linear approximation of the control flow), ages every MFMA result register by the wait states of the
 instructions that follow (1 each, s_nop N = N + 1, an MFMA = 4) and reports every non-MFMA access younger than NEED.
 
-usage: mfma_result_hazard_scan.py file.s [NEED=20]"""
+usage: mfma_result_hazard_scan.py file.s [NEED=16]"""
 import re
 import sys
 
@@ -26,7 +26,7 @@ def regs(text):
     return out
 
 
-def main(path, need=20):
+def main(path, need=16):
     kern, age, bad, in_asm = '?', {}, 0, False
     for line in open(path):
         t = line.split(';')[0].strip() if not line.strip().startswith(';;#') else line.strip()
@@ -74,4 +74,4 @@ def main(path, need=20):
 
 
 if __name__ == '__main__':
-    sys.exit(1 if main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 20) else 0)
+    sys.exit(1 if main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 16) else 0)
