@@ -565,3 +565,77 @@ def test_column_absmax_matches_torch(shape):
     out = ops.column_absmax(x)[0]
     assert bool(torch.isnan(out[C // 2])) and int(torch.isnan(out).sum()) == 1
     assert ops.column_absmax(torch.empty(0, 5, device='cuda')).tolist() == [[0.0] * 5]
+
+
+def _split_desc(a, w, out, tile_n=0, tile_list=None, tile_live=None, accumulate=0, k_split=1):
+    """``tfep_masked_linear_gemm`` on split operands made here (rows of ``a`` per row, ``w`` per tensor)."""
+    import ctypes
+    from tfep_amd import _lib, ops
+    asp, a_inv = ops.split_rows(a, a.shape[1])
+    wsp, w_inv = ops.split_rows(w, w.shape[1], per_tensor=True)
+    d = _lib.GemmDesc()
+    d.split, d.x_inv_scale, d.w_inv_scale = 1, a_inv.data_ptr(), w_inv.data_ptr()
+    d.x, d.ldx, d.w, d.ldw = asp.data_ptr(), asp.shape[1], wsp.data_ptr(), wsp.shape[1]
+    d.y, d.ldy = out.data_ptr(), out.shape[-1]
+    d.B, d.N, d.n_rows_w, d.k_padded, d.act, d.accumulate = a.shape[0], w.shape[0], w.shape[0], w.shape[1], 0, accumulate
+    d.tile_n = tile_n
+    if tile_list is not None:
+        d.tile_list, d.n_tile_list = tile_list.data_ptr(), tile_list.shape[0]
+    if tile_live is not None:
+        d.tile_live = tile_live.data_ptr()
+    if k_split > 1:
+        d.k_split, d.slab_stride = k_split, out.shape[-2] * out.shape[-1]
+    _lib.call('tfep_masked_linear_gemm', ctypes.byref(d), _lib.stream_of(a))
+    return out
+
+
+@pytest.mark.parametrize('B,K,N', [(700, 1024, 1000), (257, 96, 401), (1, 32, 3), (513, 2048, 400)])
+def test_wide_linear_tile_matches_float64_and_the_default_tile(B, K, N):
+    """The 400-column tile of the plain linear product (``tile_n = tfep_split_wide_tile_n()``, the training step's GEMMs):
+    the same sums as the 256-column tile, so the same bits; fp32-accurate against float64; split-K slabs add up."""
+    from tfep_amd import ops
+    torch.manual_seed(B + N)
+    tw = ops.split_wide_tile_n()
+    assert tw == 400
+    a = torch.randn(B, K, device='cuda')
+    w = torch.randn(N, K, device='cuda') / K ** 0.5
+    ref = a.double() @ w.double().T
+    y256 = _split_desc(a, w, torch.empty(B, N, device='cuda'))
+    y400 = _split_desc(a, w, torch.empty(B, N, device='cuda'), tile_n=tw)
+    assert torch.equal(y256, y400)
+    assert float((y400.double() - ref).abs().max()) < 2e-6 * float(ref.abs().max()) * max(1.0, K / 1024)
+    if K >= 1024:
+        slabs = _split_desc(a, w, torch.empty(2, B, N, device='cuda'), tile_n=tw, k_split=2)
+        assert float((slabs.sum(dim=0).double() - ref).abs().max()) < 2e-6 * float(ref.abs().max()) * max(1.0, K / 1024)
+
+
+@pytest.mark.parametrize('tile_n', [0, 400])
+def test_tile_list_launches_exactly_the_listed_tiles(tile_n):
+    """``tile_list``: the live tiles of a block-sparse product in an order that gives every XCD the same share
+    (``ops.xcd_balanced_tile_list``).  Listed tiles hold the product (first pass: written, second pass with ``accumulate``:
+    doubled), all other tiles are not touched."""
+    from tfep_amd import ops
+    torch.manual_seed(7)
+    tm = ops.tile_sizes()[0]
+    tn = tile_n or ops.tile_sizes()[1]
+    B, K, N = 5 * tm + 37, 256, 3 * tn + 11
+    M_t, N_t = (B + tm - 1) // tm, (N + tn - 1) // tn
+    live = torch.rand(M_t, N_t) < 0.5
+    live[0, 0], live[-1, -1] = True, False
+    tl = ops.xcd_balanced_tile_list(live)
+    listed = tl[tl[:, 0] >= 0]
+    assert tl.shape[0] % 256 == 0 and listed.shape[0] == int(live.sum())
+    assert {tuple(t) for t in listed.tolist()} == {tuple(t) for t in torch.nonzero(live).tolist()}
+    per_xcd = [int((tl[x::8, 0] >= 0).sum()) for x in range(8)]
+    assert max(per_xcd) - min(per_xcd) <= 32                    # whole groups of 32, dealt round-robin
+    a = torch.randn(B, K, device='cuda')
+    w = torch.randn(N, K, device='cuda') / K ** 0.5
+    ref = (a.double() @ w.double().T).float()
+    out = torch.full((B, N), 123.0, device='cuda')
+    _split_desc(a, w, out, tile_n=tile_n, tile_list=tl.cuda())
+    mask = live.cuda().repeat_interleave(tm, 0)[:B].repeat_interleave(tn, 1)[:, :N]
+    assert bool((out[~mask] == 123.0).all())
+    assert float((out[mask] - ref[mask]).abs().max()) < 1e-5
+    _split_desc(a, w, out, tile_n=tile_n, tile_list=tl.cuda(), accumulate=1)
+    assert bool((out[~mask] == 123.0).all())
+    assert float((out[mask] - 2 * ref[mask]).abs().max()) < 2e-5

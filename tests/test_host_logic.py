@@ -278,3 +278,22 @@ def test_which_layers_have_a_fused_kernel_and_a_blocked_inverse():
     assert lay._fused_kind() is None and not lay._blocked_ok()
     lay = layer(MixedTransformer([spline(2, 5), MoebiusTransformer(dimension=2)], [[0, 1], [2, 3, 4, 5]]))
     assert lay._fused_kind() is None and not lay._blocked_ok()
+
+
+def test_xcd_balanced_tile_list_covers_the_live_tiles_once_and_evenly():
+    """``ops.xcd_balanced_tile_list`` (launch order of a block-sparse GEMM, ``tile_list`` of ``tfep_gemm_desc``): every live
+    tile exactly once, none of the dead ones, groups of 32 dealt round-robin to the 8 XCD positions -- a triangular live
+    region (the grad_weight of a MADE layer) gives every XCD the same number of tiles to within one group."""
+    import torch
+    from tfep_amd import ops
+    for M, N in [(59, 59), (293, 38), (1, 1), (7, 3), (64, 5)]:
+        live = torch.tril(torch.ones(M, N)).bool() if M > 1 else torch.ones(M, N).bool()
+        tl = ops.xcd_balanced_tile_list(live)
+        assert tl.dtype == torch.int32 and tl.shape[1] == 2 and tl.shape[0] % (8 * 32) == 0
+        listed = tl[tl[:, 0] >= 0]
+        assert bool((tl[tl[:, 0] < 0] == -1).all())
+        assert listed.shape[0] == int(live.sum())
+        assert {tuple(t) for t in listed.tolist()} == {tuple(t) for t in torch.nonzero(live).tolist()}
+        per_xcd = [int((tl[x::8, 0] >= 0).sum()) for x in range(8)]
+        assert max(per_xcd) - min(per_xcd) <= 32, (M, N, per_xcd)
+    assert int((ops.xcd_balanced_tile_list(torch.zeros(4, 4).bool())[:, 0] >= 0).sum()) == 0
