@@ -223,21 +223,19 @@ def xcd_balanced_tile_list(live, n_xcd=8, group=32):
     gets the same number of tiles whatever the shape of the live region.  Returns an int32 (n_positions, 2) CPU tensor,
     -1 = no tile."""
     live = torch.as_tensor(live).cpu().bool()
-    M, N = live.shape
-    seq = []
-    for sn in range((N + 3) // 4):
-        for sm in range((M + 7) // 8):
-            for w in range(32):
-                mt, nt = sm * 8 + (w & 7), sn * 4 + (w >> 3)
-                if mt < M and nt < N and live[mt, nt]:
-                    seq.append((mt, nt))
-    n_groups = (len(seq) + group - 1) // group
+    mt, nt = torch.nonzero(live, as_tuple=True)
+    # order of the 8 x 4 super-tile walk: column super-tile, row super-tile, then column-major inside the super-tile
+    key = (((nt // 4) * ((live.shape[0] + 7) // 8) + mt // 8) * 4 + nt % 4) * 8 + mt % 8
+    order = torch.argsort(key)
+    mt, nt = mt[order], nt[order]
+    n = mt.numel()
+    n_groups = (n + group - 1) // group
     n_rounds = max(1, (n_groups + n_xcd - 1) // n_xcd)
     out = torch.full((n_rounds * group * n_xcd, 2), -1, dtype=torch.int32)
-    for i, (mt, nt) in enumerate(seq):
-        k, w = divmod(i, group)
-        pos = ((k // n_xcd) * group + w) * n_xcd + k % n_xcd
-        out[pos, 0], out[pos, 1] = mt, nt
+    i = torch.arange(n)
+    k, w = i // group, i % group
+    pos = ((k // n_xcd) * group + w) * n_xcd + k % n_xcd
+    out[pos, 0], out[pos, 1] = mt.to(torch.int32), nt.to(torch.int32)
     return out
 
 
