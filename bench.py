@@ -359,10 +359,18 @@ def main():
                 BoltzmannKLDivLoss()((c * yt ** 2).sum(dim=1), lt).backward()
                 opt.step()          # parameters change: every step packs its weights again, as a real loop does
             t_t = clock(train_step, 2)
+
+            def train_step_no_update():                # the same step without the optimiser: packed weights are re-used
+                for prm in layer.parameters():
+                    prm.grad = None
+                yt, lt = layer(x16)
+                BoltzmannKLDivLoss()((c * yt ** 2).sum(dim=1), lt).backward()
+            t_n = clock(train_step_no_update, 2)
             from tfep_amd.nn.flows import _backward
             free_b, total_b = torch.cuda.mem_get_info(device)
             other['training_step_one_layer'] = {
                 'rows': 16384, 'ms': 1e3 * t_t, 'samples_per_s': 16384 / t_t,
+                'ms_without_update': 1e3 * t_n, 'frac_without_update': 3.0 * flops_layer * 16384 / t_n / 1e12 / peak_other,
                 'activations_kept': bool(_backward.saves_activations_at(layer, 16384)),
                 'free_memory_gib': round(free_b / 2 ** 30, 1),
                 'roofline': {'bound': 'mfma', 'achieved': 3.0 * flops_layer * 16384 / t_t / 1e12, 'peak': peak_other,

@@ -497,7 +497,7 @@ def test_backward_in_several_batch_chunks_equals_one_chunk(monkeypatch, split, e
 
 
 @pytest.mark.parametrize('split', [False, True])
-@pytest.mark.parametrize('kind', ['spline', 'affine', 'fixed+periodic', 'fixed+periodic+5bins'])
+@pytest.mark.parametrize('kind', ['spline', 'spline4bins', 'circular', 'affine', 'fixed+periodic', 'fixed+periodic+5bins'])
 def test_activation_saving_forward_equals_the_recomputing_one(monkeypatch, split, kind):
     """A training forward keeps the hidden activations and transformer parameters for its backward when they fit
     ``_SAVE_BYTES`` (un-fused kernels on the backward's weight packing); otherwise the backward recomputes them.  Same
@@ -512,9 +512,10 @@ def test_activation_saving_forward_equals_the_recomputing_one(monkeypatch, split
     D, B = 66, 2200                    # (above the 1 MiB of transformer parameters from which activations are kept)
     if kind == 'affine':
         deg, emb, tr = generate_degrees(D, 'descending'), None, AffineTransformer()
-    elif kind == 'spline':
+    elif kind in ('spline', 'spline4bins', 'circular'):
         deg, emb = generate_degrees(D, 'ascending'), None
-        tr = NeuralSplineTransformer(torch.full((D,), -4.0), torch.full((D,), 4.0), 8)
+        tr = NeuralSplineTransformer(torch.full((D,), -4.0), torch.full((D,), 4.0), 4 if kind == 'spline4bins' else 8,
+                                     circular=kind == 'circular')
     else:
         fixed = [3, 17, 40]
         deg = generate_degrees(D, 'ascending', conditioning_indices=fixed)
@@ -540,7 +541,7 @@ def test_activation_saving_forward_equals_the_recomputing_one(monkeypatch, split
     # split-f16 operands + a fused spline layout: output layer, spline and parameter store in one launch on the backward's
     # feature-major packing (tfep_fused_output_transformer_forward_split_saving); same numbers as the un-fused kernels
     fused_saving = maf._dev.get(('fused_saving', str(x0.device)))
-    assert (fused_saving is not None) == (split and kind in ('spline', 'fixed+periodic+5bins'))
+    assert (fused_saving is not None) == (split and kind in ('spline', 'spline4bins', 'circular', 'fixed+periodic+5bins'))
     if fused_saving is not None:
         monkeypatch.setenv('TFEP_FUSED_SAVING', '0')
         maf._dev.pop(('fused_saving', str(x0.device)))
