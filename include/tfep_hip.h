@@ -260,8 +260,8 @@ typedef enum tfep_fused_kind {
 /* Feature slots per 16-wide MFMA column group (16). */
 int tfep_fused_tile_features(void);
 /* 1 if (kind, desc) is supported by the fused kernel: the affine transformer; RQ splines of 8, 5 or 4 bins, plain or
- * circular, with or without identity boundary slopes and learnable bounds, of at most 25 parameters per feature (all
- * layouts but the 8-bin ones with a learnable bound and free boundary slopes: 26 / 27). */
+ * circular, with or without identity boundary slopes and learnable bounds (11 .. 27 parameters per feature: every layout
+ * of spline.py:165-182 at these bin numbers). */
 int tfep_fused_supported(int kind, const tfep_spline_desc* desc);
 /* Packed weight rows per column tile of the fused kernel (= tile_n for tfep_mask_k_ranges):
  * P * FT * 16 where FT feature groups of 16 slots share a tile (spline: P = parameters per feature, FT = 1;

@@ -192,13 +192,16 @@ _FUSED_LAYOUTS = [
     (8, False, True, True, True),        # 25, like the plain layout: a kernel of its own
     (5, False, True, True, True),        # 16
     (4, False, True, True, True),        # 13
+    (8, False, False, True, False),      # 26: 416 accumulator registers per wave of the split kernel
+    (8, False, False, False, True),      # 26
+    (8, False, False, True, True),       # 27: 432
 ]
 
 
 @pytest.mark.parametrize('K,circular,identity,learn_lower,learn_upper', _FUSED_LAYOUTS)
 def test_spline_layouts_take_the_fused_epilogue(K, circular, identity, learn_lower, learn_upper):
-    """The fused output-GEMM + spline kernel is instantiated for 8, 5 and 4 bins and every parameter layout of at most 25
-    parameters per feature (plain / circular, identity boundary slopes, learnable bounds): such layers dispatch through
+    """The fused output-GEMM + spline kernel is instantiated for 8, 5 and 4 bins and every parameter layout (plain /
+    circular, identity boundary slopes, learnable bounds: 11 .. 27 parameters per feature): such layers dispatch through
     tfep::fused_output_transformer (fp32 and split kernels) and agree with the un-fused path, inside the domain and in
     both tails."""
     from torch.utils._python_dispatch import TorchDispatchMode
@@ -238,11 +241,10 @@ def test_spline_layouts_take_the_fused_epilogue(K, circular, identity, learn_low
             assert float((y - x).abs().max()) > 1e-2                    # (not the identity map)
 
 
-@pytest.mark.parametrize('K,identity,learn_lower,learn_upper', [(8, False, True, False), (8, False, True, True),
-                                                                (6, False, False, False), (6, True, True, True)])
+@pytest.mark.parametrize('K,identity,learn_lower,learn_upper', [(6, False, False, False), (6, True, True, True),
+                                                                (16, False, False, False), (3, False, True, False)])
 def test_spline_layouts_outside_the_fused_kernels(K, identity, learn_lower, learn_upper):
-    """More than 25 parameters per feature (8 bins with learnable bounds and free boundary slopes) and other bin numbers
-    keep the un-fused kernels -- and the library says the same."""
+    """Other bin numbers than 8, 5 and 4 keep the un-fused kernels -- and the library says the same."""
     import ctypes
     from tfep_amd import _lib
     from tfep_amd.nn.conditioners import generate_degrees

@@ -614,8 +614,8 @@ int tfep_fused_supported(int kind, const tfep_spline_desc* d) {
     if (kind == TFEP_FUSED_SPLINE && d) {
         if (d->n_bins != 8 && d->n_bins != 5 && d->n_bins != 4) return 0;
         if (d->circular && (d->learn_lower_bound || d->learn_upper_bound)) return 0;       // (not a valid spline)
-        // 8 bins: 26 / 27 accumulator tiles per wave do not fit the register file of the split kernel
-        return desc_n_params(d) <= 25;
+        // (8 bins with learnable bounds: 26 / 27 accumulator tiles per wave -- 432 of the split kernel's 512 registers)
+        return desc_n_params(d) <= 27;
     }
     return 0;
 }
@@ -682,7 +682,7 @@ static int fused_forward(const float* h, int64_t ldh, const float* w, int64_t ld
             TFEP_FUSED_SPLINE_IDB(8) TFEP_FUSED_SPLINE_IDB(5) TFEP_FUSED_SPLINE_IDB(4)
 #undef TFEP_FUSED_SPLINE_IDB
             if (!idb) {
-            TFEP_FUSED_SPLINE(8, 25) TFEP_FUSED_SPLINE(8, 23) TFEP_FUSED_SPLINE(8, 24)
+            TFEP_FUSED_SPLINE(8, 25) TFEP_FUSED_SPLINE(8, 23) TFEP_FUSED_SPLINE(8, 24) TFEP_FUSED_SPLINE(8, 26) TFEP_FUSED_SPLINE(8, 27)
             TFEP_FUSED_SPLINE(5, 16) TFEP_FUSED_SPLINE(5, 14) TFEP_FUSED_SPLINE(5, 15) TFEP_FUSED_SPLINE(5, 17) TFEP_FUSED_SPLINE(5, 18)
             TFEP_FUSED_SPLINE(4, 13) TFEP_FUSED_SPLINE(4, 11) TFEP_FUSED_SPLINE(4, 12) TFEP_FUSED_SPLINE(4, 14) TFEP_FUSED_SPLINE(4, 15)
             }

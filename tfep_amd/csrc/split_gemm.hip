@@ -449,7 +449,7 @@ int check_split_operands(const GemmArgs& g) {
     TFEP_REQUIRE(g.a_inv_scale && g.w_inv_scale, "split gemm: NULL scale pointer");
     TFEP_REQUIRE(g.k_padded > 0 && g.k_padded % SBK == 0, "split gemm: k_padded=%d must be a positive multiple of %d", g.k_padded, SBK);
     TFEP_REQUIRE(g.lda % SBK == 0 && g.ldw % SBK == 0, "split gemm: row strides must be multiples of %d elements", SBK);
-    TFEP_REQUIRE((int64_t)STile<25>::BM * g.lda * 4 < 0x7fffffffLL && (int64_t)STile<25>::BN * g.ldw * 4 < 0x7fffffffLL,
+    TFEP_REQUIRE((int64_t)STile<27>::BM * g.lda * 4 < 0x7fffffffLL && (int64_t)STile<27>::BN * g.ldw * 4 < 0x7fffffffLL,
                  "split gemm: row stride too large");
     return TFEP_OK;
 }

@@ -19,9 +19,10 @@ int launch_split_fused_layouts(const GemmArgs& g, int n_rows_w, int K, int P, in
     }
 #define TFEP_SPLIT_SPLINE(KK, PP) \
     if (K == KK && P == PP) return launch_split<PP, EPI_SPLINE, PP, KK>(g, n_rows_w, n_col_tiles, s);
-    // 8 bins: identity slopes (plain: 23; circular or with one learnable bound: 24).  26 / 27 accumulator tiles (learnable
-    // bounds without identity slopes) do not fit the register file: un-fused (tfep_fused_supported)
-    TFEP_SPLIT_SPLINE(8, 23) TFEP_SPLIT_SPLINE(8, 24)
+    // 8 bins: identity slopes (plain: 23; circular or with one learnable bound: 24); learnable bounds without identity
+    // slopes: 26 / 27 accumulator tiles -- 416 / 432 accumulator registers; the k-loop of the 27-tile kernel reloads three
+    // spilled address registers per k-tile, no accumulator leaves the register file (tools/scan_hazards.sh)
+    TFEP_SPLIT_SPLINE(8, 23) TFEP_SPLIT_SPLINE(8, 24) TFEP_SPLIT_SPLINE(8, 26) TFEP_SPLIT_SPLINE(8, 27)
     TFEP_SPLIT_SPLINE(5, 14) TFEP_SPLIT_SPLINE(5, 15) TFEP_SPLIT_SPLINE(5, 17) TFEP_SPLIT_SPLINE(5, 18)
     TFEP_SPLIT_SPLINE(4, 11) TFEP_SPLIT_SPLINE(4, 12) TFEP_SPLIT_SPLINE(4, 14) TFEP_SPLIT_SPLINE(4, 15)
 #undef TFEP_SPLIT_SPLINE

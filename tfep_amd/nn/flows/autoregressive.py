@@ -153,10 +153,10 @@ class AutoregressiveFlow(torch.nn.Module):
     @staticmethod
     def _transformer_fused_kind(tr):
         """Fused epilogue of one transformer (the rule of tfep_fused_supported): affine; RQ splines of 8, 5 or 4 bins in
-        every layout of at most 25 parameters per feature."""
+        every layout (at most 27 parameters per feature: 8 bins with both bounds learnable)."""
         if type(tr) is AffineTransformer:
             return _FUSED_AFFINE
-        if type(tr) is NeuralSplineTransformer and tr.host()['n_bins'] in (4, 5, 8) and tr.n_parameters_per_feature <= 25:
+        if type(tr) is NeuralSplineTransformer and tr.host()['n_bins'] in (4, 5, 8) and tr.n_parameters_per_feature <= 27:
             return _FUSED_SPLINE
         return None
 
