@@ -129,6 +129,9 @@ int tfep_masked_linear_narrow_tile_n(void);
 /* Widest column tile of the split-f16 kernel (400: the fused spline kernel's tile for a plain linear product, tile_n of
  * tfep_gemm_desc with split = 1, act = 0; k_ranges / tile_live / tile_list then count tiles of this width). */
 int tfep_split_wide_tile_n(void);
+/* ... and a 208-column one (same conditions): two of them cover the 400 output rows of a block of 16 degrees of an 8-bin
+ * spline layer -- the output-layer GEMM of the blocked inverse (flows/autoregressive.py:179-229) -- with 4 % padding. */
+int tfep_split_half_wide_tile_n(void);
 
 /*
  * General form of the same GEMM, used by the backward pass (MaskedLinearFunc.backward,

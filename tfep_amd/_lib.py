@@ -107,6 +107,7 @@ _SIGNATURES = {
     'tfep_masked_linear_narrow_tile_n': (c_int, []),
     'tfep_masked_linear_tile_n': (c_int, []),
     'tfep_split_wide_tile_n': (c_int, []),
+    'tfep_split_half_wide_tile_n': (c_int, []),
     'tfep_masked_linear_tile_k': (c_int, []),
     'tfep_masked_linear_tile_m': (c_int, []),
     'tfep_affine_forward': (c_int, [_P, c_int64, _P, ParamLayout, _P, c_int64, _P, c_int, c_int, c_int, _P]),

@@ -220,8 +220,9 @@ inline long long gemm_grid_blocks(int map_mode, int m_tiles, int n_tiles, int n_
 constexpr int FUSED_TILE_FEATURES = 16;
 
 // split_gemm.hip: the same GEMMs on split-f16 operands (g.a / g.w point to split rows, g.a_inv_scale / g.w_inv_scale set)
-int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s, bool wide_tile = false);
+int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s, bool wide_tile = false, bool half_wide_tile = false);
 int split_wide_tile_n();
+int split_half_wide_tile_n();
 int launch_split_fused(const GemmArgs& g, int n_rows_w, int kind, int n_col_tiles, hipStream_t s);
 bool split_fused_saving_supported(const SplineFlags& f);
 // (split_gemm_layouts.hip) the spline layouts with identity boundary slopes / learnable bounds: P != 3 K + 1

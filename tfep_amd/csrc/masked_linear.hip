@@ -455,6 +455,7 @@ int tfep_masked_linear_tile_n(void) { return Tile<LIN_MREP, LIN_NREP>::BN; }
 int tfep_masked_linear_tile_k(void) { return 2 * BK; }
 int tfep_masked_linear_narrow_tile_n(void) { return Tile<LIN_MREP, NARROW_NREP>::BN; }
 int tfep_split_wide_tile_n(void) { return split_wide_tile_n(); }
+int tfep_split_half_wide_tile_n(void) { return split_half_wide_tile_n(); }
 int tfep_fused_tile_features(void) { return FUSED_TILE_FEATURES; }
 
 int tfep_masked_weight_prepare(const float* weight_v, const float* weight_g, const float* mask, int out_features,
@@ -556,7 +557,8 @@ int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
     g.tile_live = d->tile_live; g.pre_add = d->pre_add; g.ld_pre_add = d->ld_pre_add;
     if (d->tile_list) {
         TFEP_REQUIRE(d->n_tile_list > 0 && !d->tile_order && d->k_split <= 1 &&
-                         (d->tile_n == 0 || d->tile_n == Tile<LIN_MREP, LIN_NREP>::BN || (d->split && d->tile_n == split_wide_tile_n())),
+                         (d->tile_n == 0 || d->tile_n == Tile<LIN_MREP, LIN_NREP>::BN ||
+                          (d->split && (d->tile_n == split_wide_tile_n() || d->tile_n == split_half_wide_tile_n()))),
                      "masked_linear_gemm: tile_list needs n_tile_list > 0, a wide tile, no tile_order and no k_split");
         g.tile_list = d->tile_list; g.n_tile_list = d->n_tile_list;
     }
@@ -568,17 +570,19 @@ int tfep_masked_linear_gemm(const tfep_gemm_desc* d, void* stream) {
     }
     if (d->split) {
         constexpr int SPLIT_BN = Tile<LIN_MREP, LIN_NREP>::BN;
-        const bool xwide = d->tile_n == split_wide_tile_n();
-        TFEP_REQUIRE(d->tile_n == 0 || d->tile_n == SPLIT_BN || xwide, "masked_linear_gemm: split operands need the wide tile (0, %d or %d)",
-                     SPLIT_BN, split_wide_tile_n());
-        TFEP_REQUIRE(!xwide || (d->act == 0 && !d->split_out),
-                     "masked_linear_gemm: the %d-column tile takes the plain linear product only", split_wide_tile_n());
+        const bool xwide = d->tile_n == split_wide_tile_n(), hwide = d->tile_n == split_half_wide_tile_n();
+        TFEP_REQUIRE(d->tile_n == 0 || d->tile_n == SPLIT_BN || xwide || hwide,
+                     "masked_linear_gemm: split operands need a wide tile (0, %d, %d or %d)", SPLIT_BN, split_wide_tile_n(),
+                     split_half_wide_tile_n());
+        TFEP_REQUIRE(!(xwide || hwide) || (d->act == 0 && !d->split_out),
+                     "masked_linear_gemm: the %d- and %d-column tiles take the plain linear product only", split_wide_tile_n(),
+                     split_half_wide_tile_n());
         g.a_inv_scale = d->x_inv_scale; g.w_inv_scale = d->w_inv_scale;
         if (d->split_out) {
             TFEP_REQUIRE(d->act == 1 && d->y_inv_scale, "masked_linear_gemm: split_out needs act = 1 (ELU) and y_inv_scale");
             g.y_inv_scale = d->y_inv_scale; g.w_l1max = d->w_l1max; g.bias_absmax = d->bias_absmax;
         }
-        return launch_split_linear(g, d->n_rows_w, d->act, (hipStream_t)stream, xwide);
+        return launch_split_linear(g, d->n_rows_w, d->act, (hipStream_t)stream, xwide, hwide);
     }
     constexpr int WIDE_BN = Tile<LIN_MREP, LIN_NREP>::BN, NARROW_BN = Tile<LIN_MREP, NARROW_NREP>::BN;
     TFEP_REQUIRE(d->tile_n == 0 || d->tile_n == WIDE_BN || d->tile_n == NARROW_BN,

@@ -455,10 +455,17 @@ int check_split_operands(const GemmArgs& g) {
 }
 
 int split_wide_tile_n() { return STile<25>::BN; }
+int split_half_wide_tile_n() { return STile<13>::BN; }
 
-int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s, bool wide_tile) {
+int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s, bool wide_tile, bool half_wide_tile) {
     int rc = check_split_operands(g);
     if (rc) return rc;
+    if (half_wide_tile) {
+        // 208 columns: two such tiles cover the 400 output rows of a block of 16 degrees of an 8-bin spline layer (the
+        // blocked inverse's output-layer GEMM) with 4 % padding where two 256-column tiles carry 22 %
+        TFEP_REQUIRE(act == 0 && !g.y_inv_scale, "split gemm: the 208-column tile takes the plain linear product only");
+        return launch_split<13, EPI_LINEAR, 1, 1>(g, n_rows_w, (g.N + STile<13>::BN - 1) / STile<13>::BN, s);
+    }
     if (wide_tile) {
         // the 400-column tile of the fused spline kernel for a plain product: a wave's A fragments serve 25 column groups
         // instead of 16 (+5 % on a dense 16 384 x 76 800 x 9 024 product: 468 -> 494 TFLOP/s)

@@ -907,7 +907,12 @@ class AutoregressiveFlow(torch.nn.Module):
         tm, tn = lib.tfep_masked_linear_tile_m(), lib.tfep_masked_linear_tile_n()
         # split-K slabs: enough workgroups for 256 CUs (the split kernel's tile is 256 rows x 256 columns; the block kernel
         # fetches all slabs of a value in one round trip), >= 512 k per slice
-        positions = max(1, ((y.shape[0] + 255) // 256) * ((n_out_max + 255) // 256))
+        # column tile of the output block GEMM: 208 columns where the same number of tiles then carries less padding (the
+        # 400 rows of 16 degrees x 25 parameters: 2 tiles, 4 % instead of 22 %)
+        th = lib.tfep_split_half_wide_tile_n()
+        n256, n208 = (n_out_max + 255) // 256, (n_out_max + th - 1) // th
+        self._inv_out_tile = th if n208 <= n256 and os.environ.get('TFEP_INV_HALF_WIDE_TILE', '1') != '0' else 0
+        positions = max(1, ((y.shape[0] + 255) // 256) * min(n256, n208))
         k_split = int(min(8, max(1, 256 // positions), max(1, mplan['k_pad'][L] // 512)))
         return hs, ops.pow2_inv_scale(bound), w_split, w_inv, k_split, hidden
 
@@ -925,7 +930,7 @@ class AutoregressiveFlow(torch.nn.Module):
         f32 = dict(dtype=torch.float32, device=dev)
         kr_all = bp['k_ranges']
 
-        def launch(x_in, w, bias, desc, out, out_col0, act, pre=None, pre_col0=0, wide=False, k_split=1, split=None):
+        def launch(x_in, w, bias, desc, out, out_col0, act, pre=None, pre_col0=0, wide=False, k_split=1, split=None, tile_n=0):
             """out[:, out_col0 : +n] = act(x_in W[row0 : row0+n]^T + bias[row0:] (+ pre[:, pre_col0 : +n]));
             ``k_split`` > 1: ``out`` is (k_split, B, cols) and receives the partial sums of the k slices;
             ``split = (x_inv_scale, w_inv_scale)``: ``x_in`` and ``w`` are split-f16 rows (wide tile only)."""
@@ -944,7 +949,7 @@ class AutoregressiveFlow(torch.nn.Module):
                 d.k_split, d.slab_stride = k_split, out.shape[-2] * out.shape[-1]
             if pre is not None:
                 d.pre_add, d.ld_pre_add = pre.data_ptr() + 4 * pre_col0, pre.shape[1]
-            d.tile_n = 0 if wide else narrow
+            d.tile_n = (tile_n if split is not None else 0) if wide else narrow
             _lib.call('tfep_masked_linear_gemm', ctypes.byref(d), _lib.stream_of(x_in))
 
         # every column tile of a launch shares the launch's k-range: one row-repeated table, built once
@@ -1110,7 +1115,7 @@ class AutoregressiveFlow(torch.nn.Module):
                         elif hs is not None and not new_part:
                             out, ks = (zouts[par][S_out], 1) if new_part else (zouts[par], S_out)
                             launch(hs, ws_out, None if new_part else b_out, desc, out, 0, act=0, k_split=ks,
-                                   split=(hs_inv, winv_out))
+                                   split=(hs_inv, winv_out), tile_n=getattr(self, '_inv_out_tile', 0))
                         else:
                             out, ks = (zouts[par][S_out], 1) if new_part else (zouts[par], S_out)
                             launch(h[L - 1], w_out, None if new_part else b_out, desc, out, 0, act=0,
