@@ -258,7 +258,8 @@ def test_which_layers_have_a_fused_kernel_and_a_blocked_inverse():
     for K, kw, fused in ((8, {}, True), (5, dict(identity_boundary_slopes=True), True), (4, dict(circular=True), True),
                          (5, dict(identity_boundary_slopes=True, learn_lower_bound=True, learn_upper_bound=True), True),
                          (8, dict(identity_boundary_slopes=True, learn_upper_bound=True), True),       # 24 parameters
-                         (8, dict(learn_upper_bound=True), False),                                      # 26
+                         (8, dict(learn_upper_bound=True), True),                                       # 26
+                         (8, dict(learn_lower_bound=True, learn_upper_bound=True), True),               # 27: the widest layout
                          (6, {}, False), (3, {}, False)):
         lay = layer(spline(6, K, **kw))
         assert (lay._fused_kind() == 1) == fused, (K, kw)
