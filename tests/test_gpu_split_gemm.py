@@ -639,3 +639,29 @@ def test_tile_list_launches_exactly_the_listed_tiles(tile_n):
     _split_desc(a, w, out, tile_n=tile_n, tile_list=tl.cuda(), accumulate=1)
     assert bool((out[~mask] == 123.0).all())
     assert float((out[mask] - 2 * ref[mask]).abs().max()) < 2e-5
+
+
+def test_tile_list_on_the_exact_fp32_kernel():
+    """The same launch list drives the exact-fp32 kernel (a guarded training step takes it): listed tiles written, the
+    others untouched."""
+    import ctypes
+    from tfep_amd import _lib, ops
+    torch.manual_seed(9)
+    tm, tn, tk = ops.tile_sizes()
+    B, K, N = 3 * tm + 5, 8 * tk, 2 * tn + 9
+    live = torch.tensor([[True, False, True], [False, True, False], [True, True, False], [False, False, True]])
+    tl = ops.xcd_balanced_tile_list(live).cuda()
+    a = torch.randn(B, K, device='cuda')
+    w = torch.randn(N, K, device='cuda') / K ** 0.5
+    wp = ops.masked_weight_prepare(w, None, None, n_rows_padded=ops.round_up(N, tk), k_padded=K)
+    out = torch.full((B, N), -7.0, device='cuda')
+    d = _lib.GemmDesc()
+    d.x, d.ldx, d.w, d.ldw = a.data_ptr(), K, wp.data_ptr(), K
+    d.y, d.ldy = out.data_ptr(), N
+    d.B, d.N, d.n_rows_w, d.k_padded, d.act, d.accumulate = B, N, wp.shape[0], K, 0, 0
+    d.tile_list, d.n_tile_list = tl.data_ptr(), tl.shape[0]
+    _lib.call('tfep_masked_linear_gemm', ctypes.byref(d), _lib.stream_of(a))
+    mask = live.cuda().repeat_interleave(tm, 0)[:B].repeat_interleave(tn, 1)[:, :N]
+    ref = (a.double() @ w.double().T).float()
+    assert bool((out[~mask] == -7.0).all())
+    assert float((out[mask] - ref[mask]).abs().max()) < 1e-4
