@@ -661,4 +661,35 @@ def test_cached_packed_weights_notice_updates_through_data():
             assert torch.equal(y3, y4) and torch.equal(l3, l4), (split, how)
             assert not torch.equal(y3, y1)
             y1 = y3
+    # the blocked inverse keeps its packs across calls under the same switch (a sampling loop packs once) and notices the
+    # same two kinds of update
+    layer.split_gemm = None
+    yy = torch.randn(300, D, device='cuda').clamp_(-3.9, 3.9)
+
+    def fresh_inverse():
+        made.cache_packed_weights = False
+        made.invalidate_plan()
+        with torch.no_grad():
+            out = layer.inverse(yy)
+        made.cache_packed_weights = True
+        return out
+    x0, m0 = fresh_inverse()
+    with torch.no_grad():
+        x1, m1 = layer.inverse(yy)
+        n_packed = sum(1 for plan in made._plans.values() for k in plan if isinstance(k, tuple) and k[0] in ('packed', 'packed_split'))
+        x2, m2 = layer.inverse(yy)
+    assert n_packed > 0                                 # (kept after the call)
+    assert torch.equal(x0, x1) and torch.equal(x1, x2) and torch.equal(m1, m2)
+    for how in ('versioned', 'data'):
+        with torch.no_grad():
+            for p in made.parameters():
+                if how == 'versioned':
+                    p.mul_(1.01)
+                else:
+                    p.data.mul_(0.97)
+            x3, m3 = layer.inverse(yy)
+        x4, m4 = fresh_inverse()
+        assert torch.equal(x3, x4) and torch.equal(m3, m4), how
+        assert not torch.equal(x3, x1)
+        x1 = x3
     made.cache_packed_weights = False

@@ -489,6 +489,12 @@ class AutoregressiveFlow(torch.nn.Module):
     #: Degrees per block of the two-level blocked inverse.
     inverse_block = 16
 
+    #: Blocks per SUPER-BLOCK (third level, fused block kernel on split operands only): the contribution of every hidden
+    #: unit older than the super-block to ALL rows of the super-block is one large GEMM per layer at its start; a block then
+    #: adds only what the super-block itself has produced (a short GEMM), so the old activation panels are read once per
+    #: super-block instead of once per block.  0 / 1: off.
+    inverse_super = 8
+
     def _input_columns(self):
         """Where feature column c of x enters the conditioner input: ``(first_col[c], periodic[c], limits)``.  Without an
         embedding the input IS x; a PeriodicEmbedding puts the non-periodic features first and then a (cos, sin) pair
@@ -535,10 +541,12 @@ class AutoregressiveFlow(torch.nn.Module):
     def _blocked_plan(self, device):
         """The plan of ``_blocked_plan_for`` with ``inverse_block`` degrees per block, or fewer (halved down to 2) when
         that is what lets the block's state fit the LDS of the fused block kernel."""
-        key = ('blocked', str(device), self.inverse_block)
+        n_super = int(os.environ.get('TFEP_INV_SUPER', self.inverse_super or 0))
+        key = ('blocked', str(device), self.inverse_block, n_super)
         bp = self._dev.get(key)
         if bp is not None:
             return bp
+        self._plan_n_super = n_super
         G = max(1, int(self.inverse_block))
         bp = self._blocked_plan_for(device, G)
         if bp['fused'] is None and self._fused_inverse_supported(bp['L']):
@@ -635,6 +643,8 @@ class AutoregressiveFlow(torch.nn.Module):
         i32 = dict(device=device, dtype=torch.int32)
         blocks = []
         kA_prev = None
+        n_super = max(1, int(getattr(self, '_plan_n_super', 0) or 1))
+        supers, kS, dS0 = [], None, 0
         for d0 in range(0, max_deg + 1, G):
             d1 = min(d0 + G, max_deg + 1)
             blk = dict(wide=[], steps=[])
@@ -646,9 +656,22 @@ class AutoregressiveFlow(torch.nn.Module):
             # ('kr_new': a short GEMM afterwards)
             kP = kA if kA_prev is None else kA_prev
 
+            # super-block (see ``inverse_super``): [0, kS) is what was complete when the block's super-block began
+            if len(blocks) % n_super == 0:
+                kS, dS0 = kA, d0
+                dS1 = min(d0 + G * n_super, max_deg + 1)
+                sup = dict(wide=[], out_wide=dict(layer=L, row0=base[dS0], n_rows=base[dS1] - base[dS0], kr=rng(0, kS[L])))
+                for l in range(1, L):
+                    r0, r1 = r_lo(l, dS0 - 1), r_hi(l, dS1 - 2)
+                    if r1 > r0:
+                        sup['wide'].append(dict(layer=l, row0=r0, n_rows=r1 - r0, kr=rng(0, kS[l])))
+                supers.append(sup)
+            blk['sb'], blk['sb_first'] = len(supers) - 1, len(blocks) % n_super == 0
+
             def wide_desc(l, r0, r1):
                 return dict(layer=l, row0=r0, n_rows=r1 - r0, kr=rng(0, kA[l]), kr_old=rng(0, kP[l]),
-                            kr_new=rng(kP[l], kA[l]), has_new=kA[l] > kP[l])
+                            kr_new=rng(kP[l], kA[l]), has_new=kA[l] > kP[l],
+                            kr_sbnew=rng(kS[l], kA[l]), has_sbnew=kA[l] > kS[l])
             for l in range(1, L):      # hidden layers fed by hidden layers
                 r0, r1 = r_lo(l, d0 - 1), r_hi(l, d1 - 2)
                 if r1 > r0:
@@ -681,6 +704,7 @@ class AutoregressiveFlow(torch.nn.Module):
             blocks.append(blk)
         narrow = lib.tfep_masked_linear_narrow_tile_n()
         max_rows = max([w['n_rows'] for b_ in blocks for w in b_['wide']] + [b_['out_wide']['n_rows'] for b_ in blocks] +
+                       ([w['n_rows'] for s_ in supers for w in s_['wide'] + [s_['out_wide']]] if n_super > 1 else []) +
                        [b_['fused']['wide0']['n_rows'] for b_ in blocks if b_['fused'] and b_['fused']['wide0']] +
                        [h_['n_rows'] for b_ in blocks for st in b_['steps'] for h_ in st['hidden']] +
                        [st['out']['n_rows'] for b_ in blocks for st in b_['steps']])
@@ -689,7 +713,7 @@ class AutoregressiveFlow(torch.nn.Module):
             cache_len = max(b_['fused']['cache_need'] for b_ in blocks)
             max_feats = max(b_['fused']['n_feats'] for b_ in blocks)
             fused_ok = 0 <= lib.tfep_inverse_block_lds_bytes(L, cache_len, max_feats) <= 160 * 1024
-        bp = dict(blocks=blocks, P=P, L=L, row_inv=row_inv.to(**i32), n_rows_out=cur,
+        bp = dict(blocks=blocks, P=P, L=L, row_inv=row_inv.to(**i32), n_rows_out=cur, supers=supers if n_super > 1 else None,
                   fused=dict(cache_len=cache_len, max_feats=max_feats) if fused_ok else None,
                   max_tiles=(max_rows + narrow - 1) // narrow,
                   k_ranges=torch.tensor(kr, dtype=torch.int32).reshape(-1, 2).to(device))
@@ -1121,6 +1145,55 @@ class AutoregressiveFlow(torch.nn.Module):
                             launch(h[L - 1], w_out, None if new_part else b_out, desc, out, 0, act=0,
                                    wide=wd['n_rows'] > 4 * narrow, k_split=ks)
 
+                # ---- super-blocks (``inverse_super``): old panels read once per super-block.  Per layer one buffer of
+                # S_sb + 1 slabs in the super-block's row layout: slabs [0, S_sb) = the large GEMM over [0, kS) for every row of
+                # the super-block (split-K), slab S_sb = the block's short GEMM over [kS, kA), written at the block's columns.
+                supers = bp.get('supers')
+                use_sb = bool(supers) and hs is not None and not look and all(l in hs_hidden for l in range(1, L)) and \
+                    all(wd['layer'] >= 1 for b_ in bp['blocks'] for wd in b_['wide'])
+                if use_sb:
+                    tw = ops.split_wide_tile_n()
+                    m_tiles256 = (B + 255) // 256
+                    sb_rows = {l: max([w['n_rows'] for s_ in supers for w in s_['wide'] if w['layer'] == l] or [0]) for l in range(1, L)}
+                    sb_rows[L] = max(s_['out_wide']['n_rows'] for s_ in supers)
+                    sb_tile = {l: (tw if (-sb_rows[l]) % tw <= (-sb_rows[l]) % 256 else 0) for l in sb_rows}
+                    sb_S, sb_buf = {}, {}
+                    for l, n_l in sb_rows.items():
+                        if n_l == 0:
+                            continue
+                        n_tiles = (n_l + (sb_tile[l] or 256) - 1) // (sb_tile[l] or 256)
+                        sb_S[l] = int(min(8, max(1, 256 // max(1, m_tiles256 * n_tiles)), max(1, mplan['k_pad'][l] // 512)))
+                        sb_buf[l] = torch.empty(sb_S[l] + 1, B, ops.round_up(n_l, 4), **f32)
+
+                    def super_gemms(sup):
+                        for wd in sup['wide'] + [sup['out_wide']]:
+                            l = wd['layer']
+                            if wd['n_rows'] == 0:
+                                continue
+                            out = sb_buf[l][:sb_S[l]] if sb_S[l] > 1 else sb_buf[l][0]
+                            if l < L:
+                                hsl, hsl_inv, wsl, winvl = hs_hidden[l]
+                                launch(hsl, wsl, packs[l][1], wd, out, 0, act=0, k_split=sb_S[l], split=(hsl_inv, winvl),
+                                       tile_n=sb_tile[l])
+                            else:
+                                launch(hs, ws_out, b_out, wd, out, 0, act=0, k_split=sb_S[l], split=(hs_inv, winv_out),
+                                       tile_n=sb_tile[l])
+
+                    def block_gemms_sb(blk, sup):
+                        """The short GEMMs of a block over what its super-block has produced so far, into the extra slab."""
+                        for wd in blk['wide'] + [blk['out_wide']]:
+                            if not wd['has_sbnew']:
+                                continue
+                            l = wd['layer']
+                            sd = sup['out_wide'] if l == L else [w for w in sup['wide'] if w['layer'] == l][0]
+                            desc = dict(wd, kr=wd['kr_sbnew'])
+                            if l < L:
+                                hsl, hsl_inv, wsl, winvl = hs_hidden[l]
+                                launch(hsl, wsl, None, desc, sb_buf[l][sb_S[l]], wd['row0'] - sd['row0'], act=0,
+                                       split=(hsl_inv, winvl))
+                            else:
+                                launch(hs, ws_out, None, desc, sb_buf[l][sb_S[l]], wd['row0'] - sd['row0'], act=0,
+                                       split=(hs_inv, winv_out), tile_n=getattr(self, '_inv_out_tile', 0))
                 if look:
                     main, side = torch.cuda.current_stream(dev), _side_stream(dev)
                     wide_gemms(bp['blocks'][0], 0, 'kr_old')
@@ -1133,13 +1206,20 @@ class AutoregressiveFlow(torch.nn.Module):
                     fb = blk['fused']
                     par = i_blk & 1 if look else 0
                     z, zout = zs[par], zouts[par]
-                    if look:
+                    if use_sb:
+                        sup = supers[blk['sb']]
+                        if blk['sb_first']:
+                            super_gemms(sup)
+                        block_gemms_sb(blk, sup)
+                    elif look:
                         if old_done is not None:
                             main.wait_event(old_done)
                         wide_gemms(blk, par, 'kr_new')
                     else:
                         wide_gemms(blk, par, 'kr')
                     w0 = fb['wide0']                           # layer 0: every feature of an earlier block
+                    if w0 is not None and use_sb:
+                        launch(xpad, packs[0][0], packs[0][1], w0, z[0], 0, act=0, k_split=S)
                     if w0 is not None and look and (i_blk == 0 or not w0['look']):
                         launch(xpad, packs[0][0], packs[0][1], w0, z[0], 0, act=0, k_split=S)      # whole, no look-ahead
                     extra = {wd['layer']: int(look and wd['has_new']) for wd in blk['wide'] + [ow]}
@@ -1150,6 +1230,17 @@ class AutoregressiveFlow(torch.nn.Module):
                     for l in range(L):
                         d.z_slabs[l] = S + extra.get(l, 0)
                     d.zout, d.zout_slabs = zout.data_ptr() - 4 * ow['row0'], S_out + extra[L]
+                    if use_sb:
+                        # the kernel indexes by packed row: the buffers' column 0 is the super-block's first row
+                        for wd in blk['wide']:
+                            l = wd['layer']
+                            sd = [w for w in sup['wide'] if w['layer'] == l][0]
+                            d.z[l] = sb_buf[l].data_ptr() - 4 * sd['row0']
+                            d.ldz[l], d.z_slab_stride[l] = sb_buf[l].shape[-1], B * sb_buf[l].shape[-1]
+                            d.z_slabs[l] = sb_S[l] + int(wd['has_sbnew'])
+                        d.zout = sb_buf[L].data_ptr() - 4 * sup['out_wide']['row0']
+                        d.ldzout, d.zout_slab_stride = sb_buf[L].shape[-1], B * sb_buf[L].shape[-1]
+                        d.zout_slabs = sb_S[L] + int(ow['has_sbnew'])
                 else:
                     for wd in blk['wide']:
                         l = wd['layer']
