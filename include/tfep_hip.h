@@ -472,6 +472,10 @@ int tfep_transpose(const float* in, int64_t ld_in, int R, int C, float* out, int
  * Same bits as the two-step form. */
 int tfep_transpose_split(const float* in, int64_t ld_in, int R, int C, void* out_split, int64_t ld_out, int R_pad, int mode,
                          const float* scale_src, float* inv_scale_out, void* stream);
+/* The transpose of split rows that share one scale (a packed weight matrix, tfep_masked_weight_prepare_split): out (C rows,
+ * ld_out >= R) <- in (R rows, ld_in >= C), fp16 halves moved as they are (exact).  R, C multiples of 8.  The training
+ * step gets W^T of grad_input = g W (masked.py:279-302) from the split pack of W without an fp32 copy of the matrix. */
+int tfep_transpose_split_rows(const void* in_split, int64_t ld_in, int R, int C, void* out_split, int64_t ld_out, void* stream);
 /* tfep_column_sums that also returns absmax[c] = max_r |in[r, c]| from the same pass. */
 int tfep_column_sums_absmax(const float* in, int64_t ld, int R, int C, float* out, int accumulate, float* absmax, void* stream);
 /* out[c] (+)= sum_r in[r, c]      grad_bias = grad_output.sum(0)  (masked.py:299-300) */

@@ -665,3 +665,19 @@ def test_tile_list_on_the_exact_fp32_kernel():
     ref = (a.double() @ w.double().T).float()
     assert bool((out[~mask] == -7.0).all())
     assert float((out[mask] - ref[mask]).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize('R,C', [(64, 64), (8, 32), (200, 96), (1000, 320), (96, 4128)])
+def test_transpose_of_split_rows_moves_the_halves(R, C):
+    """``tfep_transpose_split_rows``: the transpose of a split matrix with one scale, made from its fp16 halves -- bit for
+    bit the split rows of the transposed matrix at that scale."""
+    from tfep_amd import _lib, ops
+    torch.manual_seed(R + C)
+    w = torch.randn(R, C, device='cuda') * torch.logspace(-3, 2, C, device='cuda')
+    ws, inv = ops.split_rows(w, C, per_tensor=True)
+    out = torch.full((C, R), float('nan'), device='cuda')
+    _lib.call('tfep_transpose_split_rows', _lib.ptr(ws), C, R, C, _lib.ptr(out), R, _lib.stream_of(ws))
+    ref = torch.empty(C, R, device='cuda')
+    _lib.call('tfep_transpose_split', _lib.ptr(w), C, R, C, _lib.ptr(ref), R, R, 0, _lib.ptr(inv), None, _lib.stream_of(w))
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
+    assert float((unsplit(out, inv, R) - w.t()).abs().max()) <= 2.0 ** -21 * float(w.abs().max())

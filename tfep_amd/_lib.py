@@ -159,6 +159,7 @@ _SIGNATURES = {
     'tfep_masked_linear_gemm': (c_int, [POINTER(GemmDesc), _P]),
     'tfep_transpose': (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, _P]),
     'tfep_transpose_split': (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, c_int, c_int, _P, _P, _P]),
+    'tfep_transpose_split_rows': (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, _P]),
     'tfep_column_sums_absmax': (c_int, [_P, c_int64, c_int, c_int, _P, c_int, _P, _P]),
     'tfep_column_sums': (c_int, [_P, c_int64, c_int, c_int, _P, c_int, _P]),
     'tfep_add_inplace': (c_int, [_P, c_int64, _P, c_int64, c_int, c_int, _P]),

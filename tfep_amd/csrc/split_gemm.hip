@@ -208,6 +208,45 @@ __global__ void __launch_bounds__(256) transpose_split_kernel(const float* __res
     }
 }
 
+// Transpose of split rows that share ONE scale (a packed weight matrix): out[c][r] = in[r][c], halves moved as they are.
+// 64 x 64 tiles through two fp16 planes in LDS, 16-byte accesses on both sides; R, C multiples of 8.
+__global__ void __launch_bounds__(256) transpose_split_rows_kernel(const uint4* __restrict__ in, int64_t ld_in, int R, int C,
+                                                                   uint4* __restrict__ out, int64_t ld_out) {
+    constexpr int PITCH = 72;                                     // halves per plane row: 144 B, 16-byte aligned
+    __shared__ __attribute__((aligned(16))) _Float16 plane[2][64 * PITCH];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int item = threadIdx.x + 256 * p;                  // 64 input rows x 8 groups of 8 columns
+        const int rr = item & 63, g = item >> 6;
+        const int r = r0 + rr, cg = c0 + 8 * g;
+        uint4 hq = make_uint4(0u, 0u, 0u, 0u), lq = hq;
+        if (r < R && cg < C) {
+            const uint4* src = in + (int64_t)r * (ld_in / 4) + (cg >> 3) * 2;
+            hq = src[0];
+            lq = src[1];
+        }
+        const f16x8 hi = *reinterpret_cast<const f16x8*>(&hq), lo = *reinterpret_cast<const f16x8*>(&lq);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            plane[0][(8 * g + k) * PITCH + rr] = hi[k];
+            plane[1][(8 * g + k) * PITCH + rr] = lo[k];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int item = threadIdx.x + 256 * p;                  // 64 output rows x 8 groups of 8
+        const int cc = item & 63, g = item >> 6;
+        const int c = c0 + cc, rg = r0 + 8 * g;
+        if (c < C && rg < R) {
+            uint4* dr = out + (int64_t)c * (ld_out / 4) + (rg >> 3) * 2;
+            dr[0] = *reinterpret_cast<const uint4*>(&plane[0][cc * PITCH + 8 * g]);
+            dr[1] = *reinterpret_cast<const uint4*>(&plane[1][cc * PITCH + 8 * g]);
+        }
+    }
+}
+
 // |.| reductions for row-scale bounds, one wave per row.  mode 0: out[row] = max_k |src[row, k]|;  mode 1: out[0] =
 // max_row sum_k |src[row, k]| (the infinity norm; out[0] cleared by zero_u32_kernel first; non-negative floats order
 // like their bit patterns, so the maximum is an integer atomicMax -- exact and order-independent).
@@ -548,6 +587,18 @@ int tfep_transpose_split(const float* in, int64_t ld_in, int R, int C, void* out
 }
 
 
+
+int tfep_transpose_split_rows(const void* in_split, int64_t ld_in, int R, int C, void* out_split, int64_t ld_out, void* stream) {
+    TFEP_REQUIRE(R >= 0 && C >= 0, "transpose_split_rows: negative size");
+    if (R == 0 || C == 0) return TFEP_OK;
+    TFEP_REQUIRE(in_split && out_split, "transpose_split_rows: NULL pointer");
+    TFEP_REQUIRE(R % 8 == 0 && C % 8 == 0 && ld_in >= C && ld_out >= R && ld_in % 4 == 0 && ld_out % 4 == 0,
+                 "transpose_split_rows: R, C must be multiples of 8 and the rows at least that wide, in whole 16-byte units");
+    TFEP_REQUIRE((uintptr_t)in_split % 16 == 0 && (uintptr_t)out_split % 16 == 0, "transpose_split_rows: operands must be 16-byte aligned");
+    dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
+    transpose_split_rows_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const uint4*)in_split, ld_in, R, C, (uint4*)out_split, ld_out);
+    return check_launch("transpose_split_rows_kernel");
+}
 
 int tfep_split_rows(const float* src, int64_t ld_src, int64_t rows, int64_t cols, void* dst, int64_t ld_dst,
                     int64_t cols_padded, float* inv_scale, int per_tensor, void* stream) {
