@@ -595,6 +595,7 @@ int tfep_transpose_split_rows(const void* in_split, int64_t ld_in, int R, int C,
     TFEP_REQUIRE(R % 8 == 0 && C % 8 == 0 && ld_in >= C && ld_out >= R && ld_in % 4 == 0 && ld_out % 4 == 0,
                  "transpose_split_rows: R, C must be multiples of 8 and the rows at least that wide, in whole 16-byte units");
     TFEP_REQUIRE((uintptr_t)in_split % 16 == 0 && (uintptr_t)out_split % 16 == 0, "transpose_split_rows: operands must be 16-byte aligned");
+    TFEP_REQUIRE((R + 63) / 64 <= 65535, "transpose_split_rows: too many rows for one launch");
     dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64));
     transpose_split_rows_kernel<<<grid, 256, 0, (hipStream_t)stream>>>((const uint4*)in_split, ld_in, R, C, (uint4*)out_split, ld_out);
     return check_launch("transpose_split_rows_kernel");
