@@ -681,3 +681,41 @@ def test_transpose_of_split_rows_moves_the_halves(R, C):
     _lib.call('tfep_transpose_split', _lib.ptr(w), C, R, C, _lib.ptr(ref), R, R, 0, _lib.ptr(inv), None, _lib.stream_of(w))
     assert torch.equal(out.view(torch.int32), ref.view(torch.int32))
     assert float((unsplit(out, inv, R) - w.t()).abs().max()) <= 2.0 ** -21 * float(w.abs().max())
+
+
+@pytest.mark.parametrize('layout', ['plain', 'circular', 'learn_both', 'five_bins'])
+def test_fused_forward_and_training_step_repeat_bit_for_bit(layout):
+    """The same call twice gives the same bits, forward (fused split kernel) and training step (saving forward + backward).
+    The matrix-core products of these kernels are inline asm whose result latency the compiler does not know: a spill store or
+    a merge copy placed ahead of the hand-written wait once read accumulators before the matrix pipe had written them --
+    results off by ~1e-7 on a few rows, different from run to run (tools/scan_hazards.sh scans the listings)."""
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    torch.manual_seed(21)
+    D, B = 70, 900
+    kw = dict(plain={}, circular=dict(circular=True), learn_both=dict(learn_lower_bound=True, learn_upper_bound=True), five_bins={})[layout]
+    lo, hi = (0.0, 2.0) if layout == 'circular' else (-4.0, 4.0)
+    maf = MAF(generate_degrees(D, 'ascending'), transformer=NeuralSplineTransformer(torch.full((D,), lo), torch.full((D,), hi),
+                                                                                   5 if layout == 'five_bins' else 8, **kw),
+              hidden_layers=[150, 130], initialize_identity=False).cuda()
+    maf.split_gemm, maf.fused = True, True
+    x0 = (torch.rand(B, D, device='cuda') * (hi - lo) + lo) * 0.98
+    c = torch.linspace(0.1, 0.4, D, device='cuda')
+    with torch.no_grad():
+        outs = [maf(x0) for _ in range(4)]
+    for y, l in outs[1:]:
+        assert torch.equal(y, outs[0][0]) and torch.equal(l, outs[0][1])
+
+    def step():
+        for p in maf.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        y, l = maf(x)
+        BoltzmannKLDivLoss()((c * y ** 2).sum(dim=1), l).backward()
+        return [y.detach(), l.detach(), x.grad] + [p.grad.clone() for p in maf.parameters()]
+    first = step()
+    for _ in range(2):
+        for a, b in zip(first, step()):
+            assert torch.equal(a, b)
