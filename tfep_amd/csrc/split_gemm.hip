@@ -404,6 +404,23 @@ __global__ void __launch_bounds__(PFX_THREADS) weight_prepare_split_prefix_kerne
     extern __shared__ float srow[];
     const int o = blockIdx.x, tid = threadIdx.x;
     const float* vr = v + (int64_t)o * K;
+    // The permutation entries of this thread's column groups (at most 4: K <= 16 384 columns, 512 threads, 8 columns per
+    // group) are fetched FIRST, so that their L2 round trips run beside the row load and the norm instead of in front of
+    // every gather pass (2.6 -> 2.4 ms for the cfg2 output layer; a persistent, register-pipelined version of this kernel
+    // measured the same: the kernel is not latency bound any more, see profiles/NOTES.md).
+    const int cut = min(col_cut[o], K);
+    const int n_groups = (cut + 7) >> 3;
+    const bool vec_idx = in_of_col && ((uintptr_t)in_of_col & 15u) == 0;
+    int4 ia[4], ib[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int g8 = tid + u * PFX_THREADS;
+        ia[u] = ib[u] = make_int4(0, 0, 0, 0);
+        if (vec_idx && g8 < n_groups && g8 * 8 + 8 <= K) {
+            ia[u] = reinterpret_cast<const int4*>(in_of_col)[2 * g8];
+            ib[u] = reinterpret_cast<const int4*>(in_of_col)[2 * g8 + 1];
+        }
+    }
     {
         // 16-byte loads with several in flight per lane: at two workgroups per CU (the row takes 60 KB of LDS at
         // K = 14 998) 4-byte loads leave too few bytes in flight to cover the HBM latency.  Rows start 8-byte aligned at
@@ -444,16 +461,17 @@ __global__ void __launch_bounds__(PFX_THREADS) weight_prepare_split_prefix_kerne
     }
     const float s = pow2_scale_for(__uint_as_float(*max_bits));
     if (o == 0 && tid == 0) inv_scale[0] = 1.0f / s;
-    const int cut = min(col_cut[o], K);
     const int64_t orow = row_of_out ? row_of_out[o] : o;
     uint4* dr = w_out + orow * (ldw / 4);
     float l1 = 0.f;
-    const int n_groups = (cut + 7) >> 3;
-    for (int g8 = tid; g8 < n_groups; g8 += PFX_THREADS) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int g8 = tid + u * PFX_THREADS;
+        if (g8 >= n_groups) break;
         f16x8 hi, lo;
         int idx[8];
-        if (in_of_col && g8 * 8 + 8 <= K && ((uintptr_t)in_of_col & 15u) == 0) {
-            const int4 a = reinterpret_cast<const int4*>(in_of_col)[2 * g8], b = reinterpret_cast<const int4*>(in_of_col)[2 * g8 + 1];
+        if (vec_idx && g8 * 8 + 8 <= K) {
+            const int4 a = ia[u], b = ib[u];
             idx[0] = a.x; idx[1] = a.y; idx[2] = a.z; idx[3] = a.w; idx[4] = b.x; idx[5] = b.y; idx[6] = b.z; idx[7] = b.w;
         } else {
 #pragma unroll
