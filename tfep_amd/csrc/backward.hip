@@ -33,11 +33,23 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float* __restrict_
 }
 
 // out[c] (+)= sum_r in[r, c]   (bias gradient, masked.py:299-300)
-// A workgroup owns 64 columns; its four waves each sum a contiguous quarter of the rows (a wave reads 256 contiguous
-// bytes per row) with 8 independent fp64 partial sums per thread, and the quarters are added in a fixed order through
+// A workgroup owns 64 columns; its 16 waves each sum a contiguous sixteenth of the rows (a wave reads 256 contiguous
+// bytes per row) with 8 independent fp64 partial sums per thread, and the slices are added in a fixed order through
 // LDS: four times the loads in flight per column and four times the workgroups of a thread-per-column pass (which left
 // most CUs idle on the (1024 x 800) .. (1024 x 3200) gradients of a small flow: 48 us per call whatever the size).
-constexpr int CS_COLS = 64, CS_SLICES = 4;
+constexpr int CS_COLS = 64, CS_SLICES = 16;          // (16 row slices: 4 left the 4.9 GB gradient pass at 2.3 TB/s)
+
+// the slices' partial sums in a fixed pairwise order (both kernels below: the same bits)
+__device__ __forceinline__ double slice_tree_sum(const double (&part)[CS_SLICES][CS_COLS], int cx) {
+    double t[CS_SLICES];
+#pragma unroll
+    for (int q = 0; q < CS_SLICES; ++q) t[q] = part[q][cx];
+#pragma unroll
+    for (int w = 1; w < CS_SLICES; w *= 2)
+#pragma unroll
+        for (int q = 0; q + w < CS_SLICES; q += 2 * w) t[q] += t[q + w];
+    return t[0];
+}
 
 __global__ void __launch_bounds__(CS_COLS * CS_SLICES) colsum_kernel(const float* __restrict__ in, int64_t ld, int R, int C,
                                                                     float* __restrict__ out, int accumulate) {
@@ -59,7 +71,7 @@ __global__ void __launch_bounds__(CS_COLS * CS_SLICES) colsum_kernel(const float
     part[sl][cx] = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
     __syncthreads();
     if (sl == 0 && c < C) {
-        const double s = (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]);
+        const double s = slice_tree_sum(part, cx);
         out[c] = accumulate ? (float)((double)out[c] + s) : (float)s;
     }
 }
@@ -96,9 +108,12 @@ __global__ void __launch_bounds__(CS_COLS * CS_SLICES) colsum_absmax_kernel(cons
     pmax[sl][cx] = fmaxf(fmaxf(fmaxf(m[0], m[1]), fmaxf(m[2], m[3])), fmaxf(fmaxf(m[4], m[5]), fmaxf(m[6], m[7])));
     __syncthreads();
     if (sl == 0 && c < C) {
-        const double s = (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]);
+        const double s = slice_tree_sum(part, cx);
         out[c] = accumulate ? (float)((double)out[c] + s) : (float)s;
-        amax[c] = fmaxf(fmaxf(pmax[0][cx], pmax[1][cx]), fmaxf(pmax[2][cx], pmax[3][cx]));
+        float mx = 0.f;
+#pragma unroll
+        for (int q = 0; q < CS_SLICES; ++q) mx = fmaxf(mx, pmax[q][cx]);
+        amax[c] = mx;
     }
 }
 
