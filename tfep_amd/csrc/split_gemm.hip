@@ -184,8 +184,8 @@ __global__ void __launch_bounds__(256) transpose_split_kernel(const float* __res
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const int item = threadIdx.x + 256 * p;                  // 64 output rows x 8 groups of 8
-        const int cc = item & 63, g = item >> 6;
+        const int item = threadIdx.x + 256 * p;                  // 64 output rows x 8 groups of 8: the 8 groups of a row
+        const int g = item & 7, cc = item >> 3;                  // on neighbouring lanes (256 contiguous bytes per row)
         const int c = c0 + cc, rg = r0 + 8 * g;
         if (c < C && rg < R_pad) {
             float s = s_all;
@@ -236,8 +236,8 @@ __global__ void __launch_bounds__(256) transpose_split_rows_kernel(const uint4* 
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        const int item = threadIdx.x + 256 * p;                  // 64 output rows x 8 groups of 8
-        const int cc = item & 63, g = item >> 6;
+        const int item = threadIdx.x + 256 * p;                  // 64 output rows x 8 groups of 8, a row's groups on
+        const int g = item & 7, cc = item >> 3;                  // neighbouring lanes
         const int c = c0 + cc, rg = r0 + 8 * g;
         if (c < C && rg < R) {
             uint4* dr = out + (int64_t)c * (ld_out / 4) + (rg >> 3) * 2;
