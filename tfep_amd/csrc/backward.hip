@@ -7,6 +7,7 @@
 // features (coalesced per parameter row); all derivative arithmetic in fp64.
 #include "common.h"
 #include "spline.h"
+#include "fp64_fast.h"
 
 namespace tfep {
 
@@ -146,7 +147,14 @@ struct SplineArgsB {
     int P;
 };
 
-__device__ inline double sigmoid_d(double z) { return z > 20.0 ? 1.0 : 1.0 / (1.0 + exp(-z)); }
+// sigmoid on the softmax's exponential (both signs through exp of a non-positive argument) and the hardware-seeded
+// reciprocal: ~1e-11 relative, a fifth of the instructions of exp() + an IEEE division
+__device__ inline double sigmoid_d(double z) {
+    if (z > 20.0) return 1.0;
+    const double e = exp_nonpos(-fabs(z));
+    const double r = fast_rcp64(1.0 + e);
+    return z >= 0.0 ? r : e * r;
+}
 
 // Reverse mode through rq_spline_element (spline.h), FORWARD direction, all variants.
 template <int KMAX>
@@ -197,10 +205,13 @@ __device__ inline void rq_spline_backward(const float (&w)[KMAX], const float (&
             sh += ph[k];
         }
     }
+    {
+        const double isw = fast_rcp64(sw), ish = fast_rcp64(sh);       // (sums >= 1: the largest term is exp(0))
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        pw[k] /= sw;
-        ph[k] /= sh;
+        for (int k = 0; k < KMAX; ++k) {
+            pw[k] *= isw;
+            ph[k] *= ish;
+        }
     }
 
     double kx = x0, ky = y0, bw = 0.0, bh = 0.0;
@@ -223,6 +234,10 @@ __device__ inline void rq_spline_backward(const float (&w)[KMAX], const float (&
         }
 
     double gw[KMAX], gh[KMAX], gd[KMAX + 1];      // grads wrt widths, heights, slopes (values)
+    // the (at most two) knots whose slope enters the element, and the derivative of their softplus: only these raw slopes
+    // get a gradient, so only their sigmoids are evaluated (there were K + 1 of them, each an exp and a division)
+    int ja = -1, jb2 = -1;
+    double sga = 0.0, sgb = 0.0;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         gw[k] = 0.0;
@@ -245,7 +260,9 @@ __device__ inline void rq_spline_backward(const float (&w)[KMAX], const float (&
         }
         const double d = slope(rs);
         const double bx = lower_tail ? x0 : kx;
-        const double gdb = gy * (v - bx) + gl / d;
+        const double gdb = gy * (v - bx) + gl * fast_rcp64(d);
+        ja = jb;
+        sga = sigmoid_d((double)rs + (double)f.slope_offset);
         // boundary knot: (x0', y0') below, (x0' + W + K mb, y0' + H + K mb) above
         gx0 = -gy * d;
         gy0 = gy;
@@ -266,23 +283,30 @@ __device__ inline void rq_spline_backward(const float (&w)[KMAX], const float (&
                 rs1 = sraw[k + 1];
             }
         const double dk = slope(rs0), dk1 = slope(rs1);
-        const double s = bh / bw, t = dk1 + dk - 2.0 * s;
-        const double eps = (v - kx) / bw, om = 1.0 - eps, e1 = eps * om;
+        ja = kbin;
+        jb2 = kbin + 1;
+        sga = sigmoid_d((double)rs0 + (double)f.slope_offset);
+        sgb = sigmoid_d((double)rs1 + (double)f.slope_offset);
+        // four reciprocals (hardware seed + Newton, fp64_fast.h) instead of sixteen IEEE divisions
+        const double ibw = fast_rcp64(bw);
+        const double s = bh * ibw, t = dk1 + dk - 2.0 * s;
+        const double eps = (v - kx) * ibw, om = 1.0 - eps, e1 = eps * om;
         const double A = s * eps * eps + dk * e1;
         const double Dn = s + t * e1;
         const double Q = dk1 * eps * eps + 2.0 * s * e1 + dk * om * om;
-        const double dy_dA = bh / Dn, dy_dDn = -bh * A / (Dn * Dn);
+        const double iDn = fast_rcp64(Dn), iQ = fast_rcp64(Q), is = fast_rcp64(s);
+        const double dy_dA = bh * iDn, dy_dDn = -bh * A * iDn * iDn;
         const double gs = gy * (dy_dA * eps * eps + dy_dDn * (1.0 - 2.0 * e1)) +
-                          gl * (2.0 / s + 2.0 * e1 / Q - 2.0 * (1.0 - 2.0 * e1) / Dn);
+                          gl * (2.0 * is + 2.0 * e1 * iQ - 2.0 * (1.0 - 2.0 * e1) * iDn);
         const double geps = gy * (dy_dA * (2.0 * s * eps + dk * (1.0 - 2.0 * eps)) + dy_dDn * t * (1.0 - 2.0 * eps)) +
-                            gl * ((2.0 * dk1 * eps + 2.0 * s * (1.0 - 2.0 * eps) - 2.0 * dk * om) / Q -
-                                  2.0 * t * (1.0 - 2.0 * eps) / Dn);
-        const double gdk = gy * (dy_dA * e1 + dy_dDn * e1) + gl * (om * om / Q - 2.0 * e1 / Dn);
-        const double gdk1 = gy * (dy_dDn * e1) + gl * (eps * eps / Q - 2.0 * e1 / Dn);
-        const double gh_bin = gy * A / Dn + gs / bw;
-        const double gw_bin = -gs * s / bw - geps * eps / bw;
-        const double gxk = -geps / bw;
-        gv = geps / bw;
+                            gl * ((2.0 * dk1 * eps + 2.0 * s * (1.0 - 2.0 * eps) - 2.0 * dk * om) * iQ -
+                                  2.0 * t * (1.0 - 2.0 * eps) * iDn);
+        const double gdk = gy * (dy_dA * e1 + dy_dDn * e1) + gl * (om * om * iQ - 2.0 * e1 * iDn);
+        const double gdk1 = gy * (dy_dDn * e1) + gl * (eps * eps * iQ - 2.0 * e1 * iDn);
+        const double gh_bin = gy * A * iDn + gs * ibw;
+        const double gw_bin = -gs * s * ibw - geps * eps * ibw;
+        const double gxk = -geps * ibw;
+        gv = geps * ibw;
         gx0 = gxk;
         gy0 = gy;
 #pragma unroll
@@ -316,7 +340,7 @@ __device__ inline void rq_spline_backward(const float (&w)[KMAX], const float (&
     }
     // softplus backward
 #pragma unroll
-    for (int j = 0; j <= KMAX; ++j) gus[j] = (j <= K) ? gd[j] * sigmoid_d((double)sraw[j] + (double)f.slope_offset) : 0.0;
+    for (int j = 0; j <= KMAX; ++j) gus[j] = j == ja ? gd[j] * sga : (j == jb2 ? gd[j] * sgb : 0.0);
     *glast = f.circular ? gv : 0.0;
     *glast2 = 0.0;
     if (learn) {
@@ -334,68 +358,98 @@ __device__ inline void rq_spline_backward(const float (&w)[KMAX], const float (&
 }
 
 template <int KMAX>
-__global__ void __launch_bounds__(256) spline_backward_kernel(const float* __restrict__ x, int64_t ldx,
+__global__ void __launch_bounds__(256, 3) spline_backward_kernel(const float* __restrict__ x, int64_t ldx,
                                                               const float* __restrict__ params, tfep_param_layout L,
                                                               SplineArgsB a, const float* __restrict__ gy, int64_t ldgy,
                                                               const float* __restrict__ gldj,
                                                               float* __restrict__ gparams, tfep_param_layout GL,
                                                               float* __restrict__ gx, int64_t ldgx, int B, int D) {
-    const int b = blockIdx.x * ROWS_PER_BLOCK_B + (threadIdx.x >> 6);
+    // Feature-major parameters (stride_p = 1, stride_f = P: the training step's layout): a lane's P values sit 4 P bytes from
+    // its neighbour's, so element loads / stores touch 64 different cache lines per instruction.  The 64 P contiguous floats of
+    // a batch of 64 features go through LDS instead: whole 256-byte rows in and out, the lanes read / write their own P
+    // values at an odd pitch (P + 1 when P is even: conflict free).
+    extern __shared__ float sb_stage[];
+    const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * ROWS_PER_BLOCK_B + wave;
     if (b >= B) return;
     const int lane = threadIdx.x & 63;
     const int K = a.f.K;
+    const int P = a.P;
+    const bool staged = KMAX <= 16 && L.stride_p == 1 && L.stride_f == P && GL.stride_p == 1 && GL.stride_f == P && P <= 3 * KMAX + 3;
+    const int pitch = P | 1;
+    float* stage = sb_stage + wave * 64 * (3 * KMAX + 4);
     const double gl = gldj ? (double)gldj[b] : 0.0;
-    for (int f = lane; f < D; f += 64) {
+    for (int f0 = 0; f0 < D; f0 += 64) {
+        const int f = f0 + lane;
+        const int nf = min(64, D - f0);
+        const bool live = f < D;
         const float* pf = params + (int64_t)b * L.ld + f * L.stride_f;
         float* gp = gparams + (int64_t)b * GL.ld + f * GL.stride_f;
-        float w[KMAX], h[KMAX], sraw[KMAX + 1];
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            w[k] = 0.f;
-            h[k] = 0.f;
-            if (k < K) {
-                w[k] = pf[k * L.stride_p];
-                h[k] = pf[(K + k) * L.stride_p];
-            }
+        int sp = L.stride_p, gsp = GL.stride_p;                     // strides of this lane's own parameter reads / writes
+        if (staged) {
+            const float* src = params + (int64_t)b * L.ld + (int64_t)f0 * P;
+            for (int i = lane; i < nf * P; i += 64) stage[(i / P) * pitch + i % P] = src[i];
+            __builtin_amdgcn_wave_barrier();
+            pf = stage + lane * pitch;
+            gp = stage + lane * pitch;
+            sp = gsp = 1;
         }
+        if (live) {
+            float w[KMAX], h[KMAX], sraw[KMAX + 1];
 #pragma unroll
-        for (int j = 0; j <= KMAX; ++j) {
-            sraw[j] = 0.f;
-            if (j <= K) {
+            for (int k = 0; k < KMAX; ++k) {
+                w[k] = 0.f;
+                h[k] = 0.f;
+                if (k < K) {
+                    w[k] = pf[k * sp];
+                    h[k] = pf[(K + k) * sp];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j <= KMAX; ++j) {
+                sraw[j] = 0.f;
+                if (j <= K) {
+                    const int pi = spline_slope_param(j, K, a.f.circular, a.f.identity);
+                    if (pi >= 0) sraw[j] = pf[pi * sp];
+                }
+            }
+            const bool has_last = a.f.circular || a.f.learn_lower || a.f.learn_upper;
+            const bool has_last2 = a.f.learn_lower && a.f.learn_upper;
+            const float last = has_last ? pf[(P - 1) * sp] : 0.f;
+            const float last2 = has_last2 ? pf[(P - 2) * sp] : 0.f;
+            double guw[KMAX], guh[KMAX], gus[KMAX + 1], glast, glast2, gxin;
+            rq_spline_backward<KMAX>(w, h, sraw, last, last2, a.f, a.x0[f], a.xf[f], a.y0[f], a.yf[f],
+                                     x[(int64_t)b * ldx + f], (double)gy[(int64_t)b * ldgy + f], gl, guw, guh, gus, &glast,
+                                     &glast2, &gxin);
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+                if (k < K) {
+                    gp[k * gsp] = (float)guw[k];
+                    gp[(K + k) * gsp] = (float)guh[k];
+                }
+            // slopes: knot K of a circular spline shares the parameter of knot 0; identity boundary
+            // slopes have no parameter.
+            double g0 = gus[0];
+#pragma unroll
+            for (int j = 0; j <= KMAX; ++j)
+                if (j == K && a.f.circular && !a.f.identity) g0 += gus[j];
+#pragma unroll
+            for (int j = 0; j <= KMAX; ++j) {
+                if (j > K) continue;
+                if (a.f.circular && !a.f.identity && j == K) continue;
                 const int pi = spline_slope_param(j, K, a.f.circular, a.f.identity);
-                if (pi >= 0) sraw[j] = pf[pi * L.stride_p];
+                if (pi >= 0) gp[pi * gsp] = (float)(j == 0 ? g0 : gus[j]);
             }
+            if (has_last) gp[(P - 1) * gsp] = (float)glast;
+            if (has_last2) gp[(P - 2) * gsp] = (float)glast2;
+            gx[(int64_t)b * ldgx + f] = (float)gxin;
         }
-        const bool has_last = a.f.circular || a.f.learn_lower || a.f.learn_upper;
-        const bool has_last2 = a.f.learn_lower && a.f.learn_upper;
-        const float last = has_last ? pf[(a.P - 1) * L.stride_p] : 0.f;
-        const float last2 = has_last2 ? pf[(a.P - 2) * L.stride_p] : 0.f;
-        double guw[KMAX], guh[KMAX], gus[KMAX + 1], glast, glast2, gxin;
-        rq_spline_backward<KMAX>(w, h, sraw, last, last2, a.f, a.x0[f], a.xf[f], a.y0[f], a.yf[f],
-                                 x[(int64_t)b * ldx + f], (double)gy[(int64_t)b * ldgy + f], gl, guw, guh, gus, &glast,
-                                 &glast2, &gxin);
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-            if (k < K) {
-                gp[k * GL.stride_p] = (float)guw[k];
-                gp[(K + k) * GL.stride_p] = (float)guh[k];
-            }
-        // slopes: knot K of a circular spline shares the parameter of knot 0; identity boundary
-        // slopes have no parameter.
-        double g0 = gus[0];
-#pragma unroll
-        for (int j = 0; j <= KMAX; ++j)
-            if (j == K && a.f.circular && !a.f.identity) g0 += gus[j];
-#pragma unroll
-        for (int j = 0; j <= KMAX; ++j) {
-            if (j > K) continue;
-            if (a.f.circular && !a.f.identity && j == K) continue;
-            const int pi = spline_slope_param(j, K, a.f.circular, a.f.identity);
-            if (pi >= 0) gp[pi * GL.stride_p] = (float)(j == 0 ? g0 : gus[j]);
+        if (staged) {
+            __builtin_amdgcn_wave_barrier();
+            float* dst = gparams + (int64_t)b * GL.ld + (int64_t)f0 * P;
+            for (int i = lane; i < nf * P; i += 64) dst[i] = stage[(i / P) * pitch + i % P];
+            __builtin_amdgcn_wave_barrier();
         }
-        if (has_last) gp[(a.P - 1) * GL.stride_p] = (float)glast;
-        if (has_last2) gp[(a.P - 2) * GL.stride_p] = (float)glast2;
-        gx[(int64_t)b * ldgx + f] = (float)gxin;
     }
 }
 
@@ -742,9 +796,9 @@ int tfep_spline_backward(const float* x, int64_t ldx, const float* params, tfep_
     a.P = spline_n_params(a.f.K, a.f.circular, a.f.identity, a.f.learn_lower, a.f.learn_upper);
     hipStream_t s = (hipStream_t)stream;
     if (a.f.K <= 8)
-        spline_backward_kernel<8><<<row_blocks_b(B), 256, 0, s>>>(x, ldx, params, layout, a, gy, ldgy, g_log_det_J, gparams, glayout, gx, ldgx, B, D);
+        spline_backward_kernel<8><<<row_blocks_b(B), 256, 4 * 64 * (3 * 8 + 4) * sizeof(float), s>>>(x, ldx, params, layout, a, gy, ldgy, g_log_det_J, gparams, glayout, gx, ldgx, B, D);
     else if (a.f.K <= 16)
-        spline_backward_kernel<16><<<row_blocks_b(B), 256, 0, s>>>(x, ldx, params, layout, a, gy, ldgy, g_log_det_J, gparams, glayout, gx, ldgx, B, D);
+        spline_backward_kernel<16><<<row_blocks_b(B), 256, 4 * 64 * (3 * 16 + 4) * sizeof(float), s>>>(x, ldx, params, layout, a, gy, ldgy, g_log_det_J, gparams, glayout, gx, ldgx, B, D);
     else
         spline_backward_kernel<32><<<row_blocks_b(B), 256, 0, s>>>(x, ldx, params, layout, a, gy, ldgy, g_log_det_J, gparams, glayout, gx, ldgx, B, D);
     return check_launch("spline_backward_kernel");
