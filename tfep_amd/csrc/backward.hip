@@ -544,19 +544,54 @@ __global__ void __launch_bounds__(WNB_THREADS) weight_norm_backward_prefix_kerne
         }
         for (int i = head + 4 * n4 + tid; i < K; i += WNB_THREADS) srow[i] = vr[i];
     }
-    __syncthreads();
     const int cut = min(col_cut[o], K);
     const float* gr = gw_packed + (int64_t)(row_of_out ? row_of_out[o] : o) * ldw;
     float* gvr = gv + (int64_t)o * K;
+    // The live prefix of the packed gradient row and its permutation entries: 4 columns per thread and step, every step's
+    // 16-byte loads issued up front (8 steps cover 16 384 columns) -- they were fetched element by element, twice, each
+    // pass a chain of dependent L2 round trips (4.1 ms for the cfg2 output layer at 2.7 TB/s).
+    constexpr int WNB_U = 8;
+    const bool vec = ((uintptr_t)gr & 15u) == 0 && (!in_of_col || ((uintptr_t)in_of_col & 15u) == 0);
+    float4 gq[WNB_U];
+    int4 iq[WNB_U];
+#pragma unroll
+    for (int u = 0; u < WNB_U; ++u) {
+        const int c4 = (tid + u * WNB_THREADS) * 4;
+        gq[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        iq[u] = make_int4(c4, c4 + 1, c4 + 2, c4 + 3);
+        if (c4 < cut) {
+            if (vec && c4 + 4 <= K) {
+                gq[u] = *reinterpret_cast<const float4*>(gr + c4);
+                if (in_of_col) iq[u] = *reinterpret_cast<const int4*>(in_of_col + c4);
+            } else {
+                float* ge = reinterpret_cast<float*>(&gq[u]);
+                int* ie = reinterpret_cast<int*>(&iq[u]);
+                for (int j = 0; j < 4; ++j)
+                    if (c4 + j < cut) {
+                        ge[j] = gr[c4 + j];
+                        if (in_of_col) ie[j] = in_of_col[c4 + j];
+                    }
+            }
+        }
+    }
+    __syncthreads();                              // v[o, :] is in LDS
     double ss = 0.0, dot = 0.0;
     if (g) {
         for (int i = tid; i < K; i += WNB_THREADS) ss += (double)srow[i] * (double)srow[i];
-        for (int c = tid; c < cut; c += WNB_THREADS) dot += (double)gr[c] * (double)srow[in_of_col ? in_of_col[c] : c];
+#pragma unroll
+        for (int u = 0; u < WNB_U; ++u) {
+            const int c4 = (tid + u * WNB_THREADS) * 4;
+            const float ge[4] = {gq[u].x, gq[u].y, gq[u].z, gq[u].w};
+            const int ie[4] = {iq[u].x, iq[u].y, iq[u].z, iq[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c4 + j < cut) dot += (double)ge[j] * (double)srow[ie[j]];
+        }
         ss = wave_sum(ss);
         dot = wave_sum(dot);
         if (lane == 0) { red[0][wave] = ss; red[1][wave] = dot; }
     }
-    __syncthreads();                              // (also: every read of v for the sums is done before it is overwritten)
+    __syncthreads();
     double n = 1.0, go = 0.0, gg_o = 0.0;
     bool dead = false;
     if (g) {
@@ -568,15 +603,46 @@ __global__ void __launch_bounds__(WNB_THREADS) weight_norm_backward_prefix_kerne
         gg_o = dead ? 0.0 : dot / n;
         go = (double)g[o];
     }
-    // results in place of v: live entries first (each reads its own v before writing), then the masked ones
+    // the live results in registers (each reads its own v), then the row is cleared and they are scattered into it: the
+    // masked entries need no permutation lookup
     const double a = (g && !dead) ? go / n : 0.0, b = (g && !dead) ? go * dot / (n * n * n) : 0.0;
-    for (int c = tid; c < cut; c += WNB_THREADS) {
-        const int i = in_of_col ? in_of_col[c] : c;
-        srow[i] = g ? (float)(a * (double)gr[c] - b * (double)srow[i]) : gr[c];
+    float4 res[WNB_U];
+#pragma unroll
+    for (int u = 0; u < WNB_U; ++u) {
+        const int c4 = (tid + u * WNB_THREADS) * 4;
+        const float ge[4] = {gq[u].x, gq[u].y, gq[u].z, gq[u].w};
+        const int ie[4] = {iq[u].x, iq[u].y, iq[u].z, iq[u].w};
+        float re[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c4 + j < cut) re[j] = g ? (float)(a * (double)ge[j] - b * (double)srow[ie[j]]) : ge[j];
+        res[u] = make_float4(re[0], re[1], re[2], re[3]);
     }
-    for (int c = cut + tid; c < K; c += WNB_THREADS) srow[in_of_col ? in_of_col[c] : c] = 0.f;
+    __syncthreads();                              // every read of v is done
+    for (int i = tid; i < K; i += WNB_THREADS) srow[i] = 0.f;
     __syncthreads();
-    for (int i = tid; i < K; i += WNB_THREADS) gvr[i] = srow[i];
+#pragma unroll
+    for (int u = 0; u < WNB_U; ++u) {
+        const int c4 = (tid + u * WNB_THREADS) * 4;
+        const float re[4] = {res[u].x, res[u].y, res[u].z, res[u].w};
+        const int ie[4] = {iq[u].x, iq[u].y, iq[u].z, iq[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c4 + j < cut) srow[ie[j]] = re[j];
+    }
+    __syncthreads();
+    {
+        // the row of results out in 16-byte stores (head / body / tail like the load of v)
+        const int head = min(K, (int)(((16u - (uint32_t)((uintptr_t)gvr & 15u)) & 15u) >> 2));
+        const int n4 = (K - head) >> 2;
+        float4* o4 = reinterpret_cast<float4*>(gvr + head);
+        if (tid < head) gvr[tid] = srow[tid];
+        for (int i = tid; i < n4; i += WNB_THREADS) {
+            const float* sp = srow + head + 4 * i;
+            o4[i] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        }
+        for (int i = head + 4 * n4 + tid; i < K; i += WNB_THREADS) gvr[i] = srow[i];
+    }
     if (g && tid == 0) gg[o] = (float)gg_o;
 }
 
