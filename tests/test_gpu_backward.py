@@ -717,3 +717,37 @@ def test_cfg2_width_gradients_by_directional_derivative():
         lm = loss64((x.detach() - eps_x * dx).clamp(-4.99, 4.99))
     fd_x = (lp - lm) / (2 * eps_x)
     assert abs(fd_x - analytic_x) <= 0.03 * abs(analytic_x) + 1e-3, (fd_x, analytic_x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('embedding', [False, True])
+def test_parameter_gradients_do_not_depend_on_whether_the_input_needs_one(embedding):
+    """The first layer of a flow sees data that needs no gradient: its backward skips the grad_input GEMM of the first masked
+    linear (and the embedding's VJP).  The parameter gradients are the same bits either way."""
+    from tfep_amd.loss import BoltzmannKLDivLoss
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.embeddings import PeriodicEmbedding
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    torch.manual_seed(8)
+    D, B = 60, 700
+    emb = PeriodicEmbedding(D, limits=[0.0, 2.0], periodic_indices=list(range(0, D, 3))) if embedding else None
+    lo, hi = (0.0, 2.0) if embedding else (-4.0, 4.0)
+    maf = MAF(generate_degrees(D, 'ascending'), transformer=NeuralSplineTransformer(torch.full((D,), lo), torch.full((D,), hi), 8,
+                                                                                   circular=embedding),
+              embedding=emb, hidden_layers=[140, 120], initialize_identity=False).cuda()
+    x0 = (torch.rand(B, D, device='cuda') * (hi - lo) + lo) * 0.97
+    c = torch.linspace(0.1, 0.4, D, device='cuda')
+    for split in (False, True):
+        maf.split_gemm = split
+        out = {}
+        for needs in (True, False):
+            for p in maf.parameters():
+                p.grad = None
+            x = x0.clone().requires_grad_(needs)
+            y, l = maf(x)
+            BoltzmannKLDivLoss()((c * y ** 2).sum(dim=1), l).backward()
+            out[needs] = [p.grad.clone() for p in maf.parameters()]
+            assert (x.grad is not None) == needs
+        for a, b in zip(out[True], out[False]):
+            assert torch.equal(a, b)

@@ -179,7 +179,8 @@ class MAFLayerFunction(torch.autograd.Function):
         del kept
         from .autoregressive import _RangeGuard
         with torch.no_grad(), _RangeGuard(layer, x, force=ctx.guard_exact):
-            gx, gparams = layer_backward(layer, x, gy, gldj, saved=saved)
+            # (the first layer of a flow: the data needs no gradient -- its grad_input GEMM and embedding VJP are skipped)
+            gx, gparams = layer_backward(layer, x, gy, gldj, saved=saved, need_gx=ctx.needs_input_grad[1])
         # parameters this backward does not hand a gradient to (torch.autograd.grad(loss, [x]), a subset of the
         # parameters): their hooks will not run, so their "already masked" tags must not outlive this call
         for prm, needed in zip(trainable_tensors(layer), ctx.needs_input_grad[2:]):
@@ -721,8 +722,9 @@ def forward_saving(layer, x):
     return y, ldj, dict(h=h, theta=theta)
 
 
-def layer_backward(layer, x, gy, gldj, saved=None):
-    """Returns (gx, [grads in trainable_tensors() order]).  ``saved``: activations kept by ``forward_saving``."""
+def layer_backward(layer, x, gy, gldj, saved=None, need_gx=True):
+    """Returns (gx, [grads in trainable_tensors() order]).  ``saved``: activations kept by ``forward_saving``.
+    ``need_gx`` False: the gradient w.r.t. the layer's input is not wanted (None is returned for it)."""
     if not supported(layer):
         raise NotImplementedError(
             'tfep_amd: backward needs a transformer with a VJP kernel (affine / neural-spline / Moebius / '
@@ -754,7 +756,7 @@ def layer_backward(layer, x, gy, gldj, saved=None):
     # those are read afterwards (weight_norm_backward*: the live prefix, or a select on the mask): no 5.5 GB clear.
     gW = [(ops.zeros if B == 0 else torch.empty)(n_pad[l], k_pad[l], **f32) for l in range(L + 1)]      # (empty batch: no chunk writes)
     gb = [ops.zeros(n_pad[l], **f32) for l in range(L + 1)]
-    gx = torch.empty(B, D, **f32)
+    gx = torch.empty(B, D, **f32) if need_gx else None
     emb_generic = emb is not None and type(emb) is not PeriodicEmbedding
     emb_params = _embedding_params(layer)
     g_emb = [torch.zeros_like(p) for p in emb_params]
@@ -833,6 +835,8 @@ def layer_backward(layer, x, gy, gldj, saved=None):
                       tile_list=bplan['live_list'][l])
                 del gT, hT
             # grad_input = g W  (x ELU'(h) for hidden inputs)
+            if l == 0 and not need_gx and not emb_params:
+                break                                   # nothing upstream wants the gradient of the conditioner's input
             gin = torch.empty(Bc, k_pad[l], **f32)
             tbl = (bplan['wide'] if split else None) or bplan
             _gemm(g, WT[l], gin, Bc, k_pad[l], k_pad[l], k_ranges=tbl['dx_ranges'][l],
@@ -840,6 +844,8 @@ def layer_backward(layer, x, gy, gldj, saved=None):
             g = gin
 
         # ---- gradient w.r.t. the layer input: through the conditioner + direct
+        if not need_gx and not emb_params:
+            continue
         if emb_generic:
             g_in = torch.autograd.grad(cin_graph, [x_emb] + emb_params, g[:, :cin.shape[1]].contiguous(), allow_unused=True)
             gxc = g_in[0].contiguous() if g_in[0] is not None else torch.zeros(Bc, D, **f32)
@@ -860,8 +866,9 @@ def layer_backward(layer, x, gy, gldj, saved=None):
             ops.scatter_columns(gx_dir, tables['tr'], direct)
         else:
             direct = gx_dir
-        _lib.call('tfep_add_inplace', _lib.ptr(direct), direct.shape[1], _lib.ptr(gxc), D, Bc, D, stream)
-        gx[b0:b1] = gxc
+        if need_gx:
+            _lib.call('tfep_add_inplace', _lib.ptr(direct), direct.shape[1], _lib.ptr(gxc), D, Bc, D, stream)
+            gx[b0:b1] = gxc
 
     # ---- packed weight / bias gradients -> parameter gradients
     grads = []
