@@ -345,6 +345,14 @@ int tfep_split_columns_scaled(const float* src, int64_t ld_src, int64_t rows, in
 int tfep_masked_weight_prepare_split(const float* weight_v, const float* weight_g, const float* mask, int out_features,
                                      int in_features, const int32_t* row_of_out, const int32_t* in_of_col, const int32_t* col_cut,
                                      void* w_split_out, int64_t ldw, int k_padded, float* inv_scale, void* stream);
+/* The same pass writing BOTH forms of the effective weights: split rows (as above) and fp32 rows (w32_out, the packing of
+ * tfep_masked_weight_prepare with the same row / column order: the same bits), from one read of weight_v.  Prefix masks
+ * (col_cut) and rows of 8192 .. 16384 weights only (TFEP_ERR_UNSUPPORTED otherwise: use the two entry points).  The blocked
+ * inverse (flows/autoregressive.py:179-229) needs the fp32 matrix for its block kernel and the split one for its GEMMs. */
+int tfep_masked_weight_prepare_split_both(const float* weight_v, const float* weight_g, int out_features, int in_features,
+                                          const int32_t* row_of_out, const int32_t* in_of_col, const int32_t* col_cut,
+                                          void* w_split_out, int64_t ldw, float* w32_out, int64_t ldw32, int k_padded,
+                                          float* inv_scale, void* stream);
 
 /* tfep_fused_output_transformer_forward on split operands: h_split (B rows, per-row h_inv_scale) and w_split (one
  * w_inv_scale); every other argument as above.  k_ranges must be multiples of 32. */

@@ -719,3 +719,37 @@ def test_fused_forward_and_training_step_repeat_bit_for_bit(layout):
     for _ in range(2):
         for a, b in zip(first, step()):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('weight_norm', [True, False])
+def test_one_pass_pack_of_both_weight_forms_equals_the_two_packs(weight_norm):
+    """``MADE._pack_layer_both`` (``tfep_masked_weight_prepare_split_both``: the blocked inverse's fp32 and split packs of a
+    layer from one read of the parameters): bit for bit the packs of ``_pack_layer`` and ``_pack_layer_split``."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import AffineTransformer
+    torch.manual_seed(12)
+    D = 24
+    maf = MAF(generate_degrees(D, 'ascending'), transformer=AffineTransformer(), hidden_layers=[64, 8300], weight_norm=weight_norm,
+              initialize_identity=False).cuda()
+    made = maf._conditioner
+    dev = torch.device('cuda', torch.cuda.current_device())
+    plan = made.plan(dev)
+    lins = made._linears()
+    li, lin = 2, lins[2]                                    # 48 output rows of 8300 weights each
+    assert lin.in_features == 8300
+    with torch.no_grad():
+        w32, b32 = made._pack_layer(plan, li, lin)
+        w32, b32 = w32.clone(), b32.clone()
+        ws, winv, bs, bmax = made._pack_layer_split(plan, li, lin)
+        ws, winv, bs = ws.clone(), winv.clone(), bs.clone()
+        made.invalidate_plan()
+        plan = made.plan(dev)
+        with made.frozen_weights():
+            assert made._pack_layer_both(plan, li, lin)
+            w32b, b32b = made._pack_layer(plan, li, lin)             # served from what the one pass left
+            wsb, winvb, bsb, _ = made._pack_layer_split(plan, li, lin)
+            assert torch.equal(w32b, w32) and torch.equal(b32b, b32)
+            assert torch.equal(wsb.view(torch.int32), ws.view(torch.int32)) and torch.equal(winvb[0], winv[0]) and torch.equal(bsb, bs)
+            assert float(winvb[2]) == float(winv[2])                  # the row-L1 bound of the split pack
+        assert made._pack_layer_both(plan, 1, lins[1]) is False      # 64-weight rows: the two methods pack on their own

@@ -134,6 +134,7 @@ _SIGNATURES = {
                                                       c_int, c_int, c_int, _P]),
     'tfep_split_tile_k': (c_int, []),
     'tfep_masked_weight_prepare_split': (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, _P, c_int64, c_int, _P, _P]),
+    'tfep_masked_weight_prepare_split_both': (c_int, [_P, _P, c_int, c_int, _P, _P, _P, _P, c_int64, _P, c_int64, c_int, _P, _P]),
     'tfep_split_rows': (c_int, [_P, c_int64, c_int64, c_int64, _P, c_int64, c_int64, _P, c_int, _P]),
     'tfep_abs_reduce': (c_int, [_P, c_int64, c_int64, c_int64, c_int, _P, _P]),
     'tfep_range_flag': (c_int, [_P, c_int64, c_int64, c_int64, c_int, _P, _P]),

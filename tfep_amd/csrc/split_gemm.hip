@@ -394,13 +394,17 @@ __global__ void __launch_bounds__(256) weight_prepare_split_kernel(const float* 
 // live prefix [0, cut) of the packed row is written, in whole 32-byte groups -- the masked suffix was zeroed when the
 // buffer was allocated and nothing ever writes it (the k-ranges of the GEMMs do not even read it).
 constexpr int PFX_THREADS = 512;
+// BOTH: the same effective weights also as fp32 rows (w32, the packing of tfep_masked_weight_prepare_prefix: same bits) --
+// the blocked inverse needs the fp32 matrix for its block kernel and the split one for its block GEMMs: one read of v.
+template <bool BOTH>
 __global__ void __launch_bounds__(PFX_THREADS) weight_prepare_split_prefix_kernel(const float* __restrict__ v, const float* __restrict__ g,
                                                                           int N, int K, const int32_t* __restrict__ row_of_out,
                                                                           const int32_t* __restrict__ in_of_col,
                                                                           const int32_t* __restrict__ col_cut,
                                                                           uint4* __restrict__ w_out, int64_t ldw, int k_padded,
                                                                           const uint32_t* __restrict__ max_bits,
-                                                                          float* __restrict__ inv_scale) {
+                                                                          float* __restrict__ inv_scale,
+                                                                          float* __restrict__ w32, int64_t ldw32) {
     extern __shared__ float srow[];
     const int o = blockIdx.x, tid = threadIdx.x;
     const float* vr = v + (int64_t)o * K;
@@ -480,11 +484,13 @@ __global__ void __launch_bounds__(PFX_THREADS) weight_prepare_split_prefix_kerne
                 idx[j] = (in_of_col && c < K) ? in_of_col[c] : min(c, K - 1);
             }
         }
+        float e32[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = g8 * 8 + j;
             float val = 0.f;
             if (c < cut) val = srow[idx[j]] * wn;
+            e32[j] = val;
             l1 += fabsf(val);
             val *= s;
             const _Float16 h = (_Float16)val;
@@ -493,6 +499,11 @@ __global__ void __launch_bounds__(PFX_THREADS) weight_prepare_split_prefix_kerne
         }
         dr[g8 * 2] = *reinterpret_cast<uint4*>(&hi);
         dr[g8 * 2 + 1] = *reinterpret_cast<uint4*>(&lo);
+        if constexpr (BOTH) {
+            float4* d32 = reinterpret_cast<float4*>(w32 + orow * ldw32 + (int64_t)g8 * 8);
+            d32[0] = make_float4(e32[0], e32[1], e32[2], e32[3]);
+            d32[1] = make_float4(e32[4], e32[5], e32[6], e32[7]);
+        }
     }
     l1 = wave_sum(l1);
     if ((tid & 63) == 0 && l1 < INFINITY) {                   // look before the atomic (see weight_prepare_split_kernel)
@@ -733,15 +744,40 @@ int tfep_masked_weight_prepare_split(const float* weight_v, const float* weight_
     // (short rows stay with the one-wave-per-row kernel: a workgroup per 3000-element row is mostly launch overhead)
     if (col_cut && lds_rows && in_features >= 8192 && (size_t)in_features * 4 <= 64 * 1024) {
         // prefix masks: the row goes through LDS once; the masked suffix of each packed row is NOT written (see the kernel)
-        weight_prepare_split_prefix_kernel<<<(unsigned)out_features, PFX_THREADS, (size_t)in_features * 4, s>>>(
+        weight_prepare_split_prefix_kernel<false><<<(unsigned)out_features, PFX_THREADS, (size_t)in_features * 4, s>>>(
             weight_v, weight_g, out_features, in_features, row_of_out, in_of_col, col_cut, (uint4*)w_split_out, ldw, k_padded,
-            max_bits, inv_scale);
+            max_bits, inv_scale, nullptr, 0);
         return check_launch("weight_prepare_split_prefix_kernel");
     }
     weight_prepare_split_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, s>>>(
         weight_v, weight_g, mask, out_features, in_features, row_of_out, in_of_col, col_cut, (uint4*)w_split_out, ldw,
         k_padded, max_bits, inv_scale);
     return check_launch("weight_prepare_split_kernel");
+}
+
+int tfep_masked_weight_prepare_split_both(const float* weight_v, const float* weight_g, int out_features, int in_features,
+                                          const int32_t* row_of_out, const int32_t* in_of_col, const int32_t* col_cut,
+                                          void* w_split_out, int64_t ldw, float* w32_out, int64_t ldw32, int k_padded,
+                                          float* inv_scale, void* stream) {
+    TFEP_REQUIRE(weight_v && w_split_out && w32_out && inv_scale && col_cut, "masked_weight_prepare_split_both: NULL pointer");
+    TFEP_REQUIRE(out_features >= 0 && in_features >= 0, "masked_weight_prepare_split_both: negative size");
+    TFEP_REQUIRE(k_padded >= in_features && k_padded % SBK == 0 && ldw >= k_padded && ldw % 4 == 0 && ldw32 >= k_padded && ldw32 % 4 == 0,
+                 "masked_weight_prepare_split_both: k_padded=%d must be a multiple of %d >= in_features, rows at least that wide", k_padded, SBK);
+    TFEP_REQUIRE((uintptr_t)w_split_out % 16 == 0 && (uintptr_t)w32_out % 16 == 0, "masked_weight_prepare_split_both: outputs must be 16-byte aligned");
+    if (!(in_features >= 8192 && (size_t)in_features * 4 <= 64 * 1024))
+        return fail(TFEP_ERR_UNSUPPORTED, "masked_weight_prepare_split_both: rows of 8192 .. 16384 weights only (the LDS-staged kernel)");
+    if (out_features == 0) return TFEP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* max_bits = reinterpret_cast<uint32_t*>(inv_scale + 1);
+    zero_u32_kernel<<<1, 1, 0, s>>>(max_bits, 2);
+    if (weight_g)
+        absmax_kernel<<<1, 256, 0, s>>>(weight_g, 0, 1, out_features, max_bits);
+    else
+        absmax_kernel<<<(unsigned)((out_features + 3) / 4), 256, 0, s>>>(weight_v, in_features, out_features, in_features, max_bits);
+    weight_prepare_split_prefix_kernel<true><<<(unsigned)out_features, PFX_THREADS, (size_t)in_features * 4, s>>>(
+        weight_v, weight_g, out_features, in_features, row_of_out, in_of_col, col_cut, (uint4*)w_split_out, ldw, k_padded,
+        max_bits, inv_scale, w32_out, ldw32);
+    return check_launch("weight_prepare_split_prefix_kernel<both>");
 }
 
 int tfep_diag_split_mfma_peak(float* scratch, int blocks, int iters, void* stream) {

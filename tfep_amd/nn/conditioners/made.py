@@ -393,6 +393,45 @@ class MADE(Conditioner):
             ops.scatter_columns(lin.bias.detach()[None, :], row_of_out, bias)
         return bias[0]
 
+    def _pack_layer_both(self, plan, li, lin, row_of_out=None, n_rows=None):
+        """Fill the caches of ``_pack_layer`` (fp32) AND ``_pack_layer_split`` for layer ``li`` from one pass over the
+        parameters (``tfep_masked_weight_prepare_split_both``) -- inside ``frozen_weights()`` / with ``cache_packed_weights``,
+        for a layer whose mask rows are prefixes and whose rows hold 8192 .. 16 384 weights; otherwise nothing happens and the
+        two methods pack on their own.  The blocked inverse wants both forms of every layer."""
+        if not self._keep_packed(plan) or not (8192 <= lin.in_features <= 16384):
+            return False
+        row_of_out = plan['row_of_out'][li] if row_of_out is None else row_of_out
+        n_rows = plan['n_pad'][li] if n_rows is None else n_rows
+        rptr = None if row_of_out is None else row_of_out.data_ptr()
+        ck32, cks = ('packed', li, n_rows, rptr), ('packed_split', li, n_rows, rptr)
+        if ck32 in plan and cks in plan:
+            return True
+        cut = self._mask_prefix_cuts(plan, li, lin)
+        in_of_col = plan['in_of_col'][li]
+        if cut is None or (in_of_col is None and plan['col_of_in'][li] is not None) or os.environ.get('TFEP_PACK_BOTH', '1') == '0':
+            return False
+        if lin.has_weight_norm:
+            v, g = lin.weight_v.detach(), lin.weight_g.detach()
+        else:
+            v, g = lin._parameters['weight'].detach(), None
+        k32, ks = ('w', li, n_rows, rptr), ('ws', li, n_rows, rptr)
+        e32 = plan.get(k32)
+        if e32 is None:
+            e32 = plan[k32] = (ops.zeros(n_rows, plan['k_pad'][li], dtype=torch.float32, device=v.device), row_of_out)
+        es = plan.get(ks)
+        if es is None:
+            es = plan[ks] = (ops.zeros(n_rows, plan['k_pad'][li], dtype=torch.float32, device=v.device),
+                             ops.zeros(4, dtype=torch.float32, device=v.device), row_of_out)
+        v_c = v.contiguous()
+        g_c = None if g is None else g.contiguous()
+        ops.call('tfep_masked_weight_prepare_split_both', ops.ptr(v_c), ops.ptr(g_c), v.shape[0], v.shape[1], ops.ptr(row_of_out),
+                  ops.ptr(in_of_col), ops.ptr(cut), ops.ptr(es[0]), es[0].shape[1], ops.ptr(e32[0]), e32[0].shape[1],
+                  plan['k_pad'][li], ops.ptr(es[1]), ops.stream_of(v))
+        bias = self._pack_bias(lin, row_of_out, n_rows)
+        plan[ck32] = (e32[0], bias)
+        plan[cks] = (es[0], es[1], bias, ops.abs_reduce(bias.reshape(1, -1), 'row_max'))
+        return True
+
     def _pack_layer_split(self, plan, li, lin, row_of_out=None, n_rows=None):
         """Weight norm + mask + permutation + padding of layer ``li`` written directly as split-f16 rows (one scale
         for the matrix).  Returns ``(w_split, w_inv_scale, bias)``."""

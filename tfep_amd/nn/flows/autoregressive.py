@@ -983,6 +983,12 @@ class AutoregressiveFlow(torch.nn.Module):
             bp['kr_tiles'] = krs
 
         with made.frozen_weights():
+            if bp['fused'] is not None and self._split_inverse_bound(dev) is not None:
+                # the block kernel reads fp32 weights, the block GEMMs split ones: both from one pass over the parameters
+                for l in range(1, L):
+                    if self.split_inverse_hidden:
+                        made._pack_layer_both(mplan, l, lins[l])
+                made._pack_layer_both(mplan, L, lins[L], row_of_out=bp['row_inv'], n_rows=bp['n_rows_out'])
             packs = [made._pack_layer(mplan, l, lins[l]) for l in range(L)]
             w_out, b_out = made._pack_layer(mplan, L, lins[L], row_of_out=bp['row_inv'], n_rows=bp['n_rows_out'])
             x = ops.zeros(B, D, **f32)
