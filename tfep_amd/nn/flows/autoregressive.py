@@ -538,16 +538,38 @@ class AutoregressiveFlow(torch.nn.Module):
             ops.scatter_columns(torch.cos(t), info['cos_cols'], xpad)
             ops.scatter_columns(torch.sin(t), info['sin_cols'], xpad)
 
-    def _blocked_plan(self, device):
+    def _blocked_plan(self, device, batch=None):
         """The plan of ``_blocked_plan_for`` with ``inverse_block`` degrees per block, or fewer (halved down to 2) when
-        that is what lets the block's state fit the LDS of the fused block kernel."""
+        that is what lets the block's state fit the LDS of the fused block kernel.  ``batch``: the rows of the call -- when
+        the 16-row layout of the block kernel is not resident at once with ``inverse_block`` degrees per block but is with
+        half of them (its LDS stage shrinks with the block), the halved plan is taken (cfg4-i at B = 16 384: 74.1 -> 70.1 ms)."""
         n_super = int(os.environ.get('TFEP_INV_SUPER', self.inverse_super or 0))
-        key = ('blocked', str(device), self.inverse_block, n_super)
+        G0 = max(1, int(os.environ.get('TFEP_INV_BLOCK', self.inverse_block)))
+        if batch is not None and G0 >= 4 and 'TFEP_INV_BLOCK' not in os.environ and os.environ.get('TFEP_INV_BLOCK_BY_BATCH', '1') != '0':
+            full = self._blocked_plan(device)
+            if full['fused'] is not None and batch <= 16384:
+                lib = _lib.load()
+                need = (int(batch) + 15) // 16
+
+                def resident(bp_):
+                    f_ = bp_['fused']
+                    lds16 = lib.tfep_inverse_block_lds_bytes_rows(bp_['L'], f_['cache_len'], f_['max_feats'], 16)
+                    return 0 < lds16 <= 160 * 1024 and need <= 256 * ((160 * 1024) // int(lds16))
+                if not resident(full):
+                    hkey = ('blocked', str(device), G0 // 2, n_super)
+                    half = self._dev.get(hkey)
+                    if half is None:
+                        self._plan_n_super = n_super
+                        half = self._dev[hkey] = self._blocked_plan_for(device, G0 // 2)
+                    if half['fused'] is not None and resident(half):
+                        return half
+            return full
+        key = ('blocked', str(device), G0, n_super)
         bp = self._dev.get(key)
         if bp is not None:
             return bp
         self._plan_n_super = n_super
-        G = max(1, int(self.inverse_block))
+        G = G0
         bp = self._blocked_plan_for(device, G)
         if bp['fused'] is None and self._fused_inverse_supported(bp['L']):
             g = G
@@ -945,7 +967,7 @@ class AutoregressiveFlow(torch.nn.Module):
         B, D = y.shape
         dev = y.device
         tables = self._tables(dev)
-        bp = self._blocked_plan(dev)
+        bp = self._blocked_plan(dev, batch=B)
         made = self._conditioner
         mplan = made.plan(dev)
         lins = made._linears()
