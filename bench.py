@@ -189,6 +189,37 @@ def cfg5_arm(device, n=256, B=16384, n_evals=3):
                          'arithmetic': 'split-f16 (fp16 MFMA / 3)' if split else 'fp32 MFMA'}}
 
 
+def spawn_ranks(n, argv=None):
+    """``python bench.py --gpus N`` without an outer launcher: start ``python -m torch.distributed.run --nproc-per-node N
+    bench.py ...`` as a CHILD process and hand its output and exit code through.  The parent has made no HIP call
+    (importing torch and parsing arguments initialise nothing) and never replaces itself (no exec): it only waits."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)]
+    cmd += list(sys.argv[1:] if argv is None else argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.call(cmd, env=env)                        # stdout / stderr inherited: rank 0's JSON line passes through
+
+
+def _rehearsal_stats(work):
+    """TFEP_BENCH_BACKEND=gloo only (no GPU, no kernels): the 9 statistics of ``tfep_tfep_reduce`` for the plain estimator,
+    in torch on the CPU, so that the launch / sharding / all-gather plumbing of the N-rank bench can be rehearsed."""
+    r = work.double()
+    e = -r
+    m = e.max()
+    ninf = float('-inf')
+    return torch.stack([torch.tensor(float(r.numel()), dtype=torch.float64), r.sum(), torch.tensor(ninf, dtype=torch.float64),
+                        torch.tensor(0.0, dtype=torch.float64), torch.tensor(0.0, dtype=torch.float64), m,
+                        torch.exp(e - m).sum(), torch.tensor(ninf, dtype=torch.float64), torch.tensor(0.0, dtype=torch.float64)])
+
+
 def rows_for_rank(batch, rank, world, scaling='strong'):
     """Rows ``[row0, row1)`` of the global batch that ``rank`` maps, and the global batch size.  strong (BASELINE
     cfg3): ``batch`` rows sharded contiguously (8192 per GPU at N = 8); weak: ``batch`` rows on every rank."""
@@ -216,20 +247,35 @@ def main():
                     help='skip the cached-repack and exact-fp32 arms and the one-layer inverse / training-step lines')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # not under a launcher: the ranks are CHILD processes of this one, which has not touched the GPU and never will
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
-    if world != args.gpus:
-        if rank == 0 and world == 1 and args.gpus > 1:
-            sys.exit(f'--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`')
+    if world != args.gpus and rank == 0:
+        print(f'bench.py: --gpus {args.gpus} but the launcher started {world} ranks; reporting n_gpus = {world}', file=sys.stderr)
     import torch.distributed as dist
-    device = torch.device('cuda', local_rank)
-    torch.cuda.set_device(device)
+    # TFEP_BENCH_BACKEND=gloo: a REHEARSAL of the N-rank launch on a box without GPUs (tests/test_distributed_cpu.py) --
+    # the spawn, the rendezvous, the row sharding and the statistics all-gather run; no kernel does, the flow is the
+    # identity, and the line says so ("data": "rehearsal ..."): never a measurement.
+    backend = os.environ.get('TFEP_BENCH_BACKEND', 'nccl')
+    rehearsal = backend != 'nccl'
     use_dist = world > 1 or 'RANK' in os.environ          # launched by torch.distributed.run
-    if use_dist:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        dist.init_process_group('nccl', device_id=device)
+    if rehearsal:
+        device = torch.device('cpu')
+        args.no_extra_arms = args.no_cpu_baseline = True
+        if use_dist:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group(backend)
+    else:
+        device = torch.device('cuda', local_rank)
+        torch.cuda.set_device(device)
+        if use_dist:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group('nccl', device_id=device)
 
     from tfep_amd.analysis import fep_estimator
     D = args.features
@@ -244,7 +290,7 @@ def main():
     u_A = torch.randn(B, device=device, generator=gen)
 
     fused_layers = [l for l in flow if l._fused_kind() is not None]
-    assert len(fused_layers) == len(flow), 'bench expects the fused HIP path on every layer'
+    assert rehearsal or len(fused_layers) == len(flow), 'bench expects the fused HIP path on every layer'
     # algorithmic flops of the fused output kernel: 2 * nnz(mask_out) per sample
     nnz_out = [float(torch.count_nonzero(l._conditioner.layers[-1].mask)) for l in flow]
     nnz_all = [sum(float(torch.count_nonzero(m.mask)) for m in l._conditioner.layers[::2]) for l in flow]
@@ -255,10 +301,19 @@ def main():
         work = u_B - ldj - u_A                       # reduced work of the mapped samples
         return y, ldj, fep_estimator(work, distributed=use_dist)
 
+    if rehearsal:
+        from tfep_amd.distributed import allreduce_stats
+
+        def step():                                  # noqa: F811  (no kernels: identity map, statistics in torch)
+            st = _rehearsal_stats(u_B - u_A)
+            st = allreduce_stats(st) if use_dist else st
+            return x, torch.zeros(B), -(st[5] + torch.log(st[6]) - torch.log(st[0]))
+
     def sync():
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        if not rehearsal:
+            torch.cuda.synchronize(device)
 
     def timed(n_warmup, n_steps):
         """W untimed steps, then exactly K steps between barrier + synchronize; MAX over ranks.  Returns
@@ -284,8 +339,18 @@ def main():
 
     # ---------------------------------------------------------------- headline: weights re-packed every step
     elapsed, out, kern_ms, kern_flops = timed(args.warmup, args.steps)
-    achieved = sum(kern_flops) / (sum(kern_ms) * 1e-3) / 1e12
-    split = all(l._use_split_gemm() for l in flow)
+    achieved = sum(kern_flops) / (sum(kern_ms) * 1e-3) / 1e12 if kern_ms else 0.0
+    split = rehearsal or all(l._use_split_gemm() for l in flow)
+    # every rank's fused-kernel rate (HIP events on its own stream): rank 0 reports its own as `achieved`, all of them
+    # and their sum beside it
+    per_rank = torch.tensor([achieved, float(np.mean(kern_ms)) if kern_ms else 0.0], dtype=torch.float64, device=device)
+    if use_dist:
+        gathered = [torch.empty_like(per_rank) for _ in range(world)]
+        dist.all_gather(gathered, per_rank)
+        per_rank_tf = [float(g[0]) for g in gathered]
+        per_rank_ms = [float(g[1]) for g in gathered]
+    else:
+        per_rank_tf, per_rank_ms = [achieved], [float(per_rank[1])]
 
     # ---------------------------------------------------------------- extra arms (same process, same device)
     extra = {}
@@ -423,12 +488,16 @@ def main():
     if rank == 0:
         res = {
             'metric': 'samples/s (fwd+log|detJ|) MAF+RQ-spline, 3N=3000, batch 64k',
-            'value': global_batch * args.steps / elapsed,
+            'value': None if rehearsal else global_batch * args.steps / elapsed,
             'unit': 'samples/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': args.scaling, 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic', 'repack': 'every_step',
+            'dtype': 'f32', 'repack': 'every_step',
+            'data': 'synthetic' if not rehearsal else
+                    f'rehearsal on {backend} without a GPU: identity flow, no kernels -- NOT a measurement',
+            'collective_world_size': dist.get_world_size() if use_dist else 1,
+            'collective_backend': (dist.get_backend() if use_dist else None),
             'gemm_arithmetic': ('fp32 operands as fp16 hi+lo halves, 3 fp16 MFMAs per product, fp32 accumulate '
                                 '(fp32-equivalent; spline / log-det in fp64)' if split else
                                 'fp32 MFMA, fp32 accumulate (spline / log-det in fp64)'),
@@ -447,11 +516,17 @@ def main():
                          # 16x16x32 f16 MFMA loop on toggling operands: 1914 TFLOP/s at the power limit, / 3)
                          'vs_power_limited_mfma_ceiling': (achieved / (1914.0 / 3.0)) if split else None,
                          'power_limited_ceiling_source': 'profiles/r01_mfma_shape_probe.txt' if split else None,
-                         'flops_per_launch': kern_flops[0], 'avg_launch_ms': float(np.mean(kern_ms)),
+                         'flops_per_launch': kern_flops[0] if kern_flops else None,
+                         'avg_launch_ms': float(np.mean(kern_ms)) if kern_ms else None,
+                         # N > 1: `achieved` / `frac` are rank 0's GPU; every rank's rate and the whole job's beside them
+                         'per_gpu_tflops': per_rank_tf, 'per_gpu_avg_launch_ms': per_rank_ms,
+                         'aggregate_tflops': float(sum(per_rank_tf)), 'aggregate_peak': peak * world,
+                         'aggregate_frac': float(sum(per_rank_tf)) / (peak * world),
                          # the same launches counted as dense GEMMs (no credit for skipping the masked half)
                          'dense_equivalent_tflops': achieved * sum(float(l._conditioner.layers[-1].mask.numel()) for l in flow)
                          / sum(nnz_out),
-                         'whole_step_tflops': 2.0 * sum(nnz_all) * B * args.steps / elapsed / 1e12},
+                         'whole_step_tflops': 2.0 * sum(nnz_all) * B * args.steps / elapsed / 1e12,
+                         'whole_step_aggregate_tflops': 2.0 * sum(nnz_all) * global_batch * args.steps / elapsed / 1e12},
             'delta_f_estimate': float(out[2]),
         }
         res.update(extra)

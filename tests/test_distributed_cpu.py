@@ -263,3 +263,41 @@ def test_bench_strong_scaling_shards_one_global_batch():
     ref = oloss.fep_estimator(work.astype(np.float32).astype(np.float64))
     for r in res:
         np.testing.assert_allclose(r[4], ref, rtol=1e-6)
+
+
+def test_bench_spawns_its_own_ranks_when_run_without_a_launcher():
+    """``python bench.py --gpus 2`` (the form the driver uses) with no WORLD_SIZE in the environment: the parent starts
+    ``torch.distributed.run`` as a child, never touches a GPU itself, and hands rank 0's JSON line and the exit code
+    through.  Rehearsed on gloo (TFEP_BENCH_BACKEND): identity flow, no kernels -- the launch, the rendezvous, the row
+    sharding and the 9-scalar all-gather are what is under test."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['TFEP_BENCH_BACKEND'] = 'gloo'
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--features', '66', '--batch', '1000',
+           '--steps', '2', '--warmup', '1']
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout                           # ONE line, from rank 0
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['collective_world_size'] == 2 and res['collective_backend'] == 'gloo'
+    assert res['config']['global_batch'] == 1000 and res['config']['rows_per_gpu'] == 500 and res['scaling'] == 'strong'
+    assert res['value'] is None and 'rehearsal' in res['data']          # never mistaken for a measurement
+    assert len(res['roofline']['per_gpu_tflops']) == 2 and 'aggregate_frac' in res['roofline']
+    # the estimate of the WHOLE batch from the two shards' statistics: -log mean exp(-(u_B - u_A)) with the bench's own streams
+    work = []
+    for rank in range(2):
+        gen = torch.Generator().manual_seed(1234 + rank)
+        torch.randn(500, 66, generator=gen)
+        u_b, u_a = torch.randn(500, generator=gen), torch.randn(500, generator=gen)
+        work.append((u_b - u_a).double())
+    w = torch.cat(work)
+    ref = -(torch.logsumexp(-w, 0) - np.log(1000.0))
+    np.testing.assert_allclose(res['delta_f_estimate'], float(ref), rtol=1e-6)
+    # a failing child's exit code reaches the caller (the parent relays, it does not swallow)
+    env['TFEP_BENCH_BACKEND'] = 'no-such-backend'               # accepted by the parent, fails in every rank
+    bad = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith('{')]
