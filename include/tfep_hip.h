@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define TFEP_HIP_ABI_VERSION 7
+#define TFEP_HIP_ABI_VERSION 8
 
 typedef enum tfep_status {
     TFEP_OK = 0,
@@ -463,6 +463,42 @@ int64_t tfep_inverse_block_lds_bytes(int n_layers, int cache_len, int max_feats)
 int64_t tfep_inverse_block_lds_bytes_rows(int n_layers, int cache_len, int max_feats, int rows_per_wave);
 int64_t tfep_inverse_block_lds_bytes_paired(int n_layers, int cache_len, int max_feats);
 int tfep_inverse_block(const tfep_inverse_block_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* One MAF layer in one launch (csrc/maf_layer.hip)                            */
+/* ------------------------------------------------------------------------- */
+
+/* AutoregressiveFlow.forward (flows/autoregressive.py:144-177) of a layer whose conditioner is a MADE of 1 .. 3 hidden
+ * layers (conditioners/made.py:286-329, :355; masked.py:265-277) and whose transformer is the Moebius map of 2-vectors
+ * (transformers/moebius.py:374-478), on split-f16 operands: every masked linear, ELU, the map and log|det J| for a
+ * workgroup's 256 sample rows in ONE kernel -- for conditioners whose weights stay cache-resident (BASELINE cfg4-ii).
+ *   a0 (B, lda0) / a0_inv_scale (B): the conditioner input as split rows (tfep_split_rows), lda0 a multiple of 32;
+ *   w[l] (n_rows_w[l], ldw[l]) / w_scales[l] (4 floats) / bias[l]: the packed split weights of linear l
+ *     (tfep_masked_weight_prepare_split: hidden units sorted by degree; the output layer in feature order), n_out[l] its
+ *     real (padded to 32 for hidden layers) width, bias_absmax[l] (1 float, hidden layers) = max |bias|;
+ *   k_ranges[l]: per column tile of tfep_maf_layer_tile_n() columns the [begin, end) of non-zero input columns
+ *     (tfep_mask_k_ranges), multiples of 32;
+ *   scratch[0], scratch[1] (B, ld_scratch): work panels for the hidden activations (split rows; every workgroup touches its
+ *     own rows only), ld_scratch a multiple of 32 and >= every hidden width;
+ *   kind 2 (the only one built): Moebius, moebius_dim = 2; x (B, ldx) fp32 is the map's input (feature c = column c of the
+ *     output layer), y (B, ldy) and log_det_J (B) are written.  x, y: 8-byte aligned rows (even ldx / ldy).
+ * Same arithmetic as tfep_split_rows + tfep_masked_linear_gemm (split, ELU, split_out) x hidden + (linear) +
+ * tfep_moebius_forward: the accumulation order of a dot product and the row scales are those of the separate launches. */
+typedef struct tfep_maf_layer_desc {
+    int32_t B, n_linears;
+    const void* a0; int64_t lda0; const float* a0_inv_scale;
+    const void* w[4]; int64_t ldw[4]; int32_t n_rows_w[4]; int32_t n_out[4];
+    const float* w_scales[4]; const float* bias[4]; const float* bias_absmax[4]; const int32_t* k_ranges[4];
+    void* scratch[2]; int64_t ld_scratch;
+    int32_t kind;
+    const float* x; int64_t ldx; float* y; int64_t ldy; float* log_det_J;
+    int32_t n_features, moebius_dim, moebius_unit_sphere; float moebius_max_radius;
+} tfep_maf_layer_desc;
+int tfep_maf_layer_tile_n(void);
+int tfep_maf_layer_forward_split(const tfep_maf_layer_desc* desc, void* stream);
+/* Diagnostics (TFEP_DIAG_MAF_LAYER=1 in the environment of the library): out[5] = cycles of wave 0 summed over the workgroups of
+ * the launches so far in {k-loops, hidden epilogues, Moebius epilogues, whole kernel}, and the number of workgroups; clears them. */
+int tfep_diag_maf_layer_cycles(unsigned long long* out);
 
 /* ------------------------------------------------------------------------- */
 /* Backward (training step, app/base.py:780-840 calls loss.backward())         */

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f'{name} declared in tfep_hip.h but not exported'
     # the ctypes binding covers exactly the declared entry points
     assert set(_lib.EXPORTED_SYMBOLS) == declared
-    assert _lib.load().tfep_hip_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.load().tfep_hip_abi_version() == _lib.ABI_VERSION == 8
 
 
 def test_no_cpu_fallback():

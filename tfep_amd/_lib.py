@@ -13,7 +13,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TFEP_HIP_LIB') or os.path.join(_HERE, 'lib', 'libtfep_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
@@ -52,6 +52,16 @@ class InverseBlockDesc(Structure):
                 ('cache_len', c_int32), ('max_feats', c_int32), ('spline', c_void_p),
                 ('moebius_dim', c_int32), ('moebius_unit_sphere', c_int32), ('moebius_max_radius', c_float),
                 ('rows_per_wave', c_int32), ('n_spline_groups', c_int32), ('waves_per_workgroup', c_int32), ('paired', c_int32)]
+
+
+class MafLayerDesc(Structure):
+    _fields_ = [('B', c_int32), ('n_linears', c_int32), ('a0', c_void_p), ('lda0', c_int64), ('a0_inv_scale', c_void_p),
+                ('w', c_void_p * 4), ('ldw', c_int64 * 4), ('n_rows_w', c_int32 * 4), ('n_out', c_int32 * 4),
+                ('w_scales', c_void_p * 4), ('bias', c_void_p * 4), ('bias_absmax', c_void_p * 4), ('k_ranges', c_void_p * 4),
+                ('scratch', c_void_p * 2), ('ld_scratch', c_int64), ('kind', c_int32),
+                ('x', c_void_p), ('ldx', c_int64), ('y', c_void_p), ('ldy', c_int64), ('log_det_J', c_void_p),
+                ('n_features', c_int32), ('moebius_dim', c_int32), ('moebius_unit_sphere', c_int32),
+                ('moebius_max_radius', c_float)]
 
 
 class SplineDesc(Structure):
@@ -156,6 +166,9 @@ _SIGNATURES = {
     'tfep_inverse_block_lds_bytes_rows': (c_int64, [c_int, c_int, c_int, c_int]),
     'tfep_inverse_block_lds_bytes_paired': (c_int64, [c_int, c_int, c_int]),
     'tfep_inverse_block': (c_int, [POINTER(InverseBlockDesc), _P]),
+    'tfep_maf_layer_tile_n': (c_int, []),
+    'tfep_maf_layer_forward_split': (c_int, [POINTER(MafLayerDesc), _P]),
+    'tfep_diag_maf_layer_cycles': (c_int, [_P]),
     'tfep_diag_mfma_peak': (c_int, [_P, c_int, c_int, _P]),
     'tfep_masked_linear_gemm': (c_int, [POINTER(GemmDesc), _P]),
     'tfep_transpose': (c_int, [_P, c_int64, c_int, c_int, _P, c_int64, _P]),

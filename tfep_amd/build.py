@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, 'lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libtfep_hip.so')
 SOURCES = ['transformers.hip', 'masked_linear.hip', 'split_gemm.hip', 'split_gemm_layouts.hip', 'inverse_block.hip',
-           'reduce.hip', 'backward.hip', 'egnn.hip']
+           'reduce.hip', 'backward.hip', 'egnn.hip', 'maf_layer.hip']
 # Per-file flags.  egnn.hip: the edge kernels are bound by vector-instruction issue, and on gfx950 a packed fp32
 # instruction (v_pk_fma_f32 ...) is no cheaper than the two scalar ones it replaces (the fp32 vector peak is reached
 # without packing; beside MFMAs a packed op costs more) -- keep clang's SLP vectoriser from forming them.

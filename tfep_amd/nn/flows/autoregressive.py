@@ -335,6 +335,80 @@ class AutoregressiveFlow(torch.nn.Module):
             made.drop_packed_ahead()
         return y, ldj
 
+    # ------------------------------------------------------------------ the whole layer in one kernel
+    #: ``tfep_maf_layer_forward_split``: conditioner + transformer of the layer in ONE launch (csrc/maf_layer.hip) where that
+    #: kernel exists -- a plain MADE (no embedding, no conditioning / fixed features) of 1 .. 3 hidden layers up to 4096 wide
+    #: feeding a Moebius transformer of dimension 2, on the split-f16 arithmetic.  OPT-IN (True, or ``TFEP_LAYER_KERNEL=1``
+    #: for every layer that qualifies): measured SLOWER than the launch-by-launch path at BASELINE cfg4-ii (11.5 against
+    #: 10.6 ms; csrc/maf_layer.hip says why), so None / False leave it off.
+    layer_kernel = None
+
+    def _layer_kernel_ok(self, x):
+        want = self.layer_kernel if self.layer_kernel is not None else os.environ.get('TFEP_LAYER_KERNEL', '0') == '1'
+        if not want or self.fused is False:
+            return False
+        made, tr = self._conditioner, self._transformer
+        if type(tr) is not MoebiusTransformer or tr.dimension != 2 or not isinstance(made, MADE):
+            return False
+        if getattr(made, 'embedding', None) is not None or self.has_fixed_indices or len(self._conditioner_indices) > 0:
+            return False
+        lins = made._linears()
+        if not (2 <= len(lins) <= 4) or max(l.out_features for l in lins) > 4096 or lins[-1].out_features != x.shape[1]:
+            return False
+        if x.shape[1] % 2 or made.dimension_in != x.shape[1]:
+            return False
+        return True
+
+    def _layer_plan(self, device):
+        """k-ranges of every masked linear for the layer kernel's 256-column tiles (hidden units sorted by degree, the output
+        layer in feature order), once per device and mask version."""
+        made = self._conditioner
+        mplan = made.plan(device)
+        lp = mplan.get('layer_kernel')
+        if lp is None:
+            tn = _lib.load().tfep_maf_layer_tile_n()
+            lins = made._linears()
+            kr = []
+            for li, lin in enumerate(lins):
+                n_pad = mplan['n_pad'][li]
+                kr.append(ops.mask_k_ranges(lin.mask, tn, (n_pad + tn - 1) // tn, mplan['k_pad'][li], mplan['row_of_out'][li],
+                                            mplan['col_of_in'][li]))
+            lp = mplan['layer_kernel'] = dict(k_ranges=kr, ld_scratch=max(mplan['n_pad'][:-1]))
+        return lp, mplan
+
+    def _forward_layer_kernel(self, x):
+        x, ldx = _lib.rows(x, 'x')
+        if ldx % 2 or x.data_ptr() % 8:
+            x, ldx = x.contiguous(), x.shape[1]
+        B, D = x.shape
+        dev = x.device
+        made, tr = self._conditioner, self._transformer
+        made.begin_call()
+        lp, mplan = self._layer_plan(dev)
+        lins = made._linears()
+        xs, xs_inv = ops.split_rows(x, mplan['k_pad'][0])
+        y = torch.empty(B, D, dtype=torch.float32, device=dev)
+        ldj = torch.empty(B, dtype=torch.float32, device=dev)
+        scratch = [torch.empty(B, lp['ld_scratch'], dtype=torch.float32, device=dev) for _ in range(2 if len(lins) > 2 else 1)]
+        d = _lib.MafLayerDesc()
+        d.B, d.n_linears, d.kind = B, len(lins), 2
+        d.a0, d.lda0, d.a0_inv_scale = xs.data_ptr(), xs.shape[1], xs_inv.data_ptr()
+        keep = [xs, xs_inv]
+        for li, lin in enumerate(lins):
+            ws, w_sc, b, bmax = made._pack_layer_split(mplan, li, lin)
+            keep += [ws, w_sc, b, bmax]
+            d.w[li], d.ldw[li], d.n_rows_w[li] = ws.data_ptr(), ws.shape[1], ws.shape[0]
+            d.n_out[li] = mplan['n_pad'][li] if li + 1 < len(lins) else lin.out_features
+            d.w_scales[li], d.bias[li], d.bias_absmax[li] = w_sc.data_ptr(), b.data_ptr(), bmax.data_ptr()
+            d.k_ranges[li] = lp['k_ranges'][li].data_ptr()
+        d.scratch[0], d.scratch[1], d.ld_scratch = scratch[0].data_ptr(), scratch[-1].data_ptr(), lp['ld_scratch']
+        d.x, d.ldx, d.y, d.ldy, d.log_det_J = x.data_ptr(), ldx, y.data_ptr(), D, ldj.data_ptr()
+        d.n_features, d.moebius_dim, d.moebius_unit_sphere = D, 2, int(tr.unit_sphere)
+        d.moebius_max_radius = tr.max_radius
+        _lib.call('tfep_maf_layer_forward_split', ctypes.byref(d), _lib.stream_of(x))
+        made.drop_packed_ahead()
+        return y, ldj
+
     # ------------------------------------------------------------------ reference API
     def forward(self, x: torch.Tensor):
         """``(y, log_det_J)`` of the push-forward (reference autoregressive.py:144-177).
@@ -390,6 +464,8 @@ class AutoregressiveFlow(torch.nn.Module):
         return wgs >= int(os.environ.get('TFEP_FUSED_MIN_WGS', self.fused_min_workgroups))
 
     def _forward_impl(self, x: torch.Tensor):
+        if self._layer_kernel_ok(x):
+            return self._forward_layer_kernel(x)
         kind = self._fused_kind()
         if kind is not None and self._fused_pays(x, kind):
             return self._forward_fused(x, kind)
