@@ -455,8 +455,26 @@ typedef struct tfep_inverse_block_desc {
     int32_t paired;             /* rows_per_wave = 16 only: every workgroup is a PAIR of waves on the same 16 rows -- a consumer
                                    (the chain) and a loader that stages the next stage's weights and pre-activations into
                                    the other half of a double-buffered LDS stage (LDS: tfep_inverse_block_lds_bytes_paired) */
+    /* SUPER-BLOCK launch (n_blocks > 0; rows_per_wave = 16, paired = 1): one launch runs the blocks blocks[0 .. n_blocks) one
+     * after the other.  steps / feat_* / in_cols are then the concatenated tables of those blocks and every block has a record
+     * of tfep_inverse_block_record_ints() int32:
+     *   [0] n_steps, [1] first step record, [2] first entry of feat_cols / feat_sel / feat_in / feat_periodic (the step
+     *   records' feat_off stay block-relative), [3] first entry of in_cols, [4 .. 7] cache_col0[l], [8 .. 11] cache_n_old[l],
+     *   [12 + 4 l .. 15 + 4 l] for l = 0 .. n_layers (the last one = the output layer): (row0, n_rows, kb, ke) -- BEFORE the
+     *   block's chain the pair adds, for its own 16 sample rows, the contribution of packed columns [kb, ke) of layer l - 1
+     *   (l = 0: of the conditioner-input entries in_cols[kb .. ke), absolute positions in the concatenated table) to the
+     *   packed rows [row0, row0 + n_rows) of layer l: exact-fp32 MFMA products of w[l] / wout with h[l - 1] / xpad, written
+     *   to z_extra[l] / zout_extra (indexed like z[l] / zout) -- what earlier blocks of the same launch produced, i.e. what a
+     *   caller of the one-block form supplies through short GEMMs between launches.  kb, ke multiples of 32 for l >= 1.
+     * z_slabs[l] / zout_slabs then count the slabs of z[l] / zout WITHOUT the extra one (added per block when ke > kb);
+     * n_steps, cache_col0 and cache_n_old of the descriptor are ignored. */
+    int32_t n_blocks;
+    const int32_t* blocks;
+    float* z_extra[4];
+    float* zout_extra;
 } tfep_inverse_block_desc;
 int tfep_inverse_block_step_ints(void);
+int tfep_inverse_block_record_ints(void);
 /* LDS bytes a launch with these sizes needs (activation cache + input entries + the weight stage); a block fits iff
  * this is <= 160 KiB.  -1 for invalid arguments.  (_rows: for the given rows_per_wave; the plain form is 64.) */
 int64_t tfep_inverse_block_lds_bytes(int n_layers, int cache_len, int max_feats);

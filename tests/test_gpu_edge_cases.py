@@ -693,3 +693,40 @@ def test_cached_packed_weights_notice_updates_through_data():
         assert not torch.equal(x3, x1)
         x1 = x3
     made.cache_packed_weights = False
+
+
+@pytest.mark.parametrize('order,hidden,periodic,B', [('ascending', [1100, 1300], False, 333), ('descending', [900], False, 16),
+                                                     ('random', [700, 800, 900], True, 200), ('ascending', [1200, 1200], True, 1)])
+def test_super_block_launch_matches_block_by_block_launches(order, hidden, periodic, B):
+    """``tfep_inverse_block`` with ``n_blocks`` (one launch per super-block: the pair of waves that owns 16 sample rows forms
+    the short products over what the super-block has produced so far itself, exact-fp32 MFMA on its own rows) against the
+    block-by-block launches with their short split-f16 GEMMs in between: the same sums in another association -- and against
+    the forward map.  Monotone and random degree orders (layer 0 gathers its input columns), a periodic embedding (two
+    input entries per feature), one to three hidden layers, a single row and a ragged last wave."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.embeddings import PeriodicEmbedding
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    D = 150
+    torch.manual_seed(11)
+    lo, hi = (0.0, 2.0) if periodic else (-4.0, 4.0)
+    emb = PeriodicEmbedding(D, limits=[lo, hi], periodic_indices=list(range(0, D, 3))) if periodic else None
+    maf = MAF(generate_degrees(D, order), transformer=NeuralSplineTransformer(torch.full((D,), lo), torch.full((D,), hi), 8, circular=periodic),
+              embedding=emb, hidden_layers=hidden, initialize_identity=False).cuda()
+    maf.split_inverse = True
+    gen = torch.Generator().manual_seed(5)
+    x = (torch.rand(B, D, generator=gen) * 2.0 if periodic else torch.randn(B, D, generator=gen) * 1.3).cuda()
+    with torch.no_grad():
+        y, l = maf(x)
+        xs, ls = maf.inverse(y)
+        assert maf.last_inverse_schedule == 'super_kernel'
+        xs2, ls2 = maf.inverse(y)
+        assert torch.equal(xs, xs2) and torch.equal(ls, ls2)
+        maf.inverse_super_kernel = False
+        xb, lb = maf.inverse(y)
+        assert maf.last_inverse_schedule == 'block_by_block'
+    d, dx = (xs - xb).abs(), (xs - x).abs()
+    if periodic:
+        d, dx = torch.minimum(d, 2.0 - d), torch.minimum(dx, 2.0 - dx)
+    assert float(d.max()) < 5e-5 and torch.allclose(ls, lb, rtol=1e-5, atol=5e-4)
+    assert float(dx.max()) < 5e-3 and torch.allclose(ls + l, torch.zeros_like(l), atol=5e-3)

@@ -311,6 +311,16 @@ def test_random_medium_size_split_inverse(seed):
         assert maf._blocked_plan(x.device)['fused'] is not None
         xs2, ls2 = maf.inverse(y)
         assert torch.equal(xs, xs2) and torch.equal(ls, ls2)          # deterministic
+        # one launch per super-block where there are super-blocks (the pair of waves of 16 rows forms the short products
+        # itself) against the block-by-block launches with their short GEMMs: the same sums, in another association
+        if maf.last_inverse_schedule == 'super_kernel':
+            maf.inverse_super_kernel = False
+            xb, lb = maf.inverse(y)
+            assert maf.last_inverse_schedule == 'block_by_block'
+            maf.inverse_super_kernel = None
+            db = (xs - xb).abs()
+            db = torch.minimum(db, 2.0 - db) if circular else db
+            assert float((db / xb.abs().amax(dim=1, keepdim=True).clamp_min(1.0)).max()) < 2e-4 and torch.allclose(ls, lb, rtol=1e-4, atol=2e-3)
         maf.split_inverse = False
         maf._dev.clear()
         xf, lf = maf.inverse(y)

@@ -51,7 +51,8 @@ class InverseBlockDesc(Structure):
                 ('cache_col0', c_int32 * 4), ('cache_n_old', c_int32 * 4),
                 ('cache_len', c_int32), ('max_feats', c_int32), ('spline', c_void_p),
                 ('moebius_dim', c_int32), ('moebius_unit_sphere', c_int32), ('moebius_max_radius', c_float),
-                ('rows_per_wave', c_int32), ('n_spline_groups', c_int32), ('waves_per_workgroup', c_int32), ('paired', c_int32)]
+                ('rows_per_wave', c_int32), ('n_spline_groups', c_int32), ('waves_per_workgroup', c_int32), ('paired', c_int32),
+                ('n_blocks', c_int32), ('blocks', c_void_p), ('z_extra', c_void_p * 4), ('zout_extra', c_void_p)]
 
 
 class MafLayerDesc(Structure):
@@ -162,6 +163,7 @@ _SIGNATURES = {
     'tfep_diag_split_mfma_peak': (c_int, [_P, c_int, c_int, _P]),
     'tfep_diag_split_cycles': (c_int, [_P]),
     'tfep_inverse_block_step_ints': (c_int, []),
+    'tfep_inverse_block_record_ints': (c_int, []),
     'tfep_inverse_block_lds_bytes': (c_int64, [c_int, c_int, c_int]),
     'tfep_inverse_block_lds_bytes_rows': (c_int64, [c_int, c_int, c_int, c_int]),
     'tfep_inverse_block_lds_bytes_paired': (c_int64, [c_int, c_int, c_int]),

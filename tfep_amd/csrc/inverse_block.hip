@@ -938,6 +938,364 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
     if (consumer && writer) a.ldj[row] = (float)((double)a.ldj[row] + ldj_acc);
 }
 
+
+// =====================================================================================================================
+// SUPER-BLOCK launch (round 4): ONE launch of the paired 16-row kernel runs every block of a super-block.
+//
+// Launched block by block (the kernel above), a block of 16 degrees cost its chain (~173 us at cfg2, B = 8192) PLUS, in series
+// on the stream, three short GEMMs over what the super-block had produced so far (their launch floor: 25 - 40 us each on 64
+// workgroups) and two re-scaling launches for the split copies of the new units: ~108 us per block, 21 of the 81 ms of a cfg2
+// layer's inverse.  Nothing in those products couples sample rows: a pair of waves can form them for ITS OWN 16 rows.  Here
+// the pair loops over the blocks, and at the head of every block both waves compute, on the matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32 products of the fp32 packs, the h / x values the pair itself stored a moment ago),
+//   z_extra[l][rows of the block] = sum over the columns [kb, ke) that EARLIER blocks of this super-block produced
+// for every layer -- layer 0 from the conditioner-input entries of those blocks (gathered columns of W0 and xpad) -- and
+// store it to the slab the short GEMMs used to write, which the chain then adds to the super-block GEMM's slabs exactly as
+// before.  Five 16-unit tiles share one fetch of the activations; operands go global -> registers as 16-byte loads in the
+// MFMA layouts (lane = (unit or row) l % 16, four consecutive k at 4 (l / 16)), two 32-column steps in flight.
+// Same-workgroup visibility of the stores (h, xpad, z_extra) across the block boundary: __syncthreads().
+// =====================================================================================================================
+constexpr int IB_BLK_INTS = 36;      // per-block record: [n_steps, steps_off, feat_off, in_off, c0[4], n_old[4], (row0, n, kb, ke) x 5 layers, pad]
+constexpr int IB_PROD_TILES = 5;     // 16-unit tiles that share a fetch of the activations
+
+struct InverseSuperArgs {
+    InverseBlockArgs a;
+    int n_blocks;
+    const int32_t* blocks;
+    float* z_extra[IB_MAX_LAYERS];      // slab written by the in-kernel products (same indexing as a.z[l]: by packed row)
+    float* zout_extra;
+};
+
+// One group of up to IB_PROD_TILES 16-row tiles of W (rows row0 + 16 t .. ) against the wave's 16 sample rows:
+//   dst[(wave_row0 + j) * ldd + row0 + u] = sum_{k in [kb, ke)} W[row0 + u][k] src[(wave_row0 + j)][k]        (GATHER: k -> cols[k])
+// kb, ke multiples of 16 unless GATHER (entries past ke read as zero).
+template <bool GATHER>
+__device__ __forceinline__ void ib_product_group(const float* __restrict__ W, int64_t ldw, int row0, int n_rows, int ntiles,
+                                                 const float* __restrict__ src, int64_t lds_, int kb, int ke,
+                                                 const int32_t* __restrict__ cols, float* __restrict__ dst, int64_t ldd,
+                                                 int wave_row0, int B, int lane) {
+    const int u = lane & 15, kq = lane >> 4;
+    const bool live = wave_row0 + u < B;
+    const float* srow = src + (int64_t)(live ? wave_row0 + u : 0) * lds_;
+    ib_f4 acc[IB_PROD_TILES];
+#pragma unroll
+    for (int t = 0; t < IB_PROD_TILES; ++t) acc[t] = ib_f4{0.f, 0.f, 0.f, 0.f};
+    const float* wrow[IB_PROD_TILES];
+    bool won[IB_PROD_TILES];
+#pragma unroll
+    for (int t = 0; t < IB_PROD_TILES; ++t) {
+        const int r = t * 16 + u;
+        won[t] = t < ntiles && r < n_rows;
+        wrow[t] = W + (int64_t)(row0 + (won[t] ? r : 0)) * ldw;
+    }
+    auto fetch = [&](ib_f4 (&wa)[IB_PROD_TILES], ib_f4& xb, int k) __attribute__((always_inline)) {
+        if constexpr (GATHER) {
+            int c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = k + 4 * kq + j < ke ? cols[k + 4 * kq + j] : -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xb[j] = c[j] >= 0 ? srow[c[j]] : 0.f;
+#pragma unroll
+            for (int t = 0; t < IB_PROD_TILES; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wa[t][j] = (won[t] && c[j] >= 0) ? wrow[t][c[j]] : 0.f;
+        } else {
+            xb = *(const ib_f4_alias*)(srow + k + 4 * kq);
+#pragma unroll
+            for (int t = 0; t < IB_PROD_TILES; ++t)
+                wa[t] = won[t] ? *(const ib_f4_alias*)(wrow[t] + k + 4 * kq) : ib_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto multiply = [&](const ib_f4 (&wa)[IB_PROD_TILES], const ib_f4& xb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < IB_PROD_TILES; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t][j], xb[j], acc[t], 0, 0, 0);
+    };
+    // two 16-column steps per pass, the next pass' loads issued before this pass' products
+    ib_f4 wa0[IB_PROD_TILES], wa1[IB_PROD_TILES], xb0, xb1;
+    if (kb < ke) {
+        fetch(wa0, xb0, kb);
+        fetch(wa1, xb1, kb + 16);                                 // (past ke: GATHER reads zeros; else ke - kb is a multiple of 32)
+    }
+    for (int k = kb; k < ke; k += 32) {
+        ib_f4 wc0[IB_PROD_TILES], wc1[IB_PROD_TILES];
+#pragma unroll
+        for (int t = 0; t < IB_PROD_TILES; ++t) { wc0[t] = wa0[t]; wc1[t] = wa1[t]; }
+        const ib_f4 xc0 = xb0, xc1 = xb1;
+        if (k + 32 < ke) {
+            fetch(wa0, xb0, k + 32);
+            fetch(wa1, xb1, k + 48);
+        }
+        multiply(wc0, xc0);
+        multiply(wc1, xc1);
+    }
+    // D: register r of lane l = unit 4 (l / 16) + r of the tile, sample row l % 16
+    if (live) {
+        float* drow = dst + (int64_t)(wave_row0 + u) * ldd + row0;
+#pragma unroll
+        for (int t = 0; t < IB_PROD_TILES; ++t)
+            if (t < ntiles) {
+                const int r0 = t * 16 + 4 * kq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (r0 + r < n_rows) drow[r0 + r] = acc[t][r];
+            }
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArgs sa) {
+    extern __shared__ float cache_all[];
+    const InverseBlockArgs& a = sa.a;
+    const int lane = threadIdx.x & 63;
+    const int wave_in_wg = threadIdx.x >> 6;
+    const bool consumer = wave_in_wg == 0, loader = wave_in_wg == 1;
+    float* const cache = cache_all;
+    const int s = lane >> 2, part = lane & 3;
+    const int wave_row0 = (int)blockIdx.x * Q4_ROWS;
+    if (wave_row0 >= a.B) return;                  // (both waves of a pair alike)
+    const int row = wave_row0 + s;
+    const bool live = row < a.B;
+    const bool writer = live && part == 0;
+    const int64_t r = live ? row : 0;
+    const bool live16 = wave_row0 + (lane & 15) < a.B;
+    const int64_t r16 = live16 ? wave_row0 + (lane & 15) : 0;
+    float* xc = cache + (size_t)a.L * a.cache_len * Q4_ROWS;
+    const int gstride = a.stage_gstride;
+    constexpr int HROWS = 8;
+    const size_t h_floats = (size_t)HROWS * (gstride >> 3) + IB_LDS_SLACK + (size_t)HROWS * Q4_Z_PITCH;
+    const size_t o_floats = (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
+    float* const stg0 = xc + (size_t)a.max_feats * Q4_ROWS;
+    float* const zs0 = stg0 + (size_t)HROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* pb = zs0 + (size_t)HROWS * Q4_Z_PITCH;
+    float* const stg1 = pb + (size_t)IB_MAX_P * Q4_P_PITCH;
+    float* const zs1 = stg1 + (size_t)HROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* const ostg0 = stg0 + 2 * h_floats + (size_t)IB_MAX_P * Q4_P_PITCH;
+    float* const ozs0 = ostg0 + (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* const ostg1 = ostg0 + o_floats;
+    float* const ozs1 = ozs0 + o_floats;
+    const int lds_total = a.lds_floats;
+
+    double ldj_acc = 0.0;
+    for (int blk = 0; blk < sa.n_blocks; ++blk) {
+        const int32_t* rec = sa.blocks + (size_t)blk * IB_BLK_INTS;
+        const int n_steps = rec[0];
+        const int32_t* steps = a.steps + (size_t)rec[1] * IB_STEP_INTS;
+        const int feat_base = rec[2];
+        const int32_t* in_cols = a.in_cols + rec[3];
+        __syncthreads();            // the previous block is complete in both waves: its LDS is free, its h / x stores are visible
+
+        // ---- what earlier blocks of the super-block add to this block's rows, for the pair's own 16 sample rows
+        {
+            int g = 0;
+            for (int l = 0; l <= a.L; ++l) {
+                const int row0 = rec[12 + 4 * l], n_rows = rec[13 + 4 * l], kb = rec[14 + 4 * l], ke = rec[15 + 4 * l];
+                if (ke <= kb || n_rows <= 0) continue;
+                const float* W = l < a.L ? a.w[l] : a.wout;
+                const int64_t ldw = l < a.L ? a.ldw[l] : a.ldwout;
+                float* dst = l < a.L ? sa.z_extra[l] : sa.zout_extra;
+                const int64_t ldd = l < a.L ? a.ldz[l] : a.ldzout;
+                for (int t0 = 0; t0 < n_rows; t0 += 16 * IB_PROD_TILES, ++g) {
+                    if ((g & 1) != wave_in_wg) continue;
+                    const int nr = min(n_rows - t0, 16 * IB_PROD_TILES);
+                    if (l == 0)
+                        ib_product_group<true>(W, ldw, row0 + t0, nr, (nr + 15) >> 4, a.xpad, a.ldxpad, kb, ke, a.in_cols, dst, ldd, wave_row0,
+                                               a.B, lane);
+                    else
+                        ib_product_group<false>(W, ldw, row0 + t0, nr, (nr + 15) >> 4, a.h[l - 1], a.ldh[l - 1], kb, ke, nullptr, dst, ldd,
+                                                wave_row0, a.B, lane);
+                }
+            }
+        }
+        float* stg = stg0;
+        float* zs = zs0;
+        int parity = 0;
+        if (consumer) {
+            for (int j = lane * 4; j < lds_total; j += 256) *(ib_f4_alias*)(cache + j) = ib_f4{0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_wave_barrier();
+            for (int l = 0; l < a.L; ++l) {
+                const float* hr = a.h[l] + r * a.ldh[l] + rec[4 + l];
+                float* cl = cache + (size_t)l * a.cache_len * Q4_ROWS;
+                const int n_old = rec[8 + l];
+                for (int j = part; j < n_old; j += 4) cl[j * Q4_ROWS + s] = hr[j];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();            // the products are stored (the loader's stages read them), the cache is initialised
+        // slabs of the pre-activations: those of the super-block GEMMs, plus the one just written where this block has one
+        int z_slabs[IB_MAX_LAYERS];
+#pragma unroll
+        for (int l = 0; l < IB_MAX_LAYERS; ++l) z_slabs[l] = l < a.L ? a.z_slabs[l] + (rec[15 + 4 * l] > rec[14 + 4 * l] ? 1 : 0) : 0;
+        const int zout_slabs = a.zout_slabs + (rec[15 + 4 * a.L] > rec[14 + 4 * a.L] ? 1 : 0);
+
+        int oj = 0;
+        auto fill_out = [&](int step, int f, int buf) __attribute__((always_inline)) {
+            const int32_t* sr = steps + step * IB_STEP_INTS;
+            const int o_row0 = sr[4 * IB_MAX_LAYERS], o_nd = sr[4 * IB_MAX_LAYERS + 1], o_kb = sr[4 * IB_MAX_LAYERS + 2],
+                      o_ke = sr[4 * IB_MAX_LAYERS + 3];
+            float* os = buf ? ostg1 : ostg0;
+            float* oz = buf ? ozs1 : ozs0;
+            if constexpr (KIND == 2) {
+                stage_rows(os, gstride, a.wout, a.ldwout, o_row0 + f, 1, a.mb_dim, o_kb, o_ke, lane);
+                stage_z16(oz, a.zout, a.ldzout, wave_row0, a.B, o_row0 + f, 1, a.mb_dim, zout_slabs, a.zout_slab_stride, lane);
+            } else {
+                const int o_P = KIND == 3 ? a.spg[sr[4 * IB_MAX_LAYERS + 5]].P : a.P;
+                stage_rows(os, gstride, a.wout, a.ldwout, o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
+                stage_z16(oz, a.zout, a.ldzout, wave_row0, a.B, o_row0 + f, o_nd, o_P, zout_slabs, a.zout_slab_stride, lane);
+            }
+        };
+        auto fill_next_out = [&](int step, int f) __attribute__((always_inline)) {
+            const int df = KIND == 2 ? a.mb_dim : 1;
+            int ns = step, nf = f + df;
+            while (ns < n_steps && nf >= steps[ns * IB_STEP_INTS + 4 * IB_MAX_LAYERS + 1]) { ++ns; nf = 0; }
+            if (ns < n_steps) fill_out(ns, nf, (oj + 1) & 1);
+        };
+        if (loader) {                               // the first output stage: before anything is handed over
+            int ns = 0;
+            while (ns < n_steps && steps[ns * IB_STEP_INTS + 4 * IB_MAX_LAYERS + 1] <= 0) ++ns;
+            if (ns < n_steps) fill_out(ns, 0, 0);
+        }
+
+        for (int st_i = 0; st_i < n_steps; ++st_i) {
+            const int32_t* st = steps + st_i * IB_STEP_INTS;
+            // ---- hidden units of this degree, layer by layer
+            for (int l = 0; l < a.L; ++l) {
+                const int row0 = st[4 * l], n = st[4 * l + 1], kb = st[4 * l + 2], ke = st[4 * l + 3];
+                const int c0l = rec[4 + l];
+                float* cl = cache + (size_t)l * a.cache_len * Q4_ROWS;
+                float* h16 = a.h[l] + r16 * a.ldh[l];
+                const float* act = l == 0 ? xc : cache + ((size_t)(l - 1) * a.cache_len + (kb - rec[4 + l - 1])) * Q4_ROWS;
+                const int len = ib_round8(l == 0 ? ke : ke - kb);
+                for (int ub = row0; ub < row0 + n; ub += HROWS) {
+                    const int nb = min(HROWS, row0 + n - ub);
+                    if (loader) {
+                        if (l == 0) stage_gather(stg, gstride, a.w[0], a.ldw[0], ub, nb, in_cols, ke, lane);
+                        else stage_rows(stg, gstride, a.w[l], a.ldw[l], ub, 1, nb, kb, ke, lane);
+                        stage_z16(zs, a.z[l], a.ldz[l], wave_row0, a.B, ub, 1, nb, z_slabs[l], a.z_slab_stride[l], lane);
+                    }
+                    __syncthreads();
+                    if (consumer) {
+                        for (int u0 = ub; u0 < ub + nb; u0 += 16)
+                            hidden_mfma16(stg, gstride, u0 - ub, zs, act, len, min(16, ub + nb - u0), cl + (size_t)(u0 - c0l) * Q4_ROWS,
+                                          h16 + u0, live16, lane);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    parity ^= 1;
+                    stg = parity ? stg1 : stg0;
+                    zs = parity ? zs1 : zs0;
+                }
+            }
+            // ---- parameters and transformer inverse of this degree's features
+            const int out_row0 = st[4 * IB_MAX_LAYERS], n_d = st[4 * IB_MAX_LAYERS + 1];
+            const int okb = st[4 * IB_MAX_LAYERS + 2], oke = st[4 * IB_MAX_LAYERS + 3], foff = st[4 * IB_MAX_LAYERS + 4] + feat_base;
+            (void)out_row0;
+            const float* cp = cache + ((size_t)(a.L - 1) * a.cache_len + (okb - rec[4 + a.L - 1])) * Q4_ROWS;
+            const int olen = ib_round8(oke - okb);
+            auto emit = [&](int fi, float xv) {
+                const int col = a.feat_cols[fi], e0 = a.feat_in[fi], icol = in_cols[e0];
+                float in0 = xv, in1 = 0.f;
+                const bool per = a.feat_per[fi] != 0;
+                if (per) sincosf((xv - a.emb_lower) * a.emb_scale, &in1, &in0);
+                xc[e0 * Q4_ROWS + s] = in0;
+                if (per) xc[(e0 + 1) * Q4_ROWS + s] = in1;
+                if (writer) {
+                    a.x[r * a.ldx + col] = xv;
+                    a.xpad[r * a.ldxpad + icol] = in0;
+                    if (per) a.xpad[r * a.ldxpad + icol + 1] = in1;
+                }
+            };
+            if constexpr (KIND == 2) {
+                const int dim = a.mb_dim;
+                for (int f = 0; f < n_d; f += dim) {
+                    __syncthreads();                                        // output stage oj was filled a feature ago
+                    if (loader) fill_next_out(st_i, f);
+                    if (consumer) {
+                        float acc[IB_MAX_P];
+                        out_dot_mfma16(acc, (oj & 1) ? ostg1 : ostg0, gstride, (oj & 1) ? ozs1 : ozs0, cp, pb, olen, dim, lane);
+                        double yv[MOEBIUS_MAX_DIM], wv[MOEBIUS_MAX_DIM], xv[MOEBIUS_MAX_DIM];
+#pragma unroll
+                        for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+                            if (i < dim) {
+                                yv[i] = (double)a.y[r * a.ldy + a.feat_sel[foff + f + i]];
+                                wv[i] = (double)(-acc[i]);
+                            }
+                        ldj_acc += moebius_vector(yv, wv, dim, a.mb_max_radius, a.mb_unit_sphere, xv);
+#pragma unroll
+                        for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
+                            if (i < dim) emit(foff + f + i, (float)xv[i]);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    ++oj;
+                }
+            } else {
+            const SplineArgs& spa = KIND == 3 ? a.spg[st[4 * IB_MAX_LAYERS + 5]] : a.sp;      // (wave uniform)
+            const int nP = KIND == 3 ? spa.P : a.P;
+            for (int f = 0; f < n_d; ++f) {
+                float prm[IB_MAX_P];
+                __syncthreads();                                            // output stage oj was filled a feature ago
+                if (!consumer) {                     // the loader fetches the NEXT feature's rows beside this one's dot
+                    fill_next_out(st_i, f);
+                    ++oj;
+                    continue;
+                }
+                out_dot_mfma16(prm, (oj & 1) ? ostg1 : ostg0, gstride, (oj & 1) ? ozs1 : ozs0, cp, pb, olen, nP, lane);
+                const int sel = a.feat_sel[foff + f];
+                const float yv = a.y[r * a.ldy + sel];
+                float xv;
+                if constexpr (KIND == 0) {                                  // affine.py:361-363
+                    xv = (yv - prm[0]) * expf(-prm[1]);
+                    ldj_acc -= (double)prm[1];
+                } else {
+                    const SplineFlags& fl = spa.f;
+                    const int K = fl.K;
+                    if (KIND == 3 && K == 0) {                              // a plain shift member (affine.py:366-456): log-det 0
+                        xv = yv - prm[0];
+                    } else {
+                    float w[8], hh[8], sraw[9];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        w[k] = k < K ? prm[k] : 0.f;
+                        hh[k] = k < K ? prm[K + k] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j <= 8; ++j) {
+                        sraw[j] = 0.f;
+                        if (j <= K) {
+                            const int pi = spline_slope_param(j, K, fl.circular, fl.identity);
+                            if (pi >= 0) sraw[j] = prm[pi];
+                        }
+                    }
+                    float last = 0.f, last2 = 0.f;
+                    if (fl.circular || fl.learn_lower || fl.learn_upper) last = prm[nP - 1];
+                    if (fl.learn_lower && fl.learn_upper) last2 = prm[nP - 2];
+                    double ld;
+                    xv = (float)rq_spline_element<8, true>(w, hh, sraw, last, last2, fl, spa.x0[sel], spa.xf[sel],
+                                                           spa.y0[sel], spa.yf[sel], yv, &ld);
+                    ldj_acc -= ld;
+                    }
+                }
+                const int col = a.feat_cols[foff + f];
+                const int e0 = a.feat_in[foff + f], icol = in_cols[e0];
+                float in0 = xv, in1 = 0.f;
+                const bool per = a.feat_per[foff + f] != 0;
+                if (per) sincosf((xv - a.emb_lower) * a.emb_scale, &in1, &in0);
+                xc[e0 * Q4_ROWS + s] = in0;
+                if (per) xc[(e0 + 1) * Q4_ROWS + s] = in1;
+                if (writer) {
+                    a.x[r * a.ldx + col] = xv;
+                    a.xpad[r * a.ldxpad + icol] = in0;
+                    if (per) a.xpad[r * a.ldxpad + icol + 1] = in1;
+                }
+                __builtin_amdgcn_wave_barrier();
+                ++oj;
+            }
+            }
+        }
+    }
+    if (consumer && writer) a.ldj[row] = (float)((double)a.ldj[row] + ldj_acc);
+}
+
 }  // namespace tfep
 
 using namespace tfep;
@@ -945,6 +1303,7 @@ using namespace tfep;
 extern "C" {
 
 int tfep_inverse_block_step_ints(void) { return IB_STEP_INTS; }
+int tfep_inverse_block_record_ints(void) { return IB_BLK_INTS; }
 
 int64_t tfep_inverse_block_lds_bytes(int n_layers, int cache_len, int max_feats) {
     if (n_layers < 1 || cache_len < 0 || max_feats < 0) return -1;
@@ -964,8 +1323,8 @@ int64_t tfep_inverse_block_lds_bytes_rows(int n_layers, int cache_len, int max_f
 
 int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
     TFEP_REQUIRE(d != nullptr, "inverse_block: NULL descriptor");
-    TFEP_REQUIRE(d->B >= 0 && d->n_steps >= 0, "inverse_block: negative size");
-    if (d->B == 0 || d->n_steps == 0) return TFEP_OK;
+    TFEP_REQUIRE(d->B >= 0 && d->n_steps >= 0 && d->n_blocks >= 0, "inverse_block: negative size");
+    if (d->B == 0 || (d->n_steps == 0 && d->n_blocks == 0)) return TFEP_OK;
     TFEP_REQUIRE(d->n_layers >= 1 && d->n_layers <= IB_MAX_LAYERS, "inverse_block: 1..%d hidden layers", IB_MAX_LAYERS);
     TFEP_REQUIRE(d->kind >= 0 && d->kind <= 3,
                  "inverse_block: kind must be 0 (affine), 1 (spline), 2 (Moebius) or 3 (splines of several layouts)");
@@ -1031,6 +1390,41 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
     TFEP_REQUIRE(a.P <= IB_MAX_P, "inverse_block: too many parameters per feature");
     TFEP_REQUIRE(d->rows_per_wave == 0 || d->rows_per_wave == 16 || d->rows_per_wave == 64,
                  "inverse_block: rows_per_wave must be 64 (or 0: one sample row per lane) or 16 (four lanes per row)");
+    if (d->n_blocks > 0) {
+        // ---- super-block launch: every block of the list in one launch of the paired 16-row kernel
+        TFEP_REQUIRE(d->rows_per_wave == 16 && d->paired != 0 && d->waves_per_workgroup <= 1,
+                     "inverse_block: a super-block launch (n_blocks > 0) needs rows_per_wave = 16 and paired = 1");
+        TFEP_REQUIRE(d->blocks != nullptr && d->zout_extra != nullptr, "inverse_block: super-block launch without block records / extra slab");
+        InverseSuperArgs sa = {};
+        a.n_steps = 0;
+        a.stage_gstride = 8 * ib_stage_cols_q4(d->cache_len, d->max_feats);
+        for (int l = 0; l < d->n_layers; ++l) {
+            TFEP_REQUIRE(d->z_extra[l] != nullptr, "inverse_block: super-block launch without the extra slab of layer %d", l);
+            TFEP_REQUIRE(d->ldh[l] % 4 == 0 && ((uintptr_t)d->h[l] & 15) == 0, "inverse_block: h[%d] not aligned to 4 floats", l);
+            sa.z_extra[l] = d->z_extra[l];
+            a.z_slabs[l] = d->z_slabs[l] > 0 ? d->z_slabs[l] : 0;         // slabs of the super-block GEMMs; the records add the extra one
+        }
+        a.zout_slabs = d->zout_slabs > 0 ? d->zout_slabs : 0;
+        sa.zout_extra = d->zout_extra;
+        sa.n_blocks = d->n_blocks;
+        sa.blocks = d->blocks;
+        const size_t lds_s = ib_lds_floats_q4_paired(d->n_layers, d->cache_len, d->max_feats) * sizeof(float);
+        TFEP_REQUIRE(lds_s <= 160 * 1024, "inverse_block: the pair needs %zu bytes of LDS (> 160 KiB)", lds_s);
+        a.lds_floats = (int)(lds_s / sizeof(float));
+        sa.a = a;
+        void (*skernel)(InverseSuperArgs) = d->kind == 0 ? inverse_superblock_kernel<0> : d->kind == 1 ? inverse_superblock_kernel<1>
+                                            : d->kind == 2 ? inverse_superblock_kernel<2> : inverse_superblock_kernel<3>;
+        static size_t lds_attr_s[4][TFEP_MAX_DEVICES] = {};
+        size_t& attr = lds_attr_s[d->kind][current_device_slot()];
+        if (lds_s > attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)skernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+            if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds_s, hipGetErrorString(e));
+            attr = lds_s;
+        }
+        const long long n_pairs = (d->B + Q4_ROWS - 1) / Q4_ROWS;
+        skernel<<<(unsigned)n_pairs, 128, lds_s, (hipStream_t)stream>>>(sa);
+        return check_launch("inverse_superblock_kernel");
+    }
     const bool q4 = d->rows_per_wave == 16;
     size_t lds = (q4 ? ib_lds_floats_q4(d->n_layers, d->cache_len, d->max_feats)
                            : ib_lds_floats(d->n_layers, d->cache_len, d->max_feats)) * sizeof(float);

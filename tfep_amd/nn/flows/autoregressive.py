@@ -571,6 +571,14 @@ class AutoregressiveFlow(torch.nn.Module):
     #: super-block instead of once per block.  0 / 1: off.
     inverse_super = 8
 
+    #: Run every block of a super-block in ONE launch (``tfep_inverse_block`` with ``n_blocks``): the pair of waves that owns
+    #: 16 sample rows forms, at the head of each block, what the earlier blocks of the super-block add to the block's rows
+    #: (exact-fp32 MFMA products on its own rows) instead of three short GEMM launches + two re-scaling launches per block in
+    #: series with the chain.  None: whenever super-blocks and the paired kernel are in use (``TFEP_INV_SUPER_KERNEL=0``: off).
+    inverse_super_kernel = None
+    #: which schedule the last ``_inverse_blocked`` call ran: 'super_kernel' or 'block_by_block' (tests, probes)
+    last_inverse_schedule = None
+
     def _input_columns(self):
         """Where feature column c of x enters the conditioner input: ``(first_col[c], periodic[c], limits)``.  Without an
         embedding the input IS x; a PeriodicEmbedding puts the non-periodic features first and then a (cos, sin) pair
@@ -763,13 +771,20 @@ class AutoregressiveFlow(torch.nn.Module):
                     r0, r1 = r_lo(l, dS0 - 1), r_hi(l, dS1 - 2)
                     if r1 > r0:
                         sup['wide'].append(dict(layer=l, row0=r0, n_rows=r1 - r0, kr=rng(0, kS[l])))
+                # layer 0 of the whole super-block (the super-block kernel, ``inverse_super_kernel``): every conditioner input
+                # known before the super-block -- bounding column range; what the super-block itself produces is still zero
+                r0, r1 = r_lo(0, dS0 - 1), r_hi(0, dS1 - 2)
+                known = torch.nonzero(deg_in <= dS0 - 1).flatten()
+                kb0, ke0 = ((int(known.min()) // tk) * tk, min(up(int(known.max()) + 1), mplan['k_pad'][0])) if len(known) else (0, 0)
+                sup['wide0'] = dict(layer=0, row0=r0, n_rows=max(r1 - r0, 0), kr=rng(kb0, ke0))
+                sup['blocks'] = []
                 supers.append(sup)
             blk['sb'], blk['sb_first'] = len(supers) - 1, len(blocks) % n_super == 0
 
             def wide_desc(l, r0, r1):
                 return dict(layer=l, row0=r0, n_rows=r1 - r0, kr=rng(0, kA[l]), kr_old=rng(0, kP[l]),
                             kr_new=rng(kP[l], kA[l]), has_new=kA[l] > kP[l],
-                            kr_sbnew=rng(kS[l], kA[l]), has_sbnew=kA[l] > kS[l])
+                            kr_sbnew=rng(kS[l], kA[l]), has_sbnew=kA[l] > kS[l], sb_range=(kS[l], kA[l]))
             for l in range(1, L):      # hidden layers fed by hidden layers
                 r0, r1 = r_lo(l, d0 - 1), r_hi(l, d1 - 2)
                 if r1 > r0:
@@ -799,10 +814,12 @@ class AutoregressiveFlow(torch.nn.Module):
                                              n_d=len(sel), sel_host=sel, cols_host=tr_idx[sel], member=g, local_host=loc))
             blk['fused'] = self._fused_block_tables(d0, d1, blk, kA, r_lo, r_hi, parts, tr_idx, deg_in, mplan, L,
                                                     rng, up, i32, d0_prev=d0 - G if d0 > 0 else None)
+            blk['rows0'] = (r_lo(0, d0 - 1), max(r_hi(0, d1 - 2) - r_lo(0, d0 - 1), 0))      # layer-0 units of the block
+            supers[-1]['blocks'].append(len(blocks))
             blocks.append(blk)
         narrow = lib.tfep_masked_linear_narrow_tile_n()
         max_rows = max([w['n_rows'] for b_ in blocks for w in b_['wide']] + [b_['out_wide']['n_rows'] for b_ in blocks] +
-                       ([w['n_rows'] for s_ in supers for w in s_['wide'] + [s_['out_wide']]] if n_super > 1 else []) +
+                       ([w['n_rows'] for s_ in supers for w in s_['wide'] + [s_['out_wide'], s_['wide0']]] if n_super > 1 else []) +
                        [b_['fused']['wide0']['n_rows'] for b_ in blocks if b_['fused'] and b_['fused']['wide0']] +
                        [h_['n_rows'] for b_ in blocks for st in b_['steps'] for h_ in st['hidden']] +
                        [st['out']['n_rows'] for b_ in blocks for st in b_['steps']])
@@ -1037,6 +1054,45 @@ class AutoregressiveFlow(torch.nn.Module):
         positions = max(1, ((y.shape[0] + 255) // 256) * min(n256, n208))
         k_split = int(min(8, max(1, 256 // positions), max(1, mplan['k_pad'][L] // 512)))
         return hs, ops.pow2_inv_scale(bound), w_split, w_inv, k_split, hidden
+
+    def _super_tables(self, bp, sup, L, device):
+        """Concatenated step / feature tables and the per-block records of ``tfep_inverse_block`` (``n_blocks`` form) for one
+        super-block, built once per plan."""
+        st = sup.get('tables')
+        if st is not None:
+            return st
+        lib = _lib.load()
+        n_rec = lib.tfep_inverse_block_record_ints()
+        blocks = [bp['blocks'][i] for i in sup['blocks']]
+        steps, cols, sel, feat_in, feat_per, in_cols, recs = [], [], [], [], [], [], []
+        n_steps = n_feat = n_in = 0
+        in0 = 0                                           # first input entry of the super-block in the concatenated table
+        for blk in blocks:
+            fb = blk['fused']
+            nf, ni = fb['cols'].numel() - 1, fb['in_cols'].numel() - 1       # (the per-block tables carry one padding entry)
+            rec = [0] * n_rec
+            rec[0], rec[1], rec[2], rec[3] = fb['n_steps'], n_steps, n_feat, n_in
+            for l in range(L):
+                rec[4 + l], rec[8 + l] = fb['c0'][l], fb['n_old'][l]
+            # products at the head of the block: layer 0 from the super-block's earlier input entries, layer l >= 1 from the
+            # packed columns [kS, kA) of layer l - 1
+            r0, n0 = blk['rows0']
+            rec[12:16] = [r0, n0, in0, n_in]
+            for wd in blk['wide'] + [blk['out_wide']]:
+                l = wd['layer']
+                rec[12 + 4 * l:16 + 4 * l] = [wd['row0'], wd['n_rows'], wd['sb_range'][0], wd['sb_range'][1]]
+            recs.append(rec)
+            steps.append(fb['steps'])
+            cols.append(fb['cols'][:nf]); sel.append(fb['sel'][:nf]); feat_in.append(fb['feat_in'][:nf]); feat_per.append(fb['feat_per'][:nf])
+            in_cols.append(fb['in_cols'][:ni])
+            n_steps += fb['n_steps']; n_feat += nf; n_in += ni
+        pad = torch.zeros(1, dtype=torch.int32, device=device)
+        cat = lambda v: torch.cat(v + [pad]).contiguous()
+        st = sup['tables'] = dict(
+            steps=torch.cat(steps).contiguous(), cols=cat(cols), sel=cat(sel), feat_in=cat(feat_in), feat_per=cat(feat_per),
+            in_cols=cat(in_cols), records=torch.tensor(recs, dtype=torch.int32).reshape(-1, n_rec).to(device), n_blocks=len(blocks),
+            unit_range=[(blocks[0]['fused']['unit_range'][l][0], blocks[-1]['fused']['unit_range'][l][1]) for l in range(L)])
+        return st
 
     def _inverse_blocked(self, y):
         y, _ = _lib.rows(y, 'y')
@@ -1302,6 +1358,51 @@ class AutoregressiveFlow(torch.nn.Module):
                     main, side = torch.cuda.current_stream(dev), _side_stream(dev)
                     wide_gemms(bp['blocks'][0], 0, 'kr_old')
                     old_done = None
+                # ---- ONE launch per super-block (``inverse_super_kernel``)
+                sk = self.inverse_super_kernel
+                if os.environ.get('TFEP_INV_SUPER_KERNEL') is not None:
+                    sk = os.environ['TFEP_INV_SUPER_KERNEL'] != '0'
+                if (sk is None or sk) and use_sb and paired and rows_per_wave == 16:
+                    # layer 0 joins the super-block scheme: its own slabs, one GEMM per super-block over the inputs known before
+                    n0_max = max(s_['wide0']['n_rows'] for s_ in supers)
+                    S0 = int(min(8, max(1, 256 // max(1, 2 * m_tiles)), max(1, mplan['k_pad'][0] // 512)))
+                    sb_buf0 = torch.empty(S0 + 1, B, ops.round_up(max(n0_max, 1), 4), **f32)
+                    d.rows_per_wave, d.paired, d.waves_per_workgroup = 16, 1, 0
+                    self.last_inverse_schedule = 'super_kernel'
+                    for sup in supers:
+                        tb = self._super_tables(bp, sup, L, dev)
+                        super_gemms(sup)
+                        w0 = sup['wide0']
+                        if w0['n_rows'] > 0:
+                            launch(xpad, packs[0][0], packs[0][1], w0, sb_buf0[:S0] if S0 > 1 else sb_buf0[0], 0, act=0, k_split=S0)
+                        d.n_blocks, d.blocks = tb['n_blocks'], tb['records'].data_ptr()
+                        d.steps, d.feat_cols, d.feat_sel = tb['steps'].data_ptr(), tb['cols'].data_ptr(), tb['sel'].data_ptr()
+                        d.feat_in, d.feat_periodic, d.in_cols = tb['feat_in'].data_ptr(), tb['feat_per'].data_ptr(), tb['in_cols'].data_ptr()
+                        # the kernel indexes the slabs by packed row: column 0 of a buffer is the super-block's first row
+                        d.z[0] = sb_buf0.data_ptr() - 4 * w0['row0']
+                        d.ldz[0], d.z_slab_stride[0], d.z_slabs[0] = sb_buf0.shape[-1], B * sb_buf0.shape[-1], S0
+                        d.z_extra[0] = d.z[0] + 4 * S0 * d.z_slab_stride[0]
+                        for sd in sup['wide']:
+                            l = sd['layer']
+                            d.z[l] = sb_buf[l].data_ptr() - 4 * sd['row0']
+                            d.ldz[l], d.z_slab_stride[l], d.z_slabs[l] = sb_buf[l].shape[-1], B * sb_buf[l].shape[-1], sb_S[l]
+                            d.z_extra[l] = d.z[l] + 4 * sb_S[l] * d.z_slab_stride[l]
+                        d.zout = sb_buf[L].data_ptr() - 4 * sup['out_wide']['row0']
+                        d.ldzout, d.zout_slab_stride, d.zout_slabs = sb_buf[L].shape[-1], B * sb_buf[L].shape[-1], sb_S[L]
+                        d.zout_extra = d.zout + 4 * sb_S[L] * d.zout_slab_stride
+                        _lib.call('tfep_inverse_block', ctypes.byref(d), stream)
+                        # the super-block's new units as split rows, for the GEMMs of the super-blocks to come
+                        lo, hi = tb['unit_range'][L - 1]
+                        if hi > lo:
+                            g0 = lo // 8 * 8
+                            ops.split_columns_scaled(h[L - 1], g0, hi - g0, hs, hs_inv)
+                        for l_next, (hsl, hsl_inv, _, _) in hs_hidden.items():
+                            lo, hi = tb['unit_range'][l_next - 1]
+                            if hi > lo:
+                                g0 = lo // 8 * 8
+                                ops.split_columns_scaled(h[l_next - 1], g0, hi - g0, hsl, hsl_inv)
+                    return x, ldj
+            self.last_inverse_schedule = 'block_by_block'
             for i_blk, blk in enumerate(bp['blocks']):
                 # ---- contribution of all earlier degrees to the whole block, once
                 ow = blk['out_wide']

@@ -1,0 +1,25 @@
+#!/usr/bin/env python
+"""One schedule of the blocked inverse of a cfg2 layer, N calls (for a kernel trace): SUPER=1 / 0."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
+
+dev = torch.device('cuda')
+D, B, N = int(os.environ.get('D', 3000)), int(os.environ.get('B', 8192)), int(os.environ.get('N', 4))
+layer = bench.build_flow(D, 1, 8, dev)[0]
+layer.inverse_super_kernel = os.environ.get('SUPER', '1') != '0'
+x = torch.randn(B, D, device=dev, generator=torch.Generator(device=dev).manual_seed(1234)).clamp_(-4.9, 4.9)
+with torch.no_grad():
+    y, _ = layer(x)
+    layer.inverse(y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(N):
+        layer.inverse(y)
+    torch.cuda.synchronize()
+print('ms per inverse', 1e3 * (time.perf_counter() - t0) / N, 'schedule', layer.last_inverse_schedule, 'calls', N + 1)
