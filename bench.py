@@ -94,6 +94,42 @@ def cpu_baseline(flow, D, n_bins, chunks):
     }, check
 
 
+def fp64_check(flow, made, D, n_bins, device, rows=256):
+    """The asserted comparison of tests/test_gpu_parity.py::test_cfg2_layer_vs_fp64_oracle, reported in the bench line: layer
+    0 on ``rows`` samples through the default (split-f16) and the exact-fp32 GEMMs against the torch-CPU restatement in
+    FLOAT64 on the same float32 weights and inputs (row chunks of the weight matrices: 8192 output units at a time), with
+    the float32 restatement's own distance from it as the noise floor."""
+    from oracle import torch_cpu
+    x = torch.randn(rows, D, generator=torch.Generator().manual_seed(4321)).clamp_(-4.9, 4.9)
+
+    def cpu(dtype):
+        h = x.to(dtype)
+        for i, layer in enumerate(made):
+            outs = []
+            for r0 in range(0, layer['bias'].numel(), 8192):
+                part = {k: v[r0:r0 + 8192].to(dtype) for k, v in layer.items()}
+                outs.append(torch.nn.functional.linear(h, torch_cpu.effective_weight(part), part['bias']))
+            h = torch.cat(outs, dim=1)
+            if i + 1 < len(made):
+                h = torch.nn.functional.elu(h)
+        return torch_cpu.spline_forward(x.to(dtype), h, torch.full((D,), -5.0, dtype=dtype), torch.full((D,), 5.0, dtype=dtype), n_bins)
+    with torch.no_grad():
+        y64, l64 = cpu(torch.float64)
+        y32, l32 = cpu(torch.float32)
+        out = {'rows': rows, 'reference': 'oracle/torch_cpu.py in float64 on the float32 weights and inputs',
+               'fp32_cpu': {'rel_l2_y': float((y32.double() - y64).norm() / y64.norm()), 'max_abs_ldj': float((l32.double() - l64).abs().max())},
+               'ldj_abs_median': float(l64.abs().median())}
+        layer = flow[0]
+        for name, split in (('split_f16_default', None), ('exact_fp32', False)):
+            layer.split_gemm = split
+            yg, lg = layer(x.to(device))
+            out[name] = {'rel_l2_y': float((yg.cpu().double() - y64).norm() / y64.norm()),
+                         'max_abs_ldj': float((lg.cpu().double() - l64).abs().max())}
+        layer.split_gemm = None
+    out['tolerance'] = 'north star: <= 1e-5 rel on y and log|det J| (asserted in tests/test_gpu_parity.py at 512 rows)'
+    return out
+
+
 def _clock(fn, n, device):
     fn()
     torch.cuda.synchronize(device)
@@ -131,9 +167,16 @@ def cfg4_i_arm(device, D=512, B=131072, n_layers=4):
     with torch.no_grad():
         dt = _clock(lambda: flow(x), 3, device)
         y, _ = flow(x)
+        Bi = 16384                                                  # the blocked inverse of the same flow (4 x 512 degrees)
+        dti = _clock(lambda: flow.inverse(y[:Bi]), 2, device)
+        xi, _ = flow.inverse(y[:Bi])
+    dcirc = (xi - x[:Bi]).abs()
     return {'workload': f'cfg4-i: {n_layers}-layer MAF + circular RQ-8 + periodic embedding, {D} torsions, batch {B}, forward + log|det J|',
             'rows': B, 'ms': 1e3 * dt, 'samples_per_s': B / dt, 'y_in_domain': bool(((y >= 0) & (y <= 1)).all()),
-            'roofline': _mfma_roofline(flow, B, dt, 'fused output GEMM + circular spline epilogue')}
+            'roofline': _mfma_roofline(flow, B, dt, 'fused output GEMM + circular spline epilogue'),
+            'inverse': {'rows': Bi, 'ms': 1e3 * dti, 'samples_per_s': Bi / dti,
+                        'roundtrip_circle_max': float(torch.minimum(dcirc, 1 - dcirc).max()),
+                        'roofline': _mfma_roofline(flow, Bi, dti, 'blocked inverse: one forward of flops; 4 x 512 sequential degrees')}}
 
 
 def cfg4_ii_arm(device, D=512, B=131072, n_layers=4):
@@ -412,11 +455,25 @@ def main():
                 layer._conditioner.invalidate_plan()
             other['inverse_one_layer'] = {
                 'rows': 8192, 'ms': 1e3 * t_i, 'samples_per_s': 8192 / t_i, 'ms_cached_packs': 1e3 * t_ic,
-                'roundtrip_max_abs': float((xi - x[:8192]).abs().max()),
+                'roundtrip_max_abs': float((xi - x[:8192]).abs().max()), 'schedule': layer.last_inverse_schedule,
                 'roofline': {'bound': 'mfma', 'achieved': flops_layer * 8192 / t_i / 1e12, 'peak': peak_other, 'unit': 'TFLOP/s',
                              'frac': flops_layer * 8192 / t_i / 1e12 / peak_other,
                              'note': 'one forward of flops; 3000 sequential degree steps (blocked forward substitution)'}}
             del y8, xi
+            if 'inverse' in arms:
+                # the same layer's inverse at the FULL batch of the headline (65 536 rows: one sample row per lane of the
+                # block kernel, block-by-block launches -- the 16-row pairs of the 8192-row call would not be resident)
+                with torch.no_grad():
+                    yf, _ = layer(x)
+                    t_if = clock(lambda: layer.inverse(yf), 1)
+                    xf_, _ = layer.inverse(yf)
+                other['inverse_full_batch'] = {
+                    'rows': B, 'ms': 1e3 * t_if, 'samples_per_s': B / t_if, 'schedule': layer.last_inverse_schedule,
+                    'roundtrip_max_abs': float((xf_ - x).abs().max()),
+                    'roofline': {'bound': 'mfma', 'achieved': flops_layer * B / t_if / 1e12, 'peak': peak_other, 'unit': 'TFLOP/s',
+                                 'frac': flops_layer * B / t_if / 1e12 / peak_other, 'note': 'one forward of flops'}}
+                del yf, xf_
+                torch.cuda.empty_cache()
             c = torch.rand(D, device=device, generator=gen) * 0.3
             x16 = x[:16384]
 
@@ -544,6 +601,12 @@ def main():
             except Exception as e:                              # the headline number must still print
                 res['cpu_baseline'] = {'value': None, 'unit': 'samples/s', 'cores': os.cpu_count(), 'kind': 'port',
                                        'sample': f'failed: {type(e).__name__}: {e}'}
+            try:
+                sd = flow[0]._conditioner.state_dict()
+                made = [{k: sd[f'layers.{2 * i}.{k}'].detach().cpu() for k in ('bias', 'mask', 'weight_g', 'weight_v')} for i in range(3)]
+                res.setdefault('cpu_check', {})['vs_fp64'] = fp64_check(flow, made, D, args.bins, device)
+            except Exception as e:
+                res.setdefault('cpu_check', {})['vs_fp64'] = {'failed': f'{type(e).__name__}: {e}'}
         print(json.dumps(res), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -306,6 +306,36 @@ class TransformerInverseFunction(torch.autograd.Function):
         return None, u, -gtheta
 
 
+def _differentiable_inverse(tr):
+    """``(y, theta) -> (x, log_det_J)`` of ``tr.inverse`` as autograd nodes on the HIP kernels: Moebius as its forward function
+    on negated parameters (reference moebius.py:142-147 defines the inverse that way), the element-wise transformers through
+    ``TransformerInverseFunction``, a mixed transformer with a Moebius member (reference mixed.py:165-186: plain autograd
+    through every member) member by member on its own columns and parameter block, a user's torch transformer by plain
+    autograd."""
+    from .partial import _GatherColumns, _ReplaceColumns
+    if type(tr) is MoebiusTransformer:
+        return lambda y_tr, theta: TransformerFunction.apply(tr, y_tr, -theta)
+    if _elementwise(tr):
+        return lambda y_tr, theta: TransformerInverseFunction.apply(tr, y_tr, theta)
+    if type(tr) is MixedTransformer:
+        members = [_differentiable_inverse(t) for t in tr._transformers]
+
+        def inverse(y_tr, theta):
+            splits = tr.host_splits() + [theta.shape[1]]
+            x, ldj = torch.zeros_like(y_tr), None
+            for inv_g, ind, a, b in zip(members, tr._indices, splits[:-1], splits[1:]):
+                idx = ind.to(device=y_tr.device, dtype=torch.int32)
+                x_g, l_g = inv_g(_GatherColumns.apply(y_tr, idx), theta[:, a:b].contiguous())
+                x = _ReplaceColumns.apply(x, x_g, idx)
+                ldj = l_g if ldj is None else ldj + l_g
+            return x, ldj
+        return inverse
+    if not isinstance(tr, _HIP_TRANSFORMERS):                # a user's torch transformer: plain autograd
+        return lambda y_tr, theta: tr.inverse(y_tr, theta)
+    raise NotImplementedError('tfep_amd: no backward for the inverse of ' + type(tr).__name__ +
+                              ' (a subclass of a HIP-backed transformer)')
+
+
 def generic_inverse(layer, y):
     """Differentiable ``AutoregressiveFlow.inverse``: the reference's algorithm (autoregressive.py:179-229: one full
     conditioner pass per autoregressive degree, the degree's columns committed after each pass, the log-det of the LAST
@@ -323,18 +353,7 @@ def generic_inverse(layer, y):
     def conditioner(x):
         cond_in = _GatherColumns.apply(x, t['cond']) if len(layer._conditioner_indices) > 0 else x
         return made.layers(made._embed(cond_in)) if isinstance(made, MADE) else made(cond_in)
-    if type(tr) is MoebiusTransformer:
-        def inverse(y_tr, theta):
-            return TransformerFunction.apply(tr, y_tr, -theta)
-    elif _elementwise(tr):
-        def inverse(y_tr, theta):
-            return TransformerInverseFunction.apply(tr, y_tr, theta)
-    elif not isinstance(tr, _HIP_TRANSFORMERS):              # a user's torch transformer: plain autograd
-        def inverse(y_tr, theta):
-            return tr.inverse(y_tr, theta)
-    else:
-        raise NotImplementedError('tfep_amd: no backward for the inverse of ' + type(tr).__name__ + ' (a mixed transformer '
-                                  'with a Moebius member, or a subclass of a HIP-backed transformer)')
+    inverse = _differentiable_inverse(tr)
     if layer.has_fixed_indices:
         x = _ReplaceColumns.apply(torch.zeros_like(y), _GatherColumns.apply(y, t['fixed']), t['fixed'])
         y_tr = _GatherColumns.apply(y, t['tr'])
