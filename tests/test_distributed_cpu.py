@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 
 import golden_util as gu
 from oracle import loss as oloss
-from tfep_amd.distributed import allreduce_gradients, allreduce_stats, combine_stats, shard_rows
+from tfep_amd.distributed import OverlappedGradientSync, allreduce_gradients, allreduce_stats, combine_stats, shard_rows
 
 
 def shard_stats(uB, ldj, uA, lw, bias, kT=1.0, ignore_nan=False):
@@ -301,3 +301,67 @@ def test_bench_spawns_its_own_ranks_when_run_without_a_launcher():
     env['TFEP_BENCH_BACKEND'] = 'no-such-backend'               # accepted by the parent, fails in every rank
     bad = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith('{')]
+
+
+def _overlap_worker(rank, world, port, q):
+    """Two stacked linears with gradients above / below the in-place threshold: ``allreduce_gradients`` and the hook-driven
+    ``OverlappedGradientSync`` must both give the sum over ranks WITHOUT a staging copy of the large gradients."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(64, 48), torch.nn.Tanh(), torch.nn.Linear(48, 32))    # weights 12 KB / 6 KB, biases < 200 B
+        x = torch.randn(10, 64, generator=torch.Generator().manual_seed(100 + rank))
+        small = 4096                                        # bytes: both weight gradients count as "large" here
+        copied = []
+        real_cat = torch.cat
+        torch.cat = lambda ts, *a, **k: (copied.extend(int(t.numel()) for t in ts), real_cat(ts, *a, **k))[1]
+        try:
+            net(x).square().sum().backward()
+            ptrs = [p.grad.data_ptr() for p in net.parameters()]
+            allreduce_gradients(net, small_bytes=small)
+            g_plain = [p.grad.clone() for p in net.parameters()]
+            assert ptrs == [p.grad.data_ptr() for p in net.parameters()]          # reduced where they lie
+            for p in net.parameters():
+                p.grad = None
+            sync = OverlappedGradientSync(net, small_bytes=small)
+            net(x).square().sum().backward()
+            launched = sync.launched_in_backward                                 # queued by the hooks, before wait()
+            sync.wait()
+            g_hook = [p.grad.clone() for p in net.parameters()]
+            sync.remove()
+        finally:
+            torch.cat = real_cat
+        q.put((rank, [g.flatten().tolist() for g in g_plain], [g.flatten().tolist() for g in g_hook], launched, max(copied) if copied else 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gradient_sync_in_place_and_overlapped_with_the_backward():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single process: the sum of the two ranks' gradients
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(64, 48), torch.nn.Tanh(), torch.nn.Linear(48, 32))
+    total = None
+    for rank in range(world):
+        for p in net.parameters():
+            p.grad = None
+        net(torch.randn(10, 64, generator=torch.Generator().manual_seed(100 + rank))).square().sum().backward()
+        g = [p.grad.flatten().clone() for p in net.parameters()]
+        total = g if total is None else [a + b for a, b in zip(total, g)]
+    for _, g_plain, g_hook, launched, biggest_copy in res:
+        for a, b, t in zip(g_plain, g_hook, total):
+            np.testing.assert_allclose(a, t.numpy(), rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(b, t.numpy(), rtol=1e-5, atol=1e-6)
+        assert launched == 2                                 # both weight gradients left during the backward
+        assert biggest_copy <= 48                            # only the biases went through a flat buffer

@@ -586,3 +586,34 @@ def test_split_exact_and_float64_oracle_at_64_atoms(cutoff):
     for name, (ev, ej) in errs.items():
         assert ev <= 5e-6 and ej <= 1e-5, (name, ev, ej)
     assert errs['default'] == errs['split']                 # the default arithmetic of the dynamics is the split chain
+
+
+def test_grad_mode_at_cfg5_size_fails_with_the_reason_or_stays_on_the_kernels():
+    """BASELINE cfg5's size under grad mode: a fresh module has trainable parameters, so ``flow(x)`` without
+    ``torch.no_grad()`` takes the differentiable route -- the dynamics as DENSE torch operators, B n^2 (2F + G) values per
+    layer (3.4 TB per evaluation of the dynamics here, 40 evaluations per flow).  That must fail with a message that says so (not with an allocator error), and the same call
+    with frozen parameters and an input that needs no gradient must run on the kernels, grad mode or not, bit for bit like
+    ``torch.no_grad()``."""
+    from tfep_amd import _lib
+    from tfep_amd.nn.dynamics import EGNNDynamics
+    from tfep_amd.nn.flows import ContinuousFlow
+    B, n = 16384, 256
+    gen = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.randn(B, 3 * n, device='cuda', generator=gen)
+    torch.manual_seed(0)
+    dyn = EGNNDynamics(node_types=[i % 4 for i in range(n)], r_cutoff=4.0, speed_factor=0.02, initialize_identity=False).cuda()
+    flow = ContinuousFlow(dyn, solver='rk4', solver_options={'step_size': 0.5}, regularization=False)
+    assert dyn.dense_route_bytes(B) > 3 * 2 ** 40              # 3.4 TB for ONE evaluation of the dynamics (a flow keeps 40)
+    with pytest.raises(_lib.TfepHipError, match='torch.no_grad'):
+        flow(x)
+    small = x[:64].contiguous()
+    flow.ode_func.fixed_noise = torch.randn(1, 64, 3 * n, device='cuda', generator=gen)
+    with torch.no_grad():
+        y0, t0 = flow(small)
+    for p in flow.parameters():
+        p.requires_grad_(False)
+    y1, t1 = flow(small)                                      # grad mode on, nothing to differentiate: the kernels
+    assert torch.equal(y0, y1) and torch.equal(t0, t1) and not y1.requires_grad
+    flow.ode_func.fixed_noise = None
+    y2, _ = flow(x[:2048])                                    # ... at a size the dense route could not hold (0.4 TB per evaluation)
+    assert bool(torch.isfinite(y2).all())

@@ -47,59 +47,108 @@ def shard_rows(n_rows, rank, world_size):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def allreduce_gradients(module, group=None, bucket_bytes=1 << 30, average=False, reduce_scatter=None):
-    """Data-parallel training: SUM the ``.grad`` of every parameter across ranks.
+#: Gradients below this size are packed into one small flat buffer per call (a handful of biases and weight-norm gains: a
+#: collective per 60 KB tensor would be latency only); everything larger is reduced IN PLACE.
+SMALL_GRADIENT_BYTES = 1 << 20
+
+
+def _reduce_small(grads, group, world, average):
+    """One all-reduce for the small gradients of a call (copied into a flat buffer and back: a few MB at cfg2)."""
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= world
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n
+
+
+def allreduce_gradients(module, group=None, bucket_bytes=None, average=False, reduce_scatter=None, small_bytes=None):
+    """Data-parallel training: SUM the ``.grad`` of every parameter across ranks, between ``loss.backward()`` and
+    ``optimizer.step()``.
 
     The sum is what pairs with ``BoltzmannKLDivLoss(distributed=True)``: that loss is the loss of the GLOBAL batch and
     its backward already weights every local sample by ``1/N_global`` (or by the global softmax weight), so the
     gradient of the reported loss is the sum of the ranks' local gradients.  ``average=True`` divides by the world
     size afterwards -- only for a loss that each rank normalises by its LOCAL batch (``distributed=False``).
 
-    Gradients are copied into a few large flat buckets (default 1 GiB: the 22 GB of cfg2 gradients
-    go out as ~22 collectives, each long enough to run at link bandwidth on the point-to-point
-    xGMI fabric).  On RCCL (``backend='nccl'``) each bucket goes out as an explicit reduce-scatter followed by an
-    all-gather (``reduce_scatter=None``: chosen when the backend supports it) -- the two halves of a ring all-reduce,
-    with the averaging applied to the 1/world shard between them; ``gloo`` (CPU tests) uses ``all_reduce``.
-    Call between ``loss.backward()`` and ``optimizer.step()``.
+    NO staging copy (round 4; rounds 1-3 concatenated 1 GiB buckets: a 22 GB copy out and back per cfg2 step): every gradient
+    of ``small_bytes`` (default 1 MiB) or more -- at cfg2 the twelve weight_v gradients of 0.18 / 0.9 / 4.5 GB, each long
+    enough to run at link bandwidth on the point-to-point xGMI fabric -- is all-reduced IN PLACE, all of them queued
+    asynchronously before the first wait; the small ones (biases, weight-norm gains) share one flat buffer.  RCCL's
+    all-reduce is itself the reduce-scatter + all-gather ring.  ``bucket_bytes`` / ``reduce_scatter`` are accepted for
+    compatibility and ignored.  To overlap the collectives with the backward itself use ``OverlappedGradientSync``.
     """
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
     world = dist.get_world_size(group)
+    small_bytes = SMALL_GRADIENT_BYTES if small_bytes is None else small_bytes
     grads = [p.grad for p in module.parameters() if p.grad is not None]
-    if reduce_scatter is None:
-        reduce_scatter = dist.get_backend(group) == 'nccl'
-    bucket, size = [], 0
+    big = [g for g in grads if g.numel() * g.element_size() >= small_bytes and g.is_contiguous()]
+    big_ids = {id(g) for g in big}
+    handles = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True) for g in big]
+    _reduce_small([g for g in grads if id(g) not in big_ids], group, world, average)
+    for h in handles:
+        h.wait()
+    if average:
+        for g in big:
+            g /= world
 
-    def flush():
-        nonlocal bucket, size
-        if not bucket:
+
+class OverlappedGradientSync:
+    """Gradient all-reduce that OVERLAPS the backward: a post-accumulate hook on every parameter queues the (asynchronous,
+    in-place) all-reduce of a large gradient the moment autograd has produced it, so the collective of MAF layer k travels
+    over xGMI while layer k - 1's backward kernels run (one autograd node per MAF layer, ``flows/_backward.py``: a layer's
+    gradients appear together).  ``wait()`` -- between ``loss.backward()`` and ``optimizer.step()`` -- reduces the small
+    gradients in one flat buffer and waits for everything in flight.  Sums, like ``allreduce_gradients``
+    (``average=True`` divides by the world size).  No-op without an initialised process group.
+
+        sync = OverlappedGradientSync(flow)
+        for batch in loader:
+            optimizer.zero_grad(set_to_none=True)
+            loss_fn(*flow(batch)).backward()      # collectives start inside
+            sync.wait()
+            optimizer.step()
+    """
+
+    def __init__(self, module, group=None, average=False, small_bytes=None):
+        self.group, self.average = group, average
+        self.small_bytes = SMALL_GRADIENT_BYTES if small_bytes is None else small_bytes
+        self._pending, self._small = [], []
+        self.launched_in_backward = 0            # (diagnostics / tests: collectives queued by the hooks since the last wait)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in module.parameters() if p.requires_grad]
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _on_grad(self, p):
+        if not self._active() or p.grad is None:
             return
-        flat = torch.cat([g.reshape(-1) for g in bucket])
-        if reduce_scatter:
-            n = flat.numel()
-            padded = (n + world - 1) // world * world
-            if padded != n:
-                flat = torch.cat([flat, flat.new_zeros(padded - n)])
-            shard = torch.empty(padded // world, dtype=flat.dtype, device=flat.device)
-            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=group)
-            if average:
-                shard /= world
-            dist.all_gather_into_tensor(flat, shard, group=group)
+        g = p.grad
+        if g.numel() * g.element_size() >= self.small_bytes and g.is_contiguous():
+            self._pending.append((g, dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)))
+            self.launched_in_backward += 1
         else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-            if average:
-                flat /= world
-        off = 0
-        for g in bucket:
-            n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
-            off += n
-        bucket, size = [], 0
+            self._small.append(g)
 
-    for g in grads:
-        nbytes = g.numel() * g.element_size()
-        if size + nbytes > bucket_bytes and bucket:
-            flush()
-        bucket.append(g)
-        size += nbytes
-    flush()
+    def wait(self):
+        if not self._active():
+            self._pending, self._small = [], []
+            return
+        world = dist.get_world_size(self.group)
+        _reduce_small(self._small, self.group, world, self.average)
+        for g, h in self._pending:
+            h.wait()
+            if self.average:
+                g /= world
+        self._pending, self._small = [], []
+        self.launched_in_backward = 0
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -88,6 +88,13 @@ class EGNNDynamics(FixedGraph):
             return self.torch_forward(t, x)                    # widths beyond the kernels' 64: the same map, slower
         return self._run(t, x)[0]
 
+    def dense_route_bytes(self, batch, dtype=torch.float32):
+        """Lower bound on what ``torch_forward`` keeps alive for a backward at this batch size: per layer the pair tensors
+        ``[B, n, n, .]`` of the message MLP's two hidden activations (2 F), the radial basis (G) and a few scalars per pair."""
+        _, F, G = self._dims
+        n = self.n_nodes
+        return int(batch) * n * n * (2 * F + G + 8) * torch.empty((), dtype=dtype).element_size() * self._n_layers
+
     def kernels_supported(self):
         """The HIP kernels cover ``node_feat_dim, distance_feat_dim <= 64`` (one wave holds a feature column in
         registers); wider dynamics run on ``torch_forward`` (and a ``ContinuousFlow`` over them on autograd, like any
@@ -112,6 +119,19 @@ class EGNNDynamics(FixedGraph):
         if x.dim() != 2 or x.shape[1] != 3 * n:
             raise ValueError(f'x must have shape (batch_size, {3 * n}), got {tuple(x.shape)}')
         dt, dev = x.dtype, x.device
+        # The dense formulation keeps B n^2 (2F + G) values per layer alive for the backward (more with ``create_graph``):
+        # 800 TB at BASELINE cfg5's size (B = 16 384, n = 256).  Fail with the reason, not with an allocator error
+        # somewhere inside the composite.
+        if torch.is_grad_enabled():
+            need = self.dense_route_bytes(B, dt)
+            free = torch.cuda.mem_get_info(dev)[0] + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+            if need > free:
+                raise _lib.TfepHipError(
+                    f'EGNNDynamics: the differentiable (autograd) route needs about {need / 2 ** 30:.0f} GiB for batch {B} x {n} nodes '
+                    f'({self._n_layers} layers x B n^2 (2F + G) values kept for the backward) and {free / 2 ** 30:.0f} GiB are free.  '
+                    'It is taken because grad mode is on and the input or a parameter requires a gradient: for inference call under '
+                    'torch.no_grad() (or freeze the parameters) -- that runs on the HIP kernels at any size; for training reduce the '
+                    'batch (the kernels have no parameter-gradient pass yet: DESIGN.md section 7).')
         t = torch.as_tensor(t, dtype=dt, device=dev).reshape(1)
         te = self.time_embedding
         t_emb = torch.exp(-torch.exp(te._log_gammas.to(dt)) * (t[:, None] - te._means.to(dt)) ** 2)[0]      # radial.py:110-130
