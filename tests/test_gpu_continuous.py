@@ -606,7 +606,9 @@ def test_grad_mode_at_cfg5_size_fails_with_the_reason_or_stays_on_the_kernels():
     assert dyn.dense_route_bytes(B) > 3 * 2 ** 40              # 3.4 TB for ONE evaluation of the dynamics (a flow keeps 40)
     with pytest.raises(_lib.TfepHipError, match='torch.no_grad'):
         flow(x)
-    small = x[:64].contiguous()
+    # (the differentiable route marks its input as requiring a gradient, in place, like the reference: continuous.py:243)
+    x = x.detach().requires_grad_(False)
+    small = x[:64].clone()
     flow.ode_func.fixed_noise = torch.randn(1, 64, 3 * n, device='cuda', generator=gen)
     with torch.no_grad():
         y0, t0 = flow(small)

@@ -551,6 +551,9 @@ __global__ void __launch_bounds__(WNB_THREADS) weight_norm_backward_prefix_kerne
     // 16-byte loads issued up front (8 steps cover 16 384 columns) -- they were fetched element by element, twice, each
     // pass a chain of dependent L2 round trips (4.1 ms for the cfg2 output layer at 2.7 TB/s).
     constexpr int WNB_U = 8;
+    // the live prefix of a packed gradient row is held in registers: WNB_U 16-byte loads per thread.  The host requires
+    // in_features * 4 <= 64 KB (the row staged in LDS), i.e. at most 16 384 columns -- tie the two together
+    static_assert(WNB_U * WNB_THREADS * 4 >= 16384, "weight_norm_backward_prefix: the register tile must cover the largest staged row");
     const bool vec = ((uintptr_t)gr & 15u) == 0 && (!in_of_col || ((uintptr_t)in_of_col & 15u) == 0);
     float4 gq[WNB_U];
     int4 iq[WNB_U];

@@ -83,6 +83,13 @@ class GraphedTrainingStep:
 
     def __init__(self, flow, loss_fn, optimizer, batch_size, n_features, device=None, warmup=3, sample_input=None):
         self.flow, self.loss_fn, self.optimizer = flow, loss_fn, optimizer
+        for group in optimizer.param_groups:
+            # State that the warm-up steps create is zeroed again before the capture; for SGD's momentum buffer that equals a
+            # fresh optimiser only when the first step's buffer is the plain gradient: with dampening != 0 a fresh optimiser
+            # starts from buf = grad where a zeroed buffer gives (1 - dampening) grad.
+            if isinstance(optimizer, torch.optim.SGD) and group.get('momentum', 0) != 0 and group.get('dampening', 0) != 0:
+                raise ValueError('GraphedTrainingStep: SGD with momentum and dampening != 0 is not supported (the first replayed '
+                                 'step would differ from a fresh optimiser\'s); use dampening = 0')
         self.params = [p for group in optimizer.param_groups for p in group['params'] if p.requires_grad]
         if _held_by_a_live_graph(self.params):
             # The gradient accumulator of a parameter belongs to the stream on which the first live graph over it was built.
@@ -93,12 +100,6 @@ class GraphedTrainingStep:
                                'from the flow outside torch.no_grad()?): delete it before capturing the step')
         device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.static_in = torch.zeros(batch_size, n_features, dtype=torch.float32, device=device)
-        if sample_input is not None:
-            self.static_in.copy_(sample_input)
-        # what the warm-up steps must not leave behind: parameter values and optimiser state
-        saved_params = [p.detach().clone() for p in self.params]
-        saved_state = {id(p): {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in optimizer.state.get(p, {}).items()}
-                       for p in self.params}
         if sample_input is not None:
             self.static_in.copy_(sample_input)
         # what the warm-up steps must not leave behind: parameter values and optimiser state

@@ -556,6 +556,7 @@ def _weights(layer, dev):
     the backward's row order.  Kept on the layer until a parameter or mask changes (``Tensor._version``): the
     activation-saving forward and the backward of the same step share one preparation."""
     made = layer._conditioner
+    made.begin_call()            # a pack request that does not come through MADE.forward: a fresh parameter checksum for this call
     mplan, lins, L, n_out, n_out_pad, n_pad, k_pad = _dims(layer, dev)
     bplan = _backward_plan(layer, dev)
     split = layer._use_split_gemm()

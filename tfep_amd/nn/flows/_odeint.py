@@ -92,7 +92,9 @@ def odeint(f, y0, t0, t1, method='dopri5', options=None, rtol=1e-4, atol=1e-4, a
     """Integrate ``y' = f(t, y)`` from ``t0`` to ``t1`` (either order); returns the state at ``t1``.
 
     ``options``: ``step_size`` (fixed grid), ``first_step`` / ``max_num_steps`` (adaptive pairs; ``max_num_steps``
-    counts accepted + rejected steps and defaults to 100 000 -- every one costs a full set of dynamics evaluations).
+    counts accepted + rejected steps; default 2^31 - 1 like torchdiffeq's, which the reference's ContinuousFlow inherits --
+    pass a smaller one through ``ContinuousFlow(solver_options={'max_num_steps': n})`` to bound a run: every step costs a
+    full set of dynamics evaluations).
     ``stats``: a dict that receives ``n_steps``, ``n_rejected`` and ``n_evaluations``.
 
     The adaptive pairs stop loudly instead of spinning: a non-finite state or error estimate (a NaN sample in the batch
@@ -124,7 +126,7 @@ def odeint(f, y0, t0, t1, method='dopri5', options=None, rtol=1e-4, atol=1e-4, a
     elif method in ADAPTIVE:
         order, C, A, Bw, E, fsal = _TABLEAUS[method]
         n_stages = len(C)
-        max_steps = int(options.pop('max_num_steps', 100_000))
+        max_steps = int(options.pop('max_num_steps', 2 ** 31 - 1))       # torchdiffeq's default, which the reference's ContinuousFlow inherits
         t = t0
         k1 = fe(t, y)
         h = options.pop('first_step', None)
