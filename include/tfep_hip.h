@@ -465,7 +465,8 @@ typedef struct tfep_inverse_block_desc {
      *   (l = 0: of the conditioner-input entries in_cols[kb .. ke), absolute positions in the concatenated table) to the
      *   packed rows [row0, row0 + n_rows) of layer l: exact-fp32 MFMA products of w[l] / wout with h[l - 1] / xpad, written
      *   to z_extra[l] / zout_extra (indexed like z[l] / zout) -- what earlier blocks of the same launch produced, i.e. what a
-     *   caller of the one-block form supplies through short GEMMs between launches.  kb, ke multiples of 32 for l >= 1.
+     *   caller of the one-block form supplies through short GEMMs between launches.  kb, ke multiples of 32 for l >= 1;
+     *   [32] the number of features of the block (<= max_feats: the kernel keeps their indices, domains and y values in LDS).
      * z_slabs[l] / zout_slabs then count the slabs of z[l] / zout WITHOUT the extra one (added per block when ke > kb);
      * n_steps, cache_col0 and cache_n_old of the descriptor are ignored. */
     int32_t n_blocks;
@@ -481,6 +482,11 @@ int64_t tfep_inverse_block_lds_bytes(int n_layers, int cache_len, int max_feats)
 int64_t tfep_inverse_block_lds_bytes_rows(int n_layers, int cache_len, int max_feats, int rows_per_wave);
 int64_t tfep_inverse_block_lds_bytes_paired(int n_layers, int cache_len, int max_feats);
 int tfep_inverse_block(const tfep_inverse_block_desc* desc, void* stream);
+/* Diagnostics (TFEP_DIAG_INVERSE=1 in the library's environment; spline layers): cycles of the consumer wave of every pair of the
+ * super-block launches so far, summed, in out[0..7] = {products at the head of a block, cache / table initialisation, waiting at a
+ * hidden-layer hand-over, hidden dots, waiting at an output hand-over, parameter dot, transformer inverse + stores, whole kernel},
+ * out[8] = pairs counted; clears the counters. */
+int tfep_diag_inverse_cycles(unsigned long long* out);
 
 /* ------------------------------------------------------------------------- */
 /* One MAF layer in one launch (csrc/maf_layer.hip)                            */

@@ -168,6 +168,7 @@ _SIGNATURES = {
     'tfep_inverse_block_lds_bytes_rows': (c_int64, [c_int, c_int, c_int, c_int]),
     'tfep_inverse_block_lds_bytes_paired': (c_int64, [c_int, c_int, c_int]),
     'tfep_inverse_block': (c_int, [POINTER(InverseBlockDesc), _P]),
+    'tfep_diag_inverse_cycles': (c_int, [_P]),
     'tfep_maf_layer_tile_n': (c_int, []),
     'tfep_maf_layer_forward_split': (c_int, [POINTER(MafLayerDesc), _P]),
     'tfep_diag_maf_layer_cycles': (c_int, [_P]),

@@ -18,6 +18,8 @@
 //   hidden units: packed fp32 FMA; the 25 spline parameters of a feature: two 32 x 32 fp32 MFMA tiles (out_dot_mfma);
 //   the transformer inverse is spline.h's rq_spline_element / moebius.h's moebius_vector (same code as the stand-alone
 //     kernels) or the affine map.
+#include <stdlib.h>
+
 #include "common.h"
 #include "spline.h"
 #include "moebius.h"
@@ -515,6 +517,7 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
 // =====================================================================================================================
 constexpr int Q4_ROWS = 16;
 constexpr int Q4_Z_PITCH = 24;       // floats per value of the pre-activation stage: 8 values x 8 rows per store instruction, conflict free
+constexpr int IB_FTAB_WORDS = 28;   // super-block kernel: per feature 9 table words (padded to 12) + y of the pair's 16 rows
 constexpr int Q4_P_PITCH = 20;       // floats per parameter of the MFMA hand-over [IB_MAX_P parameters][16 rows + 4]
 
 // columns per 8-row group of the weight stage: + 4 puts consecutive groups 32 banks apart -- a 16 x 4 operand fragment (two
@@ -532,7 +535,9 @@ __host__ __device__ inline size_t ib_lds_floats_q4_paired(int L, int cache_len, 
     const size_t cols = ib_stage_cols_q4(cache_len, max_feats);
     const size_t h = 8 * cols + IB_LDS_SLACK + 8 * (size_t)Q4_Z_PITCH;                                   // hidden-layer stage (8 rows)
     const size_t o = (size_t)IB_STAGE_ROWS * cols + IB_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;   // output-rows stage
-    return ((size_t)L * ib_round4(cache_len) + ib_round4(max_feats)) * Q4_ROWS + (size_t)IB_MAX_P * Q4_P_PITCH + 2 * h + 2 * o;
+    // (+ the per-feature table of the super-block kernel: IB_FTAB_WORDS words per feature of a block, see inverse_superblock_kernel)
+    return ((size_t)L * ib_round4(cache_len) + ib_round4(max_feats)) * Q4_ROWS + (size_t)IB_MAX_P * Q4_P_PITCH + 2 * h + 2 * o +
+           (size_t)IB_FTAB_WORDS * ib_round4(max_feats);
 }
 
 // zs[v * Q4_Z_PITCH + i] = sum_s z[s * slab_stride + (wave_row0 + i) * ldz + base + v * vstride],  v < nv <= 32, i < 16
@@ -955,7 +960,7 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
 // MFMA layouts (lane = (unit or row) l % 16, four consecutive k at 4 (l / 16)), two 32-column steps in flight.
 // Same-workgroup visibility of the stores (h, xpad, z_extra) across the block boundary: __syncthreads().
 // =====================================================================================================================
-constexpr int IB_BLK_INTS = 36;      // per-block record: [n_steps, steps_off, feat_off, in_off, c0[4], n_old[4], (row0, n, kb, ke) x 5 layers, pad]
+constexpr int IB_BLK_INTS = 36;      // per-block record: [n_steps, steps_off, feat_off, in_off, c0[4], n_old[4], (row0, n, kb, ke) x 5 layers, n_feats, pad]
 constexpr int IB_PROD_TILES = 5;     // 16-unit tiles that share a fetch of the activations
 
 struct InverseSuperArgs {
@@ -1044,8 +1049,23 @@ __device__ __forceinline__ void ib_product_group(const float* __restrict__ W, in
     }
 }
 
-template <int KIND>
+// TFEP_DIAG_INVERSE=1 (kind 1 only): cycles of the CONSUMER wave of every pair, summed over the pairs, in
+// [0] products at the head of a block, [1] cache / table initialisation, [2] waiting at a hidden-layer hand-over, [3] hidden dots,
+// [4] waiting at an output hand-over, [5] parameter dot, [6] transformer inverse + stores, [7] whole kernel; [8] = pairs counted
+static __device__ unsigned long long g_ib_cycles[12];
+
+template <int KIND, bool DIAG = false>
 __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArgs sa) {
+    unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_mark = DIAG ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long t_kernel0 = t_mark;
+    auto lap = [&](int slot) __attribute__((always_inline)) {
+        if (DIAG) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            dg[slot] += now - t_mark;
+            t_mark = now;
+        }
+    };
     extern __shared__ float cache_all[];
     const InverseBlockArgs& a = sa.a;
     const int lane = threadIdx.x & 63;
@@ -1076,6 +1096,13 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
     float* const ostg1 = ostg0 + o_floats;
     float* const ozs1 = ozs0 + o_floats;
     const int lds_total = a.lds_floats;
+    // Per-feature table of the current block, filled by the consumer at the head of the block: what the chain used to fetch
+    // from global memory feature by feature, each fetch a dependent round trip on the critical path (index -> y, domain)
+    // -- 3.9 of 76.6 ms per cfg2 layer (probe build without them).  [feature][12]: sel, x column, first input entry, its
+    // xpad column, periodic, x0, xf, y0, yf;  then [feature][16 rows]: y of the pair's rows.
+    float* const ftab = ozs1 + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
+    float* const ytab = ftab + 12 * (size_t)a.max_feats;
+    const SplineArgs& sp0 = KIND == 3 ? a.spg[0] : a.sp;            // (kind 3: every member indexes the same domain arrays)
 
     double ldj_acc = 0.0;
     for (int blk = 0; blk < sa.n_blocks; ++blk) {
@@ -1085,6 +1112,7 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
         const int feat_base = rec[2];
         const int32_t* in_cols = a.in_cols + rec[3];
         __syncthreads();            // the previous block is complete in both waves: its LDS is free, its h / x stores are visible
+        lap(6);
 
         // ---- what earlier blocks of the super-block add to this block's rows, for the pair's own 16 sample rows
         {
@@ -1108,6 +1136,7 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
                 }
             }
         }
+        lap(0);
         float* stg = stg0;
         float* zs = zs0;
         int parity = 0;
@@ -1120,9 +1149,22 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
                 const int n_old = rec[8 + l];
                 for (int j = part; j < n_old; j += 4) cl[j * Q4_ROWS + s] = hr[j];
             }
+            const int n_feat = min(rec[32], a.max_feats);
+            for (int i = lane; i < n_feat; i += 64) {
+                const int fi = feat_base + i;
+                const int sel = a.feat_sel[fi], e0 = a.feat_in[fi];
+                int* ft = reinterpret_cast<int*>(ftab) + 12 * i;
+                ft[0] = sel; ft[1] = a.feat_cols[fi]; ft[2] = e0; ft[3] = in_cols[e0]; ft[4] = a.feat_per[fi];
+                if constexpr (KIND == 1 || KIND == 3) {
+                    ftab[12 * i + 5] = sp0.x0[sel]; ftab[12 * i + 6] = sp0.xf[sel];
+                    ftab[12 * i + 7] = sp0.y0[sel]; ftab[12 * i + 8] = sp0.yf[sel];
+                }
+            }
+            for (int i = part; i < n_feat; i += 4) ytab[i * Q4_ROWS + s] = a.y[r * a.ldy + a.feat_sel[feat_base + i]];
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();            // the products are stored (the loader's stages read them), the cache is initialised
+        lap(1);
         // slabs of the pre-activations: those of the super-block GEMMs, plus the one just written where this block has one
         int z_slabs[IB_MAX_LAYERS];
 #pragma unroll
@@ -1169,18 +1211,23 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
                 const int len = ib_round8(l == 0 ? ke : ke - kb);
                 for (int ub = row0; ub < row0 + n; ub += HROWS) {
                     const int nb = min(HROWS, row0 + n - ub);
+#ifndef TFEP_PROBE_NO_HSTAGE          // (timing probe, wrong results: the chain without the loader's hidden-layer fetches)
                     if (loader) {
                         if (l == 0) stage_gather(stg, gstride, a.w[0], a.ldw[0], ub, nb, in_cols, ke, lane);
                         else stage_rows(stg, gstride, a.w[l], a.ldw[l], ub, 1, nb, kb, ke, lane);
                         stage_z16(zs, a.z[l], a.ldz[l], wave_row0, a.B, ub, 1, nb, z_slabs[l], a.z_slab_stride[l], lane);
                     }
+#endif
+                    lap(6);
                     __syncthreads();
+                    lap(2);
                     if (consumer) {
                         for (int u0 = ub; u0 < ub + nb; u0 += 16)
                             hidden_mfma16(stg, gstride, u0 - ub, zs, act, len, min(16, ub + nb - u0), cl + (size_t)(u0 - c0l) * Q4_ROWS,
                                           h16 + u0, live16, lane);
                         __builtin_amdgcn_wave_barrier();
                     }
+                    lap(3);
                     parity ^= 1;
                     stg = parity ? stg1 : stg0;
                     zs = parity ? zs1 : zs0;
@@ -1188,14 +1235,15 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
             }
             // ---- parameters and transformer inverse of this degree's features
             const int out_row0 = st[4 * IB_MAX_LAYERS], n_d = st[4 * IB_MAX_LAYERS + 1];
-            const int okb = st[4 * IB_MAX_LAYERS + 2], oke = st[4 * IB_MAX_LAYERS + 3], foff = st[4 * IB_MAX_LAYERS + 4] + feat_base;
+            const int okb = st[4 * IB_MAX_LAYERS + 2], oke = st[4 * IB_MAX_LAYERS + 3], floc = st[4 * IB_MAX_LAYERS + 4];
             (void)out_row0;
+            const int* const fti = reinterpret_cast<const int*>(ftab);
             const float* cp = cache + ((size_t)(a.L - 1) * a.cache_len + (okb - rec[4 + a.L - 1])) * Q4_ROWS;
             const int olen = ib_round8(oke - okb);
-            auto emit = [&](int fi, float xv) {
-                const int col = a.feat_cols[fi], e0 = a.feat_in[fi], icol = in_cols[e0];
+            auto emit = [&](int fi, float xv) {                 // fi: the feature's position in the block
+                const int col = fti[12 * fi + 1], e0 = fti[12 * fi + 2], icol = fti[12 * fi + 3];
                 float in0 = xv, in1 = 0.f;
-                const bool per = a.feat_per[fi] != 0;
+                const bool per = fti[12 * fi + 4] != 0;
                 if (per) sincosf((xv - a.emb_lower) * a.emb_scale, &in1, &in0);
                 xc[e0 * Q4_ROWS + s] = in0;
                 if (per) xc[(e0 + 1) * Q4_ROWS + s] = in1;
@@ -1217,13 +1265,13 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
 #pragma unroll
                         for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
                             if (i < dim) {
-                                yv[i] = (double)a.y[r * a.ldy + a.feat_sel[foff + f + i]];
+                                yv[i] = (double)ytab[(floc + f + i) * Q4_ROWS + s];
                                 wv[i] = (double)(-acc[i]);
                             }
                         ldj_acc += moebius_vector(yv, wv, dim, a.mb_max_radius, a.mb_unit_sphere, xv);
 #pragma unroll
                         for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
-                            if (i < dim) emit(foff + f + i, (float)xv[i]);
+                            if (i < dim) emit(floc + f + i, (float)xv[i]);
                         __builtin_amdgcn_wave_barrier();
                     }
                     ++oj;
@@ -1233,15 +1281,18 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
             const int nP = KIND == 3 ? spa.P : a.P;
             for (int f = 0; f < n_d; ++f) {
                 float prm[IB_MAX_P];
+                lap(3);
                 __syncthreads();                                            // output stage oj was filled a feature ago
+                lap(4);
                 if (!consumer) {                     // the loader fetches the NEXT feature's rows beside this one's dot
                     fill_next_out(st_i, f);
                     ++oj;
                     continue;
                 }
                 out_dot_mfma16(prm, (oj & 1) ? ostg1 : ostg0, gstride, (oj & 1) ? ozs1 : ozs0, cp, pb, olen, nP, lane);
-                const int sel = a.feat_sel[foff + f];
-                const float yv = a.y[r * a.ldy + sel];
+                lap(5);
+                const float yv = ytab[(floc + f) * Q4_ROWS + s];
+                const float* const ftf = ftab + 12 * (floc + f);
                 float xv;
                 if constexpr (KIND == 0) {                                  // affine.py:361-363
                     xv = (yv - prm[0]) * expf(-prm[1]);
@@ -1270,15 +1321,19 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
                     if (fl.circular || fl.learn_lower || fl.learn_upper) last = prm[nP - 1];
                     if (fl.learn_lower && fl.learn_upper) last2 = prm[nP - 2];
                     double ld;
-                    xv = (float)rq_spline_element<8, true>(w, hh, sraw, last, last2, fl, spa.x0[sel], spa.xf[sel],
-                                                           spa.y0[sel], spa.yf[sel], yv, &ld);
+#ifdef TFEP_PROBE_NO_SPLINE          // (timing probe, wrong results: the chain without the fp64 spline inverse)
+                    xv = yv * 0.5f + 1e-3f * (w[0] + hh[1] + sraw[2] + last + last2);
+                    ld = 0.0;
+#else
+                    xv = (float)rq_spline_element<8, true>(w, hh, sraw, last, last2, fl, ftf[5], ftf[6], ftf[7], ftf[8], yv, &ld);
+#endif
                     ldj_acc -= ld;
                     }
                 }
-                const int col = a.feat_cols[foff + f];
-                const int e0 = a.feat_in[foff + f], icol = in_cols[e0];
+                const int col = fti[12 * (floc + f) + 1];
+                const int e0 = fti[12 * (floc + f) + 2], icol = fti[12 * (floc + f) + 3];
                 float in0 = xv, in1 = 0.f;
-                const bool per = a.feat_per[foff + f] != 0;
+                const bool per = fti[12 * (floc + f) + 4] != 0;
                 if (per) sincosf((xv - a.emb_lower) * a.emb_scale, &in1, &in0);
                 xc[e0 * Q4_ROWS + s] = in0;
                 if (per) xc[(e0 + 1) * Q4_ROWS + s] = in1;
@@ -1294,6 +1349,13 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
         }
     }
     if (consumer && writer) a.ldj[row] = (float)((double)a.ldj[row] + ldj_acc);
+    if (DIAG && threadIdx.x == 0) {
+        lap(6);
+#pragma unroll
+        for (int i = 0; i < 7; ++i) atomicAdd(&g_ib_cycles[i], dg[i]);
+        atomicAdd(&g_ib_cycles[7], __builtin_readcyclecounter() - t_kernel0);
+        atomicAdd(&g_ib_cycles[8], 1ull);
+    }
 }
 
 }  // namespace tfep
@@ -1304,6 +1366,17 @@ extern "C" {
 
 int tfep_inverse_block_step_ints(void) { return IB_STEP_INTS; }
 int tfep_inverse_block_record_ints(void) { return IB_BLK_INTS; }
+
+/* TFEP_DIAG_INVERSE=1: per-phase cycle totals of the consumer waves of the super-block kernel (kind 1); out[9]; reads and clears. */
+int tfep_diag_inverse_cycles(unsigned long long* out) {
+    TFEP_REQUIRE(out != nullptr, "diag_inverse_cycles: NULL");
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ib_cycles), 9 * sizeof(unsigned long long));
+    if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipMemcpyFromSymbol: %s", hipGetErrorString(e));
+    unsigned long long zero[12] = {};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_ib_cycles), zero, sizeof(zero));
+    if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipMemcpyToSymbol: %s", hipGetErrorString(e));
+    return TFEP_OK;
+}
 
 int64_t tfep_inverse_block_lds_bytes(int n_layers, int cache_len, int max_feats) {
     if (n_layers < 1 || cache_len < 0 || max_feats < 0) return -1;
@@ -1412,10 +1485,11 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
         TFEP_REQUIRE(lds_s <= 160 * 1024, "inverse_block: the pair needs %zu bytes of LDS (> 160 KiB)", lds_s);
         a.lds_floats = (int)(lds_s / sizeof(float));
         sa.a = a;
-        void (*skernel)(InverseSuperArgs) = d->kind == 0 ? inverse_superblock_kernel<0> : d->kind == 1 ? inverse_superblock_kernel<1>
+        static const bool diag = getenv("TFEP_DIAG_INVERSE") != nullptr && atoi(getenv("TFEP_DIAG_INVERSE")) != 0;
+        void (*skernel)(InverseSuperArgs) = d->kind == 0 ? inverse_superblock_kernel<0> : d->kind == 1 ? (diag ? inverse_superblock_kernel<1, true> : inverse_superblock_kernel<1>)
                                             : d->kind == 2 ? inverse_superblock_kernel<2> : inverse_superblock_kernel<3>;
-        static size_t lds_attr_s[4][TFEP_MAX_DEVICES] = {};
-        size_t& attr = lds_attr_s[d->kind][current_device_slot()];
+        static size_t lds_attr_s[5][TFEP_MAX_DEVICES] = {};
+        size_t& attr = lds_attr_s[d->kind == 1 && diag ? 4 : d->kind][current_device_slot()];
         if (lds_s > attr) {
             hipError_t e = hipFuncSetAttribute((const void*)skernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
             if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds_s, hipGetErrorString(e));

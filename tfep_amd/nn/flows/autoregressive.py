@@ -1072,6 +1072,7 @@ class AutoregressiveFlow(torch.nn.Module):
             nf, ni = fb['cols'].numel() - 1, fb['in_cols'].numel() - 1       # (the per-block tables carry one padding entry)
             rec = [0] * n_rec
             rec[0], rec[1], rec[2], rec[3] = fb['n_steps'], n_steps, n_feat, n_in
+            rec[32] = nf                                   # features of the block (the kernel's per-feature LDS table)
             for l in range(L):
                 rec[4 + l], rec[8 + l] = fb['c0'][l], fb['n_old'][l]
             # products at the head of the block: layer 0 from the super-block's earlier input entries, layer l >= 1 from the

@@ -22,4 +22,16 @@ with torch.no_grad():
     for _ in range(N):
         layer.inverse(y)
     torch.cuda.synchronize()
+if os.environ.get('TFEP_DIAG_INVERSE'):
+    import ctypes
+    from tfep_amd import _lib
+    buf = (ctypes.c_ulonglong * 9)()
+    _lib.call('tfep_diag_inverse_cycles', buf)
+    with torch.no_grad():
+        layer.inverse(y)
+    torch.cuda.synchronize()
+    _lib.call('tfep_diag_inverse_cycles', buf)
+    names = ['products', 'block_init', 'wait_hidden', 'hidden_dots', 'wait_output', 'parameter_dot', 'transformer_inverse_and_stores', 'kernel']
+    n = max(1, buf[8])
+    print({k: round(buf[i] / n * 24 / 1e6, 3) for i, k in enumerate(names)}, 'M cycles per pair and inverse (24 launches);', int(buf[8]), 'pair-launches')
 print('ms per inverse', 1e3 * (time.perf_counter() - t0) / N, 'schedule', layer.last_inverse_schedule, 'calls', N + 1)
