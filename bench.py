@@ -175,13 +175,18 @@ def cfg4_i_arm(device, D=512, B=131072, n_layers=4):
         Bi = 16384                                                  # the blocked inverse of the same flow (4 x 512 degrees)
         dti = _clock(lambda: flow.inverse(y[:Bi]), 2, device)
         xi, _ = flow.inverse(y[:Bi])
+        sched = flow[0].last_inverse_schedule
+        dti8 = _clock(lambda: flow.inverse(y[:8192]), 2, device)      # ... and at 8192 rows, where every pair of waves is resident
+        sched8 = flow[0].last_inverse_schedule
     dcirc = (xi - x[:Bi]).abs()
     return {'workload': f'cfg4-i: {n_layers}-layer MAF + circular RQ-8 + periodic embedding, {D} torsions, batch {B}, forward + log|det J|',
             'rows': B, 'ms': 1e3 * dt, 'samples_per_s': B / dt, 'y_in_domain': bool(((y >= 0) & (y <= 1)).all()),
             'roofline': _mfma_roofline(flow, B, dt, 'fused output GEMM + circular spline epilogue'),
-            'inverse': {'rows': Bi, 'ms': 1e3 * dti, 'samples_per_s': Bi / dti,
+            'inverse': {'rows': Bi, 'ms': 1e3 * dti, 'samples_per_s': Bi / dti, 'schedule': sched,
                         'roundtrip_circle_max': float(torch.minimum(dcirc, 1 - dcirc).max()),
-                        'roofline': _mfma_roofline(flow, Bi, dti, 'blocked inverse: one forward of flops; 4 x 512 sequential degrees')}}
+                        'roofline': _mfma_roofline(flow, Bi, dti, 'blocked inverse: one forward of flops; 4 x 512 sequential degrees'),
+                        'at_8192_rows': {'ms': 1e3 * dti8, 'samples_per_s': 8192 / dti8, 'schedule': sched8,
+                                         'roofline': _mfma_roofline(flow, 8192, dti8, 'one launch per super-block (paired 16-row kernel)')}}}
 
 
 def cfg4_ii_arm(device, D=512, B=131072, n_layers=4):

@@ -516,6 +516,11 @@ __global__ void __launch_bounds__(64) inverse_block_kernel(InverseBlockArgs a) {
 // (MFMA accumulation order), i.e. the last bits of an inverse depend on which layout the batch size selects.
 // =====================================================================================================================
 constexpr int Q4_ROWS = 16;
+// floats after a weight stage of the 16-row layouts.  Their dots prefetch one slice ahead of the last one they use: at most 3
+// columns (x 8 rows) past a row group -- values that are never used, they only have to be addresses inside the allocation.
+// (The 64-row kernel's IB_LDS_SLACK of 768 floats was carried over at first: 10 KB per pair, and the difference between one
+// and two resident pairs per CU for cfg4-i.)
+constexpr int Q4_LDS_SLACK = 128;
 constexpr int Q4_Z_PITCH = 24;       // floats per value of the pre-activation stage: 8 values x 8 rows per store instruction, conflict free
 constexpr int IB_FTAB_WORDS = 28;   // super-block kernel: per feature 9 table words (padded to 12) + y of the pair's 16 rows
 constexpr int Q4_P_PITCH = 20;       // floats per parameter of the MFMA hand-over [IB_MAX_P parameters][16 rows + 4]
@@ -527,14 +532,14 @@ __host__ __device__ inline int ib_stage_cols_q4(int cache_len, int max_feats) {
 }
 __host__ __device__ inline size_t ib_lds_floats_q4(int L, int cache_len, int max_feats) {
     return ((size_t)L * ib_round4(cache_len) + ib_round4(max_feats)) * Q4_ROWS + (size_t)IB_STAGE_ROWS * ib_stage_cols_q4(cache_len, max_feats) +
-           IB_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH + (size_t)IB_MAX_P * Q4_P_PITCH;
+           Q4_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH + (size_t)IB_MAX_P * Q4_P_PITCH;
 }
 
 // the paired (loader + consumer) launch: a second weight stage and a second pre-activation stage
 __host__ __device__ inline size_t ib_lds_floats_q4_paired(int L, int cache_len, int max_feats) {
     const size_t cols = ib_stage_cols_q4(cache_len, max_feats);
-    const size_t h = 8 * cols + IB_LDS_SLACK + 8 * (size_t)Q4_Z_PITCH;                                   // hidden-layer stage (8 rows)
-    const size_t o = (size_t)IB_STAGE_ROWS * cols + IB_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;   // output-rows stage
+    const size_t h = 8 * cols + Q4_LDS_SLACK + 8 * (size_t)Q4_Z_PITCH;                                   // hidden-layer stage (8 rows)
+    const size_t o = (size_t)IB_STAGE_ROWS * cols + Q4_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;   // output-rows stage
     // (+ the per-feature table of the super-block kernel: IB_FTAB_WORDS words per feature of a block, see inverse_superblock_kernel)
     return ((size_t)L * ib_round4(cache_len) + ib_round4(max_feats)) * Q4_ROWS + (size_t)IB_MAX_P * Q4_P_PITCH + 2 * h + 2 * o +
            (size_t)IB_FTAB_WORDS * ib_round4(max_feats);
@@ -724,15 +729,15 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
     // FULL stages for the output rows of a feature, alternating per feature -- the loader fills the output stage of the
     // NEXT feature while the consumer works on the current one (the big fill beside the big dot + transformer inverse).
     constexpr int HROWS = PAIR ? 8 : IB_STAGE_ROWS;
-    const size_t h_floats = (size_t)HROWS * (gstride >> 3) + IB_LDS_SLACK + (size_t)HROWS * Q4_Z_PITCH;
-    const size_t o_floats = (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
+    const size_t h_floats = (size_t)HROWS * (gstride >> 3) + Q4_LDS_SLACK + (size_t)HROWS * Q4_Z_PITCH;
+    const size_t o_floats = (size_t)IB_STAGE_ROWS * (gstride >> 3) + Q4_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
     float* const stg0 = xc + (size_t)a.max_feats * Q4_ROWS;
-    float* const zs0 = stg0 + (size_t)HROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* const zs0 = stg0 + (size_t)HROWS * (gstride >> 3) + Q4_LDS_SLACK;
     float* pb = zs0 + (size_t)HROWS * Q4_Z_PITCH;
     float* const stg1 = pb + (size_t)IB_MAX_P * Q4_P_PITCH;                      // PAIR only from here on
-    float* const zs1 = stg1 + (size_t)HROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* const zs1 = stg1 + (size_t)HROWS * (gstride >> 3) + Q4_LDS_SLACK;
     float* const ostg0 = stg0 + (PAIR ? 2 * h_floats + (size_t)IB_MAX_P * Q4_P_PITCH : 0);
-    float* const ozs0 = ostg0 + (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* const ozs0 = ostg0 + (size_t)IB_STAGE_ROWS * (gstride >> 3) + Q4_LDS_SLACK;
     float* const ostg1 = ostg0 + o_floats;
     float* const ozs1 = ozs0 + o_floats;
     const int lds_total = a.lds_floats;                 // (per wave, or per pair: ib_lds_floats_q4 / _paired)
@@ -1084,15 +1089,15 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
     float* xc = cache + (size_t)a.L * a.cache_len * Q4_ROWS;
     const int gstride = a.stage_gstride;
     constexpr int HROWS = 8;
-    const size_t h_floats = (size_t)HROWS * (gstride >> 3) + IB_LDS_SLACK + (size_t)HROWS * Q4_Z_PITCH;
-    const size_t o_floats = (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
+    const size_t h_floats = (size_t)HROWS * (gstride >> 3) + Q4_LDS_SLACK + (size_t)HROWS * Q4_Z_PITCH;
+    const size_t o_floats = (size_t)IB_STAGE_ROWS * (gstride >> 3) + Q4_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
     float* const stg0 = xc + (size_t)a.max_feats * Q4_ROWS;
-    float* const zs0 = stg0 + (size_t)HROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* const zs0 = stg0 + (size_t)HROWS * (gstride >> 3) + Q4_LDS_SLACK;
     float* pb = zs0 + (size_t)HROWS * Q4_Z_PITCH;
     float* const stg1 = pb + (size_t)IB_MAX_P * Q4_P_PITCH;
-    float* const zs1 = stg1 + (size_t)HROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* const zs1 = stg1 + (size_t)HROWS * (gstride >> 3) + Q4_LDS_SLACK;
     float* const ostg0 = stg0 + 2 * h_floats + (size_t)IB_MAX_P * Q4_P_PITCH;
-    float* const ozs0 = ostg0 + (size_t)IB_STAGE_ROWS * (gstride >> 3) + IB_LDS_SLACK;
+    float* const ozs0 = ostg0 + (size_t)IB_STAGE_ROWS * (gstride >> 3) + Q4_LDS_SLACK;
     float* const ostg1 = ostg0 + o_floats;
     float* const ozs1 = ozs0 + o_floats;
     const int lds_total = a.lds_floats;

@@ -631,6 +631,33 @@ class AutoregressiveFlow(torch.nn.Module):
         G0 = max(1, int(os.environ.get('TFEP_INV_BLOCK', self.inverse_block)))
         if batch is not None and G0 >= 4 and 'TFEP_INV_BLOCK' not in os.environ and os.environ.get('TFEP_INV_BLOCK_BY_BATCH', '1') != '0':
             full = self._blocked_plan(device)
+            # Round 4: the PAIRED 16-row kernel (and with it the one-launch-per-super-block schedule) needs every pair of the
+            # call resident at once; its LDS grows with the degrees per block.  Where the full block does not fit twice per
+            # CU but three quarters or half of it do, take the smaller block -- the super-block keeps its span of degrees
+            # (cfg4-i at B = 8192: 85 KB per pair -> one pair per CU -> block by block, 56.2 ms; 12 degrees per block: 44.2).
+            if full['fused'] is not None and n_super > 1 and self.inverse_paired is not False and \
+                    os.environ.get('TFEP_INV_PAIRED', '1') != '0':
+                lib = _lib.load()
+                need = (int(batch) + 15) // 16
+
+                def pairs_resident(bp_):
+                    f_ = bp_['fused']
+                    if f_ is None:
+                        return False
+                    ldsp = int(lib.tfep_inverse_block_lds_bytes_paired(bp_['L'], f_['cache_len'], f_['max_feats']))
+                    return 0 < ldsp <= 160 * 1024 and need <= 256 * min((160 * 1024) // ldsp, 4)
+                if not pairs_resident(full):
+                    for g in (3 * G0 // 4, G0 // 2):
+                        if g < 2 or g == G0:
+                            continue
+                        ns = max(2, int(round(n_super * G0 / g)))
+                        pkey = ('blocked', str(device), g, ns)
+                        cand = self._dev.get(pkey)
+                        if cand is None:
+                            self._plan_n_super = ns
+                            cand = self._dev[pkey] = self._blocked_plan_for(device, g)
+                        if pairs_resident(cand):
+                            return cand
             if full['fused'] is not None and batch <= 16384:
                 lib = _lib.load()
                 need = (int(batch) + 15) // 16
