@@ -537,7 +537,7 @@ def main():
         # dense fp16 peak
         peak = PEAK_F16_MFMA_TFLOPS / 3.0
         kernel = 'split_gemm_kernel<25,EPI_SPLINE> (fused MADE output layer + RQ spline + log-det; 3 x v_mfma_f32_16x16x32_f16 per fp32 product)'
-        tnames = ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_final_pmc_traffic.json')
+        tnames = ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_final_pmc_traffic.json')
     else:
         peak = PEAK_FP32_MFMA_TFLOPS
         kernel = 'gemm_kernel<2,25,EPI_SPLINE> (fused MADE output layer + RQ spline + log-det; v_mfma_f32_16x16x4_f32)'
