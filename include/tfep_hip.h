@@ -467,12 +467,21 @@ typedef struct tfep_inverse_block_desc {
      *   to z_extra[l] / zout_extra (indexed like z[l] / zout) -- what earlier blocks of the same launch produced, i.e. what a
      *   caller of the one-block form supplies through short GEMMs between launches.  kb, ke multiples of 32 for l >= 1;
      *   [32] the number of features of the block (<= max_feats: the kernel keeps their indices, domains and y values in LDS).
+     * waves_per_workgroup = 4 puts TWO pairs into a workgroup (2 x tfep_inverse_block_lds_bytes_paired of LDS): the same chains in
+     * lockstep, the products' weight rows fetched once for both pairs' rows.
      * z_slabs[l] / zout_slabs then count the slabs of z[l] / zout WITHOUT the extra one (added per block when ke > kb);
      * n_steps, cache_col0 and cache_n_old of the descriptor are ignored. */
     int32_t n_blocks;
     const int32_t* blocks;
     float* z_extra[4];
     float* zout_extra;
+    /* optional, super-block launches: the products of layer l = 1 .. n_layers (n_layers = the output layer) on split-f16 operands
+     * -- ws[l]: the layer's split pack (tfep_masked_weight_prepare_split; rows in the order of w[l] / wout, row stride ldws[l]
+     * floats), ws_inv_scale[l]: its 1/scale, h_inv_scale[l] (B): the per-row 1/scale fixed for the panel the layer reads
+     * (h[l - 1]; a power of two, the one its split copy uses).  NULL: exact-fp32 products.  Index 0 is unused (layer 0 reads x). */
+    const void* ws[5]; int64_t ldws[5];
+    const float* ws_inv_scale[5];
+    const float* h_inv_scale[5];
 } tfep_inverse_block_desc;
 int tfep_inverse_block_step_ints(void);
 int tfep_inverse_block_record_ints(void);

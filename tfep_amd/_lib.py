@@ -52,7 +52,8 @@ class InverseBlockDesc(Structure):
                 ('cache_len', c_int32), ('max_feats', c_int32), ('spline', c_void_p),
                 ('moebius_dim', c_int32), ('moebius_unit_sphere', c_int32), ('moebius_max_radius', c_float),
                 ('rows_per_wave', c_int32), ('n_spline_groups', c_int32), ('waves_per_workgroup', c_int32), ('paired', c_int32),
-                ('n_blocks', c_int32), ('blocks', c_void_p), ('z_extra', c_void_p * 4), ('zout_extra', c_void_p)]
+                ('n_blocks', c_int32), ('blocks', c_void_p), ('z_extra', c_void_p * 4), ('zout_extra', c_void_p),
+                ('ws', c_void_p * 5), ('ldws', c_int64 * 5), ('ws_inv_scale', c_void_p * 5), ('h_inv_scale', c_void_p * 5)]
 
 
 class MafLayerDesc(Structure):

@@ -535,14 +535,26 @@ __host__ __device__ inline size_t ib_lds_floats_q4(int L, int cache_len, int max
            Q4_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH + (size_t)IB_MAX_P * Q4_P_PITCH;
 }
 
+// weight stages of the paired layouts, in floats: the fp32 image [row group][column][8 rows], or (super-block kernel, split
+// dots) the split image [k-group][row][32 bytes] + 16 bytes per k-group -- whichever is larger
+__host__ __device__ inline size_t ib_q4_hstage_floats(int cols, int cache_len) {
+    const size_t f = 8 * (size_t)cols, sd = ((size_t)(ib_round8(cache_len) >> 3) * (8 * 32 + 16) + 3) / 4;
+    return f > sd ? f : sd;
+}
+__host__ __device__ inline size_t ib_q4_ostage_floats(int cols, int cache_len) {
+    const size_t f = (size_t)IB_STAGE_ROWS * cols, sd = ((size_t)(ib_round8(cache_len) >> 3) * (IB_STAGE_ROWS * 32 + 16) + 3) / 4;
+    return f > sd ? f : sd;
+}
+constexpr int IB_SCALE_FLOATS = 2 * (IB_MAX_LAYERS + 1) * Q4_ROWS;     // super-block kernel: per-row scales of the split dots
+
 // the paired (loader + consumer) launch: a second weight stage and a second pre-activation stage
 __host__ __device__ inline size_t ib_lds_floats_q4_paired(int L, int cache_len, int max_feats) {
     const size_t cols = ib_stage_cols_q4(cache_len, max_feats);
-    const size_t h = 8 * cols + Q4_LDS_SLACK + 8 * (size_t)Q4_Z_PITCH;                                   // hidden-layer stage (8 rows)
-    const size_t o = (size_t)IB_STAGE_ROWS * cols + Q4_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;   // output-rows stage
-    // (+ the per-feature table of the super-block kernel: IB_FTAB_WORDS words per feature of a block, see inverse_superblock_kernel)
-    return ((size_t)L * ib_round4(cache_len) + ib_round4(max_feats)) * Q4_ROWS + (size_t)IB_MAX_P * Q4_P_PITCH + 2 * h + 2 * o +
-           (size_t)IB_FTAB_WORDS * ib_round4(max_feats);
+    const size_t h = ib_q4_hstage_floats((int)cols, cache_len) + Q4_LDS_SLACK + 8 * (size_t)Q4_Z_PITCH;                  // hidden-layer stage (8 rows)
+    const size_t o = ib_q4_ostage_floats((int)cols, cache_len) + Q4_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;      // output-rows stage
+    // (+ the per-feature table of the super-block kernel: IB_FTAB_WORDS words per feature of a block, and its scale table)
+    return ((size_t)L * ib_round8(cache_len) + ib_round4(max_feats)) * Q4_ROWS + (size_t)IB_MAX_P * Q4_P_PITCH + 2 * h + 2 * o +
+           (size_t)IB_FTAB_WORDS * ib_round4(max_feats) + IB_SCALE_FLOATS;
 }
 
 // zs[v * Q4_Z_PITCH + i] = sum_s z[s * slab_stride + (wave_row0 + i) * ldz + base + v * vstride],  v < nv <= 32, i < 16
@@ -966,6 +978,7 @@ __global__ void __launch_bounds__(512) inverse_block_q4_kernel(InverseBlockArgs 
 // Same-workgroup visibility of the stores (h, xpad, z_extra) across the block boundary: __syncthreads().
 // =====================================================================================================================
 constexpr int IB_BLK_INTS = 36;      // per-block record: [n_steps, steps_off, feat_off, in_off, c0[4], n_old[4], (row0, n, kb, ke) x 5 layers, n_feats, pad]
+constexpr int IB_PROD_DEPTH = 3;     // 32-column steps of the split products in flight
 constexpr int IB_PROD_TILES = 5;     // 16-unit tiles that share a fetch of the activations
 
 struct InverseSuperArgs {
@@ -974,22 +987,36 @@ struct InverseSuperArgs {
     const int32_t* blocks;
     float* z_extra[IB_MAX_LAYERS];      // slab written by the in-kernel products (same indexing as a.z[l]: by packed row)
     float* zout_extra;
+    // optional (all or none, layers 1 .. L; index L = the output layer): the split-f16 pack of the layer's weights (its rows in
+    // the order of w[l] / wout), its 1/scale, and the per-row 1/scale fixed for the panel the layer READS (h[l - 1]) -- the
+    // products then run as 3 x v_mfma_f32_16x16x32_f16 per 32 columns instead of 8 x v_mfma_f32_16x16x4_f32
+    const float* ws[IB_MAX_LAYERS + 1]; int64_t ldws[IB_MAX_LAYERS + 1];
+    const float* ws_inv[IB_MAX_LAYERS + 1];
+    const float* hs_inv[IB_MAX_LAYERS + 1];
 };
 
-// One group of up to IB_PROD_TILES 16-row tiles of W (rows row0 + 16 t .. ) against the wave's 16 sample rows:
-//   dst[(wave_row0 + j) * ldd + row0 + u] = sum_{k in [kb, ke)} W[row0 + u][k] src[(wave_row0 + j)][k]        (GATHER: k -> cols[k])
+// One group of up to IB_PROD_TILES 16-row tiles of W (rows row0 + 16 t .. ) against NSETS sets of 16 sample rows (the pairs of
+// the workgroup: rows row_base + 16 s + j) -- one fetch of the weights serves every set:
+//   dst[(row_base + 16 s + j) * ldd + row0 + u] = sum_{k in [kb, ke)} W[row0 + u][k] src[row_base + 16 s + j][k]      (GATHER: k -> cols[k])
 // kb, ke multiples of 16 unless GATHER (entries past ke read as zero).
-template <bool GATHER>
+template <bool GATHER, int NSETS>
 __device__ __forceinline__ void ib_product_group(const float* __restrict__ W, int64_t ldw, int row0, int n_rows, int ntiles,
                                                  const float* __restrict__ src, int64_t lds_, int kb, int ke,
                                                  const int32_t* __restrict__ cols, float* __restrict__ dst, int64_t ldd,
-                                                 int wave_row0, int B, int lane) {
+                                                 int row_base, int B, int lane) {
     const int u = lane & 15, kq = lane >> 4;
-    const bool live = wave_row0 + u < B;
-    const float* srow = src + (int64_t)(live ? wave_row0 + u : 0) * lds_;
-    ib_f4 acc[IB_PROD_TILES];
+    bool live[NSETS];
+    const float* srow[NSETS];
 #pragma unroll
-    for (int t = 0; t < IB_PROD_TILES; ++t) acc[t] = ib_f4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < NSETS; ++s) {
+        live[s] = row_base + 16 * s + u < B;
+        srow[s] = src + (int64_t)(live[s] ? row_base + 16 * s + u : 0) * lds_;
+    }
+    ib_f4 acc[NSETS][IB_PROD_TILES];
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s)
+#pragma unroll
+        for (int t = 0; t < IB_PROD_TILES; ++t) acc[s][t] = ib_f4{0.f, 0.f, 0.f, 0.f};
     const float* wrow[IB_PROD_TILES];
     bool won[IB_PROD_TILES];
 #pragma unroll
@@ -998,41 +1025,47 @@ __device__ __forceinline__ void ib_product_group(const float* __restrict__ W, in
         won[t] = t < ntiles && r < n_rows;
         wrow[t] = W + (int64_t)(row0 + (won[t] ? r : 0)) * ldw;
     }
-    auto fetch = [&](ib_f4 (&wa)[IB_PROD_TILES], ib_f4& xb, int k) __attribute__((always_inline)) {
+    auto fetch = [&](ib_f4 (&wa)[IB_PROD_TILES], ib_f4 (&xb)[NSETS], int k) __attribute__((always_inline)) {
         if constexpr (GATHER) {
             int c[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) c[j] = k + 4 * kq + j < ke ? cols[k + 4 * kq + j] : -1;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xb[j] = c[j] >= 0 ? srow[c[j]] : 0.f;
+            for (int s = 0; s < NSETS; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xb[s][j] = c[j] >= 0 ? srow[s][c[j]] : 0.f;
 #pragma unroll
             for (int t = 0; t < IB_PROD_TILES; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) wa[t][j] = (won[t] && c[j] >= 0) ? wrow[t][c[j]] : 0.f;
         } else {
-            xb = *(const ib_f4_alias*)(srow + k + 4 * kq);
+#pragma unroll
+            for (int s = 0; s < NSETS; ++s) xb[s] = *(const ib_f4_alias*)(srow[s] + k + 4 * kq);
 #pragma unroll
             for (int t = 0; t < IB_PROD_TILES; ++t)
                 wa[t] = won[t] ? *(const ib_f4_alias*)(wrow[t] + k + 4 * kq) : ib_f4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto multiply = [&](const ib_f4 (&wa)[IB_PROD_TILES], const ib_f4& xb) __attribute__((always_inline)) {
+    auto multiply = [&](const ib_f4 (&wa)[IB_PROD_TILES], const ib_f4 (&xb)[NSETS]) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < IB_PROD_TILES; ++t)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t][j], xb[j], acc[t], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int s = 0; s < NSETS; ++s) acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[t][j], xb[s][j], acc[s][t], 0, 0, 0);
     };
     // two 16-column steps per pass, the next pass' loads issued before this pass' products
-    ib_f4 wa0[IB_PROD_TILES], wa1[IB_PROD_TILES], xb0, xb1;
+    ib_f4 wa0[IB_PROD_TILES], wa1[IB_PROD_TILES], xb0[NSETS], xb1[NSETS];
     if (kb < ke) {
         fetch(wa0, xb0, kb);
         fetch(wa1, xb1, kb + 16);                                 // (past ke: GATHER reads zeros; else ke - kb is a multiple of 32)
     }
     for (int k = kb; k < ke; k += 32) {
-        ib_f4 wc0[IB_PROD_TILES], wc1[IB_PROD_TILES];
+        ib_f4 wc0[IB_PROD_TILES], wc1[IB_PROD_TILES], xc0[NSETS], xc1[NSETS];
 #pragma unroll
         for (int t = 0; t < IB_PROD_TILES; ++t) { wc0[t] = wa0[t]; wc1[t] = wa1[t]; }
-        const ib_f4 xc0 = xb0, xc1 = xb1;
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s) { xc0[s] = xb0[s]; xc1[s] = xb1[s]; }
         if (k + 32 < ke) {
             fetch(wa0, xb0, k + 32);
             fetch(wa1, xb1, k + 48);
@@ -1041,17 +1074,318 @@ __device__ __forceinline__ void ib_product_group(const float* __restrict__ W, in
         multiply(wc1, xc1);
     }
     // D: register r of lane l = unit 4 (l / 16) + r of the tile, sample row l % 16
-    if (live) {
-        float* drow = dst + (int64_t)(wave_row0 + u) * ldd + row0;
 #pragma unroll
-        for (int t = 0; t < IB_PROD_TILES; ++t)
-            if (t < ntiles) {
-                const int r0 = t * 16 + 4 * kq;
+    for (int s = 0; s < NSETS; ++s)
+        if (live[s]) {
+            float* drow = dst + (int64_t)(row_base + 16 * s + u) * ldd + row0;
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (r0 + r < n_rows) drow[r0 + r] = acc[t][r];
+            for (int t = 0; t < IB_PROD_TILES; ++t)
+                if (t < ntiles) {
+                    const int r0 = t * 16 + 4 * kq;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r0 + r < n_rows) drow[r0 + r] = acc[s][t][r];
+                }
+        }
+}
+
+typedef _Float16 ib_h8 __attribute__((ext_vector_type(8)));
+
+// The same products on split-f16 operands (csrc/split_gemm.hip: v s = hi + lo in fp16, hi hi + lo hi + hi lo on
+// v_mfma_f32_16x16x32_f16, fp32 accumulate): the weights from the layer's split pack (32 contiguous bytes per lane and 8 columns:
+// the bytes of the fp32 form), the activations converted in registers with the row scale the split copy of the panel uses
+// (split_columns_scaled_kernel's arithmetic).  A = weights (unit l % 16, columns 8 (l / 16) .. + 7), B = activations, D as in
+// the fp32 form.  kb, ke multiples of 32.
+template <int NSETS>
+__device__ __forceinline__ void ib_product_group_split(const float* __restrict__ Ws, int64_t ldws, float w_inv, int row0, int n_rows,
+                                                       int ntiles, const float* __restrict__ src, int64_t lds_,
+                                                       const float* __restrict__ src_inv, int kb, int ke, float* __restrict__ dst,
+                                                       int64_t ldd, int row_base, int B, int lane) {
+    const int u = lane & 15, kg = lane >> 4;
+    bool live[NSETS];
+    const float* srow[NSETS];
+    float sc[NSETS], unsc[NSETS];
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s) {
+        live[s] = row_base + 16 * s + u < B;
+        const int64_t rr = live[s] ? row_base + 16 * s + u : 0;
+        srow[s] = src + rr * lds_;
+        const float inv = src_inv[rr];
+        sc[s] = 1.0f / inv;
+        unsc[s] = inv * w_inv;
+    }
+    ib_f4 acc[NSETS][IB_PROD_TILES];
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s)
+#pragma unroll
+        for (int t = 0; t < IB_PROD_TILES; ++t) acc[s][t] = ib_f4{0.f, 0.f, 0.f, 0.f};
+    const float* wrow[IB_PROD_TILES];
+    bool won[IB_PROD_TILES];
+#pragma unroll
+    for (int t = 0; t < IB_PROD_TILES; ++t) {
+        const int r = t * 16 + u;
+        won[t] = t < ntiles && r < n_rows;
+        wrow[t] = Ws + (int64_t)(row0 + (won[t] ? r : 0)) * ldws;
+    }
+    struct Step { ib_f4 wh[IB_PROD_TILES], wl[IB_PROD_TILES], x0[NSETS], x1[NSETS]; };
+    auto fetch = [&](Step& st, int k) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s) {
+            st.x0[s] = *(const ib_f4_alias*)(srow[s] + k + 8 * kg);
+            st.x1[s] = *(const ib_f4_alias*)(srow[s] + k + 8 * kg + 4);
+        }
+#pragma unroll
+        for (int t = 0; t < IB_PROD_TILES; ++t) {
+            st.wh[t] = won[t] ? *(const ib_f4_alias*)(wrow[t] + k + 8 * kg) : ib_f4{0.f, 0.f, 0.f, 0.f};           // 8 hi halves
+            st.wl[t] = won[t] ? *(const ib_f4_alias*)(wrow[t] + k + 8 * kg + 4) : ib_f4{0.f, 0.f, 0.f, 0.f};       // 8 lo halves
+        }
+    };
+    auto multiply = [&](const Step& st) __attribute__((always_inline)) {
+        ib_h8 xh[NSETS], xl[NSETS];
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s) {
+            const float v[8] = {st.x0[s][0], st.x0[s][1], st.x0[s][2], st.x0[s][3], st.x1[s][0], st.x1[s][1], st.x1[s][2], st.x1[s][3]};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = v[j] * sc[s];
+                const _Float16 h = (_Float16)t;
+                xh[s][j] = h;
+                xl[s][j] = (_Float16)(t - (float)h);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < IB_PROD_TILES; ++t) {
+            const ib_h8 wh = __builtin_bit_cast(ib_h8, st.wh[t]), wl = __builtin_bit_cast(ib_h8, st.wl[t]);
+#pragma unroll
+            for (int s = 0; s < NSETS; ++s) {
+                acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh[s], acc[s][t], 0, 0, 0);
+                acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh[s], acc[s][t], 0, 0, 0);
+                acc[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl[s], acc[s][t], 0, 0, 0);
+            }
+        }
+    };
+    // one 32-column step per pass, IB_PROD_DEPTH passes in flight: a pass is ~500 cycles of matrix products, a fetch from L2
+    // ~2 000 -- with two in flight the phase waited for its loads (the fp32 and the split form took the same time)
+    Step ring[IB_PROD_DEPTH];
+#pragma unroll
+    for (int d = 0; d < IB_PROD_DEPTH; ++d)
+        if (kb + 32 * d < ke) fetch(ring[d], kb + 32 * d);
+    for (int k = kb; k < ke; k += 32 * IB_PROD_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < IB_PROD_DEPTH; ++d)
+            if (k + 32 * d < ke) {
+                const Step cur = ring[d];
+                if (k + 32 * (d + IB_PROD_DEPTH) < ke) fetch(ring[d], k + 32 * (d + IB_PROD_DEPTH));
+                multiply(cur);
             }
     }
+#pragma unroll
+    for (int s = 0; s < NSETS; ++s)
+        if (live[s]) {
+            float* drow = dst + (int64_t)(row_base + 16 * s + u) * ldd + row0;
+#pragma unroll
+            for (int t = 0; t < IB_PROD_TILES; ++t)
+                if (t < ntiles) {
+                    const int r0 = t * 16 + 4 * kg;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r0 + r < n_rows) drow[r0 + r] = acc[s][t][r] * unsc[s];
+                }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// SPLIT DOTS (round 4): the dots of the chain itself on split-f16 operands.  A degree's chain is three short dots and the
+// transformer inverse, strictly one after the other; as exact-fp32 products (v_mfma_f32_16x16x4_f32: 32 cycles per 4 columns,
+// one 4-byte LDS read per lane, operand and step) the two dots over hidden units were 40 % of it.  On split operands a dot
+// takes 3 x v_mfma_f32_16x16x32_f16 (48 cycles) and four 16-byte LDS reads per 32 columns.  The layer-0 dot (the block's own
+// inputs, gathered columns of the fp32 pack) stays as it was.
+//   activations of layers 0 .. L - 1 in LDS as split halves, [k-group of 8][sample row 16][32 bytes: 8 hi, 8 lo], with the per-row
+//     scale of the panel's split copy (the bound-based one of the block GEMMs);
+//   weight stages [k-group][row][32 bytes] from the layer's split pack; a k-group block is padded by 16 bytes (the loader writes
+//     consecutive k-groups of a row from consecutive lanes);
+//   in both, rows 4 q .. 4 q + 3 with odd q hold (lo, hi) instead of (hi, lo): the 16 rows of a k-group then spread a 16-byte
+//     read over all banks twice, the minimum.
+// Arithmetic: fp32-equivalent like the block GEMMs and the forward pass (2^-22 of the row's bound), not bit-identical to the
+// exact-fp32 dots of the one-block kernels.
+// ---------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline int sd_group_bytes(int rows) { return rows * 32 + 16; }
+__device__ __forceinline__ int sd_hi_off(int row) { return row * 32 + (((row >> 2) & 1) ? 16 : 0); }
+__device__ __forceinline__ int sd_lo_off(int row) { return row * 32 + (((row >> 2) & 1) ? 0 : 16); }
+
+// stage rows r < nrows (packed rows row0 + r * row_stride of the split pack ws), k-groups of columns [kb, ke) (kb a multiple of 8)
+__device__ __forceinline__ void stage_rows_split(char* __restrict__ st, int R, const float* __restrict__ ws, int64_t ldws, int row0,
+                                                 int row_stride, int nrows, int kb, int ke, int lane) {
+    const int ng = (ke - kb + 7) >> 3;
+    const int gb = sd_group_bytes(R);
+    const int total = nrows * ng;
+    for (int i0 = 0; i0 < total; i0 += 128) {
+        ib_f4 hi[2], lo[2];
+        int rr[2], gg[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int i = i0 + 64 * t + lane;
+            rr[t] = i < total ? i / ng : -1;
+            gg[t] = i - (rr[t] < 0 ? 0 : rr[t]) * ng;
+            if (rr[t] >= 0) {
+                const float* src = ws + (int64_t)(row0 + rr[t] * row_stride) * ldws + kb + 8 * gg[t];
+                hi[t] = *(const ib_f4_alias*)src;
+                lo[t] = *(const ib_f4_alias*)(src + 4);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+            if (rr[t] >= 0) {
+                *(ib_f4_alias*)(st + gg[t] * gb + sd_hi_off(rr[t])) = hi[t];
+                *(ib_f4_alias*)(st + gg[t] * gb + sd_lo_off(rr[t])) = lo[t];
+            }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// value `hv` of unit k (position in the layer's cache) for sample row `row`, scaled, into the split activation cache
+__device__ __forceinline__ void sd_store_act(char* __restrict__ act, int k, int row, float hv, float scale) {
+    const float t = hv * scale;
+    const _Float16 h = (_Float16)t;
+    const _Float16 l = (_Float16)(t - (float)h);
+    char* g = act + (size_t)(k >> 3) * (16 * 32);
+    *reinterpret_cast<_Float16*>(g + sd_hi_off(row) + 2 * (k & 7)) = h;
+    *reinterpret_cast<_Float16*>(g + sd_lo_off(row) + 2 * (k & 7)) = l;
+}
+
+// ELU of the nu <= 16 units of a tile held in the MFMA accumulator layout (register r of lane l = unit 4 (l / 16) + r, sample row
+// l % 16), stored to the fp32 panel in global memory and to the split cache of the layer
+__device__ __forceinline__ void sd_finish_hidden(const ib_f4& d, int nu, int k0, char* __restrict__ act_out, float scale_out,
+                                                 float* __restrict__ h_u0, bool live16, int lane) {
+    const int col = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int u = 4 * kq + r;
+        if (u < nu) {
+            const float hv = elu_ib(d[r]);
+            sd_store_act(act_out, k0 + u, col, hv, scale_out);
+            if (live16) h_u0[u] = hv;
+        }
+    }
+}
+
+// layer 0: the fp32 dot of hidden_mfma16 (gathered inputs), its result into the split cache
+__device__ __forceinline__ void hidden_mfma16_l0_sd(const float* __restrict__ stg, int gstride, int ug, const float* __restrict__ zs,
+                                                    const float* __restrict__ act, int len, int nu, int k0, char* __restrict__ act_out,
+                                                    float scale_out, float* __restrict__ h_u0, bool live16, int lane) {
+    const int col = lane & 15, kq = lane >> 4;
+    ib_f4 d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = 4 * kq + r < nu ? zs[(ug + 4 * kq + r) * Q4_Z_PITCH + col] : 0.f;
+    const int srow = ug + col;
+    const float* wp = stg + (srow >> 3) * gstride + kq * 8 + (srow & 7);
+    const float* ap = act + kq * Q4_ROWS + col;
+    const bool on = col < nu;
+    float w[2], b[2];
+    auto load = [&](int k) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            w[q] = on ? wp[(k + 4 * q) * 8] : 0.f;
+            b[q] = ap[(k + 4 * q) * Q4_ROWS];
+        }
+    };
+    load(0);
+    for (int k = 0; k < len; k += 8) {
+        float wc[2], bc[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { wc[q] = w[q]; bc[q] = b[q]; }
+        load(k + 8);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wc[q], bc[q], d, 0, 0, 0);
+    }
+    sd_finish_hidden(d, nu, k0, act_out, scale_out, h_u0, live16, lane);
+}
+
+// D[unit][sample row] = sum over the k-groups [0, ng) of stage rows `srow` x the split activations; 3 MFMAs per 32 columns
+__device__ __forceinline__ ib_f4 sd_dot(const char* __restrict__ stg, int gb, int srow, bool row_on, const char* __restrict__ act, int ng,
+                                        int lane) {
+    const int col = lane & 15, kg = lane >> 4;
+    const int a_hi = sd_hi_off(srow), a_lo = sd_lo_off(srow), b_hi = sd_hi_off(col), b_lo = sd_lo_off(col);
+    const ib_h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    ib_f4 d = ib_f4{0.f, 0.f, 0.f, 0.f};
+    ib_h8 ah, al, bh, bl;
+    auto load = [&](int g0) {
+        const int G = g0 + kg;
+        const bool v = G < ng;
+        ah = (v && row_on) ? *(const ib_h8*)(stg + G * gb + a_hi) : zero;
+        al = (v && row_on) ? *(const ib_h8*)(stg + G * gb + a_lo) : zero;
+        bh = v ? *(const ib_h8*)(act + G * (16 * 32) + b_hi) : zero;
+        bl = v ? *(const ib_h8*)(act + G * (16 * 32) + b_lo) : zero;
+    };
+    load(0);
+    for (int g0 = 0; g0 < ng; g0 += 4) {
+        const ib_h8 cah = ah, cal = al, cbh = bh, cbl = bl;
+        load(g0 + 4);                                   // (past ng: zeros, no LDS access)
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(cah, cbh, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(cal, cbh, d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(cah, cbl, d, 0, 0, 0);
+    }
+    return d;
+}
+
+// hidden units of a layer l >= 1: stage rows ug .. ug + nu of the split stage against the split cache of layer l - 1
+__device__ __forceinline__ void hidden_mfma16_sd(const char* __restrict__ stg, int gb, int ug, const float* __restrict__ zs,
+                                                 const char* __restrict__ act, int ng, int nu, float unscale, int k0,
+                                                 char* __restrict__ act_out, float scale_out, float* __restrict__ h_u0, bool live16,
+                                                 int lane) {
+    const int col = lane & 15, kq = lane >> 4;
+    ib_f4 d = sd_dot(stg, gb, ug + col, col < nu, act, ng, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] = 4 * kq + r < nu ? fmaf(d[r], unscale, zs[(ug + 4 * kq + r) * Q4_Z_PITCH + col]) : 0.f;
+    sd_finish_hidden(d, nu, k0, act_out, scale_out, h_u0, live16, lane);
+}
+
+// the P <= 32 parameters of a feature (out_dot_mfma16 on split operands): two tiles, then through LDS to the rows' lanes
+__device__ __forceinline__ void out_dot_mfma16_sd(float (&prm)[IB_MAX_P], const char* __restrict__ stg, int gb, const float* __restrict__ zso,
+                                                  const char* __restrict__ act, float* __restrict__ pb, int ng, int P, float unscale,
+                                                  int lane) {
+    const int col = lane & 15, kq = lane >> 4;
+    ib_f4 d0 = ib_f4{0.f, 0.f, 0.f, 0.f}, d1 = ib_f4{0.f, 0.f, 0.f, 0.f};
+    {
+        const int kg = kq;
+        const int a0_hi = sd_hi_off(col), a0_lo = sd_lo_off(col), a1_hi = sd_hi_off(16 + col), a1_lo = sd_lo_off(16 + col);
+        const int b_hi = sd_hi_off(col), b_lo = sd_lo_off(col);
+        const bool on0 = col < P, on1 = 16 + col < P, two = P > 16;
+        const ib_h8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        ib_h8 a0h, a0l, a1h, a1l, bh, bl;
+        auto load = [&](int g0) {
+            const int G = g0 + kg;
+            const bool v = G < ng;
+            a0h = (v && on0) ? *(const ib_h8*)(stg + G * gb + a0_hi) : zero;
+            a0l = (v && on0) ? *(const ib_h8*)(stg + G * gb + a0_lo) : zero;
+            a1h = (v && on1) ? *(const ib_h8*)(stg + G * gb + a1_hi) : zero;
+            a1l = (v && on1) ? *(const ib_h8*)(stg + G * gb + a1_lo) : zero;
+            bh = v ? *(const ib_h8*)(act + G * (16 * 32) + b_hi) : zero;
+            bl = v ? *(const ib_h8*)(act + G * (16 * 32) + b_lo) : zero;
+        };
+        load(0);
+        for (int g0 = 0; g0 < ng; g0 += 4) {
+            const ib_h8 c0h = a0h, c0l = a0l, c1h = a1h, c1l = a1l, cbh = bh, cbl = bl;
+            load(g0 + 4);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0h, cbh, d0, 0, 0, 0);
+            if (two) d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1h, cbh, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0l, cbh, d0, 0, 0, 0);
+            if (two) d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1l, cbh, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c0h, cbl, d0, 0, 0, 0);
+            if (two) d1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1h, cbl, d1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = 4 * kq + r;
+        pb[m * Q4_P_PITCH + col] = m < P ? fmaf(d0[r], unscale, zso[m * Q4_Z_PITCH + col]) : 0.f;
+        pb[(16 + m) * Q4_P_PITCH + col] = 16 + m < P ? fmaf(d1[r], unscale, zso[(16 + m) * Q4_Z_PITCH + col]) : 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int s = lane >> 2;
+#pragma unroll
+    for (int m = 0; m < IB_MAX_P; ++m) prm[m] = m < P ? pb[m * Q4_P_PITCH + s] : 0.f;
+    __builtin_amdgcn_wave_barrier();
 }
 
 // TFEP_DIAG_INVERSE=1 (kind 1 only): cycles of the CONSUMER wave of every pair, summed over the pairs, in
@@ -1059,8 +1393,12 @@ __device__ __forceinline__ void ib_product_group(const float* __restrict__ W, in
 // [4] waiting at an output hand-over, [5] parameter dot, [6] transformer inverse + stores, [7] whole kernel; [8] = pairs counted
 static __device__ unsigned long long g_ib_cycles[12];
 
-template <int KIND, bool DIAG = false>
-__global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArgs sa) {
+// PAIRS = 2: two pairs per workgroup (4 waves, each pair its own LDS region and its own 16 rows).  The chain of a pair is what it was;
+// the hand-overs are workgroup barriers, so the two pairs move in lockstep -- they run the same records on different rows -- and
+// the PRODUCTS at the head of a block are dealt over the four waves, every wave multiplying its tiles with BOTH row sets: the
+// weight rows, the 60 GB per inverse that bound that phase (every pair read them all), are fetched once per workgroup.
+template <int KIND, bool DIAG = false, int PAIRS = 1, bool SD = false>
+__global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(InverseSuperArgs sa) {
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_mark = DIAG ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long t_kernel0 = t_mark;
@@ -1075,40 +1413,55 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
     const InverseBlockArgs& a = sa.a;
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = threadIdx.x >> 6;
-    const bool consumer = wave_in_wg == 0, loader = wave_in_wg == 1;
-    float* const cache = cache_all;
+    const int pair = wave_in_wg >> 1;
+    const bool consumer = (wave_in_wg & 1) == 0, loader = !consumer;
+    float* const cache = cache_all + (size_t)pair * a.lds_floats;
     const int s = lane >> 2, part = lane & 3;
-    const int wave_row0 = (int)blockIdx.x * Q4_ROWS;
-    if (wave_row0 >= a.B) return;                  // (both waves of a pair alike)
+    const int wg_row0 = (int)blockIdx.x * PAIRS * Q4_ROWS;
+    if (wg_row0 >= a.B) return;                    // (the whole workgroup alike)
+    // a pair past the end of the batch (an odd number of pairs) keeps walking -- every barrier needs it -- on row 0, storing nothing
+    const int wave_row0 = wg_row0 + pair * Q4_ROWS;
     const int row = wave_row0 + s;
     const bool live = row < a.B;
     const bool writer = live && part == 0;
     const int64_t r = live ? row : 0;
     const bool live16 = wave_row0 + (lane & 15) < a.B;
     const int64_t r16 = live16 ? wave_row0 + (lane & 15) : 0;
-    float* xc = cache + (size_t)a.L * a.cache_len * Q4_ROWS;
+    float* xc = cache + (size_t)a.L * a.cache_len * Q4_ROWS;            // (a.cache_len: a multiple of 8 here)
     const int gstride = a.stage_gstride;
     constexpr int HROWS = 8;
-    const size_t h_floats = (size_t)HROWS * (gstride >> 3) + Q4_LDS_SLACK + (size_t)HROWS * Q4_Z_PITCH;
-    const size_t o_floats = (size_t)IB_STAGE_ROWS * (gstride >> 3) + Q4_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
+    const size_t hst = ib_q4_hstage_floats(gstride >> 3, a.cache_len), ost = ib_q4_ostage_floats(gstride >> 3, a.cache_len);
+    const size_t h_floats = hst + Q4_LDS_SLACK + (size_t)HROWS * Q4_Z_PITCH;
+    const size_t o_floats = ost + Q4_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
     float* const stg0 = xc + (size_t)a.max_feats * Q4_ROWS;
-    float* const zs0 = stg0 + (size_t)HROWS * (gstride >> 3) + Q4_LDS_SLACK;
+    float* const zs0 = stg0 + hst + Q4_LDS_SLACK;
     float* pb = zs0 + (size_t)HROWS * Q4_Z_PITCH;
     float* const stg1 = pb + (size_t)IB_MAX_P * Q4_P_PITCH;
-    float* const zs1 = stg1 + (size_t)HROWS * (gstride >> 3) + Q4_LDS_SLACK;
+    float* const zs1 = stg1 + hst + Q4_LDS_SLACK;
     float* const ostg0 = stg0 + 2 * h_floats + (size_t)IB_MAX_P * Q4_P_PITCH;
-    float* const ozs0 = ostg0 + (size_t)IB_STAGE_ROWS * (gstride >> 3) + Q4_LDS_SLACK;
+    float* const ozs0 = ostg0 + ost + Q4_LDS_SLACK;
     float* const ostg1 = ostg0 + o_floats;
     float* const ozs1 = ozs0 + o_floats;
     const int lds_total = a.lds_floats;
+    // SD (split dots): the activation caches as split halves (same bytes: 64 per unit), byte views of the stages
+    char* const cache_b = reinterpret_cast<char*>(cache);
+    const int layer_bytes = a.cache_len * Q4_ROWS * 4;
+    constexpr int gb_h = HROWS * 32 + 16, gb_o = IB_STAGE_ROWS * 32 + 16;
     // Per-feature table of the current block, filled by the consumer at the head of the block: what the chain used to fetch
     // from global memory feature by feature, each fetch a dependent round trip on the critical path (index -> y, domain)
     // -- 3.9 of 76.6 ms per cfg2 layer (probe build without them).  [feature][12]: sel, x column, first input entry, its
     // xpad column, periodic, x0, xf, y0, yf;  then [feature][16 rows]: y of the pair's rows.
     float* const ftab = ozs1 + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;
     float* const ytab = ftab + 12 * (size_t)a.max_feats;
+    // SD: [l][16] the un-scaling of layer l's dot (1/scale of the rows of its input panel x 1/scale of its weights), then
+    // [L + 1 + l][16] the scale of the split halves of layer l's OUTPUT (the panel layer l + 1 reads), per sample row of the pair
+    float* const scl = ytab + (size_t)a.max_feats * Q4_ROWS;
     const SplineArgs& sp0 = KIND == 3 ? a.spg[0] : a.sp;            // (kind 3: every member indexes the same domain arrays)
 
+    // The hand-over of a stage inside the chain.  (__syncthreads() drains the wave's vector-memory counter too, so the consumer
+    // waits at every hand-over for the global stores it has just issued; a consumer-side barrier that waits for LDS only measured
+    // the same -- 71.1 / 71.0 ms, same box, alternating -- as it did on the one-block kernel in round 3.)
+    auto handover = [&]() __attribute__((always_inline)) { __syncthreads(); };
     double ldj_acc = 0.0;
     for (int blk = 0; blk < sa.n_blocks; ++blk) {
         const int32_t* rec = sa.blocks + (size_t)blk * IB_BLK_INTS;
@@ -1130,14 +1483,17 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
                 float* dst = l < a.L ? sa.z_extra[l] : sa.zout_extra;
                 const int64_t ldd = l < a.L ? a.ldz[l] : a.ldzout;
                 for (int t0 = 0; t0 < n_rows; t0 += 16 * IB_PROD_TILES, ++g) {
-                    if ((g & 1) != wave_in_wg) continue;
+                    if (g % (2 * PAIRS) != wave_in_wg) continue;
                     const int nr = min(n_rows - t0, 16 * IB_PROD_TILES);
                     if (l == 0)
-                        ib_product_group<true>(W, ldw, row0 + t0, nr, (nr + 15) >> 4, a.xpad, a.ldxpad, kb, ke, a.in_cols, dst, ldd, wave_row0,
-                                               a.B, lane);
+                        ib_product_group<true, PAIRS>(W, ldw, row0 + t0, nr, (nr + 15) >> 4, a.xpad, a.ldxpad, kb, ke, a.in_cols, dst, ldd,
+                                                      wg_row0, a.B, lane);
+                    else if (sa.ws[l] != nullptr)
+                        ib_product_group_split<PAIRS>(sa.ws[l], sa.ldws[l], sa.ws_inv[l][0], row0 + t0, nr, (nr + 15) >> 4, a.h[l - 1],
+                                                      a.ldh[l - 1], sa.hs_inv[l], kb, ke, dst, ldd, wg_row0, a.B, lane);
                     else
-                        ib_product_group<false>(W, ldw, row0 + t0, nr, (nr + 15) >> 4, a.h[l - 1], a.ldh[l - 1], kb, ke, nullptr, dst, ldd,
-                                                wave_row0, a.B, lane);
+                        ib_product_group<false, PAIRS>(W, ldw, row0 + t0, nr, (nr + 15) >> 4, a.h[l - 1], a.ldh[l - 1], kb, ke, nullptr, dst,
+                                                       ldd, wg_row0, a.B, lane);
                 }
             }
         }
@@ -1148,11 +1504,25 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
         if (consumer) {
             for (int j = lane * 4; j < lds_total; j += 256) *(ib_f4_alias*)(cache + j) = ib_f4{0.f, 0.f, 0.f, 0.f};
             __builtin_amdgcn_wave_barrier();
+            if constexpr (SD) {
+                if (lane < Q4_ROWS)
+                    for (int l = 1; l <= a.L; ++l) {
+                        const float inv = sa.hs_inv[l][r16];                  // rows of panel h[l - 1], read by layer l
+                        scl[l * Q4_ROWS + lane] = inv * sa.ws_inv[l][0];
+                        scl[(IB_MAX_LAYERS + 1 + l - 1) * Q4_ROWS + lane] = 1.0f / inv;
+                    }
+                __builtin_amdgcn_wave_barrier();
+            }
             for (int l = 0; l < a.L; ++l) {
                 const float* hr = a.h[l] + r * a.ldh[l] + rec[4 + l];
                 float* cl = cache + (size_t)l * a.cache_len * Q4_ROWS;
                 const int n_old = rec[8 + l];
-                for (int j = part; j < n_old; j += 4) cl[j * Q4_ROWS + s] = hr[j];
+                if constexpr (SD) {
+                    const float sc = scl[(IB_MAX_LAYERS + 1 + l) * Q4_ROWS + s];
+                    for (int j = part; j < n_old; j += 4) sd_store_act(cache_b + (size_t)l * layer_bytes, j, s, hr[j], sc);
+                } else {
+                    for (int j = part; j < n_old; j += 4) cl[j * Q4_ROWS + s] = hr[j];
+                }
             }
             const int n_feat = min(rec[32], a.max_feats);
             for (int i = lane; i < n_feat; i += 64) {
@@ -1184,11 +1554,13 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
             float* os = buf ? ostg1 : ostg0;
             float* oz = buf ? ozs1 : ozs0;
             if constexpr (KIND == 2) {
-                stage_rows(os, gstride, a.wout, a.ldwout, o_row0 + f, 1, a.mb_dim, o_kb, o_ke, lane);
+                if constexpr (SD) stage_rows_split(reinterpret_cast<char*>(os), IB_STAGE_ROWS, sa.ws[a.L], sa.ldws[a.L], o_row0 + f, 1, a.mb_dim, o_kb, o_ke, lane);
+                else stage_rows(os, gstride, a.wout, a.ldwout, o_row0 + f, 1, a.mb_dim, o_kb, o_ke, lane);
                 stage_z16(oz, a.zout, a.ldzout, wave_row0, a.B, o_row0 + f, 1, a.mb_dim, zout_slabs, a.zout_slab_stride, lane);
             } else {
                 const int o_P = KIND == 3 ? a.spg[sr[4 * IB_MAX_LAYERS + 5]].P : a.P;
-                stage_rows(os, gstride, a.wout, a.ldwout, o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
+                if constexpr (SD) stage_rows_split(reinterpret_cast<char*>(os), IB_STAGE_ROWS, sa.ws[a.L], sa.ldws[a.L], o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
+                else stage_rows(os, gstride, a.wout, a.ldwout, o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
                 stage_z16(oz, a.zout, a.ldzout, wave_row0, a.B, o_row0 + f, o_nd, o_P, zout_slabs, a.zout_slab_stride, lane);
             }
         };
@@ -1219,17 +1591,33 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
 #ifndef TFEP_PROBE_NO_HSTAGE          // (timing probe, wrong results: the chain without the loader's hidden-layer fetches)
                     if (loader) {
                         if (l == 0) stage_gather(stg, gstride, a.w[0], a.ldw[0], ub, nb, in_cols, ke, lane);
+                        else if constexpr (SD) stage_rows_split(reinterpret_cast<char*>(stg), HROWS, sa.ws[l], sa.ldws[l], ub, 1, nb, kb, ke, lane);
                         else stage_rows(stg, gstride, a.w[l], a.ldw[l], ub, 1, nb, kb, ke, lane);
                         stage_z16(zs, a.z[l], a.ldz[l], wave_row0, a.B, ub, 1, nb, z_slabs[l], a.z_slab_stride[l], lane);
                     }
 #endif
                     lap(6);
-                    __syncthreads();
+                    handover();
                     lap(2);
                     if (consumer) {
+                        if constexpr (SD) {
+                            char* const act_out = cache_b + (size_t)l * layer_bytes;
+                            const float sc_out = scl[(IB_MAX_LAYERS + 1 + l) * Q4_ROWS + (lane & 15)];
+                            for (int u0 = ub; u0 < ub + nb; u0 += 16) {
+                                const int nu = min(16, ub + nb - u0);
+                                if (l == 0)
+                                    hidden_mfma16_l0_sd(stg, gstride, u0 - ub, zs, act, len, nu, u0 - c0l, act_out, sc_out, h16 + u0, live16, lane);
+                                else
+                                    hidden_mfma16_sd(reinterpret_cast<const char*>(stg), gb_h, u0 - ub, zs,
+                                                     cache_b + (size_t)(l - 1) * layer_bytes + (size_t)((kb - rec[4 + l - 1]) >> 3) * (Q4_ROWS * 32),
+                                                     (ke - kb + 7) >> 3, nu, scl[l * Q4_ROWS + (lane & 15)], u0 - c0l, act_out, sc_out, h16 + u0,
+                                                     live16, lane);
+                            }
+                        } else {
                         for (int u0 = ub; u0 < ub + nb; u0 += 16)
                             hidden_mfma16(stg, gstride, u0 - ub, zs, act, len, min(16, ub + nb - u0), cl + (size_t)(u0 - c0l) * Q4_ROWS,
                                           h16 + u0, live16, lane);
+                        }
                         __builtin_amdgcn_wave_barrier();
                     }
                     lap(3);
@@ -1244,6 +1632,8 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
             (void)out_row0;
             const int* const fti = reinterpret_cast<const int*>(ftab);
             const float* cp = cache + ((size_t)(a.L - 1) * a.cache_len + (okb - rec[4 + a.L - 1])) * Q4_ROWS;
+            const char* cp_sd = cache_b + (size_t)(a.L - 1) * layer_bytes + (size_t)((okb - rec[4 + a.L - 1]) >> 3) * (Q4_ROWS * 32);
+            (void)cp_sd;
             const int olen = ib_round8(oke - okb);
             auto emit = [&](int fi, float xv) {                 // fi: the feature's position in the block
                 const int col = fti[12 * fi + 1], e0 = fti[12 * fi + 2], icol = fti[12 * fi + 3];
@@ -1261,10 +1651,14 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
             if constexpr (KIND == 2) {
                 const int dim = a.mb_dim;
                 for (int f = 0; f < n_d; f += dim) {
-                    __syncthreads();                                        // output stage oj was filled a feature ago
+                    handover();                                             // output stage oj was filled a feature ago
                     if (loader) fill_next_out(st_i, f);
                     if (consumer) {
                         float acc[IB_MAX_P];
+                        if constexpr (SD)
+                            out_dot_mfma16_sd(acc, reinterpret_cast<const char*>((oj & 1) ? ostg1 : ostg0), gb_o, (oj & 1) ? ozs1 : ozs0, cp_sd, pb,
+                                              (oke - okb + 7) >> 3, dim, scl[a.L * Q4_ROWS + (lane & 15)], lane);
+                        else
                         out_dot_mfma16(acc, (oj & 1) ? ostg1 : ostg0, gstride, (oj & 1) ? ozs1 : ozs0, cp, pb, olen, dim, lane);
                         double yv[MOEBIUS_MAX_DIM], wv[MOEBIUS_MAX_DIM], xv[MOEBIUS_MAX_DIM];
 #pragma unroll
@@ -1287,13 +1681,17 @@ __global__ void __launch_bounds__(128) inverse_superblock_kernel(InverseSuperArg
             for (int f = 0; f < n_d; ++f) {
                 float prm[IB_MAX_P];
                 lap(3);
-                __syncthreads();                                            // output stage oj was filled a feature ago
+                handover();                                                 // output stage oj was filled a feature ago
                 lap(4);
                 if (!consumer) {                     // the loader fetches the NEXT feature's rows beside this one's dot
                     fill_next_out(st_i, f);
                     ++oj;
                     continue;
                 }
+                if constexpr (SD)
+                    out_dot_mfma16_sd(prm, reinterpret_cast<const char*>((oj & 1) ? ostg1 : ostg0), gb_o, (oj & 1) ? ozs1 : ozs0, cp_sd, pb,
+                                      (oke - okb + 7) >> 3, nP, scl[a.L * Q4_ROWS + (lane & 15)], lane);
+                else
                 out_dot_mfma16(prm, (oj & 1) ? ostg1 : ostg0, gstride, (oj & 1) ? ozs1 : ozs0, cp, pb, olen, nP, lane);
                 lap(5);
                 const float yv = ytab[(floc + f) * Q4_ROWS + s];
@@ -1470,11 +1868,12 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
                  "inverse_block: rows_per_wave must be 64 (or 0: one sample row per lane) or 16 (four lanes per row)");
     if (d->n_blocks > 0) {
         // ---- super-block launch: every block of the list in one launch of the paired 16-row kernel
-        TFEP_REQUIRE(d->rows_per_wave == 16 && d->paired != 0 && d->waves_per_workgroup <= 1,
+        TFEP_REQUIRE(d->rows_per_wave == 16 && d->paired != 0,
                      "inverse_block: a super-block launch (n_blocks > 0) needs rows_per_wave = 16 and paired = 1");
         TFEP_REQUIRE(d->blocks != nullptr && d->zout_extra != nullptr, "inverse_block: super-block launch without block records / extra slab");
         InverseSuperArgs sa = {};
         a.n_steps = 0;
+        a.cache_len = ib_round8(d->cache_len);          // whole k-groups of 8 (the split activation cache)
         a.stage_gstride = 8 * ib_stage_cols_q4(d->cache_len, d->max_feats);
         for (int l = 0; l < d->n_layers; ++l) {
             TFEP_REQUIRE(d->z_extra[l] != nullptr, "inverse_block: super-block launch without the extra slab of layer %d", l);
@@ -1484,6 +1883,12 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
         }
         a.zout_slabs = d->zout_slabs > 0 ? d->zout_slabs : 0;
         sa.zout_extra = d->zout_extra;
+        for (int l = 1; l <= d->n_layers; ++l) {
+            if (d->ws[l] == nullptr) continue;
+            TFEP_REQUIRE(d->ws_inv_scale[l] && d->h_inv_scale[l], "inverse_block: split products of layer %d need ws_inv_scale and h_inv_scale", l);
+            TFEP_REQUIRE(((uintptr_t)d->ws[l] & 15) == 0 && d->ldws[l] % 8 == 0, "inverse_block: split pack of layer %d not aligned", l);
+            sa.ws[l] = (const float*)d->ws[l]; sa.ldws[l] = d->ldws[l]; sa.ws_inv[l] = d->ws_inv_scale[l]; sa.hs_inv[l] = d->h_inv_scale[l];
+        }
         sa.n_blocks = d->n_blocks;
         sa.blocks = d->blocks;
         const size_t lds_s = ib_lds_floats_q4_paired(d->n_layers, d->cache_len, d->max_feats) * sizeof(float);
@@ -1491,17 +1896,34 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
         a.lds_floats = (int)(lds_s / sizeof(float));
         sa.a = a;
         static const bool diag = getenv("TFEP_DIAG_INVERSE") != nullptr && atoi(getenv("TFEP_DIAG_INVERSE")) != 0;
-        void (*skernel)(InverseSuperArgs) = d->kind == 0 ? inverse_superblock_kernel<0> : d->kind == 1 ? (diag ? inverse_superblock_kernel<1, true> : inverse_superblock_kernel<1>)
-                                            : d->kind == 2 ? inverse_superblock_kernel<2> : inverse_superblock_kernel<3>;
-        static size_t lds_attr_s[5][TFEP_MAX_DEVICES] = {};
-        size_t& attr = lds_attr_s[d->kind == 1 && diag ? 4 : d->kind][current_device_slot()];
-        if (lds_s > attr) {
-            hipError_t e = hipFuncSetAttribute((const void*)skernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
-            if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds_s, hipGetErrorString(e));
-            attr = lds_s;
+        // waves_per_workgroup = 4: two pairs per workgroup (they share the weight fetches of the products); 0 / 2: one
+        const bool two = d->waves_per_workgroup == 4;
+        TFEP_REQUIRE(d->waves_per_workgroup == 0 || d->waves_per_workgroup == 2 || two,
+                     "inverse_block: a super-block launch takes waves_per_workgroup 0 / 2 (one pair) or 4 (two pairs)");
+        TFEP_REQUIRE(!two || 2 * lds_s <= 160 * 1024, "inverse_block: two pairs need %zu bytes of LDS (> 160 KiB)", 2 * lds_s);
+        // split dots: with the split pack of every layer 1 .. L (and not switched off: TFEP_INV_SPLIT_DOTS=0)
+        static const bool sd_env = getenv("TFEP_INV_SPLIT_DOTS") == nullptr || atoi(getenv("TFEP_INV_SPLIT_DOTS")) != 0;
+        bool sd = sd_env;
+        for (int l = 1; l <= d->n_layers; ++l) sd = sd && sa.ws[l] != nullptr;
+        void (*skernel)(InverseSuperArgs);
+#define TFEP_SK(KIND_, DIAG_, PAIRS_) (sd ? inverse_superblock_kernel<KIND_, DIAG_, PAIRS_, true> : inverse_superblock_kernel<KIND_, DIAG_, PAIRS_, false>)
+        if (two)
+            skernel = d->kind == 0 ? TFEP_SK(0, false, 2) : d->kind == 1 ? (diag ? TFEP_SK(1, true, 2) : TFEP_SK(1, false, 2))
+                      : d->kind == 2 ? TFEP_SK(2, false, 2) : TFEP_SK(3, false, 2);
+        else
+            skernel = d->kind == 0 ? TFEP_SK(0, false, 1) : d->kind == 1 ? (diag ? TFEP_SK(1, true, 1) : TFEP_SK(1, false, 1))
+                      : d->kind == 2 ? TFEP_SK(2, false, 1) : TFEP_SK(3, false, 1);
+#undef TFEP_SK
+        const size_t lds_wg = (two ? 2 : 1) * lds_s;
+        static size_t lds_attr_s[20][TFEP_MAX_DEVICES] = {};
+        size_t& attr = lds_attr_s[(d->kind == 1 && diag ? 4 : d->kind) + (two ? 5 : 0) + (sd ? 10 : 0)][current_device_slot()];
+        if (lds_wg > attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)skernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wg);
+            if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds_wg, hipGetErrorString(e));
+            attr = lds_wg;
         }
         const long long n_pairs = (d->B + Q4_ROWS - 1) / Q4_ROWS;
-        skernel<<<(unsigned)n_pairs, 128, lds_s, (hipStream_t)stream>>>(sa);
+        skernel<<<(unsigned)(two ? (n_pairs + 1) / 2 : n_pairs), two ? 256 : 128, lds_wg, (hipStream_t)stream>>>(sa);
         return check_launch("inverse_superblock_kernel");
     }
     const bool q4 = d->rows_per_wave == 16;

@@ -1395,8 +1395,19 @@ class AutoregressiveFlow(torch.nn.Module):
                     n0_max = max(s_['wide0']['n_rows'] for s_ in supers)
                     S0 = int(min(8, max(1, 256 // max(1, 2 * m_tiles)), max(1, mplan['k_pad'][0] // 512)))
                     sb_buf0 = torch.empty(S0 + 1, B, ops.round_up(max(n0_max, 1), 4), **f32)
-                    d.rows_per_wave, d.paired, d.waves_per_workgroup = 16, 1, 0
+                    # two pairs per workgroup (they share the weight fetches of the in-kernel products) while every workgroup is
+                    # still resident: two pairs' LDS on one CU
+                    ldsp = int(_lib.load().tfep_inverse_block_lds_bytes_paired(L, fused['cache_len'], fused['max_feats']))
+                    fit2 = (160 * 1024) // max(2 * ldsp, 1)
+                    two = fit2 >= 1 and ((B + 15) // 16 + 1) // 2 <= 256 * min(fit2, 2) and os.environ.get('TFEP_INV_TWO_PAIRS', '1') != '0'
+                    d.rows_per_wave, d.paired, d.waves_per_workgroup = 16, 1, (4 if two else 0)
                     self.last_inverse_schedule = 'super_kernel'
+                    if os.environ.get('TFEP_INV_SPLIT_PRODUCTS', '1') != '0':
+                        # the in-kernel products on split-f16 operands, like the short GEMMs they replace: the layers' split
+                        # packs and the row scales of the panels' split copies
+                        for l_, (hsl, hsl_inv, wsl, winvl) in hs_hidden.items():
+                            d.ws[l_], d.ldws[l_], d.ws_inv_scale[l_], d.h_inv_scale[l_] = wsl.data_ptr(), wsl.shape[1], winvl.data_ptr(), hsl_inv.data_ptr()
+                        d.ws[L], d.ldws[L], d.ws_inv_scale[L], d.h_inv_scale[L] = ws_out.data_ptr(), ws_out.shape[1], winv_out.data_ptr(), hs_inv.data_ptr()
                     for sup in supers:
                         tb = self._super_tables(bp, sup, L, dev)
                         super_gemms(sup)
