@@ -1262,7 +1262,13 @@ __device__ __forceinline__ void sd_finish_hidden(const ib_f4& d, int nu, int k0,
     for (int r = 0; r < 4; ++r) {
         const int u = 4 * kq + r;
         if (u < nu) {
-            const float hv = elu_ib(d[r]);
+            // ELU with the hardware exponential where the result is not small and the series to v^6 where it is (~5e-7
+            // relative; expm1f is ~40 instructions on a wave that issues one per ~8 cycles: 1.0 of 71.2 ms per cfg2 inverse)
+            const float v_ = d[r];
+            const float e_ = __expf(v_) - 1.0f;
+            float s_ = fmaf(v_, 1.0f / 720.0f, 1.0f / 120.0f);
+            s_ = fmaf(v_, s_, 1.0f / 24.0f); s_ = fmaf(v_, s_, 1.0f / 6.0f); s_ = fmaf(v_, s_, 0.5f); s_ = fmaf(v_, s_, 1.0f); s_ *= v_;
+            const float hv = v_ > 0.f ? v_ : (v_ > -0.25f ? s_ : e_);
             sd_store_act(act_out, k0 + u, col, hv, scale_out);
             if (live16) h_u0[u] = hv;
         }

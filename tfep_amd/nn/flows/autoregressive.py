@@ -1062,6 +1062,12 @@ class AutoregressiveFlow(torch.nn.Module):
             ops.abs_reduce(outside, 'row_max') * (1.0 / info['tail_slope'])
         bound = torch.clamp(x_bound, min=1.0)
         hidden = {}                 # layer l >= 1 fed by the hidden panel h[l - 1]: (split panel, its row scales, split W, W scale)
+        # key 0 (round 4): the same for layer 0 and the padded conditioner input (the super-block kernel's schedule puts layer 0's
+        # old inputs through one split GEMM per super-block): (row scales of the input panel, split W0, its scale); the split
+        # copy of xpad is made by the caller
+        if self.split_inverse_hidden and os.environ.get('TFEP_INV_SPLIT_LAYER0', '1') != '0':
+            ws0, winv0 = made._pack_layer_split(mplan, 0, lins[0])[:2]
+            hidden[0] = (None, ops.pow2_inv_scale(bound), ws0, winv0)
         for l in range(L):
             bound = torch.clamp(bound * ops.abs_reduce(packs[l][0], 'max_row_sum') +
                                 ops.abs_reduce(packs[l][1].reshape(1, -1), 'row_max'), min=1.0)
@@ -1116,7 +1122,11 @@ class AutoregressiveFlow(torch.nn.Module):
             n_steps += fb['n_steps']; n_feat += nf; n_in += ni
         pad = torch.zeros(1, dtype=torch.int32, device=device)
         cat = lambda v: torch.cat(v + [pad]).contiguous()
+        ic = torch.cat(in_cols).cpu() if in_cols else torch.zeros(0, dtype=torch.int32)
+        per_any = bool(torch.cat(feat_per).any().item()) if feat_per else False
+        in_range = (int(ic.min()), int(ic.max()) + 1) if len(ic) else (0, 0)        # (a periodic entry list names both columns)
         st = sup['tables'] = dict(
+            in_range=in_range, periodic=per_any,
             steps=torch.cat(steps).contiguous(), cols=cat(cols), sel=cat(sel), feat_in=cat(feat_in), feat_per=cat(feat_per),
             in_cols=cat(in_cols), records=torch.tensor(recs, dtype=torch.int32).reshape(-1, n_rec).to(device), n_blocks=len(blocks),
             unit_range=[(blocks[0]['fused']['unit_range'][l][0], blocks[-1]['fused']['unit_range'][l][1]) for l in range(L)])
@@ -1337,6 +1347,7 @@ class AutoregressiveFlow(torch.nn.Module):
                 # S_sb + 1 slabs in the super-block's row layout: slabs [0, S_sb) = the large GEMM over [0, kS) for every row of
                 # the super-block (split-K), slab S_sb = the block's short GEMM over [kS, kA), written at the block's columns.
                 supers = bp.get('supers')
+                x_split = hs_hidden.pop(0, None)           # (layer 0 on split operands: the super-block kernel's schedule only)
                 use_sb = bool(supers) and hs is not None and not look and all(l in hs_hidden for l in range(1, L)) and \
                     all(wd['layer'] >= 1 for b_ in bp['blocks'] for wd in b_['wide'])
                 if use_sb:
@@ -1395,6 +1406,13 @@ class AutoregressiveFlow(torch.nn.Module):
                     n0_max = max(s_['wide0']['n_rows'] for s_ in supers)
                     S0 = int(min(8, max(1, 256 // max(1, 2 * m_tiles)), max(1, mplan['k_pad'][0] // 512)))
                     sb_buf0 = torch.empty(S0 + 1, B, ops.round_up(max(n0_max, 1), 4), **f32)
+                    xs = None
+                    if x_split is not None:
+                        # split copy of the padded conditioner input, with the row scale of the bound on |x|: what is there
+                        # already (fixed / conditioning features), then the columns every super-block adds
+                        _, xs_inv, ws0, winv0 = x_split
+                        xs = ops.zeros(*xpad.shape, **f32)
+                        ops.split_columns_scaled(xpad, 0, xpad.shape[1] // 8 * 8, xs, xs_inv)
                     # two pairs per workgroup (they share the weight fetches of the in-kernel products) while every workgroup is
                     # still resident: two pairs' LDS on one CU
                     ldsp = int(_lib.load().tfep_inverse_block_lds_bytes_paired(L, fused['cache_len'], fused['max_feats']))
@@ -1412,7 +1430,9 @@ class AutoregressiveFlow(torch.nn.Module):
                         tb = self._super_tables(bp, sup, L, dev)
                         super_gemms(sup)
                         w0 = sup['wide0']
-                        if w0['n_rows'] > 0:
+                        if w0['n_rows'] > 0 and xs is not None:
+                            launch(xs, ws0, packs[0][1], w0, sb_buf0[:S0] if S0 > 1 else sb_buf0[0], 0, act=0, k_split=S0, split=(xs_inv, winv0))
+                        elif w0['n_rows'] > 0:
                             launch(xpad, packs[0][0], packs[0][1], w0, sb_buf0[:S0] if S0 > 1 else sb_buf0[0], 0, act=0, k_split=S0)
                         d.n_blocks, d.blocks = tb['n_blocks'], tb['records'].data_ptr()
                         d.steps, d.feat_cols, d.feat_sel = tb['steps'].data_ptr(), tb['cols'].data_ptr(), tb['sel'].data_ptr()
@@ -1431,6 +1451,10 @@ class AutoregressiveFlow(torch.nn.Module):
                         d.zout_extra = d.zout + 4 * sb_S[L] * d.zout_slab_stride
                         _lib.call('tfep_inverse_block', ctypes.byref(d), stream)
                         # the super-block's new units as split rows, for the GEMMs of the super-blocks to come
+                        if xs is not None and tb['in_range'][1] > tb['in_range'][0]:
+                            g0 = tb['in_range'][0] // 8 * 8
+                            g1 = min(ops.round_up(tb['in_range'][1], 8), xpad.shape[1] // 8 * 8)
+                            ops.split_columns_scaled(xpad, g0, g1 - g0, xs, xs_inv)
                         lo, hi = tb['unit_range'][L - 1]
                         if hi > lo:
                             g0 = lo // 8 * 8
