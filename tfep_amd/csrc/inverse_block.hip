@@ -1417,6 +1417,11 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
     };
     extern __shared__ float cache_all[];
     const InverseBlockArgs& a = sa.a;
+#ifdef TFEP_PROBE_FIXED_L
+    constexpr int LL = TFEP_PROBE_FIXED_L;          // (timing probe: the number of hidden layers as a compile-time constant)
+#else
+    const int LL = sa.a.L;
+#endif
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = threadIdx.x >> 6;
     const int pair = wave_in_wg >> 1;
@@ -1433,7 +1438,7 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
     const int64_t r = live ? row : 0;
     const bool live16 = wave_row0 + (lane & 15) < a.B;
     const int64_t r16 = live16 ? wave_row0 + (lane & 15) : 0;
-    float* xc = cache + (size_t)a.L * a.cache_len * Q4_ROWS;            // (a.cache_len: a multiple of 8 here)
+    float* xc = cache + (size_t)LL * a.cache_len * Q4_ROWS;            // (a.cache_len: a multiple of 8 here)
     const int gstride = a.stage_gstride;
     constexpr int HROWS = 8;
     const size_t hst = ib_q4_hstage_floats(gstride >> 3, a.cache_len), ost = ib_q4_ostage_floats(gstride >> 3, a.cache_len);
@@ -1448,6 +1453,8 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
     float* const ozs0 = ostg0 + ost + Q4_LDS_SLACK;
     float* const ostg1 = ostg0 + o_floats;
     float* const ozs1 = ozs0 + o_floats;
+    const size_t hstride = (size_t)(stg1 - stg0);       // (buffers addressed by arithmetic on the parity, not by selects: the
+    (void)ostg1; (void)ozs1; (void)zs1;                 //  compiler cloned the whole chain per combination of parities)
     const int lds_total = a.lds_floats;
     // SD (split dots): the activation caches as split halves (same bytes: 64 per unit), byte views of the stages
     char* const cache_b = reinterpret_cast<char*>(cache);
@@ -1481,13 +1488,13 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
         // ---- what earlier blocks of the super-block add to this block's rows, for the pair's own 16 sample rows
         {
             int g = 0;
-            for (int l = 0; l <= a.L; ++l) {
+            for (int l = 0; l <= LL; ++l) {
                 const int row0 = rec[12 + 4 * l], n_rows = rec[13 + 4 * l], kb = rec[14 + 4 * l], ke = rec[15 + 4 * l];
                 if (ke <= kb || n_rows <= 0) continue;
-                const float* W = l < a.L ? a.w[l] : a.wout;
-                const int64_t ldw = l < a.L ? a.ldw[l] : a.ldwout;
-                float* dst = l < a.L ? sa.z_extra[l] : sa.zout_extra;
-                const int64_t ldd = l < a.L ? a.ldz[l] : a.ldzout;
+                const float* W = l < LL ? a.w[l] : a.wout;
+                const int64_t ldw = l < LL ? a.ldw[l] : a.ldwout;
+                float* dst = l < LL ? sa.z_extra[l] : sa.zout_extra;
+                const int64_t ldd = l < LL ? a.ldz[l] : a.ldzout;
                 for (int t0 = 0; t0 < n_rows; t0 += 16 * IB_PROD_TILES, ++g) {
                     if (g % (2 * PAIRS) != wave_in_wg) continue;
                     const int nr = min(n_rows - t0, 16 * IB_PROD_TILES);
@@ -1512,14 +1519,14 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
             __builtin_amdgcn_wave_barrier();
             if constexpr (SD) {
                 if (lane < Q4_ROWS)
-                    for (int l = 1; l <= a.L; ++l) {
+                    for (int l = 1; l <= LL; ++l) {
                         const float inv = sa.hs_inv[l][r16];                  // rows of panel h[l - 1], read by layer l
                         scl[l * Q4_ROWS + lane] = inv * sa.ws_inv[l][0];
                         scl[(IB_MAX_LAYERS + 1 + l - 1) * Q4_ROWS + lane] = 1.0f / inv;
                     }
                 __builtin_amdgcn_wave_barrier();
             }
-            for (int l = 0; l < a.L; ++l) {
+            for (int l = 0; l < LL; ++l) {
                 const float* hr = a.h[l] + r * a.ldh[l] + rec[4 + l];
                 float* cl = cache + (size_t)l * a.cache_len * Q4_ROWS;
                 const int n_old = rec[8 + l];
@@ -1549,23 +1556,23 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
         // slabs of the pre-activations: those of the super-block GEMMs, plus the one just written where this block has one
         int z_slabs[IB_MAX_LAYERS];
 #pragma unroll
-        for (int l = 0; l < IB_MAX_LAYERS; ++l) z_slabs[l] = l < a.L ? a.z_slabs[l] + (rec[15 + 4 * l] > rec[14 + 4 * l] ? 1 : 0) : 0;
-        const int zout_slabs = a.zout_slabs + (rec[15 + 4 * a.L] > rec[14 + 4 * a.L] ? 1 : 0);
+        for (int l = 0; l < IB_MAX_LAYERS; ++l) z_slabs[l] = l < LL ? a.z_slabs[l] + (rec[15 + 4 * l] > rec[14 + 4 * l] ? 1 : 0) : 0;
+        const int zout_slabs = a.zout_slabs + (rec[15 + 4 * LL] > rec[14 + 4 * LL] ? 1 : 0);
 
         int oj = 0;
         auto fill_out = [&](int step, int f, int buf) __attribute__((always_inline)) {
             const int32_t* sr = steps + step * IB_STEP_INTS;
             const int o_row0 = sr[4 * IB_MAX_LAYERS], o_nd = sr[4 * IB_MAX_LAYERS + 1], o_kb = sr[4 * IB_MAX_LAYERS + 2],
                       o_ke = sr[4 * IB_MAX_LAYERS + 3];
-            float* os = buf ? ostg1 : ostg0;
-            float* oz = buf ? ozs1 : ozs0;
+            float* os = ostg0 + (size_t)buf * o_floats;
+            float* oz = ozs0 + (size_t)buf * o_floats;
             if constexpr (KIND == 2) {
-                if constexpr (SD) stage_rows_split(reinterpret_cast<char*>(os), IB_STAGE_ROWS, sa.ws[a.L], sa.ldws[a.L], o_row0 + f, 1, a.mb_dim, o_kb, o_ke, lane);
+                if constexpr (SD) stage_rows_split(reinterpret_cast<char*>(os), IB_STAGE_ROWS, sa.ws[LL], sa.ldws[LL], o_row0 + f, 1, a.mb_dim, o_kb, o_ke, lane);
                 else stage_rows(os, gstride, a.wout, a.ldwout, o_row0 + f, 1, a.mb_dim, o_kb, o_ke, lane);
                 stage_z16(oz, a.zout, a.ldzout, wave_row0, a.B, o_row0 + f, 1, a.mb_dim, zout_slabs, a.zout_slab_stride, lane);
             } else {
                 const int o_P = KIND == 3 ? a.spg[sr[4 * IB_MAX_LAYERS + 5]].P : a.P;
-                if constexpr (SD) stage_rows_split(reinterpret_cast<char*>(os), IB_STAGE_ROWS, sa.ws[a.L], sa.ldws[a.L], o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
+                if constexpr (SD) stage_rows_split(reinterpret_cast<char*>(os), IB_STAGE_ROWS, sa.ws[LL], sa.ldws[LL], o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
                 else stage_rows(os, gstride, a.wout, a.ldwout, o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
                 stage_z16(oz, a.zout, a.ldzout, wave_row0, a.B, o_row0 + f, o_nd, o_P, zout_slabs, a.zout_slab_stride, lane);
             }
@@ -1585,7 +1592,7 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
         for (int st_i = 0; st_i < n_steps; ++st_i) {
             const int32_t* st = steps + st_i * IB_STEP_INTS;
             // ---- hidden units of this degree, layer by layer
-            for (int l = 0; l < a.L; ++l) {
+            for (int l = 0; l < LL; ++l) {
                 const int row0 = st[4 * l], n = st[4 * l + 1], kb = st[4 * l + 2], ke = st[4 * l + 3];
                 const int c0l = rec[4 + l];
                 float* cl = cache + (size_t)l * a.cache_len * Q4_ROWS;
@@ -1628,8 +1635,8 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
                     }
                     lap(3);
                     parity ^= 1;
-                    stg = parity ? stg1 : stg0;
-                    zs = parity ? zs1 : zs0;
+                    stg = stg0 + (size_t)parity * hstride;
+                    zs = zs0 + (size_t)parity * hstride;
                 }
             }
             // ---- parameters and transformer inverse of this degree's features
@@ -1637,8 +1644,8 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
             const int okb = st[4 * IB_MAX_LAYERS + 2], oke = st[4 * IB_MAX_LAYERS + 3], floc = st[4 * IB_MAX_LAYERS + 4];
             (void)out_row0;
             const int* const fti = reinterpret_cast<const int*>(ftab);
-            const float* cp = cache + ((size_t)(a.L - 1) * a.cache_len + (okb - rec[4 + a.L - 1])) * Q4_ROWS;
-            const char* cp_sd = cache_b + (size_t)(a.L - 1) * layer_bytes + (size_t)((okb - rec[4 + a.L - 1]) >> 3) * (Q4_ROWS * 32);
+            const float* cp = cache + ((size_t)(LL - 1) * a.cache_len + (okb - rec[4 + LL - 1])) * Q4_ROWS;
+            const char* cp_sd = cache_b + (size_t)(LL - 1) * layer_bytes + (size_t)((okb - rec[4 + LL - 1]) >> 3) * (Q4_ROWS * 32);
             (void)cp_sd;
             const int olen = ib_round8(oke - okb);
             auto emit = [&](int fi, float xv) {                 // fi: the feature's position in the block
@@ -1662,10 +1669,10 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
                     if (consumer) {
                         float acc[IB_MAX_P];
                         if constexpr (SD)
-                            out_dot_mfma16_sd(acc, reinterpret_cast<const char*>((oj & 1) ? ostg1 : ostg0), gb_o, (oj & 1) ? ozs1 : ozs0, cp_sd, pb,
-                                              (oke - okb + 7) >> 3, dim, scl[a.L * Q4_ROWS + (lane & 15)], lane);
+                            out_dot_mfma16_sd(acc, reinterpret_cast<const char*>(ostg0 + (size_t)(oj & 1) * o_floats), gb_o, ozs0 + (size_t)(oj & 1) * o_floats, cp_sd, pb,
+                                              (oke - okb + 7) >> 3, dim, scl[LL * Q4_ROWS + (lane & 15)], lane);
                         else
-                        out_dot_mfma16(acc, (oj & 1) ? ostg1 : ostg0, gstride, (oj & 1) ? ozs1 : ozs0, cp, pb, olen, dim, lane);
+                        out_dot_mfma16(acc, ostg0 + (size_t)(oj & 1) * o_floats, gstride, ozs0 + (size_t)(oj & 1) * o_floats, cp, pb, olen, dim, lane);
                         double yv[MOEBIUS_MAX_DIM], wv[MOEBIUS_MAX_DIM], xv[MOEBIUS_MAX_DIM];
 #pragma unroll
                         for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
@@ -1695,10 +1702,10 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
                     continue;
                 }
                 if constexpr (SD)
-                    out_dot_mfma16_sd(prm, reinterpret_cast<const char*>((oj & 1) ? ostg1 : ostg0), gb_o, (oj & 1) ? ozs1 : ozs0, cp_sd, pb,
-                                      (oke - okb + 7) >> 3, nP, scl[a.L * Q4_ROWS + (lane & 15)], lane);
+                    out_dot_mfma16_sd(prm, reinterpret_cast<const char*>(ostg0 + (size_t)(oj & 1) * o_floats), gb_o, ozs0 + (size_t)(oj & 1) * o_floats, cp_sd, pb,
+                                      (oke - okb + 7) >> 3, nP, scl[LL * Q4_ROWS + (lane & 15)], lane);
                 else
-                out_dot_mfma16(prm, (oj & 1) ? ostg1 : ostg0, gstride, (oj & 1) ? ozs1 : ozs0, cp, pb, olen, nP, lane);
+                out_dot_mfma16(prm, ostg0 + (size_t)(oj & 1) * o_floats, gstride, ozs0 + (size_t)(oj & 1) * o_floats, cp, pb, olen, nP, lane);
                 lap(5);
                 const float yv = ytab[(floc + f) * Q4_ROWS + s];
                 const float* const ftf = ftab + 12 * (floc + f);
@@ -1734,7 +1741,7 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
                     xv = yv * 0.5f + 1e-3f * (w[0] + hh[1] + sraw[2] + last + last2);
                     ld = 0.0;
 #else
-                    xv = (float)rq_spline_element<8, true>(w, hh, sraw, last, last2, fl, ftf[5], ftf[6], ftf[7], ftf[8], yv, &ld);
+                    xv = (float)rq_spline_inverse_selects<8>(w, hh, sraw, last, last2, fl, ftf[5], ftf[6], ftf[7], ftf[8], yv, &ld);
 #endif
                     ldj_acc -= ld;
                     }

@@ -224,6 +224,102 @@ __device__ inline double rq_spline_element(const float (&w)[KMAX], const float (
     return out;
 }
 
+// rq_spline_element<KMAX, true> without data-dependent branches: the same arithmetic in the same order (the same bits), the
+// bin search and the tail / interior decision as selects.  The inverse block kernels evaluate one element per sample row on a
+// wave of 16 rows: with branches every row that falls into another bin took its own copy of everything behind the search
+// (the unrolled search duplicates its tail: 25 copies of the solve in the object code of the super-block kernel), and a
+// wave walked through as many of them as its rows had distinct bins.
+template <int KMAX>
+__device__ __forceinline__ double rq_spline_inverse_selects(const float (&w)[KMAX], const float (&h)[KMAX],
+                                                            const float (&sraw)[KMAX + 1], float last, float last2,
+                                                            const SplineFlags& f, float x0f, float xff, float y0f, float yff,
+                                                            float vin, double* logd) {
+    const int K = f.K;
+    const double mb = (double)f.min_bin;
+    double x0 = x0f, y0 = y0f;
+    double W = (double)xff - (double)x0f - K * mb;
+    double H = (double)yff - (double)y0f - K * mb;
+    if (f.learn_lower || f.learn_upper) {                                         // wave-uniform
+        double scale = exp((double)last);
+        W *= scale;
+        H *= scale;
+        if (f.learn_lower && f.learn_upper) {
+            x0 += (double)last2;
+            y0 += (double)last2;
+        } else if (f.learn_lower) {
+            x0 = (double)xff - W - K * mb;
+            y0 = (double)yff - H - K * mb;
+        }
+    }
+    const double v = vin;
+    float mw = -INFINITY, mh = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) {                                                              // wave-uniform
+            mw = fmaxf(mw, w[k]);
+            mh = fmaxf(mh, h[k]);
+        }
+    double ew[KMAX], eh[KMAX];
+    double sw = 0.0, sh = 0.0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        ew[k] = 0.0;
+        eh[k] = 0.0;
+        if (k < K) {
+            ew[k] = exp_nonpos((double)w[k] - (double)mw);
+            eh[k] = exp_nonpos((double)h[k] - (double)mh);
+            sw += ew[k];
+            sh += eh[k];
+        }
+    }
+    const double iw = W / sw, ih = H / sh;
+    double kx = x0, ky = y0, bw = 0.0, bh = 0.0;
+    float rs0 = sraw[0], rs1 = sraw[0], rs_last = sraw[0];
+    bool found = false;
+    const bool lower_tail = !(v > y0);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) {                                                              // wave-uniform
+            const double wk = ew[k] * iw + mb;
+            const double hk = eh[k] * ih + mb;
+            const double upper = ky + hk;
+            const bool above = v > upper;
+            const bool here = !found && !above, adv = !found && above;
+            bw = here ? wk : bw;
+            bh = here ? hk : bh;
+            rs0 = here ? sraw[k] : rs0;
+            rs1 = here ? sraw[k + 1] : rs1;
+            kx = adv ? kx + wk : kx;
+            ky = adv ? upper : ky;
+            found = found || here;
+            if (k == K - 1) rs_last = sraw[k + 1];
+        }
+    const bool tail = lower_tail || !found;
+    // tail: the boundary slope takes the place of the bin's first slope -- one softplus serves both forms
+    rs0 = tail ? (lower_tail ? sraw[0] : rs_last) : rs0;
+    const double dk = (double)(softplus_f(rs0 + f.slope_offset) + f.min_slope);
+    const double dk1 = (double)(softplus_f(rs1 + f.slope_offset) + f.min_slope);
+    const double bx = lower_tail ? x0 : kx, by = lower_tail ? y0 : ky;
+    const double out_t = bx + (v - by) / dk;                                      // spline.py:599-614
+    const double s = bh / bw;                                                     // spline.py:643
+    const double t = dk1 + dk - 2.0 * s;
+    const double ym = v - ky;                                                     // spline.py:521-536
+    const double a = bh * (s - dk) + ym * t;
+    const double b = bh * dk - ym * t;
+    const double c = -s * ym;
+    const double eps = 2.0 * c / (-b - sqrt(b * b - 4.0 * a * c));
+    const double out_i = eps * bw + kx;
+    const double e1 = eps * (1.0 - eps);                                          // spline.py:556-558
+    const double om = 1.0 - eps;
+    const double num = s * s * (dk1 * eps * eps + 2.0 * s * e1 + dk * om * om);
+    const double den = s + t * e1;
+    const double arg = tail ? dk : num / (den * den);
+    double out = tail ? out_t : out_i;
+    if (f.circular) out = py_mod(out - x0 - (double)last, (double)xff - x0) + x0;  // spline.py:257-259 (wave-uniform)
+    *logd = (double)logf((float)arg);
+    return out;
+}
+
 // The parameters of one element, expanded from the P values the conditioner produced for it (spline.py:359-380;
 // the same positions as spline_slope_param): K widths, K heights, the K + 1 knot slopes (identity boundary slopes:
 // raw slope 0 at knots 0 and K and K - 1 parameters in between; circular: knot K shares the parameter of knot 0),
