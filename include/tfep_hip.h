@@ -236,6 +236,14 @@ int tfep_moebius_forward(const float* x, int64_t ldx, const float* params, int64
                          int dimension, float max_radius, int unit_sphere, int sign,
                          float* y, int64_t ldy, float* log_det_J, int accumulate,
                          int B, int D, void* stream);
+/* The forward map of unit-sphere 2-vectors (dimension 2, unit_sphere 1, sign +1) that ALSO writes y as split-f16 rows for the
+ * masked linear that reads it next (tfep_split_rows' format, row stride ld_split floats >= D, D a multiple of 8; columns past
+ * D are not written: clear the buffer once) with the row scale of the bound |y| <= 1 (y_inv_scale[b] = 2^-14) -- the
+ * conversion pass between two MAF layers (one read + one write of the batch) disappears.  Rows of x, params, y on 8-byte
+ * boundaries. */
+int tfep_moebius_forward_split_out(const float* x, int64_t ldx, const float* params, int64_t ldp, float max_radius,
+                                   float* y, int64_t ldy, float* log_det_J, int accumulate,
+                                   void* y_split, int64_t ld_split, float* y_inv_scale, int B, int D, void* stream);
 
 /* PeriodicEmbedding.forward (embeddings/mafembed.py:112-145):
  * out = [x[:, nonperiodic]..., cos t0, sin t0, cos t1, sin t1, ...], t = (x - lower) * 2pi/(upper-lower). */

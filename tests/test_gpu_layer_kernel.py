@@ -147,3 +147,39 @@ def test_c_abi_rejects_bad_descriptors():
     assert lib.tfep_maf_layer_forward_split(ctypes.byref(d), None) != 0 and b'Moebius' in lib.tfep_last_error()
     d.kind = 2
     assert lib.tfep_maf_layer_forward_split(ctypes.byref(d), None) != 0 and b'NULL pointer' in lib.tfep_last_error()
+
+
+def test_split_rows_handed_over_between_unit_sphere_moebius_layers():
+    """cfg4-ii's layers on the launch-by-launch split path: the Moebius map writes its output as split-f16 rows too (scale of
+    the bound |y| <= 1) and leaves them on the tensor; the next layer's first GEMM takes them instead of a conversion pass
+    (``tfep_moebius_forward_split_out``).  Same result as with the pass (the row scale differs by at most one power of two: the
+    split format's own rounding), nothing handed over once the tensor has been written or when the next layer embeds it."""
+    import os
+    n_vec, B = 256, 1500
+    D = 2 * n_vec
+    torch.manual_seed(5)
+    with torch.device('cuda'):
+        flow = SequentialFlow(*[MAF(generate_degrees(D, 'ascending' if i % 2 == 0 else 'descending', repeats=2),
+                                    transformer=MoebiusTransformer(dimension=2, unit_sphere=True), initialize_identity=False)
+                                for i in range(3)])
+    for layer in flow:
+        layer.split_gemm = True
+    x = _unit_vectors(B, n_vec, seed=21)
+    with torch.no_grad():
+        y1, l1 = flow(x)
+        mid, _ = flow[0](x)
+        assert getattr(mid, '_tfep_split', None) is not None and mid._tfep_split[0].shape == (B, D)
+        os.environ['TFEP_SPLIT_HANDOVER'] = '0'
+        try:
+            y0, l0 = flow(x)
+            mid0, _ = flow[0](x)
+            assert getattr(mid0, '_tfep_split', None) is None
+        finally:
+            del os.environ['TFEP_SPLIT_HANDOVER']
+        assert torch.equal(mid, mid0)                                  # the fp32 output itself is the same kernel's
+        assert float((y1 - y0).abs().max()) <= 2e-6 and float((l1 - l0).abs().max()) <= 2e-5 * max(1.0, float(l0.abs().max()))
+        # a tensor written after the fact hands nothing over: the stale rows must not be used
+        mid.mul_(1.0)
+        ya, la = flow[1](mid)
+        yb, lb = flow[1](mid0.clone())
+        assert torch.equal(ya, yb) and torch.equal(la, lb)

@@ -133,6 +133,8 @@ _SIGNATURES = {
                                     _P, c_int, c_int, c_int, _P]),
     'tfep_moebius_forward': (c_int, [_P, c_int64, _P, c_int64, c_int, c_float, c_int, c_int,
                                      _P, c_int64, _P, c_int, c_int, c_int, _P]),
+    'tfep_moebius_forward_split_out': (c_int, [_P, c_int64, _P, c_int64, c_float, _P, c_int64, _P, c_int, _P, c_int64, _P,
+                                               c_int, c_int, _P]),
     'tfep_periodic_embedding': (c_int, [_P, c_int64, _P, c_int, _P, c_int, c_float, c_float,
                                         _P, c_int64, c_int, _P]),
     'tfep_gather_columns': (c_int, [_P, c_int64, _P, c_int, _P, c_int64, c_int, _P]),

@@ -79,6 +79,23 @@ __device__ __forceinline__ void mfma16(f32x4& acc, const f16x8& a, const f16x8& 
         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
 }
 
+// ELU of the split-row epilogue: v > 0 ? v : exp(v) - 1 by the hardware exponential (v_exp_f32) where the result is not small
+// and by the series to v^6 where it is -- ~5e-7 relative, on values that leave as split halves carrying 2^-22 of their row's
+// bound.  expm1f() is ~40 instructions per value on a wave that issues one per ~5 cycles (one wave per SIMD beside the
+// accumulators): at K <= 1024 (BASELINE cfg4-ii: 16 - 32 k-tiles per output tile) the epilogue of a tile then costs what its
+// k-loop costs (0.64 -> 0.5 ms per hidden layer of cfg4-ii); at cfg2's K = 15 008 it is 0.5 % of the step.
+__device__ __forceinline__ float elu_split_rows(float v) {
+    const float e = __expf(v) - 1.0f;
+    float s = fmaf(v, 1.0f / 720.0f, 1.0f / 120.0f);
+    s = fmaf(v, s, 1.0f / 24.0f);
+    s = fmaf(v, s, 1.0f / 6.0f);
+    s = fmaf(v, s, 0.5f);
+    s = fmaf(v, s, 1.0f);
+    s *= v;
+    const float neg = v > -0.25f ? s : e;
+    return v > 0.f ? v : neg;
+}
+
 __device__ __forceinline__ void keep_alive(const f32x4& v) { asm volatile("" ::"v"(v)); }
 
 // An empty asm that re-defines an accumulator where it lives: what follows depends on a value made HERE (see the kernel).
@@ -460,7 +477,7 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
                 const float bv = (in_range && g.bias) ? g.bias[col] : 0.f;
                 static_for<0, SMREP * 4>([&](auto ic) __attribute__((always_inline)) {
                     constexpr int m = ic.value / 4, i = ic.value % 4;
-                    const float v = in_range ? elu_f(acc[n][m][i] * rs[m][i] + bv) * so[m][i] : 0.f;
+                    const float v = in_range ? elu_split_rows(acc[n][m][i] * rs[m][i] + bv) * so[m][i] : 0.f;
                     stage[(m * 16 + rq + i) * EP_PITCH + n4c.value * 16 + cj] = v;
                 });
             });

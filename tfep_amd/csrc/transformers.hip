@@ -140,7 +140,8 @@ __global__ void __launch_bounds__(256) moebius_kernel(const float* __restrict__ 
                                                       const float* __restrict__ params, int64_t ldp, int dim_rt,
                                                       float max_radius, int unit_sphere, float sign,
                                                       float* __restrict__ y, int64_t ldy, float* __restrict__ ldj,
-                                                      int accumulate, int B, int D) {
+                                                      int accumulate, int B, int D, uint32_t* __restrict__ y_split = nullptr,
+                                                      int64_t ld_split = 0, float* __restrict__ y_inv_scale = nullptr) {
     const int b = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (b >= B) return;
     const int lane = threadIdx.x & 63;
@@ -169,11 +170,26 @@ __global__ void __launch_bounds__(256) moebius_kernel(const float* __restrict__ 
         acc += moebius_vector(xv, wv, dim, max_radius, unit_sphere, yv);
         if (vec2) {
             reinterpret_cast<float2*>(yr)[v] = float2{(float)yv[0], (float)yv[1]};
+            if (y_split) {
+                // the same row as split-f16 halves for the next layer's GEMM (tfep_split_rows' format: per 8 features 8 hi then
+                // 8 lo halves), with the scale of the bound |y| <= 1 of a unit-sphere map: 2^14
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const float t0 = (float)yv[0] * 16384.0f, t1 = (float)yv[1] * 16384.0f;
+                const _Float16 h0 = (_Float16)t0, h1 = (_Float16)t1;
+                const h2 hi = {h0, h1}, lo = {(_Float16)(t0 - (float)h0), (_Float16)(t1 - (float)h1)};
+                uint32_t* grp = y_split + (int64_t)b * ld_split + (v >> 2) * 8;        // 8 words = 32 bytes per group of 8 features
+                grp[v & 3] = __builtin_bit_cast(uint32_t, hi);
+                grp[4 + (v & 3)] = __builtin_bit_cast(uint32_t, lo);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < MOEBIUS_MAX_DIM; ++i)
                 if (i < dim) yr[v * dim + i] = (float)yv[i];
         }
+    }
+    if (y_split) {
+        // padding groups up to the row's k-tile stay zero (the caller clears the buffer once); the row's 1/scale
+        if (lane == 0) y_inv_scale[b] = 1.0f / 16384.0f;
     }
     acc = wave_sum(acc);
     if (ldj) store_ldj(ldj, b, acc, accumulate);
@@ -307,7 +323,21 @@ int tfep_moebius_forward(const float* x, int64_t ldx, const float* params, int64
     if (B == 0) return TFEP_OK;
     auto kernel = dimension == 2 ? moebius_kernel<2> : dimension == 3 ? moebius_kernel<3> : moebius_kernel<0>;
     kernel<<<row_blocks(B), 256, 0, (hipStream_t)stream>>>(x, ldx, params, ldp, dimension, max_radius, unit_sphere, (float)sign, y,
-                                                           ldy, log_det_J, accumulate, B, D);
+                                                           ldy, log_det_J, accumulate, B, D, nullptr, 0, nullptr);
+    return check_launch("moebius_kernel");
+}
+
+int tfep_moebius_forward_split_out(const float* x, int64_t ldx, const float* params, int64_t ldp, float max_radius, float* y, int64_t ldy,
+                                   float* log_det_J, int accumulate, void* y_split, int64_t ld_split, float* y_inv_scale, int B, int D,
+                                   void* stream) {
+    TFEP_REQUIRE(B == 0 || (x && params && y && y_split && y_inv_scale), "moebius_split_out: NULL pointer");
+    TFEP_REQUIRE(D % 2 == 0 && D % 8 == 0, "moebius_split_out: n_features=%d must be a multiple of 8 (whole split groups of 2-vectors)", D);
+    TFEP_REQUIRE(ld_split >= D && ld_split % 8 == 0 && ((uintptr_t)y_split & 15) == 0, "moebius_split_out: split rows too short / not aligned");
+    TFEP_REQUIRE(((uintptr_t)x & 7) == 0 && ((uintptr_t)params & 7) == 0 && ((uintptr_t)y & 7) == 0 && ldx % 2 == 0 && ldp % 2 == 0 && ldy % 2 == 0,
+                 "moebius_split_out: x, params and y rows must start on 8-byte boundaries");
+    if (B == 0) return TFEP_OK;
+    moebius_kernel<2><<<row_blocks(B), 256, 0, (hipStream_t)stream>>>(x, ldx, params, ldp, 2, max_radius, 1, 1.0f, y, ldy, log_det_J, accumulate, B,
+                                                                      D, (uint32_t*)y_split, ld_split, y_inv_scale);
     return check_launch("moebius_kernel");
 }
 

@@ -626,17 +626,28 @@ class MADE(Conditioner):
         by_batch = self.split_by_batch and batch is not None and n * int(batch) >= (1 << 35)
         return n >= (1 << 22) or by_batch
 
-    def forward_hidden_split(self, x):
+    def forward_hidden_split(self, x, split_hint=None):
         """``forward_hidden`` for the split-f16 GEMMs without fp32 intermediates: every hidden layer writes its
         ELU activations directly as split rows (scale from a bound on the row, see ``EPI_ELU_SPLIT``).
-        Returns ``(h_split, h_inv_scale, plan)`` of the last hidden layer."""
+        Returns ``(h_split, h_inv_scale, plan)`` of the last hidden layer.  ``split_hint``: ``(rows, inv_scale, version)`` of
+        ``x`` already as split rows (the ``_tfep_split`` attribute its producer left on the tensor), used when ``x`` has not
+        been written since and is the conditioner's input as it stands (no embedding)."""
         ops.check_device_tensor(x, 'x')
+        if split_hint is None:
+            split_hint = getattr(x, '_tfep_split', None)
+        hint_version = x._version
+        x_in = x
         x = self._embed(x)
+        if x is not x_in:
+            split_hint = None
         if x.shape[1] != self.dimension_in:
             raise ValueError(f'expected {self.dimension_in} input features, got {x.shape[1]}')
         plan = self.plan(x.device)
         lins = self._linears()
-        hs, h_inv = ops.split_rows(x, plan['k_pad'][0])
+        if split_hint is not None and split_hint[2] == hint_version and tuple(split_hint[0].shape) == (x.shape[0], plan['k_pad'][0]):
+            hs, h_inv = split_hint[0], split_hint[1]          # the producer of x wrote its split rows too (flows/autoregressive.py)
+        else:
+            hs, h_inv = ops.split_rows(x, plan['k_pad'][0])
         for li, lin in enumerate(lins[:-1]):
             ws, w_inv, b, bmax = self._pack_layer_split(plan, li, lin)
             if plan['n_pad'][li] != plan['k_pad'][li + 1]:
@@ -650,10 +661,13 @@ class MADE(Conditioner):
         operands (fp32-equivalent, ``csrc/split_gemm.hip``); None = the ``TFEP_SPLIT_GEMM`` default."""
         self.begin_call()
         lead = x.shape[:-1]
+        hint = getattr(x, '_tfep_split', None) if x.dim() == 2 else None      # (a reshape makes a new tensor object)
+        if hint is not None and hint[2] != x._version:
+            hint = None
         x2 = x.reshape(-1, x.shape[-1])
         split = (ops.split_gemm_enabled() and self.split_worthwhile(x2.shape[0])) if split is None else bool(split)
         if split:
-            hs, h_inv, plan = self.forward_hidden_split(x2)
+            hs, h_inv, plan = self.forward_hidden_split(x2, None if hint is None else (hint[0], hint[1], x2._version))
         else:
             h, plan = self.forward_hidden(x2)
         li = len(plan['n_pad']) - 1

@@ -470,6 +470,15 @@ class AutoregressiveFlow(torch.nn.Module):
         if kind is not None and self._fused_pays(x, kind):
             return self._forward_fused(x, kind)
         parameters = self.get_transformer_parameters(x)
+        tr = self._transformer
+        if type(tr) is MoebiusTransformer and tr.dimension == 2 and tr.unit_sphere and not self.has_fixed_indices and \
+                x.shape[1] % 8 == 0 and self._use_split_gemm(x.shape[0]) and os.environ.get('TFEP_SPLIT_HANDOVER', '1') != '0':
+            # Outputs on the unit circle: the map also writes y as the split-f16 rows the NEXT layer's first GEMM reads (scale
+            # of the bound |y| <= 1), and hands them over on the tensor -- no conversion pass between two such layers
+            # (BASELINE cfg4-ii: 0.21 of 2.5 ms per layer).  ``MADE.forward`` takes them if the tensor is still the one.
+            y, log_det_J, ys, ys_inv = ops.moebius_split_out(x, parameters, tr.max_radius, ops.round_up(x.shape[1], ops.tile_sizes()[2]))
+            y._tfep_split = (ys, ys_inv, y._version)
+            return y, log_det_J
         if self.has_fixed_indices:
             t = self._tables(x.device)
             y = x.clone()                               # fixed features propagate unchanged

@@ -111,6 +111,24 @@ def moebius(x, parameters, dimension, max_radius=0.99, unit_sphere=False, invers
     return y, ldj
 
 
+def moebius_split_out(x, parameters, max_radius, cols_padded):
+    """Forward map of unit-sphere 2-vectors that also returns y as split-f16 rows ``(y, log_det_J, y_split, y_inv_scale)`` for
+    the next masked linear (``tfep_moebius_forward_split_out``)."""
+    x, ldx = rows(x, 'x')
+    B, D = x.shape
+    parameters, ldp = _check_params(parameters, B, D)
+    if ldx % 2 or ldp % 2 or x.data_ptr() % 8 or parameters.data_ptr() % 8:
+        x, ldx, parameters, ldp = x.contiguous(), D, parameters.contiguous(), D
+    y = torch.empty(B, D, dtype=x.dtype, device=x.device)
+    ldj = torch.empty(B, dtype=x.dtype, device=x.device)
+    ys = zeros(B, cols_padded, dtype=torch.float32, device=x.device) if cols_padded > D else \
+        torch.empty(B, cols_padded, dtype=torch.float32, device=x.device)
+    ys_inv = torch.empty(max(B, 1), dtype=torch.float32, device=x.device)
+    call('tfep_moebius_forward_split_out', ptr(x), ldx, ptr(parameters), ldp, float(max_radius), ptr(y), D, ptr(ldj), 0, ptr(ys),
+         cols_padded, ptr(ys_inv), B, D, stream_of(x))
+    return y, ldj, ys, ys_inv
+
+
 # ----------------------------------------------------------------------------- embedding / index helpers
 
 def periodic_embedding(x, periodic_indices, nonperiodic_indices, lower, upper):
