@@ -67,6 +67,8 @@ struct GemmArgs {
     const float* bias_absmax;
     const float* a_inv_scale;  // split-f16 operands only: per-row 1/scale of the activations (B)
     const float* w_inv_scale;  //   and the single 1/scale of the weights
+    int kr_shift;              // split kernels with a narrower tile than the k-ranges / tile order were built for: column tile nt
+                               //   takes k_ranges[nt >> kr_shift] and launch position p the tile (tile_order[p >> kr_shift] << kr_shift) + low bits
     FusedArgs fu;
 };
 

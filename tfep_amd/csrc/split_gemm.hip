@@ -542,12 +542,26 @@ int launch_split_linear(const GemmArgs& g, int n_rows_w, int act, hipStream_t s,
     }
     constexpr int NREP = 16;
     const int n_tiles = (g.N + STile<NREP>::BN - 1) / STile<NREP>::BN;
+    // short ELU layers (K <= TFEP_SPLIT_SHORT_K, default 2048; the hidden layers of BASELINE cfg4-ii: 1024 columns): 128-column
+    // tiles, two workgroups per CU (split_gemm_kernel.h, OCC); the k-ranges / tile order stay those of the 256-column tiles.
+    // Measured (cfg4-ii, B = 131 072): 557 -> 519 us per hidden layer; the plain linear product did not gain (545 -> 556 us) and
+    // keeps the 256-column tile: a k-tile's LDS-DMA round trip (~6 000 cycles from HBM under load) is 2 - 4 x its matrix products
+    // either way, and one k-tile ahead is all the 160 KB of LDS hold
+    static const int short_k = env_int("TFEP_SPLIT_SHORT_K", 2048);
+    const bool occ2 = g.k_padded <= short_k && g.ksplit <= 1 && !g.tile_list && !g.tile_live && !g.col_map && !g.aux && !g.pre_add &&
+                      !g.accumulate && g.N > STile<8>::BN;
     if (act == 1 && g.y_inv_scale) {
         TFEP_REQUIRE(g.w_l1max && g.bias_absmax, "split gemm: split output needs w_l1max and bias_absmax");
         TFEP_REQUIRE(!g.col_map && !g.aux && !g.pre_add && !g.accumulate && g.ldy % 8 == 0 && g.N <= g.ldy && g.N % 2 == 0,
                      "split gemm: split output supports the plain ELU layer only");
+        if (occ2) {
+            GemmArgs g2 = g;
+            g2.kr_shift = 1;
+            return launch_split<8, EPI_ELU_SPLIT, 1, 1, false, 2>(g2, n_rows_w, 2 * n_tiles, s);
+        }
         return launch_split<NREP, EPI_ELU_SPLIT, 1, 1>(g, n_rows_w, n_tiles, s);
     }
+
     if (act == 1) return launch_split<NREP, EPI_ELU, 1, 1>(g, n_rows_w, n_tiles, s);
     // the hidden-layer block GEMMs of the inverse are ~100 outputs wide: a 128-column tile instead of a 256-column one
     // that would be 60 % padding

@@ -244,8 +244,12 @@ __device__ __forceinline__ void split_spline_epilogue(const GemmArgs& g, f32x4 (
 
 // SAVE: the spline kernels of a training forward (feature-major weight rows, parameter store) -- instantiations of their
 // own, so that the inference kernels keep their register allocation
-template <int NREP, int EPI, int P, int KSPL, bool SAVE = false>
-__global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int n_rows_w) {
+// OCC = 2 (NREP <= 8: 128 accumulator registers): two workgroups per CU.  At K <= ~2 000 an output tile is 16 - 64 k-tiles deep and
+// its prologue, the exposed part of every LDS-DMA round trip and its epilogue (256 ELUs + conversions per lane on a wave that is
+// alone on its SIMD) cost as much as its matrix products: 35 % matrix-pipe utilisation for BASELINE cfg4-ii's 1024 x 1024 layers
+// with the 256-column tile.  With two workgroups per CU one tile's epilogue and waits run beside the other's products.
+template <int NREP, int EPI, int P, int KSPL, bool SAVE = false, int OCC = 1>
+__global__ void __launch_bounds__(STHREADS, OCC) split_gemm_kernel(GemmArgs g, int n_rows_w) {
     using T = STile<NREP>;
     extern __shared__ __attribute__((aligned(16))) char slds[];
 
@@ -253,7 +257,7 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     int mt, ntp;
     if (!map_block(g, mt, ntp)) return;
-    int nt = g.tile_order ? g.tile_order[ntp] : ntp;
+    int nt = g.tile_order ? ((g.tile_order[ntp >> g.kr_shift] << g.kr_shift) | (ntp & ((1 << g.kr_shift) - 1))) : ntp;
     // split-K (the short-and-wide block GEMMs of the inverse): ksplit x as many column positions, position -> (column
     // tile, k slice); slice s writes its partial sums to y + s * slab_stride (gemm_common.h)
     int k_slice = 0;
@@ -271,8 +275,8 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
 
     int kb = 0, ke = g.k_padded;
     if (g.k_ranges) {
-        kb = g.k_ranges[2 * nt];
-        ke = g.k_ranges[2 * nt + 1];
+        kb = g.k_ranges[2 * (nt >> g.kr_shift)];
+        ke = g.k_ranges[2 * (nt >> g.kr_shift) + 1];
     }
     if constexpr (EPI == EPI_LINEAR) {
         if (g.ksplit > 1) {
@@ -462,6 +466,52 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
         // LDS instead, 64 columns at a time, and leaves as whole 32-byte groups (8 hi halves, 8 lo halves) -- 8 lanes write
         // 256 contiguous bytes of a row.  (4-byte pair-packed stores ran this epilogue at 1.5 TB/s: 17 % of the K = 3008
         // hidden layer.)
+        if constexpr (OCC > 1) {
+            // the 64 KB of a two-per-CU workgroup hold 32 columns of the tile at a time (36-float rows): a row's 4 groups of 8
+            // leave as 128 contiguous bytes from 4 lanes, 16 rows per instruction
+            constexpr int EPN = 36;
+            static_assert(NREP % 2 == 0 && SWAVES * 64 * EPN * 4 <= T::LDS_BYTES, "epilogue stage does not fit in LDS");
+            __syncthreads();
+            float* stage = reinterpret_cast<float*>(slds + wave * (64 * EPN * 4));
+            static_for<0, NREP / 2>([&](auto qc) __attribute__((always_inline)) {
+                constexpr int q = qc.value;
+                static_for<0, 2>([&](auto n2c) __attribute__((always_inline)) {
+                    constexpr int n = 2 * q + n2c.value;
+                    const int col = n0 + n * 16 + cj;
+                    const bool in_range = col < g.N;
+                    const float bv = (in_range && g.bias) ? g.bias[col] : 0.f;
+                    static_for<0, SMREP * 4>([&](auto ic) __attribute__((always_inline)) {
+                        constexpr int m = ic.value / 4, i = ic.value % 4;
+                        const float v = in_range ? elu_split_rows(acc[n][m][i] * rs[m][i] + bv) * so[m][i] : 0.f;
+                        stage[(m * 16 + rq + i) * EPN + n2c.value * 16 + cj] = v;
+                    });
+                });
+                __builtin_amdgcn_wave_barrier();
+                const int grp = lane & 3;
+                const int colg = n0 + q * 32 + grp * 8;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row_l = it * 16 + (lane >> 2);
+                    const int row = wrow0 + row_l;
+                    const f32x4_alias lo4 = *reinterpret_cast<const f32x4_alias*>(stage + row_l * EPN + grp * 8);
+                    const f32x4_alias hi4 = *reinterpret_cast<const f32x4_alias*>(stage + row_l * EPN + grp * 8 + 4);
+                    const float v8[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                    f16x8 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const _Float16 h = (_Float16)v8[j];
+                        hi[j] = h;
+                        lo[j] = (_Float16)(v8[j] - (float)h);
+                    }
+                    if (row < g.B && colg < g.N) {
+                        uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<char*>(g.y) + (int64_t)row * g.ldy * 4 + (int64_t)(colg >> 3) * 32);
+                        dst[0] = *reinterpret_cast<uint4*>(&hi);
+                        dst[1] = *reinterpret_cast<uint4*>(&lo);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            });
+        } else {
         constexpr int EP_PITCH = 68;                    // floats per staged row: 64 columns + 4 so that the 4 row groups
                                                         // of a tile write to different banks
         static_assert(NREP % 4 == 0, "the split-row epilogue stages 4 column tiles at a time");
@@ -506,8 +556,9 @@ __global__ void __launch_bounds__(STHREADS, 1) split_gemm_kernel(GemmArgs g, int
             }
             __builtin_amdgcn_wave_barrier();
         });
+        }
     } else {
-        if constexpr ((EPI == EPI_LINEAR || EPI == EPI_ELU) && NREP > 16) {
+        if constexpr ((EPI == EPI_LINEAR || EPI == EPI_ELU) && (NREP > 16 || OCC > 1)) {
             // a wide tile has no registers for a copy of its accumulators: one column group at a time
             static_for<0, NREP>([&](auto nc) __attribute__((always_inline)) {
                 constexpr int n = nc.value;
@@ -569,10 +620,10 @@ __global__ void __launch_bounds__(STHREADS, 1) split_peak_kernel(float* out, int
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-template <int NREP, int EPI, int P, int KSPL, bool SAVE = false>
+template <int NREP, int EPI, int P, int KSPL, bool SAVE = false, int OCC = 1>
 static int launch_split(const GemmArgs& g, int n_rows_w, int n_col_tiles, hipStream_t s) {
     using T = STile<NREP>;
-    auto kern = split_gemm_kernel<NREP, EPI, P, KSPL, SAVE>;
+    auto kern = split_gemm_kernel<NREP, EPI, P, KSPL, SAVE, OCC>;
     constexpr int LDS = split_lds_bytes<NREP, EPI, P>();
     // per device: a process may drive several GPUs
     static bool attr_set_on[TFEP_MAX_DEVICES] = {};
