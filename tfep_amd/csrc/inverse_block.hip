@@ -1403,7 +1403,10 @@ static __device__ unsigned long long g_ib_cycles[12];
 // the hand-overs are workgroup barriers, so the two pairs move in lockstep -- they run the same records on different rows -- and
 // the PRODUCTS at the head of a block are dealt over the four waves, every wave multiplying its tiles with BOTH row sets: the
 // weight rows, the 60 GB per inverse that bound that phase (every pair read them all), are fetched once per workgroup.
-template <int KIND, bool DIAG = false, int PAIRS = 1, bool SD = false>
+// SPEC (kind 1): 0 = any spline layout (bins, flags and parameter count at run time: the unpacking of a feature's parameters then
+// indexes a 32-register array dynamically, every flag is a select); 1 = 8 bins, plain layout (25 parameters); 2 = 8 bins, circular
+// (25 parameters): the layouts of BASELINE cfg2 / cfg4-i as compile-time constants.
+template <int KIND, bool DIAG = false, int PAIRS = 1, bool SD = false, int SPEC = 0>
 __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(InverseSuperArgs sa) {
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_mark = DIAG ? __builtin_readcyclecounter() : 0ull;
@@ -1690,7 +1693,7 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
                 }
             } else {
             const SplineArgs& spa = KIND == 3 ? a.spg[st[4 * IB_MAX_LAYERS + 5]] : a.sp;      // (wave uniform)
-            const int nP = KIND == 3 ? spa.P : a.P;
+            const int nP = SPEC > 0 ? 25 : (KIND == 3 ? spa.P : a.P);
             for (int f = 0; f < n_d; ++f) {
                 float prm[IB_MAX_P];
                 lap(3);
@@ -1714,7 +1717,10 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(Inverse
                     xv = (yv - prm[0]) * expf(-prm[1]);
                     ldj_acc -= (double)prm[1];
                 } else {
-                    const SplineFlags& fl = spa.f;
+                    SplineFlags fl = spa.f;
+                    if constexpr (SPEC > 0) {
+                        fl.K = 8; fl.circular = SPEC == 2; fl.identity = false; fl.learn_lower = false; fl.learn_upper = false;
+                    }
                     const int K = fl.K;
                     if (KIND == 3 && K == 0) {                              // a plain shift member (affine.py:366-456): log-det 0
                         xv = yv - prm[0];
@@ -1927,9 +1933,17 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
             skernel = d->kind == 0 ? TFEP_SK(0, false, 1) : d->kind == 1 ? (diag ? TFEP_SK(1, true, 1) : TFEP_SK(1, false, 1))
                       : d->kind == 2 ? TFEP_SK(2, false, 1) : TFEP_SK(3, false, 1);
 #undef TFEP_SK
+        // the 8-bin plain / circular layouts as compile-time constants (split dots, no diagnostics)
+        static const bool spec_env = getenv("TFEP_INV_SPEC") == nullptr || atoi(getenv("TFEP_INV_SPEC")) != 0;
+        int spec = 0;
+        if (spec_env && sd && !diag && d->kind == 1 && a.sp.f.K == 8 && !a.sp.f.identity && !a.sp.f.learn_lower && !a.sp.f.learn_upper && a.sp.P == 25)
+            spec = a.sp.f.circular ? 2 : 1;
+        if (spec == 1) skernel = two ? inverse_superblock_kernel<1, false, 2, true, 1> : inverse_superblock_kernel<1, false, 1, true, 1>;
+        if (spec == 2) skernel = two ? inverse_superblock_kernel<1, false, 2, true, 2> : inverse_superblock_kernel<1, false, 1, true, 2>;
         const size_t lds_wg = (two ? 2 : 1) * lds_s;
-        static size_t lds_attr_s[20][TFEP_MAX_DEVICES] = {};
-        size_t& attr = lds_attr_s[(d->kind == 1 && diag ? 4 : d->kind) + (two ? 5 : 0) + (sd ? 10 : 0)][current_device_slot()];
+        static size_t lds_attr_s[24][TFEP_MAX_DEVICES] = {};
+        size_t& attr = lds_attr_s[spec > 0 ? 20 + (spec - 1) * 2 + (two ? 1 : 0)
+                                           : (d->kind == 1 && diag ? 4 : d->kind) + (two ? 5 : 0) + (sd ? 10 : 0)][current_device_slot()];
         if (lds_wg > attr) {
             hipError_t e = hipFuncSetAttribute((const void*)skernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wg);
             if (e != hipSuccess) return fail(TFEP_ERR_LAUNCH, "hipFuncSetAttribute(LDS=%zu): %s", lds_wg, hipGetErrorString(e));
