@@ -1407,7 +1407,15 @@ static __device__ unsigned long long g_ib_cycles[12];
 // indexes a 32-register array dynamically, every flag is a select); 1 = 8 bins, plain layout (25 parameters); 2 = 8 bins, circular
 // (25 parameters): the layouts of BASELINE cfg2 / cfg4-i as compile-time constants.
 template <int KIND, bool DIAG = false, int PAIRS = 1, bool SD = false, int SPEC = 0>
-__global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel(InverseSuperArgs sa) {
+#ifdef TFEP_PROBE_SK_OCC2
+// (timing probe: two workgroups = four pairs per CU, two waves per SIMD at 256 registers each.  Measured at B = 16 384 with 5 degrees
+// per block so that four pairs' LDS fits (TFEP_INV_BLOCK=5 TFEP_INV_SUPER=25): 146.6 ms against 135.6 ms with one workgroup per CU
+// in two rounds -- the chain spills ~280 registers at that budget and both chain waves of a CU land on the same two SIMDs.)
+__global__ void __launch_bounds__(128 * PAIRS, 2) inverse_superblock_kernel
+#else
+__global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
+#endif
+(InverseSuperArgs sa) {
     unsigned long long dg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_mark = DIAG ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long t_kernel0 = t_mark;

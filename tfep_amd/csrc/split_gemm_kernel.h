@@ -339,15 +339,24 @@ __global__ void __launch_bounds__(STHREADS, OCC) split_gemm_kernel(GemmArgs g, i
         // Own A DMA + everybody's B DMA of tile t landed; other B stage free.  The wait is explicit: the compiler's
         // own LDS-DMA tracking was seen to emit vmcnt(1) here, leaving the last-issued chunk in flight.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!(g.diag & 8)) __syncthreads();
         const char* Bs = b_base + (t & 1) * T::B_BYTES;
         char* Bn = b_base + ((t + 1) & 1) * T::B_BYTES;
         f16x8 ah[SMREP], al[SMREP];
+#ifdef TFEP_PROBE_OLD_TILE_HEAD
+        if (!(g.diag & 8)) __syncthreads();
+#endif
+        // The wave's A rows are its own (its own DMA, waited for above): their fragment reads go out BEFORE the barrier and travel
+        // while the wave waits for the others -- a lone wave per SIMD has nothing else to cover them with.  The barrier is a
+        // bare s_barrier: everybody's B DMA of tile t has landed (each wave's vmcnt(0) above), and the stage the next DMA
+        // overwrites was read by MFMAs that have been issued; __syncthreads() would add a fence that waits for the reads.
 #pragma unroll
         for (int m = 0; m < SMREP; ++m) {
             ah[m] = *(const f16x8*)(a_wave + m * 16 * ROW_BYTES + off_hi);
             al[m] = *(const f16x8*)(a_wave + m * 16 * ROW_BYTES + off_lo);
         }
+#ifndef TFEP_PROBE_OLD_TILE_HEAD
+        if (!(g.diag & 8)) asm volatile("s_barrier" ::: "memory");
+#endif
         // B fragments run B_AHEAD column groups ahead of the MFMAs that use them (ring of B_AHEAD + 1 register sets):
         // a lone wave per SIMD has to cover the LDS latency itself.
         f16x8 bh[B_AHEAD + 1], bl[B_AHEAD + 1];
@@ -576,7 +585,7 @@ __global__ void __launch_bounds__(STHREADS, OCC) split_gemm_kernel(GemmArgs g, i
             gemm_epilogue<SMREP, NREP, EPI, P, KSPL>(g, out, nt, n0, wrow0, lane, k_slice);
         }
     }
-    if (epi_is_spline(EPI) && (g.diag & 16) && threadIdx.x == 0) {
+    if ((g.diag & 16) && threadIdx.x == 0) {
         const unsigned long long t_end = __builtin_readcyclecounter();
         atomicAdd(&g_split_cycles[0], t_loop - t_start);
         atomicAdd(&g_split_cycles[1], t_end - t_loop);

@@ -1359,6 +1359,10 @@ class AutoregressiveFlow(torch.nn.Module):
                 x_split = hs_hidden.pop(0, None)           # (layer 0 on split operands: the super-block kernel's schedule only)
                 use_sb = bool(supers) and hs is not None and not look and all(l in hs_hidden for l in range(1, L)) and \
                     all(wd['layer'] >= 1 for b_ in bp['blocks'] for wd in b_['wide'])
+                if os.environ.get('TFEP_INV_DEBUG'):
+                    print('inverse schedule:', dict(B=B, supers=bool(supers), split_state=hs is not None, look=look, paired=paired,
+                                                    rows_per_wave=rows_per_wave, hidden_split=sorted(hs_hidden), use_sb=use_sb,
+                                                    cache_len=fused['cache_len'], max_feats=fused['max_feats'], blocks=len(bp['blocks'])))
                 if use_sb:
                     tw = ops.split_wide_tile_n()
                     m_tiles256 = (B + 255) // 256

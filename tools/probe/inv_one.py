@@ -35,3 +35,14 @@ if os.environ.get('TFEP_DIAG_INVERSE'):
     n = max(1, buf[8])
     print({k: round(buf[i] / n * 24 / 1e6, 3) for i, k in enumerate(names)}, 'M cycles per pair and inverse (24 launches);', int(buf[8]), 'pair-launches')
 print('ms per inverse', 1e3 * (time.perf_counter() - t0) / N, 'schedule', layer.last_inverse_schedule, 'calls', N + 1)
+if os.environ.get('TFEP_DIAG') == '16':
+    import ctypes
+    from tfep_amd import _lib
+    buf = (ctypes.c_ulonglong * 4)()
+    _lib.call('tfep_diag_split_cycles', buf)
+    with torch.no_grad():
+        layer.inverse(y)
+    torch.cuda.synchronize()
+    _lib.call('tfep_diag_split_cycles', buf)
+    print(f'split GEMMs of one inverse: {buf[2]} workgroups, k-loops {buf[0] / 256 / 1.0e6:.2f} M cycles per CU, epilogues {buf[1] / 256 / 1.0e6:.2f} M, '
+          f'lifetimes {buf[3] / 256 / 100 / 1e3:.2f} ms per CU -> clock {(buf[0] + buf[1]) / max(1, buf[3]) * 100:.0f} MHz')
