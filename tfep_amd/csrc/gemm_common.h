@@ -58,7 +58,7 @@ struct GemmArgs {
     int n_tile_list;           //   (negative = no tile); replaces map_mode / tile_order / tile_live: the host lists the
                                //   live tiles of a block-triangular product so that every XCD gets the same number
     int diag;                  // diagnostics only (TFEP_DIAG): 1 = skip the epilogue, 4 = skip the LDS-DMA,
-                               // 8 = skip the barriers (garbage results; timing only)
+                               // 8 = skip the barriers (garbage results; timing only), 16 = per-phase cycle counters, 32 = element-wise linear epilogue
     int ksplit;                // linear epilogues: > 1 = split-K: launch position (column tile, k slice); slice s writes
     int64_t slab_stride;       //   its partial sums to y + s * slab_stride (bias / pre_add in slice 0 only); the
                                //   consumer adds the slabs (deterministic, no atomics)

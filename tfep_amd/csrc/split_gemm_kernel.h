@@ -567,7 +567,62 @@ __global__ void __launch_bounds__(STHREADS, OCC) split_gemm_kernel(GemmArgs g, i
         });
         }
     } else {
-        if constexpr ((EPI == EPI_LINEAR || EPI == EPI_ELU) && (NREP > 16 || OCC > 1)) {
+        // The plain product (no column map, no addend, nothing accumulated into): the tile leaves through LDS, QW column groups at
+        // a time, as 16-byte stores -- 16 lanes write 256 contiguous bytes of a row.  (The element-wise path below stores 4 bytes
+        // per lane with its own 64-bit address: ~190 000 cycles for a 256 x 400 tile, 18 % of a K = 4480 tile and ~90 us of every
+        // super-block GEMM of the inverse, whose workgroups run one tile each.)
+        bool staged = false;
+        if constexpr (EPI == EPI_LINEAR) {
+            constexpr int QW = (T::LDS_BYTES >= SWAVES * 64 * 68 * 4) ? 4 : 2;          // column groups per pass
+            constexpr int PITCH = QW * 16 + 4, LPR = QW * 4, RPI = 64 / LPR;           // floats per staged row, lanes per row, rows per instruction
+            static_assert(SWAVES * 64 * PITCH * 4 <= T::LDS_BYTES, "epilogue stage does not fit in LDS");
+            staged = !g.col_map && !g.pre_add && !g.aux && !g.accumulate && (g.ldy & 3) == 0 && (g.slab_stride & 3) == 0 &&
+                     (reinterpret_cast<uintptr_t>(g.y) & 15) == 0 && !(g.diag & 32);
+            if (staged) {
+                __syncthreads();                        // every wave is done with the operand stages: LDS is reused below
+                float* stage = reinterpret_cast<float*>(slds + wave * (64 * PITCH * 4));
+                float* const ybase = g.y + (int64_t)k_slice * g.slab_stride;
+                const bool with_bias = g.bias && k_slice == 0;
+                const int cj = lane & 15, rq = (lane >> 4) * 4;
+                static_for<0, (NREP + QW - 1) / QW>([&](auto qc) __attribute__((always_inline)) {
+                    constexpr int q = qc.value;
+                    constexpr int groups = (NREP - QW * q) < QW ? (NREP - QW * q) : QW;
+                    static_for<0, groups>([&](auto ngc) __attribute__((always_inline)) {
+                        constexpr int n = QW * q + ngc.value;
+                        const int col = n0 + n * 16 + cj;
+                        const float bv = (with_bias && col < g.N) ? g.bias[col] : 0.f;
+                        static_for<0, SMREP * 4>([&](auto ic) __attribute__((always_inline)) {
+                            constexpr int m = ic.value / 4, i = ic.value % 4;
+                            stage[(m * 16 + rq + i) * PITCH + ngc.value * 16 + cj] = acc[n][m][i] * rs[m][i] + bv;
+                        });
+                    });
+                    __builtin_amdgcn_wave_barrier();    // (one wave per stage: LDS is in order, this pins the compiler)
+                    const int c4 = (lane % LPR) * 4;
+                    const int colg = n0 + q * (QW * 16) + c4;
+                    if (c4 < groups * 16 && colg < g.N) {
+#pragma unroll
+                        for (int it = 0; it < 64 / RPI; ++it) {
+                            const int row_l = it * RPI + lane / LPR;
+                            const int row = wrow0 + row_l;
+                            if (row < g.B) {
+                                const f32x4_alias v = *reinterpret_cast<const f32x4_alias*>(stage + row_l * PITCH + c4);
+                                float* dst = ybase + (int64_t)row * g.ldy + colg;
+                                if (colg + 4 <= g.N) {
+                                    *reinterpret_cast<f32x4_alias*>(dst) = v;
+                                } else {
+#pragma unroll
+                                    for (int j = 0; j < 3; ++j)
+                                        if (colg + j < g.N) dst[j] = v[j];
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                });
+            }
+        }
+        if (staged) {
+        } else if constexpr ((EPI == EPI_LINEAR || EPI == EPI_ELU) && (NREP > 16 || OCC > 1)) {
             // a wide tile has no registers for a copy of its accumulators: one column group at a time
             static_for<0, NREP>([&](auto nc) __attribute__((always_inline)) {
                 constexpr int n = nc.value;

@@ -64,7 +64,7 @@ for spec in sys.argv[1:]:
     rounds = -(-tiles // 256)
     print(f'{spec:>28}: {us:9.1f} us  {tiles} tiles = {tiles / 256:.2f} rounds; per k-tile of a round {us / rounds / (K / ks / 32):.2f} us;'
           f' {2.0 * M * N * K / us / 1e6:.0f} TFLOP/s')
-    if os.environ.get('TFEP_DIAG') == '16':
+    if int(os.environ.get('TFEP_DIAG', 0)) & 16:
         buf = (ctypes.c_ulonglong * 4)()
         _lib.call('tfep_diag_split_cycles', buf)
         _lib.call('tfep_masked_linear_gemm', ctypes.byref(d), st)
