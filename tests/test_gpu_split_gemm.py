@@ -196,6 +196,64 @@ def test_default_path_is_guarded_against_rows_the_split_format_cannot_carry():
     assert cw_forced_split < 1e-3
 
 
+def test_inverse_and_graph_replays_are_guarded_too():
+    """The range guard of the split-f16 default beyond the eager forward (ADVICE r3 / VERDICT r3 item 9).  ``inverse``: its conditioner
+    inputs are its own output, so the feature scales of the x it has produced decide -- ordinary data: the split path's result, bit
+    for bit; features spanning 10 decades: the call is repeated on the exact-fp32 kernels, bit for bit the ``split_gemm = False``
+    result.  ``GraphedFlow``: the captured call runs the split kernels and computes the flag on the device; a flagged replay is
+    repeated eagerly (where the guard picks the exact kernels), an ordinary one is the graph's result."""
+    import warnings
+    from tfep_amd.graphs import GraphedFlow
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    torch.manual_seed(12)
+    D, B = 200, 512
+    layer = MAF(generate_degrees(D, 'ascending'), transformer=NeuralSplineTransformer(torch.full((D,), -5.0), torch.full((D,), 5.0), 8),
+                initialize_identity=False).cuda()
+    assert layer._conditioner.split_worthwhile(B) and layer.split_gemm is None
+    x_ok = torch.randn(B, D, device='cuda').clamp_(-4.9, 4.9)
+    decades = 10.0 * torch.arange(D, device='cuda') / (D - 1) - 10.0
+    x_wide = torch.randn(B, D, device='cuda').clamp_(-4.9, 4.9) * torch.pow(10.0, decades)[None, :]
+
+    def inv(y, split):
+        layer.split_gemm = split
+        with torch.no_grad():
+            out = layer.inverse(y)
+        layer.split_gemm = None
+        return out
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        y_ok, _ = layer(x_ok)
+        y_wide, _ = layer(x_wide)
+        # ---- inverse
+        xd, ld = inv(y_ok, None)
+        assert layer.last_split_guard == dict(feature_scales_out_of_range=False, exact=False, inverse=True)
+        xs, ls = inv(y_ok, True)
+        assert torch.equal(xd, xs) and torch.equal(ld, ls)
+        xd, ld = inv(y_wide, None)
+        assert layer.last_split_guard == dict(feature_scales_out_of_range=True, exact=True, inverse=True)
+        xe, le = inv(y_wide, False)
+        assert torch.equal(xd, xe) and torch.equal(ld, le)
+        assert float(((xd - x_wide).abs() / (x_wide.abs() + 1e-6)).max()) < 5e-2       # (and it is the inverse)
+        # ---- graph replays
+        g = GraphedFlow(layer, B, D)
+        assert g.n_guarded_calls == 1
+        yg, lg = g(x_ok)
+        ye, le = layer(x_ok)
+        assert not g.last_call_guarded and torch.equal(yg, ye) and torch.equal(lg, le)
+        yg, lg = g(x_wide)
+        ye, le = layer(x_wide)
+        assert g.last_call_guarded and layer.last_split_guard['exact'] and torch.equal(yg, ye) and torch.equal(lg, le)
+        yg, lg = g(x_ok)                                   # the flag is cleared by every replay
+        assert not g.last_call_guarded
+        gi = GraphedFlow(layer, B, D, inverse=True)
+        xg, _ = gi(y_wide)
+        assert gi.last_call_guarded and torch.equal(xg, xd)
+        xg, _ = gi(y_ok)
+        assert not gi.last_call_guarded and torch.equal(xg, xs)
+
+
 def test_split_gemm_with_mask_k_ranges_and_tile_order():
     """Block-triangular mask (sorted MADE degrees): k-ranges in units of 32 skip tiles; results as the dense product."""
     from tfep_amd import ops

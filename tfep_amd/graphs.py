@@ -10,12 +10,37 @@ the graph and reads the CURRENT parameter values at every replay (optimiser upda
 import torch
 
 
-class GraphedFlow:
-    """``g = GraphedFlow(flow, batch_size, n_features); y, log_det_J = g(x)`` (no autograd)."""
+def _capturing_flags():
+    """Context manager: the range guards of the MAF layers captured inside add their flags to the device counter ``['count']`` of
+    the returned dict."""
+    import contextlib
+    from .nn.flows import autoregressive
 
-    def __init__(self, flow, batch_size, n_features, inverse=False, device=None, warmup=2):
+    @contextlib.contextmanager
+    def ctx():
+        flags = {}
+        before = autoregressive.capture_flags
+        autoregressive.capture_flags = flags
+        try:
+            yield flags
+        finally:
+            autoregressive.capture_flags = before
+    return ctx()
+
+
+class GraphedFlow:
+    """``g = GraphedFlow(flow, batch_size, n_features); y, log_det_J = g(x)`` (no autograd).
+
+    The range guard of the split-f16 default (``AutoregressiveFlow.split_guard``) cannot choose the arithmetic inside a graph:
+    the captured call runs on the split kernels and computes every guarded layer's flag on the device; with ``check_range``
+    (default) ``g(x)`` reads the flags after the replay -- one host synchronisation -- and, if one is set, repeats the call
+    eagerly, where the guard sends the flagged layers to the exact-fp32 kernels (``last_call_guarded``)."""
+
+    def __init__(self, flow, batch_size, n_features, inverse=False, device=None, warmup=2, check_range=True):
         self.flow = flow
         self.inverse = inverse
+        self.check_range = check_range
+        self.last_call_guarded = False
         device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.static_in = torch.zeros(batch_size, n_features, dtype=torch.float32, device=device)
         fn = flow.inverse if inverse else flow.forward
@@ -28,14 +53,21 @@ class GraphedFlow:
                 fn(self.static_in)
         torch.cuda.current_stream(device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), _capturing_flags() as flags, torch.cuda.graph(self.graph):
             self.static_out, self.static_ldj = fn(self.static_in)
+        self._flag_total = flags.get('count')
+        self.n_guarded_calls = flags.get('calls', 0)
 
     def __call__(self, x):
         if x.shape != self.static_in.shape:
             raise ValueError(f'GraphedFlow was captured for shape {tuple(self.static_in.shape)}, got {tuple(x.shape)}')
         self.static_in.copy_(x)
         self.graph.replay()
+        self.last_call_guarded = False
+        if self.check_range and self._flag_total is not None and int(self._flag_total.item()):
+            self.last_call_guarded = True
+            with torch.no_grad():
+                return (self.flow.inverse if self.inverse else self.flow.forward)(self.static_in)
         return self.static_out.clone(), self.static_ldj.clone()
 
 
@@ -83,6 +115,7 @@ class GraphedTrainingStep:
 
     def __init__(self, flow, loss_fn, optimizer, batch_size, n_features, device=None, warmup=3, sample_input=None):
         self.flow, self.loss_fn, self.optimizer = flow, loss_fn, optimizer
+        self._flag_total = None
         for group in optimizer.param_groups:
             # State that the warm-up steps create is zeroed again before the capture; for SGD's momentum buffer that equals a
             # fresh optimiser only when the first step's buffer is the plain gradient: with dampening != 0 a fresh optimiser
@@ -119,8 +152,9 @@ class GraphedTrainingStep:
             torch.cuda.current_stream(device).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             optimizer.zero_grad(set_to_none=True)      # the capture allocates the gradients in the graph's own pool
-            with torch.cuda.graph(self.graph):
+            with _capturing_flags() as flags, torch.cuda.graph(self.graph):
                 self.static_loss = self._step(self.static_in)
+            self._flag_total = flags.get('count')
         finally:
             _backward.FORCE_RECOMPUTE = was
             # (also on failure: a warm-up step that produced NaN must not stay in the weights)
@@ -152,6 +186,13 @@ class GraphedTrainingStep:
             p.grad = g
         self.optimizer.step()
         return loss.detach()
+
+    def range_guard_tripped(self):
+        """True when, in the LAST replayed step, the input of a layer spanned more feature scales than the split-f16 kernels the
+        captured step runs on carry at fp32 accuracy (``AutoregressiveFlow.split_guard``; the eager path sends such a call to the
+        exact-fp32 kernels -- a replayed step cannot, its update is already applied).  One host synchronisation; pin
+        ``layer.split_gemm = False`` before capturing a step for such data."""
+        return self._flag_total is not None and bool(int(self._flag_total.item()))
 
     def __call__(self, x):
         if x.shape != self.static_in.shape:

@@ -219,7 +219,9 @@ class AutoregressiveFlow(torch.nn.Module):
     #: largest magnitude of every feature over the batch is taken, and if the non-zero ones span more than 2^19
     #: (``tfep_range_flag``) THIS call runs on the exact-fp32 MFMA kernels instead (``last_split_guard`` says so; one
     #: warning per layer).  Costs one read of x and one host synchronisation per layer call -- skipped inside a HIP-graph
-    #: capture, where the host cannot wait, and when the arithmetic was chosen explicitly (``split_gemm = True / False``).
+    #: capture, where the host cannot wait (``graphs.GraphedFlow`` checks the same flag after every replay and repeats a
+    #: flagged call eagerly), and when the arithmetic was chosen explicitly (``split_gemm = True / False``).
+    #: ``inverse`` is guarded after the fact, on the x it has produced (``_inverse_impl``).
     #: The backward of a guarded forward stays exact too.
     #: Not guarded: the hidden activations (sums over many inputs plus an fp32 bias: no output sees "only small entries")
     #: and the weights (one scale per matrix from max |g|; an entry below 2^-19 of it contributes < 2^-19 max|w| |x| to a
@@ -515,6 +517,34 @@ class AutoregressiveFlow(torch.nn.Module):
         return self._inverse_impl(y)
 
     def _inverse_impl(self, y: torch.Tensor):
+        """The inverse under the range guard of the split-f16 default (``split_guard``).  The conditioner inputs of the inverse are
+        its own OUTPUT, so the check comes after the fact: the feature scales of the x just computed decide -- one pass over x and one
+        host synchronisation per call, on a path that takes tens of milliseconds -- and where they span more than 2^19 the call is
+        repeated on the exact-fp32 kernels (``last_split_guard`` says so), the arithmetic a guarded forward of that x uses."""
+        x, log_det_J = self._inverse_values(y)
+        on = self.split_guard if self.split_guard is not None else os.environ.get('TFEP_SPLIT_GUARD', '1') != '0'
+        if on and self.split_gemm is None and not self._guard_exact and y.shape[0] > 0 and self._use_split_gemm(y.shape[0]):
+            if torch.cuda.is_current_stream_capturing():
+                _flag_for_capture(x)
+                return x, log_det_J
+            n_x = ops.range_flag([ops.column_absmax(x.detach())], bits=19)
+            self.last_split_guard = dict(feature_scales_out_of_range=bool(n_x), exact=bool(n_x), inverse=True)
+            if n_x:
+                self._guard_exact = True
+                try:
+                    x, log_det_J = self._inverse_values(y)
+                finally:
+                    self._guard_exact = False
+                if not self.__dict__.get('_guard_warned'):
+                    self.__dict__['_guard_warned'] = True
+                    import warnings
+                    warnings.warn('tfep_amd: the features of the inverse differ in scale by more than 2^19 (largest magnitude per '
+                                  'feature over the batch): more than the split-f16 GEMMs carry at fp32 accuracy with one scale per '
+                                  'row; this inverse call was repeated on the exact-fp32 MFMA kernels.  layer.split_gemm = True / '
+                                  'False pins the arithmetic.')
+        return x, log_det_J
+
+    def _inverse_values(self, y: torch.Tensor):
         if self._blocked_ok():
             return self._inverse_blocked(y)
         t = self._tables(y.device)
@@ -1597,6 +1627,20 @@ class AutoregressiveFlow(torch.nn.Module):
         return self._conditioner(x)
 
 
+#: While a HIP graph is being captured the range guard cannot read its flag back; with a dict here it adds the flag to the device
+#: counter ``capture_flags['count']`` instead (created -- cleared by a captured fill kernel, so by every replay -- at the first
+#: guarded layer call, ``capture_flags['calls']`` counts them), for the owner of the graph to read after a replay
+#: (``graphs.GraphedFlow``).
+capture_flags = None
+
+
+def _flag_for_capture(x):
+    if capture_flags is not None:
+        with torch.no_grad():
+            capture_flags['count'] = ops.range_flag_device([ops.column_absmax(x.detach())], bits=19, count=capture_flags.get('count'))
+        capture_flags['calls'] = capture_flags.get('calls', 0) + 1
+
+
 class _RangeGuard:
     def __init__(self, layer, x, force=None):
         self.layer, self.x, self.force = layer, x, force
@@ -1610,8 +1654,10 @@ class _RangeGuard:
         layer._guard_exact = False
         on = layer.split_guard if layer.split_guard is not None else os.environ.get('TFEP_SPLIT_GUARD', '1') != '0'
         x = self.x
-        if (not on or layer.split_gemm is not None or x.shape[0] == 0 or not layer._use_split_gemm(x.shape[0])
-                or torch.cuda.is_current_stream_capturing()):
+        if not on or layer.split_gemm is not None or x.shape[0] == 0 or not layer._use_split_gemm(x.shape[0]):
+            return self
+        if torch.cuda.is_current_stream_capturing():
+            _flag_for_capture(x)                        # (the captured call itself runs on the split kernels)
             return self
         with torch.no_grad():
             # per-FEATURE magnitudes over the batch (a single small value in one row is harmless -- every unit adds an

@@ -382,6 +382,23 @@ def range_flag(tensors, bits=19):
     return int(count.item())
 
 
+def range_flag_device(tensors, bits=19, count=None):
+    """``range_flag`` without the read-back: the device counter (int32, 1 element) itself, a new one or ``count`` added to --
+    capturable in a HIP graph (a new counter is cleared by a fill kernel, see ``zeros``).  ``None`` when there is nothing to check."""
+    tensors = [t for t in tensors if t is not None and t.numel() > 0]
+    if not tensors:
+        return count
+    if count is None:
+        count = zeros(1, dtype=torch.int32, device=tensors[0].device)
+    for t in tensors:
+        check_device_tensor(t, 'range_flag input')
+        if t.dim() != 2 or t.stride(1) != 1:
+            t = t.reshape(t.shape[0], -1).contiguous() if t.dim() > 1 else t.reshape(1, -1).contiguous()
+        call('tfep_range_flag', ptr(t), t.stride(0) if t.shape[0] > 1 else t.shape[1], t.shape[0], t.shape[1], int(bits),
+             ptr(count), stream_of(t))
+    return count
+
+
 def abs_reduce(x, what):
     """``what='row_max'``: max_k |x[row, k]| per row;  ``'max_row_sum'``: max_row sum_k |x[row, k]| as a 1-element tensor
     (``tfep_abs_reduce``: plain kernels, capturable in a HIP graph, unlike torch's multi-block reductions whose semaphores are
