@@ -254,6 +254,61 @@ def test_inverse_and_graph_replays_are_guarded_too():
         assert not gi.last_call_guarded and torch.equal(xg, xs)
 
 
+def test_sequence_reads_its_layers_guards_once_and_repeats_from_the_first_flagged_layer():
+    """``SequentialFlow.forward`` defers the range guards of its layers (one host synchronisation per flow call):
+    the results are those of the layers called one by one, each under its own guard -- bit for bit -- whether no layer, the first
+    or a later one is flagged."""
+    import warnings
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF, SequentialFlow
+    from tfep_amd.nn.flows import autoregressive
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    torch.manual_seed(13)
+    D, B = 200, 512
+
+    def maf(order, identity):
+        return MAF(generate_degrees(D, order), transformer=NeuralSplineTransformer(torch.full((D,), -5.0), torch.full((D,), 5.0), 8),
+                   initialize_identity=identity).cuda()
+    x_ok = torch.randn(B, D, device='cuda').clamp_(-4.9, 4.9)
+    decades = 10.0 * torch.arange(D, device='cuda') / (D - 1) - 10.0
+    x_wide = torch.randn(B, D, device='cuda').clamp_(-4.9, 4.9) * torch.pow(10.0, decades)[None, :]
+
+    def one_by_one(layers, x):
+        total, verdicts = None, []
+        for layer in layers:
+            x, l = layer(x)
+            verdicts.append(None if layer.split_gemm is not None else layer.last_split_guard['exact'])
+            total = l if total is None else total + l
+        return x, total, verdicts
+    syncs = []
+    real = autoregressive.ops.range_flag
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        # (a) random layers: ordinary data flags nothing; 10-decade data flags the first layer
+        flow = SequentialFlow(maf('ascending', False), maf('descending', False), maf('ascending', False))
+        for x, expect in ((x_ok, [False, False, False]), (x_wide, [True, False, False])):
+            y1, l1, verdicts = one_by_one(list(flow), x)
+            assert verdicts == expect
+            autoregressive.ops.range_flag = lambda *a, **k: (syncs.append(1), real(*a, **k))[1]
+            try:
+                del syncs[:]
+                y2, l2 = flow(x)
+            finally:
+                autoregressive.ops.range_flag = real
+            assert torch.equal(y1, y2) and torch.equal(l1, l2)
+            # the per-layer read-backs happen only in the repeat from the first flagged layer on
+            assert len(syncs) == (3 if expect[0] else 0)
+        # (b) a pinned identity layer first (no guard of its own): the SECOND layer sees the 10 decades
+        first = maf('ascending', True)
+        first.split_gemm = False
+        flow = SequentialFlow(first, maf('descending', False), maf('ascending', False))
+        y1, l1, verdicts = one_by_one(list(flow), x_wide)
+        assert verdicts == [None, True, False]
+        y2, l2 = flow(x_wide)
+        assert torch.equal(y1, y2) and torch.equal(l1, l2)
+        assert flow[1].last_split_guard['exact'] and not flow[2].last_split_guard['exact']
+
+
 def test_split_gemm_with_mask_k_ranges_and_tile_order():
     """Block-triangular mask (sorted MADE degrees): k-ranges in units of 32 skip tiles; results as the dense product."""
     from tfep_amd import ops

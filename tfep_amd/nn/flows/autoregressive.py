@@ -1634,6 +1634,12 @@ class AutoregressiveFlow(torch.nn.Module):
 capture_flags = None
 
 
+#: ``SequentialFlow.forward`` defers the guards of its layers: with a list here a guarded layer call leaves ``(layer, device
+#: counter)`` in it and runs on the split kernels without waiting; the sequence reads all the counters at its end -- ONE host
+#: synchronisation per flow call instead of one per layer -- and repeats the call from the first flagged layer on.
+deferred_flags = None
+
+
 def _flag_for_capture(x):
     if capture_flags is not None:
         with torch.no_grad():
@@ -1658,6 +1664,10 @@ class _RangeGuard:
             return self
         if torch.cuda.is_current_stream_capturing():
             _flag_for_capture(x)                        # (the captured call itself runs on the split kernels)
+            return self
+        if deferred_flags is not None:
+            with torch.no_grad():
+                deferred_flags.append((layer, ops.range_flag_device([ops.column_absmax(x.detach())], bits=19)))
             return self
         with torch.no_grad():
             # per-FEATURE magnitudes over the batch (a single small value in one row is harmless -- every unit adds an
