@@ -223,6 +223,16 @@ __device__ inline void chain_gemm_split(const h8* __restrict__ img, const f4 (&x
 // 64 of each per 16 edges and layer.  Measured against the float64 goldens the velocities keep their 6e-7 relative error.
 __device__ inline float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ inline float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// tanh on the same two instructions: 1 - 2 / (1 + e^{2x}) (absolute error ~2e-7: an exp and a reciprocal of 1 ulp each), and the odd
+// series to x^5 below |x| = 0.1, where that form cancels (its remainder there: 17 x^7 / 315 < 6e-9).  The library tanhf() is ~40
+// instructions, once per edge and layer, on a kernel bound by its vector instructions (tanh'(x) = 1 - tanh^2 stays as it is).
+__device__ inline float fast_tanh(float x) {
+    const float ax = fminf(fabsf(x), 15.0f);
+    const float big = 1.0f - 2.0f * fast_rcp(1.0f + fast_exp(2.0f * ax));
+    const float x2 = ax * ax;
+    const float small = ax * fmaf(x2, fmaf(x2, 2.0f / 15.0f, -1.0f / 3.0f), 1.0f);
+    return copysignf(ax < 0.1f ? small : big, x);
+}
 
 // SiLU and its derivative (torch.nn.SiLU: x * sigmoid(x)), elementwise on a tile; dz <- silu'(z) dz, z <- silu(z)
 template <int NT, bool TAN>
@@ -692,7 +702,11 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_kernel(tfep_egnn
                 }
             }
         }
+        #if TFEP_EGNN_FAST_GEOM
+        const float mag = fast_tanh(sum_over_q(s));
+#else
         const float mag = tanhf(sum_over_q(s));
+#endif
         const float k = keep ? a.speed_factor : 0.0f;
         disp0 += k * u0 * mag; disp1 += k * u1 * mag; disp2 += k * u2 * mag;
         if (TAN) {
@@ -1057,7 +1071,11 @@ __global__ __launch_bounds__(EDGE_WAVES * 64, 2) void egnn_edge_bwd_kernel(tfep_
 #pragma unroll
             for (int r = 0; r < 4; ++r) s += x2[r] * z[t][r];
         }
+        #if TFEP_EGNN_FAST_GEOM
+        const float mag = fast_tanh(sum_over_q(s));
+#else
         const float mag = tanhf(sum_over_q(s));
+#endif
         // ---- reverse chain
         const float cs_k = keep ? a.speed_factor : 0.0f;
         const float g_mag = cs_k * (u0 * gp0 + u1 * gp1 + u2 * gp2);
