@@ -522,7 +522,9 @@ constexpr int Q4_ROWS = 16;
 // and two resident pairs per CU for cfg4-i.)
 constexpr int Q4_LDS_SLACK = 128;
 constexpr int Q4_Z_PITCH = 24;       // floats per value of the pre-activation stage: 8 values x 8 rows per store instruction, conflict free
-constexpr int IB_FTAB_WORDS = 28;   // super-block kernel: per feature 9 table words (padded to 12) + y of the pair's 16 rows
+constexpr int IB_FTAB_WORDS = 28 + IB_STEP_INTS;   // super-block kernel: per feature 9 table words (padded to 12) + y of the pair's 16 rows +
+                                                   // a step record (a block has at most as many steps as features)
+constexpr int IB_REC_WORDS = 40;                   // ... and the block's own record (IB_BLK_INTS, padded)
 constexpr int Q4_P_PITCH = 20;       // floats per parameter of the MFMA hand-over [IB_MAX_P parameters][16 rows + 4]
 
 // columns per 8-row group of the weight stage: + 4 puts consecutive groups 32 banks apart -- a 16 x 4 operand fragment (two
@@ -554,7 +556,7 @@ __host__ __device__ inline size_t ib_lds_floats_q4_paired(int L, int cache_len, 
     const size_t o = ib_q4_ostage_floats((int)cols, cache_len) + Q4_LDS_SLACK + (size_t)IB_STAGE_ROWS * Q4_Z_PITCH;      // output-rows stage
     // (+ the per-feature table of the super-block kernel: IB_FTAB_WORDS words per feature of a block, and its scale table)
     return ((size_t)L * ib_round8(cache_len) + ib_round4(max_feats)) * Q4_ROWS + (size_t)IB_MAX_P * Q4_P_PITCH + 2 * h + 2 * o +
-           (size_t)IB_FTAB_WORDS * ib_round4(max_feats) + IB_SCALE_FLOATS;
+           (size_t)IB_FTAB_WORDS * ib_round4(max_feats) + IB_SCALE_FLOATS + IB_REC_WORDS;
 }
 
 // zs[v * Q4_Z_PITCH + i] = sum_s z[s * slab_stride + (wave_row0 + i) * ldz + base + v * vstride],  v < nv <= 32, i < 16
@@ -993,6 +995,7 @@ struct InverseSuperArgs {
     const float* ws[IB_MAX_LAYERS + 1]; int64_t ldws[IB_MAX_LAYERS + 1];
     const float* ws_inv[IB_MAX_LAYERS + 1];
     const float* hs_inv[IB_MAX_LAYERS + 1];
+    int diag_who;                       // DIAG kernel: 0 = the phase counters of the chain wave of pair 0, 1 = of its loader wave
 };
 
 // One group of up to IB_PROD_TILES 16-row tiles of W (rows row0 + 16 t .. ) against NSETS sets of 16 sample rows (the pairs of
@@ -1403,6 +1406,16 @@ static __device__ unsigned long long g_ib_cycles[12];
 // the hand-overs are workgroup barriers, so the two pairs move in lockstep -- they run the same records on different rows -- and
 // the PRODUCTS at the head of a block are dealt over the four waves, every wave multiplying its tiles with BOTH row sets: the
 // weight rows, the 60 GB per inverse that bound that phase (every pair read them all), are fetched once per workgroup.
+// Wave-uniform ints kept in LDS (the records of the block being worked on): a read is a broadcast ds_read, brought back to an SGPR.
+// From global memory each record field was a VECTOR load (the addresses are uniform, but the stores in between keep the compiler
+// from scalar loads) with its s_waitcnt vmcnt(0) -- which also waits for every global store the wave has issued: the chain wave
+// paid a store round trip at the head of every stage for three integers.
+struct LdsInts {
+    const int* p;
+    __device__ __forceinline__ int operator[](int i) const { return __builtin_amdgcn_readfirstlane(p[i]); }
+    __device__ __forceinline__ LdsInts operator+(int o) const { return LdsInts{p + o}; }
+};
+
 // SPEC (kind 1): 0 = any spline layout (bins, flags and parameter count at run time: the unpacking of a feature's parameters then
 // indexes a 32-register array dynamically, every flag is a select); 1 = 8 bins, plain layout (25 parameters); 2 = 8 bins, circular
 // (25 parameters): the layouts of BASELINE cfg2 / cfg4-i as compile-time constants.
@@ -1480,19 +1493,25 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
     // SD: [l][16] the un-scaling of layer l's dot (1/scale of the rows of its input panel x 1/scale of its weights), then
     // [L + 1 + l][16] the scale of the split halves of layer l's OUTPUT (the panel layer l + 1 reads), per sample row of the pair
     float* const scl = ytab + (size_t)a.max_feats * Q4_ROWS;
+    int* const lrec = reinterpret_cast<int*>(scl + IB_SCALE_FLOATS);    // the block's record and its step records
+    int* const lsteps = lrec + IB_REC_WORDS;
     const SplineArgs& sp0 = KIND == 3 ? a.spg[0] : a.sp;            // (kind 3: every member indexes the same domain arrays)
 
     // The hand-over of a stage inside the chain.  (__syncthreads() drains the wave's vector-memory counter too, so the consumer
     // waits at every hand-over for the global stores it has just issued; a consumer-side barrier that waits for LDS only measured
     // the same -- 71.1 / 71.0 ms, same box, alternating -- as it did on the one-block kernel in round 3.)
-    auto handover = [&]() __attribute__((always_inline)) { __syncthreads(); };
+    // Round 4, later: a bare s_barrier once the wave's LDS traffic has landed.  Nothing the chain stores to global memory (h, x,
+    // xpad) is read inside the block -- the barrier at the head of the next block publishes it -- and the loader's loads are in
+    // its registers before it writes LDS: neither wave needs the vmcnt(0) of __syncthreads() here.  (With the records read from
+    // global memory the same change measured nothing: their loads brought the wait back.)
+    auto handover = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     double ldj_acc = 0.0;
     for (int blk = 0; blk < sa.n_blocks; ++blk) {
-        const int32_t* rec = sa.blocks + (size_t)blk * IB_BLK_INTS;
-        const int n_steps = rec[0];
-        const int32_t* steps = a.steps + (size_t)rec[1] * IB_STEP_INTS;
-        const int feat_base = rec[2];
-        const int32_t* in_cols = a.in_cols + rec[3];
+        const int32_t* grec = sa.blocks + (size_t)blk * IB_BLK_INTS;
+        const int n_steps = min(grec[0], (int)ib_round4(a.max_feats));   // (the host checks: a block's steps fit the LDS table)
+        const int32_t* gsteps = a.steps + (size_t)grec[1] * IB_STEP_INTS;
+        const int feat_base = grec[2];
+        const int32_t* in_cols = a.in_cols + grec[3];
         __syncthreads();            // the previous block is complete in both waves: its LDS is free, its h / x stores are visible
         lap(6);
 
@@ -1500,7 +1519,7 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
         {
             int g = 0;
             for (int l = 0; l <= LL; ++l) {
-                const int row0 = rec[12 + 4 * l], n_rows = rec[13 + 4 * l], kb = rec[14 + 4 * l], ke = rec[15 + 4 * l];
+                const int row0 = grec[12 + 4 * l], n_rows = grec[13 + 4 * l], kb = grec[14 + 4 * l], ke = grec[15 + 4 * l];
                 if (ke <= kb || n_rows <= 0) continue;
                 const float* W = l < LL ? a.w[l] : a.wout;
                 const int64_t ldw = l < LL ? a.ldw[l] : a.ldwout;
@@ -1538,9 +1557,9 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
                 __builtin_amdgcn_wave_barrier();
             }
             for (int l = 0; l < LL; ++l) {
-                const float* hr = a.h[l] + r * a.ldh[l] + rec[4 + l];
+                const float* hr = a.h[l] + r * a.ldh[l] + grec[4 + l];
                 float* cl = cache + (size_t)l * a.cache_len * Q4_ROWS;
-                const int n_old = rec[8 + l];
+                const int n_old = grec[8 + l];
                 if constexpr (SD) {
                     const float sc = scl[(IB_MAX_LAYERS + 1 + l) * Q4_ROWS + s];
                     for (int j = part; j < n_old; j += 4) sd_store_act(cache_b + (size_t)l * layer_bytes, j, s, hr[j], sc);
@@ -1548,7 +1567,7 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
                     for (int j = part; j < n_old; j += 4) cl[j * Q4_ROWS + s] = hr[j];
                 }
             }
-            const int n_feat = min(rec[32], a.max_feats);
+            const int n_feat = min(grec[32], a.max_feats);
             for (int i = lane; i < n_feat; i += 64) {
                 const int fi = feat_base + i;
                 const int sel = a.feat_sel[fi], e0 = a.feat_in[fi];
@@ -1560,10 +1579,13 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
                 }
             }
             for (int i = part; i < n_feat; i += 4) ytab[i * Q4_ROWS + s] = a.y[r * a.ldy + a.feat_sel[feat_base + i]];
+            for (int i = lane; i < IB_BLK_INTS; i += 64) lrec[i] = grec[i];
+            for (int i = lane; i < n_steps * IB_STEP_INTS; i += 64) lsteps[i] = gsteps[i];
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();            // the products are stored (the loader's stages read them), the cache is initialised
         lap(1);
+        const LdsInts rec{lrec}, steps{lsteps};         // from here on the records are read from LDS
         // slabs of the pre-activations: those of the super-block GEMMs, plus the one just written where this block has one
         int z_slabs[IB_MAX_LAYERS];
 #pragma unroll
@@ -1572,7 +1594,7 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
 
         int oj = 0;
         auto fill_out = [&](int step, int f, int buf) __attribute__((always_inline)) {
-            const int32_t* sr = steps + step * IB_STEP_INTS;
+            const LdsInts sr = steps + step * IB_STEP_INTS;
             const int o_row0 = sr[4 * IB_MAX_LAYERS], o_nd = sr[4 * IB_MAX_LAYERS + 1], o_kb = sr[4 * IB_MAX_LAYERS + 2],
                       o_ke = sr[4 * IB_MAX_LAYERS + 3];
             float* os = ostg0 + (size_t)buf * o_floats;
@@ -1601,7 +1623,7 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
         }
 
         for (int st_i = 0; st_i < n_steps; ++st_i) {
-            const int32_t* st = steps + st_i * IB_STEP_INTS;
+            const LdsInts st = steps + st_i * IB_STEP_INTS;
             // ---- hidden units of this degree, layer by layer
             for (int l = 0; l < LL; ++l) {
                 const int row0 = st[4 * l], n = st[4 * l + 1], kb = st[4 * l + 2], ke = st[4 * l + 3];
@@ -1779,7 +1801,7 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
         }
     }
     if (consumer && writer) a.ldj[row] = (float)((double)a.ldj[row] + ldj_acc);
-    if (DIAG && threadIdx.x == 0) {
+    if (DIAG && threadIdx.x == (sa.diag_who ? 64 : 0)) {
         lap(6);
 #pragma unroll
         for (int i = 0; i < 7; ++i) atomicAdd(&g_ib_cycles[i], dg[i]);
@@ -1898,6 +1920,11 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
         TFEP_REQUIRE(d->rows_per_wave == 16 && d->paired != 0,
                      "inverse_block: a super-block launch (n_blocks > 0) needs rows_per_wave = 16 and paired = 1");
         TFEP_REQUIRE(d->blocks != nullptr && d->zout_extra != nullptr, "inverse_block: super-block launch without block records / extra slab");
+        // (n_steps of a super-block launch: the most steps any of its blocks has -- their records are kept in LDS beside the
+        // per-feature tables, sized for max_feats of them)
+        TFEP_REQUIRE(d->n_steps >= 1 && d->n_steps <= (int)ib_round4(d->max_feats),
+                     "inverse_block: super-block launch: n_steps (the most steps of a block, %d) must be 1 .. max_feats rounded up to 4 (%d)",
+                     d->n_steps, (int)ib_round4(d->max_feats));
         InverseSuperArgs sa = {};
         a.n_steps = 0;
         a.cache_len = ib_round8(d->cache_len);          // whole k-groups of 8 (the split activation cache)
@@ -1923,6 +1950,7 @@ int tfep_inverse_block(const tfep_inverse_block_desc* d, void* stream) {
         a.lds_floats = (int)(lds_s / sizeof(float));
         sa.a = a;
         static const bool diag = getenv("TFEP_DIAG_INVERSE") != nullptr && atoi(getenv("TFEP_DIAG_INVERSE")) != 0;
+        sa.diag_who = diag && atoi(getenv("TFEP_DIAG_INVERSE")) == 2;      // (2: the loader wave's view of the same phases)
         // waves_per_workgroup = 4: two pairs per workgroup (they share the weight fetches of the products); 0 / 2: one
         const bool two = d->waves_per_workgroup == 4;
         TFEP_REQUIRE(d->waves_per_workgroup == 0 || d->waves_per_workgroup == 2 || two,

@@ -1165,7 +1165,7 @@ class AutoregressiveFlow(torch.nn.Module):
         per_any = bool(torch.cat(feat_per).any().item()) if feat_per else False
         in_range = (int(ic.min()), int(ic.max()) + 1) if len(ic) else (0, 0)        # (a periodic entry list names both columns)
         st = sup['tables'] = dict(
-            in_range=in_range, periodic=per_any,
+            in_range=in_range, periodic=per_any, max_steps=max(b_['fused']['n_steps'] for b_ in blocks),
             steps=torch.cat(steps).contiguous(), cols=cat(cols), sel=cat(sel), feat_in=cat(feat_in), feat_per=cat(feat_per),
             in_cols=cat(in_cols), records=torch.tensor(recs, dtype=torch.int32).reshape(-1, n_rec).to(device), n_blocks=len(blocks),
             unit_range=[(blocks[0]['fused']['unit_range'][l][0], blocks[-1]['fused']['unit_range'][l][1]) for l in range(L)])
@@ -1444,7 +1444,8 @@ class AutoregressiveFlow(torch.nn.Module):
                 sk = self.inverse_super_kernel
                 if os.environ.get('TFEP_INV_SUPER_KERNEL') is not None:
                     sk = os.environ['TFEP_INV_SUPER_KERNEL'] != '0'
-                if (sk is None or sk) and use_sb and paired and rows_per_wave == 16:
+                steps_fit = all(b_['fused']['n_steps'] <= ops.round_up(fused['max_feats'], 4) for b_ in bp['blocks'])
+                if (sk is None or sk) and use_sb and paired and rows_per_wave == 16 and steps_fit:
                     # layer 0 joins the super-block scheme: its own slabs, one GEMM per super-block over the inputs known before
                     n0_max = max(s_['wide0']['n_rows'] for s_ in supers)
                     S0 = int(min(8, max(1, 256 // max(1, 2 * m_tiles)), max(1, mplan['k_pad'][0] // 512)))
@@ -1478,6 +1479,7 @@ class AutoregressiveFlow(torch.nn.Module):
                         elif w0['n_rows'] > 0:
                             launch(xpad, packs[0][0], packs[0][1], w0, sb_buf0[:S0] if S0 > 1 else sb_buf0[0], 0, act=0, k_split=S0)
                         d.n_blocks, d.blocks = tb['n_blocks'], tb['records'].data_ptr()
+                        d.n_steps = tb['max_steps']                 # (the kernel keeps a block's step records in LDS)
                         d.steps, d.feat_cols, d.feat_sel = tb['steps'].data_ptr(), tb['cols'].data_ptr(), tb['sel'].data_ptr()
                         d.feat_in, d.feat_periodic, d.in_cols = tb['feat_in'].data_ptr(), tb['feat_per'].data_ptr(), tb['in_cols'].data_ptr()
                         # the kernel indexes the slabs by packed row: column 0 of a buffer is the super-block's first row
