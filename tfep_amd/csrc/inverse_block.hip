@@ -1545,7 +1545,10 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
         float* zs = zs0;
         int parity = 0;
         if (consumer) {
-            for (int j = lane * 4; j < lds_total; j += 256) *(ib_f4_alias*)(cache + j) = ib_f4{0.f, 0.f, 0.f, 0.f};
+            // (caches and stages; the tables behind them are written whole, by the loader wave meanwhile)
+            const int zero_total = (int)(ftab - cache) & ~3;
+            for (int j = lane * 4; j < zero_total; j += 256) *(ib_f4_alias*)(cache + j) = ib_f4{0.f, 0.f, 0.f, 0.f};
+            if (lane * 4 + zero_total < lds_total && lane < 1) for (int j = zero_total; j < (int)(ftab - cache); ++j) cache[j] = 0.f;
             __builtin_amdgcn_wave_barrier();
             if constexpr (SD) {
                 if (lane < Q4_ROWS)
@@ -1567,6 +1570,9 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
                     for (int j = part; j < n_old; j += 4) cl[j * Q4_ROWS + s] = hr[j];
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            // the loader wave is done with its share of the products: the block's tables meanwhile
             const int n_feat = min(grec[32], a.max_feats);
             for (int i = lane; i < n_feat; i += 64) {
                 const int fi = feat_base + i;
