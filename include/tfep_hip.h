@@ -478,7 +478,8 @@ typedef struct tfep_inverse_block_desc {
      * waves_per_workgroup = 4 puts TWO pairs into a workgroup (2 x tfep_inverse_block_lds_bytes_paired of LDS): the same chains in
      * lockstep, the products' weight rows fetched once for both pairs' rows.
      * z_slabs[l] / zout_slabs then count the slabs of z[l] / zout WITHOUT the extra one (added per block when ke > kb);
-     * n_steps, cache_col0 and cache_n_old of the descriptor are ignored. */
+     * cache_col0 and cache_n_old of the descriptor are ignored; n_steps = the most steps any block of the list has (1 .. max_feats
+     * rounded up to 4: the kernel keeps the records of the block it works on -- [IB_BLK_INTS] + n_steps x [step_ints] -- in LDS). */
     int32_t n_blocks;
     const int32_t* blocks;
     float* z_extra[4];
