@@ -1393,6 +1393,10 @@ class AutoregressiveFlow(torch.nn.Module):
                     print('inverse schedule:', dict(B=B, supers=bool(supers), split_state=hs is not None, look=look, paired=paired,
                                                     rows_per_wave=rows_per_wave, hidden_split=sorted(hs_hidden), use_sb=use_sb,
                                                     cache_len=fused['cache_len'], max_feats=fused['max_feats'], blocks=len(bp['blocks'])))
+                sk_wanted = self.inverse_super_kernel
+                if os.environ.get('TFEP_INV_SUPER_KERNEL') is not None:
+                    sk_wanted = os.environ['TFEP_INV_SUPER_KERNEL'] != '0'
+                sk_wanted = (sk_wanted is None or bool(sk_wanted)) and bool(paired) and rows_per_wave == 16
                 if use_sb:
                     tw = ops.split_wide_tile_n()
                     m_tiles256 = (B + 255) // 256
@@ -1405,6 +1409,8 @@ class AutoregressiveFlow(torch.nn.Module):
                             continue
                         n_tiles = (n_l + (sb_tile[l] or 256) - 1) // (sb_tile[l] or 256)
                         sb_S[l] = int(min(8, max(1, 256 // max(1, m_tiles256 * n_tiles)), max(1, mplan['k_pad'][l] // 512)))
+                        if sk_wanted:
+                            sb_S[l] = min(sb_S[l], 3)       # (+ the products' slab: one pass of the chain loader's stage)
                         sb_buf[l] = torch.empty(sb_S[l] + 1, B, ops.round_up(n_l, 4), **f32)
 
                     def super_gemms(sup):
@@ -1448,7 +1454,12 @@ class AutoregressiveFlow(torch.nn.Module):
                 if (sk is None or sk) and use_sb and paired and rows_per_wave == 16 and steps_fit:
                     # layer 0 joins the super-block scheme: its own slabs, one GEMM per super-block over the inputs known before
                     n0_max = max(s_['wide0']['n_rows'] for s_ in supers)
-                    S0 = int(min(8, max(1, 256 // max(1, 2 * m_tiles)), max(1, mplan['k_pad'][0] // 512)))
+                    # split-K slices of layer 0's GEMM: one round of workgroups, and at most 3 -- with the slab of the in-kernel products
+                    # the chain's loader then adds 4 slabs, one pass of its stage (5 slabs: two dependent passes in every layer-0
+                    # slot of the chain; cfg2 layer, B = 8192: 4 -> 2 slices, 68.8 / 69.1 -> 67.4 / 67.8 ms)
+                    S0 = int(max(1, min(3, 256 // max(1, m_tiles * ((n0_max + 255) // 256)), mplan['k_pad'][0] // 512)))
+                    if os.environ.get('TFEP_INV_S0'):
+                        S0 = int(os.environ['TFEP_INV_S0'])
                     sb_buf0 = torch.empty(S0 + 1, B, ops.round_up(max(n0_max, 1), 4), **f32)
                     xs = None
                     if x_split is not None:
