@@ -1222,13 +1222,16 @@ __device__ __forceinline__ void stage_rows_split(char* __restrict__ st, int R, c
     const int ng = (ke - kb + 7) >> 3;
     const int gb = sd_group_bytes(R);
     const int total = nrows * ng;
+    // i / ng without the ~25 instructions of an integer division (the loader wave's slot is what the chain waits for):
+    // floor((i + 0.5) / ng) in fp32 is exact for i < 2^12, ng <= 2^8 -- the quotient's fraction stays 0.5 / ng away from an integer
+    const float inv_ng = 1.0f / (float)ng;
     for (int i0 = 0; i0 < total; i0 += 128) {
         ib_f4 hi[2], lo[2];
         int rr[2], gg[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int i = i0 + 64 * t + lane;
-            rr[t] = i < total ? i / ng : -1;
+            rr[t] = i < total ? (int)(((float)i + 0.5f) * inv_ng) : -1;
             gg[t] = i - (rr[t] < 0 ? 0 : rr[t]) * ng;
             if (rr[t] >= 0) {
                 const float* src = ws + (int64_t)(row0 + rr[t] * row_stride) * ldws + kb + 8 * gg[t];
