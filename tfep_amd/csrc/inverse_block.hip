@@ -1217,19 +1217,23 @@ __device__ __forceinline__ int sd_hi_off(int row) { return row * 32 + (((row >> 
 __device__ __forceinline__ int sd_lo_off(int row) { return row * 32 + (((row >> 2) & 1) ? 0 : 16); }
 
 // stage rows r < nrows (packed rows row0 + r * row_stride of the split pack ws), k-groups of columns [kb, ke) (kb a multiple of 8)
-__device__ __forceinline__ void stage_rows_split(char* __restrict__ st, int R, const float* __restrict__ ws, int64_t ldws, int row0,
-                                                 int row_stride, int nrows, int kb, int ke, int lane) {
+// CH chunks (one row's k-group: 32 bytes) per lane and pass, all of a pass's loads in flight before its first LDS write: a pass is a
+// round trip of the loader's slot.  Two for the hidden stages (<= 8 rows: one pass), four for the output rows of a degree (25 rows x
+// 14 k-groups at cfg2: two passes instead of three).
+template <int CH>
+__device__ __forceinline__ void stage_rows_split_impl(char* __restrict__ st, int R, const float* __restrict__ ws, int64_t ldws, int row0,
+                                                      int row_stride, int nrows, int kb, int ke, int lane) {
     const int ng = (ke - kb + 7) >> 3;
     const int gb = sd_group_bytes(R);
     const int total = nrows * ng;
     // i / ng without the ~25 instructions of an integer division (the loader wave's slot is what the chain waits for):
     // floor((i + 0.5) / ng) in fp32 is exact for i < 2^12, ng <= 2^8 -- the quotient's fraction stays 0.5 / ng away from an integer
     const float inv_ng = 1.0f / (float)ng;
-    for (int i0 = 0; i0 < total; i0 += 128) {
-        ib_f4 hi[2], lo[2];
-        int rr[2], gg[2];
+    for (int i0 = 0; i0 < total; i0 += 64 * CH) {
+        ib_f4 hi[CH], lo[CH];
+        int rr[CH], gg[CH];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < CH; ++t) {
             const int i = i0 + 64 * t + lane;
             rr[t] = i < total ? (int)(((float)i + 0.5f) * inv_ng) : -1;
             gg[t] = i - (rr[t] < 0 ? 0 : rr[t]) * ng;
@@ -1240,13 +1244,18 @@ __device__ __forceinline__ void stage_rows_split(char* __restrict__ st, int R, c
             }
         }
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < CH; ++t)
             if (rr[t] >= 0) {
                 *(ib_f4_alias*)(st + gg[t] * gb + sd_hi_off(rr[t])) = hi[t];
                 *(ib_f4_alias*)(st + gg[t] * gb + sd_lo_off(rr[t])) = lo[t];
             }
     }
     __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void stage_rows_split(char* __restrict__ st, int R, const float* __restrict__ ws, int64_t ldws, int row0,
+                                                 int row_stride, int nrows, int kb, int ke, int lane) {
+    if (nrows * ((ke - kb + 7) >> 3) > 128) stage_rows_split_impl<4>(st, R, ws, ldws, row0, row_stride, nrows, kb, ke, lane);
+    else stage_rows_split_impl<2>(st, R, ws, ldws, row0, row_stride, nrows, kb, ke, lane);
 }
 
 // value `hv` of unit k (position in the layer's cache) for sample row `row`, scaled, into the split activation cache
