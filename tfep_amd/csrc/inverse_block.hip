@@ -1228,7 +1228,7 @@ __device__ __forceinline__ void stage_rows_split_impl(char* __restrict__ st, int
     const int total = nrows * ng;
     // i / ng without the ~25 instructions of an integer division (the loader wave's slot is what the chain waits for):
     // floor((i + 0.5) / ng) in fp32 is exact for i < 2^12, ng <= 2^8 -- the quotient's fraction stays 0.5 / ng away from an integer
-    const float inv_ng = 1.0f / (float)ng;
+    const float inv_ng = __builtin_amdgcn_rcpf((float)ng);        // (v_rcp_f32, 1 ulp: still exact, checked for 1 ulp either way)
     for (int i0 = 0; i0 < total; i0 += 64 * CH) {
         ib_f4 hi[CH], lo[CH];
         int rr[CH], gg[CH];
