@@ -1258,6 +1258,24 @@ __device__ __forceinline__ void stage_rows_split(char* __restrict__ st, int R, c
     else stage_rows_split_impl<2>(st, R, ws, ldws, row0, row_stride, nrows, kb, ke, lane);
 }
 
+// The same stage by LDS-DMA (global_load_lds_dwordx4), one instruction per k-group: lane 2 r + s fetches half s ^ swizzle(r) of row r's
+// 32 bytes straight into the stage -- no registers, no LDS-write instructions, and nothing waits: the loader's later loads complete
+// after it (in order), and it drains its vector-memory counter before the hand-over that follows.  For the output rows of a degree
+// (nrows <= 32); the hidden stages (<= 8 rows) keep the register path, 4 loads per lane.
+__device__ __forceinline__ void stage_rows_split_dma(char* __restrict__ st, int R, const float* __restrict__ ws, int64_t ldws, int row0,
+                                                     int nrows, int kb, int ke, int lane) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    typedef const __attribute__((address_space(1))) void* glb_ptr;
+    const int ng = (ke - kb + 7) >> 3;
+    const int gb = sd_group_bytes(R);
+    const int row = lane >> 1, slot = lane & 1;
+    const int half = slot ^ ((row >> 2) & 1);                                  // 0: the 8 hi halves, 1: the 8 lo halves
+    const float* src = ws + (int64_t)(row0 + min(row, nrows - 1)) * ldws + kb + 4 * half;
+    if (row < nrows)
+        for (int g = 0; g < ng; ++g)
+            __builtin_amdgcn_global_load_lds((glb_ptr)(src + 8 * g), (lds_ptr)(st + g * gb), 16, 0, 0);
+}
+
 // value `hv` of unit k (position in the layer's cache) for sample row `row`, scaled, into the split activation cache
 __device__ __forceinline__ void sd_store_act(char* __restrict__ act, int k, int row, float hv, float scale) {
     const float t = hv * scale;
@@ -1516,7 +1534,10 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
     // xpad) is read inside the block -- the barrier at the head of the next block publishes it -- and the loader's loads are in
     // its registers before it writes LDS: neither wave needs the vmcnt(0) of __syncthreads() here.  (With the records read from
     // global memory the same change measured nothing: their loads brought the wait back.)
-    auto handover = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    auto handover = [&]() __attribute__((always_inline)) {
+        if (loader) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (its LDS-DMA of the output rows has landed too)
+        else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
     double ldj_acc = 0.0;
     for (int blk = 0; blk < sa.n_blocks; ++blk) {
         const int32_t* grec = sa.blocks + (size_t)blk * IB_BLK_INTS;
@@ -1623,8 +1644,10 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
                 stage_z16(oz, a.zout, a.ldzout, wave_row0, a.B, o_row0 + f, 1, a.mb_dim, zout_slabs, a.zout_slab_stride, lane);
             } else {
                 const int o_P = KIND == 3 ? a.spg[sr[4 * IB_MAX_LAYERS + 5]].P : a.P;
-                if constexpr (SD) stage_rows_split(reinterpret_cast<char*>(os), IB_STAGE_ROWS, sa.ws[LL], sa.ldws[LL], o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
-                else stage_rows(os, gstride, a.wout, a.ldwout, o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
+                if constexpr (SD) {
+                    if (o_nd == 1) stage_rows_split_dma(reinterpret_cast<char*>(os), IB_STAGE_ROWS, sa.ws[LL], sa.ldws[LL], o_row0 + f, o_P, o_kb, o_ke, lane);
+                    else stage_rows_split(reinterpret_cast<char*>(os), IB_STAGE_ROWS, sa.ws[LL], sa.ldws[LL], o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
+                } else stage_rows(os, gstride, a.wout, a.ldwout, o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
                 stage_z16(oz, a.zout, a.ldzout, wave_row0, a.B, o_row0 + f, o_nd, o_P, zout_slabs, a.zout_slab_stride, lane);
             }
         };
