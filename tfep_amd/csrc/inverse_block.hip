@@ -1678,7 +1678,7 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
 #ifndef TFEP_PROBE_NO_HSTAGE          // (timing probe, wrong results: the chain without the loader's hidden-layer fetches)
                     if (loader) {
                         if (l == 0) stage_gather(stg, gstride, a.w[0], a.ldw[0], ub, nb, in_cols, ke, lane);
-                        else if constexpr (SD) stage_rows_split(reinterpret_cast<char*>(stg), HROWS, sa.ws[l], sa.ldws[l], ub, 1, nb, kb, ke, lane);
+                        else if constexpr (SD) stage_rows_split_dma(reinterpret_cast<char*>(stg), HROWS, sa.ws[l], sa.ldws[l], ub, nb, kb, ke, lane);
                         else stage_rows(stg, gstride, a.w[l], a.ldw[l], ub, 1, nb, kb, ke, lane);
                         stage_z16(zs, a.z[l], a.ldz[l], wave_row0, a.B, ub, 1, nb, z_slabs[l], a.z_slab_stride[l], lane);
                     }
