@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "fp64_fast.h"
 
 namespace tfep {
 
@@ -229,7 +230,10 @@ __device__ inline double rq_spline_element(const float (&w)[KMAX], const float (
 // wave of 16 rows: with branches every row that falls into another bin took its own copy of everything behind the search
 // (the unrolled search duplicates its tail: 25 copies of the solve in the object code of the super-block kernel), and a
 // wave walked through as many of them as its rows had distinct bins.
-template <int KMAX>
+// FAST: the six fp64 divisions and the square root through fp64_fast.h (hardware seed + Newton, ~1 ulp in fp64 -- far below the
+// fp32 rounding of the result; every denominator here is positive and finite for valid inputs): ~170 vector instructions less on the
+// chain wave of the super-block inverse kernel, which is what that kernel waits for once its loader wave is out of the way.
+template <int KMAX, bool FAST = false>
 __device__ __forceinline__ double rq_spline_inverse_selects(const float (&w)[KMAX], const float (&h)[KMAX],
                                                             const float (&sraw)[KMAX + 1], float last, float last2,
                                                             const SplineFlags& f, float x0f, float xff, float y0f, float yff,
@@ -272,7 +276,8 @@ __device__ __forceinline__ double rq_spline_inverse_selects(const float (&w)[KMA
             sh += eh[k];
         }
     }
-    const double iw = W / sw, ih = H / sh;
+    auto div = [](double a_, double b_) __attribute__((always_inline)) { return FAST ? fast_div64(a_, b_) : a_ / b_; };
+    const double iw = div(W, sw), ih = div(H, sh);
     double kx = x0, ky = y0, bw = 0.0, bh = 0.0;
     float rs0 = sraw[0], rs1 = sraw[0], rs_last = sraw[0];
     bool found = false;
@@ -300,20 +305,21 @@ __device__ __forceinline__ double rq_spline_inverse_selects(const float (&w)[KMA
     const double dk = (double)(softplus_f(rs0 + f.slope_offset) + f.min_slope);
     const double dk1 = (double)(softplus_f(rs1 + f.slope_offset) + f.min_slope);
     const double bx = lower_tail ? x0 : kx, by = lower_tail ? y0 : ky;
-    const double out_t = bx + (v - by) / dk;                                      // spline.py:599-614
-    const double s = bh / bw;                                                     // spline.py:643
+    const double out_t = bx + div(v - by, dk);                                      // spline.py:599-614
+    const double s = div(bh, bw);                                                     // spline.py:643
     const double t = dk1 + dk - 2.0 * s;
     const double ym = v - ky;                                                     // spline.py:521-536
     const double a = bh * (s - dk) + ym * t;
     const double b = bh * dk - ym * t;
     const double c = -s * ym;
-    const double eps = 2.0 * c / (-b - sqrt(b * b - 4.0 * a * c));
+    const double disc = b * b - 4.0 * a * c;
+    const double eps = div(2.0 * c, -b - (FAST ? fast_sqrt64(disc) : sqrt(disc)));
     const double out_i = eps * bw + kx;
     const double e1 = eps * (1.0 - eps);                                          // spline.py:556-558
     const double om = 1.0 - eps;
     const double num = s * s * (dk1 * eps * eps + 2.0 * s * e1 + dk * om * om);
     const double den = s + t * e1;
-    const double arg = tail ? dk : num / (den * den);
+    const double arg = tail ? dk : div(num, den * den);
     double out = tail ? out_t : out_i;
     if (f.circular) out = py_mod(out - x0 - (double)last, (double)xff - x0) + x0;  // spline.py:257-259 (wave-uniform)
     *logd = (double)logf((float)arg);
