@@ -1818,7 +1818,7 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
                     xv = yv * 0.5f + 1e-3f * (w[0] + hh[1] + sraw[2] + last + last2);
                     ld = 0.0;
 #else
-                    xv = (float)rq_spline_inverse_selects<8, (SPEC > 0)>(w, hh, sraw, last, last2, fl, ftf[5], ftf[6], ftf[7], ftf[8], yv, &ld);
+                    xv = (float)rq_spline_inverse_selects<8, (SPEC > 0), (SPEC > 0)>(w, hh, sraw, last, last2, fl, ftf[5], ftf[6], ftf[7], ftf[8], yv, &ld, part);
 #endif
                     ldj_acc -= ld;
                     }

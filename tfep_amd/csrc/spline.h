@@ -233,11 +233,21 @@ __device__ inline double rq_spline_element(const float (&w)[KMAX], const float (
 // FAST: the six fp64 divisions and the square root through fp64_fast.h (hardware seed + Newton, ~1 ulp in fp64 -- far below the
 // fp32 rounding of the result; every denominator here is positive and finite for valid inputs): ~170 vector instructions less on the
 // chain wave of the super-block inverse kernel, which is what that kernel waits for once its loader wave is out of the way.
-template <int KMAX, bool FAST = false>
+// QUAD (KMAX = 8, K = 8 only): the caller evaluates the same element on the four lanes of a DPP quad (the 16-row layouts of the
+// inverse block kernels: lanes 4 s .. 4 s + 3 hold sample row s; `quad_lane` = lane & 3).  The 16 softmax exponentials -- 18 fp64
+// instructions each, the bulk of the evaluation -- are then dealt four to a lane and passed round the quad by DPP (32 moves): the
+// same values on every lane, the same sums in the same order.
+template <int J>
+__device__ __forceinline__ double quad_broadcast(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), J * 0x55, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), J * 0x55, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int KMAX, bool FAST = false, bool QUAD = false>
 __device__ __forceinline__ double rq_spline_inverse_selects(const float (&w)[KMAX], const float (&h)[KMAX],
                                                             const float (&sraw)[KMAX + 1], float last, float last2,
                                                             const SplineFlags& f, float x0f, float xff, float y0f, float yff,
-                                                            float vin, double* logd) {
+                                                            float vin, double* logd, int quad_lane = 0) {
     const int K = f.K;
     const double mb = (double)f.min_bin;
     double x0 = x0f, y0 = y0f;
@@ -265,15 +275,38 @@ __device__ __forceinline__ double rq_spline_inverse_selects(const float (&w)[KMA
         }
     double ew[KMAX], eh[KMAX];
     double sw = 0.0, sh = 0.0;
+    if constexpr (QUAD && KMAX == 8) {
+        // lane p of the quad: exp of widths 2 p, 2 p + 1 and heights 2 p, 2 p + 1
+        float aw0 = w[0], aw1 = w[1], ah0 = h[0], ah1 = h[1];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        ew[k] = 0.0;
-        eh[k] = 0.0;
-        if (k < K) {
-            ew[k] = exp_nonpos((double)w[k] - (double)mw);
-            eh[k] = exp_nonpos((double)h[k] - (double)mh);
+        for (int p = 1; p < 4; ++p) {
+            aw0 = quad_lane == p ? w[2 * p] : aw0;
+            aw1 = quad_lane == p ? w[2 * p + 1] : aw1;
+            ah0 = quad_lane == p ? h[2 * p] : ah0;
+            ah1 = quad_lane == p ? h[2 * p + 1] : ah1;
+        }
+        const double e0 = exp_nonpos((double)aw0 - (double)mw), e1 = exp_nonpos((double)aw1 - (double)mw);
+        const double e2 = exp_nonpos((double)ah0 - (double)mh), e3 = exp_nonpos((double)ah1 - (double)mh);
+        ew[0] = quad_broadcast<0>(e0); ew[1] = quad_broadcast<0>(e1); eh[0] = quad_broadcast<0>(e2); eh[1] = quad_broadcast<0>(e3);
+        ew[2] = quad_broadcast<1>(e0); ew[3] = quad_broadcast<1>(e1); eh[2] = quad_broadcast<1>(e2); eh[3] = quad_broadcast<1>(e3);
+        ew[4] = quad_broadcast<2>(e0); ew[5] = quad_broadcast<2>(e1); eh[4] = quad_broadcast<2>(e2); eh[5] = quad_broadcast<2>(e3);
+        ew[6] = quad_broadcast<3>(e0); ew[7] = quad_broadcast<3>(e1); eh[6] = quad_broadcast<3>(e2); eh[7] = quad_broadcast<3>(e3);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
             sw += ew[k];
             sh += eh[k];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            ew[k] = 0.0;
+            eh[k] = 0.0;
+            if (k < K) {
+                ew[k] = exp_nonpos((double)w[k] - (double)mw);
+                eh[k] = exp_nonpos((double)h[k] - (double)mh);
+                sw += ew[k];
+                sh += eh[k];
+            }
         }
     }
     auto div = [](double a_, double b_) __attribute__((always_inline)) { return FAST ? fast_div64(a_, b_) : a_ / b_; };
