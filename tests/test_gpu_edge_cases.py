@@ -695,6 +695,37 @@ def test_cached_packed_weights_notice_updates_through_data():
     made.cache_packed_weights = False
 
 
+def test_large_blocked_inverse_runs_shard_by_shard_with_the_same_results():
+    """Above 16 384 rows a long-chain layer is inverted shard by shard on the one-launch-per-super-block schedule, the packed weights
+    shared by the shards: row for row the results of calling ``inverse`` on each shard, bit for bit; the packs do not outlive the
+    call and ``cache_packed_weights`` is left as it was."""
+    from tfep_amd.nn.conditioners import generate_degrees
+    from tfep_amd.nn.flows import MAF
+    from tfep_amd.nn.transformers import NeuralSplineTransformer
+    torch.manual_seed(3)
+    D, B, shard = 1100, 16384 + 700, 8192
+    maf = MAF(generate_degrees(D, 'ascending'), transformer=NeuralSplineTransformer(torch.full((D,), -4.0), torch.full((D,), 4.0), 8),
+              hidden_layers=[1200, 1200], initialize_identity=False).cuda()
+    maf.split_inverse = True
+    y = (torch.randn(B, D, generator=torch.Generator().manual_seed(9)) * 1.2).cuda()
+    made = maf._conditioner
+    assert made.cache_packed_weights is False
+    with torch.no_grad():
+        x, l = maf.inverse(y)
+        assert maf.last_inverse_schedule.startswith('sharded')
+        assert made.cache_packed_weights is False
+        assert not any(isinstance(k, tuple) and k[0] in ('packed', 'packed_split') for plan in made._plans.values() for k in plan)
+        for r0 in range(0, B, shard):
+            xs, ls = maf.inverse(y[r0:r0 + shard])
+            assert torch.equal(x[r0:r0 + shard], xs) and torch.equal(l[r0:r0 + shard], ls)
+        maf.inverse_shard_rows = 0
+        xw, lw = maf.inverse(y)                              # the whole batch at once: the same map
+        assert not maf.last_inverse_schedule.startswith('sharded')
+        yy, ll = maf(x)
+    assert float((xw - x).abs().max()) < 5e-5 and torch.allclose(lw, l, rtol=1e-5, atol=5e-4)
+    assert float((yy - y).abs().max()) < 5e-3 and torch.allclose(ll + l, torch.zeros_like(l), atol=5e-3)
+
+
 @pytest.mark.parametrize('order,hidden,periodic,B', [('ascending', [1100, 1300], False, 333), ('descending', [900], False, 16),
                                                      ('random', [700, 800, 900], True, 200), ('ascending', [1200, 1200], True, 1)])
 def test_super_block_launch_matches_block_by_block_launches(order, hidden, periodic, B):

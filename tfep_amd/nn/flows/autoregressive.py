@@ -544,8 +544,24 @@ class AutoregressiveFlow(torch.nn.Module):
                                   'False pins the arithmetic.')
         return x, log_det_J
 
+    #: Rows per shard of a large blocked inverse (None: 8192; 0 / False: never shard).  The one-launch-per-super-block schedule needs
+    #: every pair of chain / loader waves resident at once: 8192 rows at cfg2's sizes.  A larger batch used to fall back to the
+    #: block-by-block schedule with one row per lane; it now runs shard after shard on the super-block kernel, the packed weights shared
+    #: by the shards of the call (cfg2 layer, 65 536 rows: 533 -> 482 ms).  Above 16 384 rows only: up to there the whole batch runs on
+    #: 16-row waves, which cfg4-i's short chains do faster than two shards (70 against 81 ms).
+    inverse_shard_rows = None
+
     def _inverse_values(self, y: torch.Tensor):
         if self._blocked_ok():
+            shard = self.inverse_shard_rows
+            if os.environ.get('TFEP_INV_SHARD_ROWS') is not None:
+                shard = int(os.environ['TFEP_INV_SHARD_ROWS'])
+            shard = 8192 if shard is None else int(shard or 0)
+            made = self._conditioner
+            # (long chains only -- at least 1024 transformed features: where the chain of degrees dominates the call)
+            if (shard > 0 and y.shape[0] > max(16384, shard) and isinstance(made, MADE) and self.__dict__.get('_shard_ok', True)
+                    and y.shape[1] - len(self._conditioner_indices) >= 1024 and not torch.cuda.is_current_stream_capturing()):
+                return self._inverse_blocked_sharded(y, shard)
             return self._inverse_blocked(y)
         t = self._tables(y.device)
         x = ops.zeros(*y.shape, dtype=y.dtype, device=y.device)
@@ -660,6 +676,30 @@ class AutoregressiveFlow(torch.nn.Module):
             t = (ops.gather_columns(values, info['per_sel']) - lo) * float(2.0 * math.pi / (hi - lo))
             ops.scatter_columns(torch.cos(t), info['cos_cols'], xpad)
             ops.scatter_columns(torch.sin(t), info['sin_cols'], xpad)
+
+    def _inverse_blocked_sharded(self, y, shard):
+        """``_inverse_blocked`` shard by shard (rows are independent); the packs made for the first shard serve the others."""
+        made = self._conditioner
+        B = y.shape[0]
+        x = torch.empty_like(y)
+        ldj = torch.empty(B, dtype=torch.float32, device=y.device)
+        keep = made.cache_packed_weights
+        made.cache_packed_weights = True                   # (the packs outlive a shard's frozen_weights() block: checked by fingerprint)
+        try:
+            for r0 in range(0, B, shard):
+                xs, ls = self._inverse_blocked(y[r0:r0 + shard])
+                x[r0:r0 + shard] = xs
+                ldj[r0:r0 + shard] = ls
+                if self.last_inverse_schedule != 'super_kernel':
+                    self.__dict__['_shard_ok'] = False      # this layer does not take the super-block kernel: whole batches from now on
+        finally:
+            made.cache_packed_weights = keep
+            if not keep:
+                for plan in made._plans.values():           # (as frozen_weights() leaves them without the cache)
+                    for k in [k for k in plan if isinstance(k, tuple) and k[0] in ('packed', 'packed_split')]:
+                        del plan[k]
+        self.last_inverse_schedule = 'sharded ' + str(self.last_inverse_schedule)
+        return x, ldj
 
     def _blocked_plan(self, device, batch=None):
         """The plan of ``_blocked_plan_for`` with ``inverse_block`` degrees per block, or fewer (halved down to 2) when
