@@ -1645,7 +1645,7 @@ __global__ void __launch_bounds__(128 * PAIRS) inverse_superblock_kernel
             } else {
                 const int o_P = KIND == 3 ? a.spg[sr[4 * IB_MAX_LAYERS + 5]].P : a.P;
                 if constexpr (SD) {
-                    if (o_nd == 1) stage_rows_split_dma(reinterpret_cast<char*>(os), IB_STAGE_ROWS, sa.ws[LL], sa.ldws[LL], o_row0 + f, o_P, o_kb, o_ke, lane);
+                    if (o_nd == 1 && o_P <= 32) stage_rows_split_dma(reinterpret_cast<char*>(os), IB_STAGE_ROWS, sa.ws[LL], sa.ldws[LL], o_row0 + f, o_P, o_kb, o_ke, lane);
                     else stage_rows_split(reinterpret_cast<char*>(os), IB_STAGE_ROWS, sa.ws[LL], sa.ldws[LL], o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
                 } else stage_rows(os, gstride, a.wout, a.ldwout, o_row0 + f, o_nd, o_P, o_kb, o_ke, lane);
                 stage_z16(oz, a.zout, a.ldzout, wave_row0, a.B, o_row0 + f, o_nd, o_P, zout_slabs, a.zout_slab_stride, lane);
